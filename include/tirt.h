@@ -1,0 +1,143 @@
+/*
+ * tirt.h -- C-ABI of libtirt.so, the MI355X (gfx950) path-tracing core that sits behind
+ * the ti-raytrace Scene / LBvh.Bvh / Camera / PT_RGB.PathTrace Python API.
+ *
+ * The reference has no FFI boundary for this path: every hot function is a @ti.kernel /
+ * @ti.func JIT-compiled by Taichi and reached only from Python.  The
+ * boundary is therefore defined here; each entry point cites the reference call it
+ * replaces.  Plain pointers and sizes only, no torch types.  Host buffers are
+ * C-contiguous f32/i32 (numpy); the caller owns them, the library copies on upload and
+ * owns all device memory.  One host thread drives one tirt_ctx (one HIP device, one
+ * stream).  Every function returns 0 on success, <0 on error (tirt_last_error() gives
+ * the message); nothing throws across the boundary.
+ */
+#ifndef TIRT_H
+#define TIRT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct tirt_ctx tirt_ctx;
+
+#define TIRT_OK 0
+#define TIRT_ERR_HIP (-1)      /* a HIP runtime call failed (no device, OOM, launch error) */
+#define TIRT_ERR_ARG (-2)      /* bad argument / call order */
+#define TIRT_ERR_BUILD (-3)    /* LBVH build did not complete (refit did not reach the root) */
+#define TIRT_ERR_STACK (-4)    /* traversal stack overflow (reference: "overflow, need larger stack") */
+
+/* tirt_pt_rgb_render / tirt_trace_* flags */
+#define TIRT_TRAVERSE_ORDERED 0     /* near-first, t-culled traversal (product default)     */
+#define TIRT_TRAVERSE_EXHAUSTIVE 1  /* reference visiting rule: no t-culling (Scene.py:702-744) */
+#define TIRT_COUNT_NODES 2          /* accumulate N_box / N_leaf pop counts into tirt_stats  */
+
+typedef struct {
+    uint64_t rays_closest;   /* closet_hit calls        (integrator/PT_RGB.py:65)  */
+    uint64_t rays_shadow;    /* closet_hit_shadow calls (integrator/PT_RGB.py:104) */
+    uint64_t box_closest;    /* compact nodes popped by closest-hit rays (TIRT_COUNT_NODES) */
+    uint64_t leaf_closest;   /* ... leaves among them */
+    uint64_t box_shadow;
+    uint64_t leaf_shadow;
+    uint64_t shaded;         /* path vertices that ran the BSDF branch */
+    uint64_t paths;          /* pixel-samples started */
+    uint64_t stack_overflow; /* rays whose traversal overflowed stack_size */
+    double ms_build;         /* last tirt_lbvh_build, HIP-event time on the ctx stream */
+    double ms_render;        /* sum of tirt_pt_rgb_render calls since reset */
+    double ms_trace_closest; /* sum over closest-hit kernel launches since reset */
+    double ms_trace_shadow;
+    double ms_shade;
+    uint64_t launches_trace_closest;
+    uint64_t launches_trace_shadow;
+    uint64_t launches_shade;
+} tirt_stats_t;
+
+const char *tirt_last_error(void);
+int tirt_version(void);
+int tirt_device_count(int *out);
+
+/* one context = one HIP device + one stream */
+int tirt_create(int device_id, tirt_ctx **out);
+void tirt_destroy(tirt_ctx *ctx);
+int tirt_sync(tirt_ctx *ctx);
+
+/* Scene.setup_data_gpu field uploads (reference Scene.py:299-308).
+ * vertex[nv*9] primitive[n*3] material[nm*10] shape[ns*10] light[nl]; light_count is
+ * Scene.light_count (may be 0 while nl == 1, Scene.py:253-261); bmin/bmax = scene AABB
+ * (LBvh.Bvh.min/max_boundary, accel/LBvh.py:193-194). */
+int tirt_scene_upload(tirt_ctx *ctx, const float *vertex, int nv, const int32_t *primitive, int n,
+                      const float *material, int nm, const float *shape, int ns,
+                      const int32_t *light, int nl, int light_count,
+                      const float bmin[3], const float bmax[3]);
+/* Re-upload the material rows only (examples edit material_cpu before setup). */
+int tirt_material_upload(tirt_ctx *ctx, const float *material, int nm);
+
+/* Texture.setup_data_gpu (texture/Texture.py:38-39): rgb_packed[w*h] 0xRRGGBB, index x*h + y */
+int tirt_env_upload(tirt_ctx *ctx, const int32_t *rgb_packed, int w, int h, float power);
+
+/* LBvh.Bvh.setup_data_gpu (accel/LBvh.py:192-226): Morton codes, stable radix sort, Karras
+ * topology, leaf boxes, bottom-up refit, DFS flatten -- all on device. */
+int tirt_lbvh_build(tirt_ctx *ctx);
+/* any of the three may be NULL: morton_sorted[n*2] (code, prim), bvh_node[(2n-1)*11],
+ * compact_node[(2n-1)*9] */
+int tirt_lbvh_download(tirt_ctx *ctx, int32_t *morton_sorted, float *bvh_node, float *compact_node);
+/* unsorted Morton pairs [n*2] as produced by build_morton_3d (accel/LBvh.py:318-336) */
+int tirt_morton_download(tirt_ctx *ctx, int32_t *morton_unsorted);
+
+/* Scene.process_normal (Scene.py:754-798); vertex_index[nv] = owning primitive (Scene.py:128) */
+int tirt_process_normal(tirt_ctx *ctx, const int32_t *vertex_index);
+int tirt_vertex_download(tirt_ctx *ctx, float *vertex);
+/* Scene.total_area (Scene.py:747-750) */
+int tirt_total_area(tirt_ctx *ctx, float *out);
+
+/* Camera.update field uploads (Camera.py:91-93) + intrinsics (Camera.py:31-34) */
+int tirt_camera_set(tirt_ctx *ctx, const float view[16], const float view_inv[16], const float eye[3],
+                    float fx, float fy, float cx, float cy);
+
+/* PathTrace.setup_data_cpu (integrator/PT_RGB.py:34-37): hdr + rgb_film, W*H*3 f32 each,
+ * index (i*H + j)*3.  This context renders the pixels whose linear index p = i*H + j lies
+ * in a tile (p / tile_size) with tile % tile_count == tile_rank (tile_count 1: all). */
+int tirt_film_create(tirt_ctx *ctx, int W, int H, int tile_rank, int tile_count, int tile_size);
+int tirt_film_clear(tirt_ctx *ctx);
+
+/* PathTrace.render x frame_count (integrator/PT_RGB.py:44-136), frames frame_begin ..
+ * frame_begin+frame_count-1 accumulated into hdr as the running mean of :134-136.
+ * Asynchronous on the ctx stream. */
+int tirt_pt_rgb_render(tirt_ctx *ctx, uint32_t frame_begin, int frame_count, uint32_t seed,
+                       int max_depth, int stack_size, int flags);
+
+/* UtilsFunc.tone_map(exposure, hdr, rgb_film) (UtilsFunc.py:583-586) */
+int tirt_tone_map(tirt_ctx *ctx, float exposure);
+/* field.to_numpy(): either pointer may be NULL */
+int tirt_film_download(tirt_ctx *ctx, float *hdr, float *rgb);
+/* device-to-device copy of hdr into / from a caller-owned device buffer of W*H*3 f32
+ * (e.g. a torch tensor that is then reduced over RCCL) */
+int tirt_film_export_device(tirt_ctx *ctx, void *dev_dst);
+int tirt_film_import_device(tirt_ctx *ctx, const void *dev_src);
+
+/* Scene.closet_hit / closet_hit_shadow on a batch of rays (Scene.py:702-744, 671-699):
+ * rays[nr*6] = origin, direction.  out_hit[nr*13] = t, pos3, gnormal3, normal3, tex3;
+ * out_prim[nr]; counts[nr*2] = N_box, N_leaf per ray (NULL unless TIRT_COUNT_NODES). */
+int tirt_trace_closest(tirt_ctx *ctx, const float *rays, int nr, int stack_size, int flags,
+                       float *out_hit, int32_t *out_prim, int32_t *counts);
+int tirt_trace_shadow(tirt_ctx *ctx, const float *rays, int nr, int stack_size, int flags,
+                      float *out_t, int32_t *out_prim, int32_t *counts);
+
+int tirt_stats(tirt_ctx *ctx, tirt_stats_t *out);
+int tirt_stats_reset(tirt_ctx *ctx);
+
+/* Device-side evaluation of the shared scalar functions (known-answer tests):
+ * fn 0 sin 1 cos 2 exp 3 log 4 pow(x,y) 5 atan2(x,y) 6 acos 7 sqrt 8 x/y */
+int tirt_kat_math(tirt_ctx *ctx, int fn, const float *x, const float *y, float *out, int n);
+/* which 0 Disney.evaluate_pdf  in: mat10,N3,V3,L3        out: f, pdf
+ *       1 Disney.sample        in: mat10,dir3,N3,rnd3    out: dir3
+ *       2 Glass.sample         in: mat10,dir3,N3,prob    out: dir3, f_or_b
+ *       3 UF.offset_ray        in: p3,n3                 out: p3
+ * in: [n*in_stride] out: [n*out_stride] */
+int tirt_kat_brdf(tirt_ctx *ctx, int which, const float *in, int in_stride, float *out, int out_stride, int n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TIRT_H */

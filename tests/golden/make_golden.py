@@ -1,0 +1,22 @@
+"""Regenerates the golden fixtures from the reference's committed artefacts (run in the
+authoring container, where /root/reference exists; the fixtures -- data, not source --
+are what travels).
+
+  nodelist.txt            verbatim copy of /root/reference/nodelist.txt, the LBVH dump the
+                          reference wrote for model/cornell_box.obj (accel/LBvh.py:164-172)
+  out_png_blocks.npy      [32,32,3] f32 means of 16x16 pixel blocks of /root/reference/out.png
+                          (Cornell, PT_RGB, 512^2, 512 spp, exposure 0.5; example/Example.py:49),
+                          sRGB in [0,1], PNG row/col order
+"""
+import shutil
+import sys
+
+import numpy as np
+from PIL import Image
+
+REF = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
+shutil.copyfile(REF + "/nodelist.txt", "nodelist.txt")
+img = np.asarray(Image.open(REF + "/out.png").convert("RGB")).astype(np.float32) / 255.0
+blocks = img.reshape(32, 16, 32, 16, 3).mean(axis=(1, 3)).astype(np.float32)
+np.save("out_png_blocks.npy", blocks)
+print(blocks.shape, blocks.reshape(-1, 3).mean(0))

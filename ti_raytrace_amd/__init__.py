@@ -1,0 +1,10 @@
+"""ti_raytrace_amd -- MI355X-native path-tracing core behind the ti-raytrace Python API.
+
+Modules keep the reference's names: ``SceneData``, ``Scene``, ``Camera``, ``LBvh``,
+``PT_RGB``, ``UtilsFunc``, ``Texture``, ``Example`` (+ ``scenes`` with the example set-ups).
+The compute path is ``csrc/libtirt.so`` (hand-written HIP for gfx950) behind the C-ABI of
+``include/tirt.h``; see DESIGN.md / INTEGRATION.md.
+"""
+from . import SceneData, UtilsFunc, Texture, Camera, LBvh, Scene, PT_RGB, Example  # noqa: F401
+
+__all__ = ["SceneData", "UtilsFunc", "Texture", "Camera", "LBvh", "Scene", "PT_RGB", "Example"]

@@ -1,0 +1,264 @@
+"""ctypes binding of libtirt.so (the HIP library; C-ABI in include/tirt.h).
+
+There is no CPU fallback: if the library is missing, or no HIP device can be opened, the
+calls raise.  (The CPU oracle under oracle/ is test infrastructure and is never loaded
+from here.)
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libtirt.so")
+
+_f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+_i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+
+
+class TirtError(RuntimeError):
+    pass
+
+
+class Stats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in (
+        "rays_closest", "rays_shadow", "box_closest", "leaf_closest", "box_shadow",
+        "leaf_shadow", "shaded", "paths", "stack_overflow")] + [
+        (n, C.c_double) for n in ("ms_build", "ms_render", "ms_trace_closest",
+                                  "ms_trace_shadow", "ms_shade")] + [
+        (n, C.c_uint64) for n in ("launches_trace_closest", "launches_trace_shadow",
+                                  "launches_shade")]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+TRAVERSE_ORDERED = 0
+TRAVERSE_EXHAUSTIVE = 1
+COUNT_NODES = 2
+
+# name -> (restype, argtypes).  tests/test_abi.py checks every name against include/tirt.h.
+_vp = C.c_void_p
+SIGNATURES = {
+    "tirt_last_error": (C.c_char_p, []),
+    "tirt_version": (C.c_int, []),
+    "tirt_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "tirt_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
+    "tirt_destroy": (None, [_vp]),
+    "tirt_sync": (C.c_int, [_vp]),
+    "tirt_scene_upload": (C.c_int, [_vp, _f32p, C.c_int, _i32p, C.c_int, _f32p, C.c_int,
+                                    _f32p, C.c_int, _i32p, C.c_int, C.c_int, _f32p, _f32p]),
+    "tirt_material_upload": (C.c_int, [_vp, _f32p, C.c_int]),
+    "tirt_env_upload": (C.c_int, [_vp, _i32p, C.c_int, C.c_int, C.c_float]),
+    "tirt_lbvh_build": (C.c_int, [_vp]),
+    "tirt_lbvh_download": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "tirt_morton_download": (C.c_int, [_vp, _i32p]),
+    "tirt_process_normal": (C.c_int, [_vp, _i32p]),
+    "tirt_vertex_download": (C.c_int, [_vp, _f32p]),
+    "tirt_total_area": (C.c_int, [_vp, C.POINTER(C.c_float)]),
+    "tirt_camera_set": (C.c_int, [_vp, _f32p, _f32p, _f32p, C.c_float, C.c_float, C.c_float, C.c_float]),
+    "tirt_film_create": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "tirt_film_clear": (C.c_int, [_vp]),
+    "tirt_pt_rgb_render": (C.c_int, [_vp, C.c_uint32, C.c_int, C.c_uint32, C.c_int, C.c_int, C.c_int]),
+    "tirt_tone_map": (C.c_int, [_vp, C.c_float]),
+    "tirt_film_download": (C.c_int, [_vp, _vp, _vp]),
+    "tirt_film_export_device": (C.c_int, [_vp, _vp]),
+    "tirt_film_import_device": (C.c_int, [_vp, _vp]),
+    "tirt_trace_closest": (C.c_int, [_vp, _f32p, C.c_int, C.c_int, C.c_int, _f32p, _i32p, _vp]),
+    "tirt_trace_shadow": (C.c_int, [_vp, _f32p, C.c_int, C.c_int, C.c_int, _f32p, _i32p, _vp]),
+    "tirt_stats": (C.c_int, [_vp, C.POINTER(Stats)]),
+    "tirt_stats_reset": (C.c_int, [_vp]),
+    "tirt_kat_math": (C.c_int, [_vp, C.c_int, _f32p, _f32p, _f32p, C.c_int]),
+    "tirt_kat_brdf": (C.c_int, [_vp, C.c_int, _f32p, C.c_int, _f32p, C.c_int, C.c_int]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libtirt.so once.  Raises TirtError (never falls back) when it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise TirtError(
+                "HIP extension %s is missing -- build it with `python -c 'import "
+                "__graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950). "
+                "There is no CPU fallback." % LIB_PATH)
+        try:
+            handle = C.CDLL(LIB_PATH)
+        except OSError as exc:
+            raise TirtError("cannot load %s: %s" % (LIB_PATH, exc))
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(code):
+    if code != 0:
+        msg = lib().tirt_last_error()
+        raise TirtError("libtirt error %d: %s" % (code, msg.decode() if msg else "?"))
+
+
+def _ptr(arr):
+    return None if arr is None else arr.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    """RAII wrapper around tirt_ctx*."""
+
+    def __init__(self, device_id=0):
+        self._h = C.c_void_p()
+        check(lib().tirt_create(int(device_id), C.byref(self._h)))
+        self.device_id = int(device_id)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            lib().tirt_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        if not self._h.value:
+            raise TirtError("context is closed")
+        return self._h
+
+    # thin typed wrappers ---------------------------------------------------------------
+    def sync(self):
+        check(lib().tirt_sync(self.handle))
+
+    def scene_upload(self, vertex, primitive, material, shape, light, light_count, bmin, bmax):
+        vertex = np.ascontiguousarray(vertex, np.float32)
+        primitive = np.ascontiguousarray(primitive, np.int32)
+        material = np.ascontiguousarray(material, np.float32)
+        shape = np.ascontiguousarray(shape, np.float32)
+        light = np.ascontiguousarray(light, np.int32)
+        check(lib().tirt_scene_upload(
+            self.handle, vertex.reshape(-1), vertex.shape[0], primitive.reshape(-1), primitive.shape[0],
+            material.reshape(-1), material.shape[0], shape.reshape(-1), shape.shape[0],
+            light.reshape(-1), light.shape[0], int(light_count),
+            np.ascontiguousarray(bmin, np.float32).reshape(-1), np.ascontiguousarray(bmax, np.float32).reshape(-1)))
+
+    def material_upload(self, material):
+        material = np.ascontiguousarray(material, np.float32)
+        check(lib().tirt_material_upload(self.handle, material.reshape(-1), material.shape[0]))
+
+    def env_upload(self, packed, power):
+        packed = np.ascontiguousarray(packed, np.int32)
+        check(lib().tirt_env_upload(self.handle, packed.reshape(-1), packed.shape[0], packed.shape[1], float(power)))
+
+    def lbvh_build(self):
+        check(lib().tirt_lbvh_build(self.handle))
+
+    def lbvh_download(self, n, want_morton=True, want_bvh=True, want_compact=True):
+        N = 2 * n - 1
+        morton = np.zeros((n, 2), np.int32) if want_morton else None
+        bvh = np.zeros((N, 11), np.float32) if want_bvh else None
+        compact = np.zeros((N, 9), np.float32) if want_compact else None
+        check(lib().tirt_lbvh_download(self.handle, _ptr(morton), _ptr(bvh), _ptr(compact)))
+        return morton, bvh, compact
+
+    def morton_download(self, n):
+        out = np.zeros((n, 2), np.int32)
+        check(lib().tirt_morton_download(self.handle, out.reshape(-1)))
+        return out
+
+    def process_normal(self, vertex_index):
+        check(lib().tirt_process_normal(self.handle, np.ascontiguousarray(vertex_index, np.int32)))
+
+    def vertex_download(self, nv):
+        out = np.zeros((nv, 9), np.float32)
+        check(lib().tirt_vertex_download(self.handle, out.reshape(-1)))
+        return out
+
+    def total_area(self):
+        v = C.c_float(0.0)
+        check(lib().tirt_total_area(self.handle, C.byref(v)))
+        return float(v.value)
+
+    def camera_set(self, view, view_inv, eye, fx, fy, cx, cy):
+        check(lib().tirt_camera_set(
+            self.handle, np.ascontiguousarray(view, np.float32).reshape(-1),
+            np.ascontiguousarray(view_inv, np.float32).reshape(-1),
+            np.ascontiguousarray(eye, np.float32).reshape(-1), float(fx), float(fy), float(cx), float(cy)))
+
+    def film_create(self, W, H, tile_rank=0, tile_count=1, tile_size=4096):
+        check(lib().tirt_film_create(self.handle, int(W), int(H), int(tile_rank), int(tile_count), int(tile_size)))
+
+    def film_clear(self):
+        check(lib().tirt_film_clear(self.handle))
+
+    def pt_rgb_render(self, frame_begin, frame_count, seed, max_depth=15, stack_size=64, flags=0):
+        check(lib().tirt_pt_rgb_render(self.handle, int(frame_begin), int(frame_count), int(seed),
+                                       int(max_depth), int(stack_size), int(flags)))
+
+    def tone_map(self, exposure):
+        check(lib().tirt_tone_map(self.handle, float(exposure)))
+
+    def film_download(self, W, H, want_hdr=True, want_rgb=False):
+        hdr = np.zeros((W, H, 3), np.float32) if want_hdr else None
+        rgb = np.zeros((W, H, 3), np.float32) if want_rgb else None
+        check(lib().tirt_film_download(self.handle, _ptr(hdr), _ptr(rgb)))
+        return hdr, rgb
+
+    def film_export_device(self, dev_ptr):
+        check(lib().tirt_film_export_device(self.handle, C.c_void_p(int(dev_ptr))))
+
+    def film_import_device(self, dev_ptr):
+        check(lib().tirt_film_import_device(self.handle, C.c_void_p(int(dev_ptr))))
+
+    def trace_closest(self, rays, stack_size=64, flags=0):
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
+        nr = rays.shape[0]
+        out = np.zeros((nr, 13), np.float32)
+        prim = np.zeros(nr, np.int32)
+        counts = np.zeros((nr, 2), np.int32) if (flags & COUNT_NODES) else None
+        check(lib().tirt_trace_closest(self.handle, rays.reshape(-1), nr, int(stack_size), int(flags),
+                                       out.reshape(-1), prim, _ptr(counts)))
+        return out, prim, counts
+
+    def trace_shadow(self, rays, stack_size=64, flags=0):
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
+        nr = rays.shape[0]
+        out = np.zeros(nr, np.float32)
+        prim = np.zeros(nr, np.int32)
+        counts = np.zeros((nr, 2), np.int32) if (flags & COUNT_NODES) else None
+        check(lib().tirt_trace_shadow(self.handle, rays.reshape(-1), nr, int(stack_size), int(flags),
+                                      out, prim, _ptr(counts)))
+        return out, prim, counts
+
+    def stats(self):
+        st = Stats()
+        check(lib().tirt_stats(self.handle, C.byref(st)))
+        return st.as_dict()
+
+    def stats_reset(self):
+        check(lib().tirt_stats_reset(self.handle))
+
+    def kat_math(self, fn, x, y=None):
+        x = np.ascontiguousarray(x, np.float32)
+        y = np.ascontiguousarray(y if y is not None else np.zeros_like(x), np.float32)
+        out = np.zeros_like(x)
+        check(lib().tirt_kat_math(self.handle, int(fn), x, y, out, x.size))
+        return out
+
+    def kat_brdf(self, which, inp, out_stride):
+        inp = np.ascontiguousarray(inp, np.float32)
+        n, stride = inp.shape
+        out = np.zeros((n, out_stride), np.float32)
+        check(lib().tirt_kat_brdf(self.handle, int(which), inp.reshape(-1), stride, out.reshape(-1), out_stride, n))
+        return out
+
+
+def device_count():
+    v = C.c_int(0)
+    check(lib().tirt_device_count(C.byref(v)))
+    return v.value

@@ -1,0 +1,99 @@
+"""Example set-ups (mirrors of the reference's ``example/cornell_box.py`` and
+``example/single_model.py``) plus the synthetic 100k-triangle headline scene of
+BASELINE.json config 3.  Model / image inputs are the reference's own data
+files, kept under ``assets/``.
+"""
+import os
+
+import numpy as np
+
+from . import Example, PT_RGB
+from . import SceneData as SCD
+
+ASSETS = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "assets")
+
+
+def asset(*parts):
+    return os.path.join(ASSETS, *parts)
+
+
+class cornell_box(Example.example):
+    """example/cornell_box.py:12-35."""
+
+    def __init__(self, imgSizeX, imgSizeY, sample_count, device_id=None, **pt_kwargs):
+        Example.example.__init__(self, imgSizeX, imgSizeY, sample_count, device_id)
+        self.scene.add_obj(asset("model", "cornell_box.obj"))
+        self.integrator = PT_RGB.PathTrace(imgSizeX, imgSizeY, self.cam, self.scene, 64, **pt_kwargs)
+
+    def build_scene(self):
+        Example.example.build_scene(self)
+        self.scene.total_area()
+        self.frame_camera(0.8)
+
+
+class single_model(Example.example):
+    """example/single_model.py:13-49 with the Teapot line enabled (BASELINE config 2):
+    material 0 -> glass (ior 1.3, extinction 5), sphere light, env.png x 5, smooth normals."""
+
+    def __init__(self, imgSizeX, imgSizeY, sample_count, model="Teapot.obj", device_id=None, **pt_kwargs):
+        Example.example.__init__(self, imgSizeX, imgSizeY, sample_count, device_id)
+        self.scene.add_obj(asset("model", model))
+        self.scene.material_cpu[0].type = SCD.MAT_GLASS
+        self.scene.material_cpu[0].setIor(1.3)
+        self.scene.material_cpu[0].setExtinciton(5.0)
+        self.add_sphere_light()
+        self.scene.add_env(asset("image", "env.png"), 5.0)
+        self.integrator = PT_RGB.PathTrace(imgSizeX, imgSizeY, self.cam, self.scene, 64, **pt_kwargs)
+
+    def build_scene(self):
+        Example.example.build_scene(self)
+        self.scene.process_normal()
+        self.scene.total_area()
+        self.frame_camera(0.8)
+
+
+# ---- synthetic scene -------------------------------------------------------------------------
+_GOLDEN = np.uint64(0x9E3779B97F4A7C15)
+
+
+def splitmix64_unit(seed, count):
+    """u[k] in [0,1) from SplitMix64 with state seed + (k+1)*golden (53-bit mantissa)."""
+    with np.errstate(over="ignore"):
+        z = np.uint64(seed) + (np.arange(1, count + 1, dtype=np.uint64) * _GOLDEN)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return (z >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+
+def synthetic_triangles(ntri=100000, seed=1234, spread=0.03):
+    """positions[ntri,3,3]: centroid c ~ U[-1,1]^3, vertex = c + U[-spread,spread]^3.
+    Twelve stream values per triangle: c.xyz, then the three vertex offsets."""
+    u = splitmix64_unit(seed, 12 * ntri).reshape(ntri, 4, 3)
+    c = u[:, 0, :] * 2.0 - 1.0
+    off = (u[:, 1:4, :] * 2.0 - 1.0) * spread
+    return c[:, None, :] + off
+
+
+class synthetic(Example.example):
+    """BASELINE config 3: ``ntri`` random triangles, one Disney material (0.8 grey, metal 0,
+    rough 0.5 = what a material-less OBJ gets, Scene.py:75-79), sphere light (0,3,0) r 0.75
+    Le 50, black env, face normals, no process_normal, cornell_box camera rule."""
+
+    def __init__(self, imgSizeX, imgSizeY, sample_count, ntri=100000, scene_seed=1234,
+                 spread=0.03, device_id=None, **pt_kwargs):
+        Example.example.__init__(self, imgSizeX, imgSizeY, sample_count, device_id)
+        mat = SCD.Material()
+        mat.type = SCD.MAT_DISNEY
+        mat.setMetal(0.0)
+        mat.setRough(0.5)
+        mat.setColor([0.8, 0.8, 0.8, 1.0])
+        mat.alebdoTex = -1
+        self.scene.add_mesh(synthetic_triangles(ntri, scene_seed, spread), mat)
+        self.add_sphere_light(pos=(0.0, 3.0, 0.0), radius=0.75, emission=50.0)
+        self.integrator = PT_RGB.PathTrace(imgSizeX, imgSizeY, self.cam, self.scene, 64, **pt_kwargs)
+
+    def build_scene(self):
+        Example.example.build_scene(self)
+        self.scene.total_area()
+        self.frame_camera(0.8)
