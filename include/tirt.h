@@ -61,6 +61,9 @@ int tirt_device_count(int *out);
 int tirt_create(int device_id, tirt_ctx **out);
 void tirt_destroy(tirt_ctx *ctx);
 int tirt_sync(tirt_ctx *ctx);
+/* options: "time_kernels" (0/1) -- bracket every trace/shade launch with HIP events on the
+ * ctx stream so that tirt_stats reports per-kernel time (bench/roofline only) */
+int tirt_set_option(tirt_ctx *ctx, const char *name, double value);
 
 /* Scene.setup_data_gpu field uploads (reference Scene.py:299-308).
  * vertex[nv*9] primitive[n*3] material[nm*10] shape[ns*10] light[nl]; light_count is

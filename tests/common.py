@@ -1,0 +1,43 @@
+"""Shared scene builders for the tests (host side only; no device work here)."""
+import numpy as np
+
+from ti_raytrace_amd import scenes, Example, PT_RGB
+from ti_raytrace_amd import SceneData as SCD
+
+
+def host_only(ex, scale=0.8):
+    """Run the host half of build_scene (packing + camera) without touching a device."""
+    ex.scene.setup_data_cpu()
+    ex.frame_camera(scale)
+    return ex
+
+
+def tiny_scene(ntri, seed=7, W=32, H=32, spread=0.2, with_light=True, device_id=None):
+    ex = scenes.synthetic(W, H, 4, ntri=ntri, scene_seed=seed, spread=spread, device_id=device_id)
+    return ex
+
+
+def duplicate_code_scene(W=32, H=32, device_id=None):
+    """Many triangles with identical centroids -> long runs of equal Morton codes (the
+    reference's special case in determineRange, accel/LBvh.py:240-251)."""
+    ex = Example.example(W, H, 4, device_id)
+    rng = np.random.RandomState(3)
+    base = rng.uniform(-1, 1, size=(40, 3))
+    tris = []
+    for c in base:
+        reps = rng.randint(1, 7)
+        for _ in range(reps):
+            off = rng.uniform(-0.05, 0.05, size=(3, 3))
+            off -= off.mean(axis=0, keepdims=True)        # same centroid -> same code
+            tris.append(c[None, :] + off)
+    mat = SCD.Material()
+    mat.type = SCD.MAT_DISNEY
+    mat.setMetal(0.0); mat.setRough(0.5); mat.setColor([0.8, 0.8, 0.8, 1.0]); mat.alebdoTex = -1
+    ex.scene.add_mesh(np.asarray(tris), mat)
+    ex.add_sphere_light(pos=(0.0, 3.0, 0.0), radius=0.75, emission=50.0)
+    ex.integrator = PT_RGB.PathTrace(W, H, ex.cam, ex.scene, 64)
+    return ex
+
+
+def rel_l2(a, b):
+    return float(np.sqrt(((a.astype(np.float64) - b) ** 2).sum() / max((b.astype(np.float64) ** 2).sum(), 1e-30)))

@@ -1,0 +1,133 @@
+"""PT_RGB image parity, HIP wavefront pipeline vs the CPU oracle at the same counter-based
+seed.  Tolerance (north star): relative L2 <= 1e-3.  Because both sides evaluate the same
+fp32 operations in the same order, the images are expected to be bit-identical; the tests
+assert the tolerance and report the identical-pixel count."""
+import numpy as np
+import pytest
+
+import oracle_api as oa
+from common import rel_l2, tiny_scene
+from ti_raytrace_amd import scenes, _native
+from ti_raytrace_amd import UtilsFunc as UF
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+
+
+def render_both(ex, W, H, frames, flags=0):
+    ex.build_scene()
+    ex.integrator.flags = flags
+    o = oa.OracleScene(ex.scene, ex.cam)
+    o.lbvh_build()
+    return ex, o
+
+
+def test_cornell_frames_and_counters(gpu_ctx_ok):
+    W = H = 96
+    ex, o = render_both(scenes.cornell_box(W, H, 8, device_id=0), W, H, 6)
+    ctx = ex.scene.ctx
+    ctx.stats_reset()
+    ex.integrator.render_frames(6)
+    got = ex.integrator.hdr.to_numpy()
+    want, ost = o.render(W, H, 0, 6, seed=ex.integrator.seed)
+    r = rel_l2(got, want)
+    print("cornell 96^2 x6: rel-L2 %.3e, identical pixels %d/%d" % (r, (got == want).all(axis=2).sum(), W * H))
+    assert r <= TOL
+    st = ctx.stats()
+    assert st["rays_closest"] == ost["rays_closest"] and st["rays_shadow"] == ost["rays_shadow"]
+    assert st["shaded"] == ost["shaded"] and st["paths"] == ost["paths"] and st["stack_overflow"] == 0
+    # tone map
+    UF.tone_map(0.5, ex.integrator.hdr, ex.integrator.rgb_film)
+    rgb = ex.integrator.rgb_film.to_numpy()
+    assert rel_l2(rgb, o.tone_map(0.5, want)) <= TOL
+
+
+def test_render_one_frame_at_a_time_equals_batch(gpu_ctx_ok):
+    W = H = 48
+    ex, o = render_both(scenes.cornell_box(W, H, 8, device_id=0), W, H, 5)
+    for _ in range(5):
+        ex.integrator.render()
+        ex.cam.update_frame()
+    a = ex.integrator.hdr.to_numpy()
+    ex.scene.ctx.film_clear(); ex.cam.frame = 0
+    ex.integrator.render_frames(5)
+    b = ex.integrator.hdr.to_numpy()
+    assert np.array_equal(a, b)
+    want, _ = o.render(W, H, 0, 5, seed=ex.integrator.seed)
+    assert rel_l2(a, want) <= TOL
+
+
+def test_exhaustive_mode_counts_match_oracle(gpu_ctx_ok):
+    W = H = 64
+    ex, o = render_both(scenes.cornell_box(W, H, 4, device_id=0), W, H, 2)
+    ctx = ex.scene.ctx
+    ctx.stats_reset()
+    ex.integrator.flags = _native.TRAVERSE_EXHAUSTIVE | _native.COUNT_NODES
+    ex.integrator.render_frames(2)
+    got = ex.integrator.hdr.to_numpy()
+    want, ost = o.render(W, H, 0, 2, seed=ex.integrator.seed)
+    assert rel_l2(got, want) <= TOL
+    st = ctx.stats()
+    for k in ("rays_closest", "rays_shadow", "box_closest", "leaf_closest", "box_shadow", "leaf_shadow", "shaded"):
+        assert st[k] == ost[k], (k, st[k], ost[k])
+
+
+def test_tiles_reassemble_to_the_full_frame(gpu_ctx_ok):
+    """Multi-GPU sharding rule on one GPU: the tiles of N ranks, rendered one after the other,
+    sum to the single-GPU film bit for bit (disjoint pixels, per-pixel RNG)."""
+    W = H = 64
+    ex = scenes.cornell_box(W, H, 4, device_id=0)
+    ex.build_scene()
+    ex.integrator.render_frames(3)
+    full = ex.integrator.hdr.to_numpy()
+    acc = np.zeros_like(full)
+    for rank in range(3):
+        ex.scene.ctx.film_create(W, H, rank, 3, 100)          # ragged: 4096 px in tiles of 100
+        ex.scene.ctx.pt_rgb_render(0, 3, ex.integrator.seed, 15, 64, 0)
+        part, _ = ex.scene.ctx.film_download(W, H)
+        assert ((part != 0).any(axis=2) & (acc != 0).any(axis=2)).sum() == 0
+        acc += part
+    assert np.array_equal(acc, full)
+
+
+def test_teapot_glass_env(gpu_ctx_ok):
+    """BASELINE config 2 at reduced size: glass teapot, sphere light, env map, smooth normals."""
+    W = H = 64
+    ex = scenes.single_model(W, H, 4, device_id=0)
+    ex.build_scene()
+    o = oa.OracleScene(ex.scene, ex.cam)
+    o.lbvh_build(); o.process_normal(ex.scene.vertex_index_np)
+    ex.integrator.render_frames(3)
+    got = ex.integrator.hdr.to_numpy()
+    want, ost = o.render(W, H, 0, 3, seed=ex.integrator.seed)
+    r = rel_l2(got, want)
+    print("teapot 64^2 x3: rel-L2 %.3e, identical pixels %d/%d, oracle max stack %d"
+          % (r, (got == want).all(axis=2).sum(), W * H, ost["max_stack"]))
+    assert np.isfinite(want).all() == np.isfinite(got).all()
+    m = np.isfinite(want).all(axis=2) & np.isfinite(got).all(axis=2)
+    assert rel_l2(got[m], want[m]) <= TOL
+
+
+def test_headline_scene_reduced(gpu_ctx_ok):
+    """BASELINE config 3 geometry (100k triangles) at 128^2 x 2 frames."""
+    W = H = 128
+    ex, o = render_both(scenes.synthetic(W, H, 4, device_id=0), W, H, 2)
+    ex.scene.ctx.stats_reset()
+    ex.integrator.render_frames(2)
+    got = ex.integrator.hdr.to_numpy()
+    want, ost = o.render(W, H, 0, 2, seed=ex.integrator.seed)
+    r = rel_l2(got, want)
+    st = ex.scene.ctx.stats()
+    print("100k 128^2 x2: rel-L2 %.3e, identical pixels %d/%d; rays %d+%d" %
+          (r, (got == want).all(axis=2).sum(), W * H, st["rays_closest"], st["rays_shadow"]))
+    assert r <= TOL
+    assert st["rays_closest"] == ost["rays_closest"] and st["rays_shadow"] == ost["rays_shadow"]
+
+
+def test_small_scene_many_bounces(gpu_ctx_ok):
+    W = H = 40
+    ex, o = render_both(tiny_scene(400, seed=21, W=W, H=H, spread=0.25, device_id=0), W, H, 4)
+    ex.integrator.render_frames(4)
+    got = ex.integrator.hdr.to_numpy()
+    want, _ = o.render(W, H, 0, 4, seed=ex.integrator.seed)
+    assert rel_l2(got, want) <= TOL

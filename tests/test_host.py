@@ -1,0 +1,90 @@
+"""Host logic (no device): OBJ/MTL ingest, struct packing, camera, texture, scene generators."""
+import numpy as np
+
+from common import host_only
+from ti_raytrace_amd import scenes, Camera, Texture, ObjLoader
+from ti_raytrace_amd import SceneData as SCD
+
+
+def test_cornell_ingest_order_and_classification():
+    ex = host_only(scenes.cornell_box(32, 32, 4))
+    s = ex.scene
+    assert s.primitive_count == 36 and s.vertex_count == 108 and s.material_count == 4
+    assert s.material_np[:, 0].tolist() == [0.0, 0.0, 0.0, 2.0]          # white red green (Disney) light
+    assert s.material_np[3, 2:5].tolist() == [10.0, 10.0, 10.0]
+    assert s.material_np[0, 5:7].tolist() == [0.0, 0.5]
+    assert s.light_np.tolist() == [34, 35] and s.light_count == 2
+    assert (np.diff(s.primitive_np[:, 2]) >= 0).all()                   # grouped by material in MTL order
+    assert s.primitive_np[:, 1].tolist() == list(range(0, 108, 3))
+    assert s.minboundarynp.tolist() == [[0.0, 0.0, np.float32(-559.2)]]
+    assert s.maxboundarynp.tolist() == [[556.0, np.float32(548.8), 0.0]]
+    # face normals were generated and are unit length
+    n = s.vertex_np[:, 3:6]
+    assert np.allclose(np.linalg.norm(n, axis=1), 1.0, atol=1e-6)
+    assert s.vertex_index_np.tolist() == [i // 3 for i in range(108)]
+
+
+def test_obj_formats_and_fan(tmp_path):
+    p = tmp_path / "m.obj"
+    p.write_text("v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nvn 0 0 1\nvt 0.5 0.25\n"
+                 "f 1/1/1 2/1/1 3/1/1 4/1/1\nusemtl other\nf 1 2 3\n")
+    w = ObjLoader.Wavefront(str(p))
+    names = list(w.materials)
+    assert names == ["default0", "other"]
+    a, b = w.materials["default0"], w.materials["other"]
+    assert a.vertex_format == "T2F_N3F_V3F" and b.vertex_format == "V3F"
+    va = a.vertices.reshape(-1, 8)
+    assert va.shape[0] == 6                                             # quad -> 2 triangles
+    assert va[:, 5:8].tolist() == [[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 0, 0], [1, 1, 0], [0, 1, 0]]
+    assert b.vertices.reshape(-1, 3).shape[0] == 3
+    assert a.transparency == 1.0 and a.diffuse[:3] == [0.8, 0.8, 0.8]
+
+
+def test_struct_packing_roundtrip():
+    m = SCD.Material(); m.type = SCD.MAT_GLASS; m.alebdoTex = -1; m.setColor([0.1, 0.2, 0.3]); m.setIor(1.3); m.setExtinciton(5.0)
+    buf = np.zeros((2, SCD.MAT_VEC_SIZE), np.float32); m.fillStruct(buf, 1)
+    assert np.allclose(buf[1], [1, -1, 0.1, 0.2, 0.3, 1.3, 5.0, 0, 0, 0])
+    sh = SCD.Shape(); sh.type = SCD.SHPAE_SPHERE; sh.pos = [1, 2, 3]; sh.setRadius(4)
+    buf = np.zeros((1, SCD.SHA_VEC_SIZE), np.float32); sh.fillStruct(buf, 0)
+    assert buf[0].tolist() == [1, 1, 2, 3, 4, 0, 0, 0, 0, 0]
+    pr = SCD.Primitive(); pr.type = SCD.PRIMITIVE_SHAPE; pr.vertex_shape_index = 7; pr.mat_index = 2
+    buf = np.zeros((1, 3), np.int32); pr.fillStruct(buf, 0)
+    assert buf[0].tolist() == [2, 7, 2]
+
+
+def test_camera_matrices():
+    cam = Camera.Camera(64, 48, 16)
+    assert cam.fx == 2.0 * 64 / 2.4 and cam.fy == cam.fx and cam.cx == 32 and cam.cy == 24
+    cam.scale = 10.0
+    cam.set_target(1.0, 2.0, 3.0)
+    assert np.allclose(cam.eye_np[0], [1, 2, 13])
+    v, vi = cam.view_np[0], cam.view_inv_np[0]
+    assert v.dtype == np.float32 and vi.dtype == np.float32
+    assert np.allclose(v @ vi, np.eye(4), atol=1e-5)
+    assert np.allclose(v[:3, :3], np.eye(3))                               # yaw = pitch = 0 looks down -z
+    cam.update_frame(); cam.update_frame(3)
+    assert cam.frame == 4 and cam.frame_cpu[0] == 4
+    Camera.Camera(8, 8, 1)                                                  # spp < 4 must not raise (quirk B6 not reproduced)
+
+
+def test_texture_packing():
+    t = Texture.Texture()
+    img = np.zeros((2, 3, 3), np.int32)
+    img[0, 1] = (10, 20, 30)            # top row, x = 1
+    t.load_array(img)
+    assert t.wid == 3 and t.hgt == 2 and t.np_img.shape == (3, 2)
+    assert t.np_img[1, 1] == (10 << 16) | (20 << 8) | 30                    # y flipped: top row -> y = hgt-1
+    assert t.np_img.sum() == t.np_img[1, 1]
+
+
+def test_synthetic_scene_is_reproducible():
+    a = scenes.synthetic_triangles(1000, 1234)
+    b = scenes.synthetic_triangles(1000, 1234)
+    assert np.array_equal(a, b) and a.shape == (1000, 3, 3)
+    c = a.mean(axis=1)
+    assert np.abs(c).max() <= 1.03 and np.abs(a - c[:, None, :]).max() <= 0.06
+    u = scenes.splitmix64_unit(1234, 4)
+    assert (u >= 0).all() and (u < 1).all() and len(set(u.tolist())) == 4
+    ex = host_only(scenes.synthetic(16, 16, 4, ntri=50))
+    assert ex.scene.primitive_count == 51 and ex.scene.light_np.tolist() == [50]
+    assert ex.scene.primitive_np[50].tolist() == [2, 0, 1]

@@ -46,6 +46,7 @@ SIGNATURES = {
     "tirt_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
     "tirt_destroy": (None, [_vp]),
     "tirt_sync": (C.c_int, [_vp]),
+    "tirt_set_option": (C.c_int, [_vp, C.c_char_p, C.c_double]),
     "tirt_scene_upload": (C.c_int, [_vp, _f32p, C.c_int, _i32p, C.c_int, _f32p, C.c_int,
                                     _f32p, C.c_int, _i32p, C.c_int, C.c_int, _f32p, _f32p]),
     "tirt_material_upload": (C.c_int, [_vp, _f32p, C.c_int]),
@@ -134,6 +135,9 @@ class Context:
     # thin typed wrappers ---------------------------------------------------------------
     def sync(self):
         check(lib().tirt_sync(self.handle))
+
+    def set_option(self, name, value):
+        check(lib().tirt_set_option(self.handle, name.encode(), float(value)))
 
     def scene_upload(self, vertex, primitive, material, shape, light, light_count, bmin, bmax):
         vertex = np.ascontiguousarray(vertex, np.float32)

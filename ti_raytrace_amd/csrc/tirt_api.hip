@@ -1,0 +1,530 @@
+// tirt_api.hip -- the C-ABI of include/tirt.h: context, uploads/downloads, camera, film,
+// tone map, Scene.process_normal / total_area kernels, known-answer-test kernels, stats.
+#include "tirt_internal.h"
+#include <mutex>
+#include <string.h>
+
+namespace tirt {
+
+static thread_local std::string g_error;
+void set_error(const std::string &msg) { g_error = msg; }
+
+SceneView scene_view(const tirt_ctx *c)
+{
+    SceneView s;
+    s.vertex = c->vertex.as<float>(); s.primitive = c->primitive.as<int>(); s.material = c->material.as<float>();
+    s.shape = c->shape.as<float>(); s.light = c->light.as<int>(); s.env = c->env.as<int>();
+    s.n = c->n; s.light_count = c->light_count; s.env_w = c->env_w; s.env_h = c->env_h; s.env_power = c->env_power;
+    return s;
+}
+BvhView bvh_view(const tirt_ctx *c)
+{
+    BvhView b;
+    b.wnode = c->wnode.as<float4>(); b.tri = c->tri.as<float4>();
+    for (int k = 0; k < 3; k++) { b.root_min[k] = c->root_min[k]; b.root_max[k] = c->root_max[k]; }
+    b.root_code = c->root_code;
+    return b;
+}
+int ensure_counters(tirt_ctx *c)
+{
+    if (!c->dev_counters.p) {
+        if (c->dev_counters.ensure(sizeof(DevCounters))) return TIRT_ERR_HIP;
+        TIRT_HIP(hipMemsetAsync(c->dev_counters.p, 0, sizeof(DevCounters), c->stream));
+    }
+    return 0;
+}
+
+// ---- Scene.total_area (Scene.py:747-750): serial so the f32 sum order is defined --------------
+__global__ void k_total_area(SceneView s, int count, float *out)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        float a = 0.0f;
+        for (int i = 0; i < count; i++) a += get_prim_area(s, s.light[i]);
+        *out = a;
+    }
+}
+
+// ---- Scene.process_normal (Scene.py:754-798): BVH point query per vertex ------------------------
+__global__ void k_smooth_normal(SceneView s, int nv, const float *compact, const int *vertex_index, float *smooth)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nv) return;
+    constexpr int MAX_STACK_SIZE = 32;              // Scene.py:19
+    int stack[MAX_STACK_SIZE + 2];
+    v3 v = vtx_pos(s, i);
+    v3 n = normalized(vtx_nor(s, i));
+    int f = vertex_index[i];
+    v3 sm = (n * get_prim_angle(s, f, v)) * get_prim_area(s, f);
+    stack[0] = 0;
+    int stack_pos = 0;
+    while ((stack_pos >= 0) & (stack_pos < MAX_STACK_SIZE)) {
+        int node = stack[stack_pos];
+        stack_pos -= 1;
+        const float *cn = compact + (size_t)node * CPN_VEC;
+        if ((((int)cn[0]) & 1) == 1) {
+            int prim = (int)cn[1];
+            const int *pr = s.primitive + (size_t)prim * PRI_VEC;
+            if (pr[0] == PRIMITIVE_TRI) {
+                for (int j = 0; j < 3; j++) {
+                    int nb = j + pr[1];
+                    if (i != nb) {
+                        v3 nvp = vtx_pos(s, nb);
+                        v3 nn = normalized(vtx_nor(s, nb));
+                        if ((norm(v - nvp) < 0.000001f) & (dot(nn, n) > 0.5f)) {
+                            float angle = get_prim_angle(s, prim, nvp);
+                            sm = sm + (nn * angle) * get_prim_area(s, prim);
+                        }
+                    }
+                }
+            }
+        } else {
+            if ((v.x >= cn[2]) & (v.y >= cn[3]) & (v.z >= cn[4]) & (v.x <= cn[5]) & (v.y <= cn[6]) & (v.z <= cn[7])) {
+                stack_pos += 1; stack[stack_pos] = node + 1;
+                stack_pos += 1; stack[stack_pos] = (int)cn[1];
+            }
+        }
+    }
+    smooth[3 * i] = sm.x; smooth[3 * i + 1] = sm.y; smooth[3 * i + 2] = sm.z;
+}
+__global__ void k_write_normal(float *vertex, int nv, const float *smooth)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nv) return;
+    v3 nn = normalized(V(smooth[3 * i], smooth[3 * i + 1], smooth[3 * i + 2]));
+    float *p = vertex + (size_t)i * VER_VEC;
+    p[3] = nn.x; p[4] = nn.y; p[5] = nn.z;
+}
+
+// UtilsFunc.py:583-586
+__global__ void k_tone_map(const float *hdr, float *rgb, long nvals, float exposure)
+{
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nvals) return;
+    rgb[i] = lrgb_to_srgb1(tone_aces1(hdr[i] * exposure));
+}
+
+// ---- known-answer-test kernels ------------------------------------------------------------------------
+__global__ void k_kat_math(int fn, const float *x, const float *y, float *out, int n)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float r = 0.0f;
+    switch (fn) {
+        case 0: r = tm_sin(x[i]); break;
+        case 1: r = tm_cos(x[i]); break;
+        case 2: r = tm_exp(x[i]); break;
+        case 3: r = tm_log(x[i]); break;
+        case 4: r = tm_pow(x[i], y[i]); break;
+        case 5: r = tm_atan2(x[i], y[i]); break;
+        case 6: r = tm_acos(x[i]); break;
+        case 7: r = tm_sqrt(x[i]); break;
+        case 8: r = x[i] / y[i]; break;
+        case 9: r = tm_rand(tm_f2u(x[i]), tm_f2u(y[i]), 3u, 5u); break;
+    }
+    out[i] = r;
+}
+__global__ void k_kat_brdf(int which, const float *in, int in_stride, float *out, int out_stride, int n)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float *a = in + (size_t)i * in_stride;
+    float *o = out + (size_t)i * out_stride;
+    if (which == 0) {
+        float pdf; float f = disney_evaluate_pdf(a, V(a[10], a[11], a[12]), V(a[13], a[14], a[15]), V(a[16], a[17], a[18]), pdf);
+        o[0] = f; o[1] = pdf;
+    } else if (which == 1) {
+        v3 r = disney_sample(a, V(a[10], a[11], a[12]), V(a[13], a[14], a[15]), a[16], a[17], a[18]);
+        o[0] = r.x; o[1] = r.y; o[2] = r.z;
+    } else if (which == 2) {
+        float fb; v3 r = glass_sample(a, V(a[10], a[11], a[12]), V(a[13], a[14], a[15]), a[16], fb);
+        o[0] = r.x; o[1] = r.y; o[2] = r.z; o[3] = fb;
+    } else if (which == 3) {
+        v3 r = offset_ray(V(a[0], a[1], a[2]), V(a[3], a[4], a[5]));
+        o[0] = r.x; o[1] = r.y; o[2] = r.z;
+    }
+}
+
+static int upload(DevBuf &b, const void *src, size_t bytes, hipStream_t st)
+{
+    if (b.ensure(bytes)) return TIRT_ERR_HIP;
+    if (bytes) TIRT_HIP(hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, st));
+    return 0;
+}
+
+static void drain_render_events(tirt_ctx *c)
+{
+    for (auto &pr : c->ev_pool) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) c->ms_render += ms;
+        (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second);
+    }
+    c->ev_pool.clear();
+}
+
+}  // namespace tirt
+
+using namespace tirt;
+
+extern "C" {
+
+const char *tirt_last_error(void) { return g_error.c_str(); }
+int tirt_version(void) { return 100; }
+
+int tirt_device_count(int *out)
+{
+    TIRT_REQUIRE(out, "tirt_device_count: null out");
+    TIRT_HIP(hipGetDeviceCount(out));
+    return TIRT_OK;
+}
+
+int tirt_create(int device_id, tirt_ctx **out)
+{
+    TIRT_REQUIRE(out, "tirt_create: null out");
+    int ndev = 0;
+    TIRT_HIP(hipGetDeviceCount(&ndev));
+    if (device_id < 0 || device_id >= ndev) { set_error("tirt_create: device " + std::to_string(device_id) + " of " + std::to_string(ndev)); return TIRT_ERR_ARG; }
+    TIRT_HIP(hipSetDevice(device_id));
+    tirt_ctx *c = new tirt_ctx();
+    c->device = device_id;
+    TIRT_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    TIRT_HIP(hipEventCreate(&c->ev0));
+    TIRT_HIP(hipEventCreate(&c->ev1));
+    memset(&c->cam, 0, sizeof(c->cam));
+    *out = c;
+    return TIRT_OK;
+}
+
+void tirt_destroy(tirt_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    drain_render_events(c);
+    DevBuf *bufs[] = {&c->vertex, &c->primitive, &c->material, &c->shape, &c->light, &c->env, &c->morton_unsorted, &c->keys_a,
+                      &c->keys_b, &c->vals_a, &c->vals_b, &c->hist, &c->morton_sorted, &c->bvh_node, &c->compact, &c->parent,
+                      &c->flag, &c->subtree, &c->build_status, &c->leaf_compact, &c->wnode, &c->tri, &c->hdr, &c->rgb,
+                      &c->path_mem, &c->queue_a, &c->queue_b, &c->queue_s, &c->counters_mem, &c->spill, &c->tr_rays,
+                      &c->tr_out, &c->tr_prim, &c->tr_counts, &c->dev_counters};
+    for (DevBuf *b : bufs) b->release();
+    (void)hipEventDestroy(c->ev0); (void)hipEventDestroy(c->ev1);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+#define CTX(c)                                                                     \
+    TIRT_REQUIRE(c, "null context");                                               \
+    TIRT_HIP(hipSetDevice((c)->device))
+
+int tirt_sync(tirt_ctx *c)
+{
+    CTX(c);
+    TIRT_HIP(hipStreamSynchronize(c->stream));
+    TIRT_HIP(hipGetLastError());
+    return TIRT_OK;
+}
+
+int tirt_set_option(tirt_ctx *c, const char *name, double value)
+{
+    CTX(c);
+    TIRT_REQUIRE(name, "tirt_set_option: null name");
+    if (!strcmp(name, "time_kernels")) { c->time_kernels = value != 0.0; return TIRT_OK; }
+    set_error(std::string("tirt_set_option: unknown option ") + name);
+    return TIRT_ERR_ARG;
+}
+
+int tirt_scene_upload(tirt_ctx *c, const float *vertex, int nv, const int32_t *primitive, int n, const float *material, int nm,
+                      const float *shape, int ns, const int32_t *light, int nl, int light_count, const float bmin[3], const float bmax[3])
+{
+    CTX(c);
+    TIRT_REQUIRE(n >= 1 && nv >= 0 && nm >= 1 && ns >= 1 && nl >= 1, "tirt_scene_upload: need n,nm,ns,nl >= 1");
+    TIRT_REQUIRE(vertex && primitive && material && shape && light && bmin && bmax, "tirt_scene_upload: null pointer");
+    TIRT_REQUIRE(light_count >= 0 && light_count <= nl, "tirt_scene_upload: light_count out of range");
+    TIRT_REQUIRE((long long)2 * n - 1 < (1ll << 24), "tirt_scene_upload: node indices are stored as f32 (exact below 2^24 nodes)");
+    // validate indices on the host so that device code can trust them
+    for (int i = 0; i < n; i++) {
+        const int32_t *pr = primitive + (size_t)i * 3;
+        if (pr[0] == PRIMITIVE_TRI) { TIRT_REQUIRE(pr[1] >= 0 && pr[1] + 2 < nv, "tirt_scene_upload: vertex index out of range"); }
+        else { TIRT_REQUIRE(pr[1] >= 0 && pr[1] < ns, "tirt_scene_upload: shape index out of range"); }
+        TIRT_REQUIRE(pr[2] >= 0 && pr[2] < nm, "tirt_scene_upload: material index out of range");
+    }
+    for (int i = 0; i < nl; i++) TIRT_REQUIRE(light[i] >= 0 && light[i] < n, "tirt_scene_upload: light index out of range");
+    hipStream_t st = c->stream;
+    c->built = false;
+    if (upload(c->vertex, vertex, sizeof(float) * 9 * (size_t)nv, st)) return TIRT_ERR_HIP;
+    if (upload(c->primitive, primitive, sizeof(int) * 3 * (size_t)n, st)) return TIRT_ERR_HIP;
+    if (upload(c->material, material, sizeof(float) * 10 * (size_t)nm, st)) return TIRT_ERR_HIP;
+    if (upload(c->shape, shape, sizeof(float) * 10 * (size_t)ns, st)) return TIRT_ERR_HIP;
+    if (upload(c->light, light, sizeof(int) * (size_t)nl, st)) return TIRT_ERR_HIP;
+    c->nv = nv; c->n = n; c->nm = nm; c->ns = ns; c->nl = nl; c->light_count = light_count;
+    for (int k = 0; k < 3; k++) { c->bmin[k] = bmin[k]; c->bmax[k] = bmax[k]; }
+    if (!c->env.p) {        // default: 1x1 black (Scene.py:295-296 loads image/black.png)
+        int32_t z = 0;
+        if (upload(c->env, &z, sizeof(int32_t), st)) return TIRT_ERR_HIP;
+        c->env_w = 1; c->env_h = 1; c->env_power = 0.0f;
+    }
+    TIRT_HIP(hipStreamSynchronize(st));
+    return TIRT_OK;
+}
+
+int tirt_material_upload(tirt_ctx *c, const float *material, int nm)
+{
+    CTX(c);
+    TIRT_REQUIRE(material && nm == c->nm, "tirt_material_upload: material count differs from the uploaded scene");
+    if (upload(c->material, material, sizeof(float) * 10 * (size_t)nm, c->stream)) return TIRT_ERR_HIP;
+    TIRT_HIP(hipStreamSynchronize(c->stream));
+    return TIRT_OK;
+}
+
+int tirt_env_upload(tirt_ctx *c, const int32_t *rgb_packed, int w, int h, float power)
+{
+    CTX(c);
+    TIRT_REQUIRE(rgb_packed && w >= 1 && h >= 1, "tirt_env_upload: bad image");
+    if (upload(c->env, rgb_packed, sizeof(int32_t) * (size_t)w * h, c->stream)) return TIRT_ERR_HIP;
+    c->env_w = w; c->env_h = h; c->env_power = power;
+    TIRT_HIP(hipStreamSynchronize(c->stream));
+    return TIRT_OK;
+}
+
+int tirt_lbvh_build(tirt_ctx *c)
+{
+    CTX(c);
+    return lbvh_build(c);
+}
+
+int tirt_lbvh_download(tirt_ctx *c, int32_t *morton_sorted, float *bvh_node, float *compact_node)
+{
+    CTX(c);
+    TIRT_REQUIRE(c->built, "tirt_lbvh_download: LBVH not built");
+    const size_t n = c->n, N = 2 * n - 1;
+    if (morton_sorted) TIRT_HIP(hipMemcpyAsync(morton_sorted, c->morton_sorted.p, sizeof(int) * 2 * n, hipMemcpyDeviceToHost, c->stream));
+    if (bvh_node) TIRT_HIP(hipMemcpyAsync(bvh_node, c->bvh_node.p, sizeof(float) * NOD_VEC * N, hipMemcpyDeviceToHost, c->stream));
+    if (compact_node) TIRT_HIP(hipMemcpyAsync(compact_node, c->compact.p, sizeof(float) * CPN_VEC * N, hipMemcpyDeviceToHost, c->stream));
+    TIRT_HIP(hipStreamSynchronize(c->stream));
+    return TIRT_OK;
+}
+
+int tirt_morton_download(tirt_ctx *c, int32_t *out)
+{
+    CTX(c);
+    TIRT_REQUIRE(c->built && out, "tirt_morton_download: LBVH not built");
+    TIRT_HIP(hipMemcpyAsync(out, c->morton_unsorted.p, sizeof(int) * 2 * (size_t)c->n, hipMemcpyDeviceToHost, c->stream));
+    TIRT_HIP(hipStreamSynchronize(c->stream));
+    return TIRT_OK;
+}
+
+int tirt_process_normal(tirt_ctx *c, const int32_t *vertex_index)
+{
+    CTX(c);
+    TIRT_REQUIRE(c->built && vertex_index, "tirt_process_normal: LBVH not built");
+    if (c->nv == 0) return TIRT_OK;
+    for (int i = 0; i < c->nv; i++) TIRT_REQUIRE(vertex_index[i] >= 0 && vertex_index[i] < c->n, "tirt_process_normal: vertex_index out of range");
+    DevBuf vi, smooth;
+    if (upload(vi, vertex_index, sizeof(int) * (size_t)c->nv, c->stream)) return TIRT_ERR_HIP;
+    if (smooth.ensure(sizeof(float) * 3 * (size_t)c->nv)) { vi.release(); return TIRT_ERR_HIP; }
+    const int B = 128, G = (c->nv + B - 1) / B;
+    hipLaunchKernelGGL(k_smooth_normal, dim3(G), dim3(B), 0, c->stream, scene_view(c), c->nv, c->compact.as<float>(), vi.as<int>(), smooth.as<float>());
+    hipLaunchKernelGGL(k_write_normal, dim3(G), dim3(B), 0, c->stream, c->vertex.as<float>(), c->nv, smooth.as<float>());
+    hipError_t e = hipStreamSynchronize(c->stream);
+    vi.release(); smooth.release();
+    TIRT_HIP(e);
+    TIRT_HIP(hipGetLastError());
+    return TIRT_OK;
+}
+
+int tirt_vertex_download(tirt_ctx *c, float *vertex)
+{
+    CTX(c);
+    TIRT_REQUIRE(vertex, "tirt_vertex_download: null");
+    TIRT_HIP(hipMemcpyAsync(vertex, c->vertex.p, sizeof(float) * 9 * (size_t)c->nv, hipMemcpyDeviceToHost, c->stream));
+    TIRT_HIP(hipStreamSynchronize(c->stream));
+    return TIRT_OK;
+}
+
+int tirt_total_area(tirt_ctx *c, float *out)
+{
+    CTX(c);
+    TIRT_REQUIRE(out && c->n >= 1, "tirt_total_area: no scene");
+    DevBuf d;
+    if (d.ensure(sizeof(float))) return TIRT_ERR_HIP;
+    int cnt = c->light_count > 0 ? c->light_count : 1;      // the light field always has >= 1 entry (Scene.py:258-261)
+    hipLaunchKernelGGL(k_total_area, dim3(1), dim3(64), 0, c->stream, scene_view(c), cnt, d.as<float>());
+    hipError_t e = hipMemcpyAsync(out, d.p, sizeof(float), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    d.release();
+    TIRT_HIP(e);
+    return TIRT_OK;
+}
+
+int tirt_camera_set(tirt_ctx *c, const float view[16], const float view_inv[16], const float eye[3], float fx, float fy, float cx, float cy)
+{
+    CTX(c);
+    TIRT_REQUIRE(view && view_inv && eye, "tirt_camera_set: null");
+    memcpy(c->view, view, sizeof(float) * 16);
+    memcpy(c->cam.view_inv, view_inv, sizeof(float) * 12);
+    memcpy(c->cam.eye, eye, sizeof(float) * 3);
+    c->cam.fx = fx; c->cam.fy = fy; c->cam.cx = cx; c->cam.cy = cy;
+    c->cam_set = true;
+    return TIRT_OK;
+}
+
+int tirt_film_create(tirt_ctx *c, int W, int H, int tile_rank, int tile_count, int tile_size)
+{
+    CTX(c);
+    TIRT_REQUIRE(W >= 1 && H >= 1 && (long long)W * H < (1ll << 30), "tirt_film_create: bad size");
+    TIRT_REQUIRE(tile_count >= 1 && tile_rank >= 0 && tile_rank < tile_count && tile_size >= 1, "tirt_film_create: bad tiling");
+    const long NP = (long)W * H;
+    if (c->hdr.ensure(sizeof(float) * 3 * (size_t)NP) || c->rgb.ensure(sizeof(float) * 3 * (size_t)NP)) return TIRT_ERR_HIP;
+    c->W = W; c->H = H; c->tile_rank = tile_rank; c->tile_count = tile_count; c->tile_size = tile_size;
+    long ntiles = (NP + tile_size - 1) / tile_size, local = 0;
+    for (long t = tile_rank; t < ntiles; t += tile_count) {
+        long beg = t * tile_size, end = beg + tile_size; if (end > NP) end = NP;
+        local += end - beg;
+    }
+    c->npix_local = local;
+    TIRT_HIP(hipMemsetAsync(c->hdr.p, 0, sizeof(float) * 3 * (size_t)NP, c->stream));
+    TIRT_HIP(hipMemsetAsync(c->rgb.p, 0, sizeof(float) * 3 * (size_t)NP, c->stream));
+    TIRT_HIP(hipStreamSynchronize(c->stream));
+    return TIRT_OK;
+}
+
+int tirt_film_clear(tirt_ctx *c)
+{
+    CTX(c);
+    TIRT_REQUIRE(c->hdr.p, "tirt_film_clear: film not created");
+    TIRT_HIP(hipMemsetAsync(c->hdr.p, 0, sizeof(float) * 3 * (size_t)c->W * c->H, c->stream));
+    TIRT_HIP(hipMemsetAsync(c->rgb.p, 0, sizeof(float) * 3 * (size_t)c->W * c->H, c->stream));
+    return TIRT_OK;
+}
+
+int tirt_pt_rgb_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed, int max_depth, int stack_size, int flags)
+{
+    CTX(c);
+    return pt_render(c, frame_begin, frame_count, seed, max_depth, stack_size, flags);
+}
+
+int tirt_tone_map(tirt_ctx *c, float exposure)
+{
+    CTX(c);
+    TIRT_REQUIRE(c->hdr.p, "tirt_tone_map: film not created");
+    long nvals = 3l * c->W * c->H;
+    hipLaunchKernelGGL(k_tone_map, dim3((unsigned)((nvals + 255) / 256)), dim3(256), 0, c->stream, c->hdr.as<float>(), c->rgb.as<float>(), nvals, exposure);
+    TIRT_HIP(hipGetLastError());
+    return TIRT_OK;
+}
+
+int tirt_film_download(tirt_ctx *c, float *hdr, float *rgb)
+{
+    CTX(c);
+    TIRT_REQUIRE(c->hdr.p, "tirt_film_download: film not created");
+    size_t bytes = sizeof(float) * 3 * (size_t)c->W * c->H;
+    if (hdr) TIRT_HIP(hipMemcpyAsync(hdr, c->hdr.p, bytes, hipMemcpyDeviceToHost, c->stream));
+    if (rgb) TIRT_HIP(hipMemcpyAsync(rgb, c->rgb.p, bytes, hipMemcpyDeviceToHost, c->stream));
+    TIRT_HIP(hipStreamSynchronize(c->stream));
+    TIRT_HIP(hipGetLastError());
+    return TIRT_OK;
+}
+
+int tirt_film_export_device(tirt_ctx *c, void *dev_dst)
+{
+    CTX(c);
+    TIRT_REQUIRE(c->hdr.p && dev_dst, "tirt_film_export_device: film not created");
+    TIRT_HIP(hipMemcpyAsync(dev_dst, c->hdr.p, sizeof(float) * 3 * (size_t)c->W * c->H, hipMemcpyDeviceToDevice, c->stream));
+    TIRT_HIP(hipStreamSynchronize(c->stream));
+    return TIRT_OK;
+}
+
+int tirt_film_import_device(tirt_ctx *c, const void *dev_src)
+{
+    CTX(c);
+    TIRT_REQUIRE(c->hdr.p && dev_src, "tirt_film_import_device: film not created");
+    TIRT_HIP(hipMemcpyAsync(c->hdr.p, dev_src, sizeof(float) * 3 * (size_t)c->W * c->H, hipMemcpyDeviceToDevice, c->stream));
+    TIRT_HIP(hipStreamSynchronize(c->stream));
+    return TIRT_OK;
+}
+
+int tirt_trace_closest(tirt_ctx *c, const float *rays, int nr, int stack_size, int flags, float *out_hit, int32_t *out_prim, int32_t *counts)
+{
+    CTX(c);
+    TIRT_REQUIRE(rays && out_hit && out_prim, "tirt_trace_closest: null");
+    return launch_trace_batch(c, rays, nr, stack_size, flags, false, out_hit, out_prim, counts);
+}
+
+int tirt_trace_shadow(tirt_ctx *c, const float *rays, int nr, int stack_size, int flags, float *out_t, int32_t *out_prim, int32_t *counts)
+{
+    CTX(c);
+    TIRT_REQUIRE(rays && out_t && out_prim, "tirt_trace_shadow: null");
+    return launch_trace_batch(c, rays, nr, stack_size, flags, true, out_t, out_prim, counts);
+}
+
+int tirt_stats(tirt_ctx *c, tirt_stats_t *out)
+{
+    CTX(c);
+    TIRT_REQUIRE(out, "tirt_stats: null");
+    if (ensure_counters(c)) return TIRT_ERR_HIP;
+    DevCounters h;
+    TIRT_HIP(hipMemcpyAsync(&h, c->dev_counters.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    TIRT_HIP(hipStreamSynchronize(c->stream));
+    drain_render_events(c);
+    out->rays_closest = h.rays_closest; out->rays_shadow = h.rays_shadow;
+    out->box_closest = h.box_closest; out->leaf_closest = h.leaf_closest;
+    out->box_shadow = h.box_shadow; out->leaf_shadow = h.leaf_shadow;
+    out->shaded = h.shaded; out->paths = h.paths; out->stack_overflow = h.stack_overflow;
+    out->ms_build = c->ms_build; out->ms_render = c->ms_render;
+    out->ms_trace_closest = c->ms_trace_closest; out->ms_trace_shadow = c->ms_trace_shadow; out->ms_shade = c->ms_shade;
+    out->launches_trace_closest = c->launches_trace_closest; out->launches_trace_shadow = c->launches_trace_shadow;
+    out->launches_shade = c->launches_shade;
+    return TIRT_OK;
+}
+
+int tirt_stats_reset(tirt_ctx *c)
+{
+    CTX(c);
+    if (ensure_counters(c)) return TIRT_ERR_HIP;
+    TIRT_HIP(hipStreamSynchronize(c->stream));
+    drain_render_events(c);
+    TIRT_HIP(hipMemsetAsync(c->dev_counters.p, 0, sizeof(DevCounters), c->stream));
+    TIRT_HIP(hipStreamSynchronize(c->stream));
+    c->ms_render = c->ms_trace_closest = c->ms_trace_shadow = c->ms_shade = 0.0;
+    c->launches_trace_closest = c->launches_trace_shadow = c->launches_shade = 0;
+    return TIRT_OK;
+}
+
+int tirt_kat_math(tirt_ctx *c, int fn, const float *x, const float *y, float *out, int n)
+{
+    CTX(c);
+    TIRT_REQUIRE(x && y && out && n >= 0, "tirt_kat_math: null");
+    if (n == 0) return TIRT_OK;
+    DevBuf dx, dy, dout;
+    int rc = TIRT_OK;
+    if (upload(dx, x, sizeof(float) * (size_t)n, c->stream) || upload(dy, y, sizeof(float) * (size_t)n, c->stream) || dout.ensure(sizeof(float) * (size_t)n)) rc = TIRT_ERR_HIP;
+    if (rc == TIRT_OK) {
+        hipLaunchKernelGGL(k_kat_math, dim3((n + 255) / 256), dim3(256), 0, c->stream, fn, dx.as<float>(), dy.as<float>(), dout.as<float>(), n);
+        hipError_t e = hipMemcpyAsync(out, dout.p, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) { set_error(std::string("tirt_kat_math: ") + hipGetErrorString(e)); rc = TIRT_ERR_HIP; }
+    }
+    dx.release(); dy.release(); dout.release();
+    return rc;
+}
+
+int tirt_kat_brdf(tirt_ctx *c, int which, const float *in, int in_stride, float *out, int out_stride, int n)
+{
+    CTX(c);
+    TIRT_REQUIRE(in && out && n >= 0 && which >= 0 && which <= 3, "tirt_kat_brdf: bad args");
+    const int need_in[4] = {19, 19, 17, 6}, need_out[4] = {2, 3, 4, 3};
+    TIRT_REQUIRE(in_stride >= need_in[which] && out_stride >= need_out[which], "tirt_kat_brdf: stride too small");
+    if (n == 0) return TIRT_OK;
+    DevBuf din, dout;
+    int rc = TIRT_OK;
+    if (upload(din, in, sizeof(float) * (size_t)n * in_stride, c->stream) || dout.ensure(sizeof(float) * (size_t)n * out_stride)) rc = TIRT_ERR_HIP;
+    if (rc == TIRT_OK) {
+        hipLaunchKernelGGL(k_kat_brdf, dim3((n + 255) / 256), dim3(256), 0, c->stream, which, din.as<float>(), in_stride, dout.as<float>(), out_stride, n);
+        hipError_t e = hipMemcpyAsync(out, dout.p, sizeof(float) * (size_t)n * out_stride, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) { set_error(std::string("tirt_kat_brdf: ") + hipGetErrorString(e)); rc = TIRT_ERR_HIP; }
+    }
+    din.release(); dout.release();
+    return rc;
+}
+
+}  // extern "C"

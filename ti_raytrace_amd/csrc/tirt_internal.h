@@ -1,0 +1,136 @@
+// tirt_internal.h -- context layout and host-side helpers shared by the .hip translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include <vector>
+#include "../../include/tirt.h"
+#include "tirt_device.h"
+
+namespace tirt {
+
+void set_error(const std::string &msg);
+
+#define TIRT_HIP(call)                                                                          \
+    do {                                                                                        \
+        hipError_t e__ = (call);                                                                \
+        if (e__ != hipSuccess) {                                                                \
+            tirt::set_error(std::string(#call) + ": " + hipGetErrorString(e__));                \
+            return TIRT_ERR_HIP;                                                                \
+        }                                                                                       \
+    } while (0)
+
+#define TIRT_REQUIRE(cond, msg)                                                                 \
+    do {                                                                                        \
+        if (!(cond)) { tirt::set_error(msg); return TIRT_ERR_ARG; }                             \
+    } while (0)
+
+// One growable device allocation.
+struct DevBuf {
+    void *p = nullptr; size_t bytes = 0;
+    int ensure(size_t want)
+    {
+        if (want <= bytes && p) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr; bytes = 0;
+        if (want == 0) want = 16;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) { set_error(std::string("hipMalloc: ") + hipGetErrorString(e)); p = nullptr; return TIRT_ERR_HIP; }
+        bytes = want;
+        return 0;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+    template <class T> T *as() const { return (T *)p; }
+};
+
+// Traversal data handed to the trace kernels by value.
+// wnode: one 64-byte record per INTERNAL compact node, indexed by its compact index:
+//   q0 = (Lmin.x, Lmin.y, Lmin.z, Lmax.x)  q1 = (Lmax.y, Lmax.z, Rmin.x, Rmin.y)
+//   q2 = (Rmin.z, Rmax.x, Rmax.y, Rmax.z)  q3 = (bits codeL, bits codeR, 0, 0)
+//   code >= 0: compact index of an internal child (box = the reference's box, bit-exact);
+//   code <  0: leaf, prim = (~code) & 0x3fffffff, bit 30 of ~code set for shape primitives
+//              (box = leaf box inflated by `pad`, only used for culling in ordered mode).
+// tri: one 48-byte record per primitive, indexed by primitive id:
+//   triangles: (v0.xyz, bits leaf_compact_index) (E1.xyz, 0) (E2.xyz, 0)
+//   spheres  : (centre.xyz, bits leaf_compact_index) (radius, 0, 0, 0) (0,0,0,0)
+struct BvhView {
+    const float4 *wnode;
+    const float4 *tri;
+    float root_min[3], root_max[3];
+    int root_code;
+};
+
+// Per-path wavefront state, struct-of-arrays in HBM (capacity = paths per batch).
+struct PathState {
+    float *ox, *oy, *oz, *dx, *dy, *dz;          // current ray
+    float *ht, *hu, *hv; int *hprim;            // closest hit of the current ray
+    float *tr, *tg, *tb;                         // throughput
+    float *rr, *rg, *rb;                         // radiance of this pixel-sample
+    float *brdf_pdf; uint32_t *flags;           // bit0 perfect_spec
+    float *sox, *soy, *soz, *sdx, *sdy, *sdz;    // shadow ray (origin on the light)
+    float *scr, *scg, *scb; int *sprim;         // contribution if sprim is the closest hit
+};
+
+struct DevCounters {          // lives in device memory; accumulated by the kernels
+    unsigned long long rays_closest, rays_shadow, box_closest, leaf_closest, box_shadow, leaf_shadow;
+    unsigned long long shaded, paths, stack_overflow;
+};
+
+}  // namespace tirt
+
+struct tirt_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+    // scene (Scene.py fields)
+    int nv = 0, n = 0, nm = 0, ns = 0, nl = 0, light_count = 0;
+    float bmin[3] = {0, 0, 0}, bmax[3] = {0, 0, 0};
+    tirt::DevBuf vertex, primitive, material, shape, light, env;
+    int env_w = 0, env_h = 0; float env_power = 0.0f;
+
+    // LBVH (accel/LBvh.py fields)
+    bool built = false;
+    tirt::DevBuf morton_unsorted;                 // int2[n] (code, prim) before the sort
+    tirt::DevBuf keys_a, keys_b, vals_a, vals_b;  // radix sort ping-pong
+    tirt::DevBuf hist;                            // radix digit histograms
+    tirt::DevBuf morton_sorted;                   // int2[n]
+    tirt::DevBuf bvh_node, compact;               // f32 [N*11], [N*9]
+    tirt::DevBuf parent, flag, subtree, build_status, leaf_compact;
+    tirt::DevBuf wnode, tri;                      // traversal layout
+    float root_min[3], root_max[3]; int root_code = 0;
+
+    // camera
+    tirt::CameraView cam; float view[16]; bool cam_set = false;
+
+    // film
+    int W = 0, H = 0, tile_rank = 0, tile_count = 1, tile_size = 4096;
+    long npix_local = 0;
+    tirt::DevBuf hdr, rgb;
+
+    // wavefront state
+    size_t path_capacity = 0;
+    tirt::DevBuf path_mem, queue_a, queue_b, queue_s, counters_mem, spill;
+    tirt::PathState ps;
+
+    // batch trace scratch
+    tirt::DevBuf tr_rays, tr_out, tr_prim, tr_counts;
+
+    // stats
+    tirt::DevBuf dev_counters;                    // DevCounters
+    double ms_build = 0, ms_render = 0, ms_trace_closest = 0, ms_trace_shadow = 0, ms_shade = 0;
+    uint64_t launches_trace_closest = 0, launches_trace_shadow = 0, launches_shade = 0;
+    bool time_kernels = false;                    // per-kernel HIP events (bench only)
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+};
+
+namespace tirt {
+SceneView scene_view(const tirt_ctx *c);
+BvhView bvh_view(const tirt_ctx *c);
+int lbvh_build(tirt_ctx *c);
+int launch_trace_batch(tirt_ctx *c, const float *rays, int nr, int stack_size, int flags, bool shadow,
+                       float *out_f, int32_t *out_prim, int32_t *counts);
+int pt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed, int max_depth, int stack_size, int flags);
+int ensure_counters(tirt_ctx *c);
+}  // namespace tirt

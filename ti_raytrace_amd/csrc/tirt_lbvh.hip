@@ -1,0 +1,470 @@
+// tirt_lbvh.hip -- LBVH build on the device (replaces accel/LBvh.py:192-226 and its kernels).
+//
+//   k_morton      build_morton_3d                          accel/LBvh.py:318-336
+//   k_rs_*        stable LSD radix sort, 4 x 8-bit digits   (reference: 30 x 1-bit passes with
+//                 Blelloch scans, accel/LBvh.py:55-72,339-386 -- any stable sort by the 30-bit
+//                 code produces the same permutation)
+//   k_karras      build_lbvh: determineRange/findSplit      accel/LBvh.py:229-314,389-450
+//   k_refit       gen_aabb + host loop, as one bottom-up pass with per-node arrival counters
+//                 (min/max are exact and order-free, so boxes equal the iterative result)
+//                                                           accel/LBvh.py:453-467,206-218
+//   k_flatten     flatten_tree/build_compact_node (host recursion in the reference): every
+//                 node finds its DFS pre-order slot from subtree sizes   accel/LBvh.py:138-173
+//   k_wnodes/k_tris  GPU-only traversal layout derived from compact_node (see tirt_internal.h)
+//
+// All integer work; the only fp32 arithmetic is the centroid/normalisation in k_morton and
+// the min/max of the boxes -- compiled with -ffp-contract=off, bit-identical to the oracle.
+#include "tirt_internal.h"
+
+namespace tirt {
+
+// ---------------------------------------------------------------------------------------------
+// Morton codes
+// ---------------------------------------------------------------------------------------------
+TD int expand_bits(int x)          // UtilsFunc.py:538-552
+{
+    x = (x | (x << 16)) & 0x030000FF;
+    x = (x | (x << 8)) & 0x0300F00F;
+    x = (x | (x << 4)) & 0x030C30C3;
+    x = (x | (x << 2)) & 0x09249249;
+    return x;
+}
+TD int morton3d(float x, float y, float z)      // UtilsFunc.py:568-580
+{
+    x = minf(maxf(x * 1024.0f, 0.0f), 1023.0f);
+    y = minf(maxf(y * 1024.0f, 0.0f), 1023.0f);
+    z = minf(maxf(z * 1024.0f, 0.0f), 1023.0f);
+    return expand_bits((int)x) | (expand_bits((int)y) << 1) | (expand_bits((int)z) << 2);
+}
+
+__global__ void k_morton(SceneView s, float bminx, float bminy, float bminz, float bmaxx, float bmaxy, float bmaxz,
+                         int2 *pairs, int *keys, int *vals)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= s.n) return;
+    const int *pr = s.primitive + (size_t)i * PRI_VEC;
+    int code;
+    if (pr[0] == PRIMITIVE_TRI) {
+        const float third = (float)(1.0 / 3.0);
+        v3 v0 = vtx_pos(s, pr[1]), v1 = vtx_pos(s, pr[1] + 1), v2 = vtx_pos(s, pr[1] + 2);
+        v3 c = ((v1 + v2) + v0) * third;
+        v3 num = c - V(bminx, bminy, bminz);
+        v3 den = V(bmaxx, bmaxy, bmaxz) - V(bminx, bminy, bminz);
+        code = morton3d(num.x / den.x, num.y / den.y, num.z / den.z);
+    } else {
+        const float *sh = s.shape + (size_t)pr[1] * SHA_VEC;     // quirk B7: (type, pos.x, pos.y), un-normalised
+        code = morton3d(sh[0], sh[1], sh[2]);
+    }
+    pairs[i] = make_int2(code, i);
+    keys[i] = code; vals[i] = i;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stable LSD radix sort, 8-bit digits.  Tile = 256 threads x 8 keys, processed as 8 chunks of
+// 256 consecutive keys so that loads/stores stay coalesced and ranks stay stable:
+// rank(key) = #equal digits in earlier tiles (scanned histogram) + #in earlier chunks of this
+// tile (running[]) + #in earlier waves of this chunk (wcount[]) + #in lower lanes of this wave
+// (ballot match + mbcnt-style popcount).
+// ---------------------------------------------------------------------------------------------
+constexpr int RS_BLOCK = 256, RS_ITEMS = 8, RS_TILE = RS_BLOCK * RS_ITEMS, RS_WAVES = RS_BLOCK / 64;
+
+__global__ __launch_bounds__(RS_BLOCK) void k_rs_hist(const int *keys, int n, int shift, int *hist, int nblocks)
+{
+    __shared__ int h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    int base = blockIdx.x * RS_TILE;
+#pragma unroll
+    for (int c = 0; c < RS_ITEMS; c++) {
+        int i = base + c * RS_BLOCK + threadIdx.x;
+        if (i < n) atomicAdd(&h[(keys[i] >> shift) & 255], 1);
+    }
+    __syncthreads();
+    hist[threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];      // digit-major
+}
+
+// exclusive scan of hist[0..total) in place, one block of 1024 threads
+__global__ __launch_bounds__(1024) void k_rs_scan(int *hist, int total)
+{
+    __shared__ int wsum[16];
+    __shared__ int carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < total; base += 1024) {
+        int i = base + tid;
+        int v = (i < total) ? hist[i] : 0;
+        int incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            int t = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += t;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int woff = 0;
+        for (int w = 0; w < wave; w++) woff += wsum[w];
+        int carry = carry_s;
+        if (i < total) hist[i] = carry + woff + incl - v;
+        __syncthreads();
+        if (tid == 1023) carry_s = carry + woff + incl;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(RS_BLOCK) void k_rs_scatter(const int *keys_in, const int *vals_in, int *keys_out, int *vals_out,
+                                                       int n, int shift, const int *hist_scanned, int nblocks)
+{
+    __shared__ int wcount[RS_WAVES][256];
+    __shared__ int running[256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    running[tid] = hist_scanned[tid * nblocks + blockIdx.x];
+    const int base = blockIdx.x * RS_TILE;
+    for (int c = 0; c < RS_ITEMS; c++) {
+#pragma unroll
+        for (int w = 0; w < RS_WAVES; w++) wcount[w][tid] = 0;
+        __syncthreads();
+        int i = base + c * RS_BLOCK + tid;
+        bool valid = i < n;
+        int key = valid ? keys_in[i] : 0;
+        int val = valid ? vals_in[i] : 0;
+        int d = (key >> shift) & 255;
+        unsigned long long mask = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            int bit = (d >> b) & 1;
+            unsigned long long bal = __ballot(valid && bit);
+            mask &= bit ? bal : ~bal;
+        }
+        int rank_w = __popcll(mask & lt_mask);
+        if (valid && rank_w == 0) wcount[wave][d] = __popcll(mask);
+        __syncthreads();
+        if (valid) {
+            int off = running[d];
+            for (int w = 0; w < wave; w++) off += wcount[w][d];
+            int dst = off + rank_w;
+            keys_out[dst] = key; vals_out[dst] = val;
+        }
+        __syncthreads();
+        int add = 0;
+#pragma unroll
+        for (int w = 0; w < RS_WAVES; w++) add += wcount[w][tid];
+        running[tid] += add;
+        __syncthreads();
+    }
+}
+
+__global__ void k_pack_sorted(const int *keys, const int *vals, int2 *pairs, int n)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) pairs[i] = make_int2(keys[i], vals[i]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Karras topology with the reference's duplicate-code rule
+// ---------------------------------------------------------------------------------------------
+TD int common_upper_bits(int a, int b) { int x = a ^ b; return x == 0 ? 32 : __builtin_clz((unsigned)x); }   // UtilsFunc.py:555-566
+TD int delta_at(const int *codes, int n, int self_code, int j)
+{ return (0 <= j && j < n) ? common_upper_bits(self_code, codes[j]) : -1; }
+
+TD void determine_range(const int *codes, int n, int idx, int &lo, int &hi)     // accel/LBvh.py:229-294
+{
+    lo = 0; hi = n - 1;
+    if (idx == 0) return;
+    int self_code = codes[idx], l_code = codes[idx - 1], r_code = codes[idx + 1];
+    if (l_code == self_code && r_code == self_code) {
+        lo = idx;
+        while (idx < n - 1) {
+            idx += 1;
+            if (idx >= n - 1) break;
+            if (codes[idx] != codes[idx + 1]) break;
+        }
+        hi = idx;
+    } else {
+        int L_delta = common_upper_bits(self_code, l_code), R_delta = common_upper_bits(self_code, r_code);
+        int d = (R_delta > L_delta) ? 1 : -1;
+        int delta_min = L_delta < R_delta ? L_delta : R_delta;
+        int l_max = 2;
+        int delta = delta_at(codes, n, self_code, idx + d * l_max);
+        while (delta > delta_min) {
+            l_max <<= 1;
+            delta = delta_at(codes, n, self_code, idx + d * l_max);
+        }
+        int l = 0;
+        for (int t = l_max >> 1; t > 0; t >>= 1) {
+            delta = delta_at(codes, n, self_code, idx + (l + t) * d);
+            if (delta > delta_min) l += t;
+        }
+        lo = idx; hi = idx + l * d;
+        if (d < 0) { int tmp = lo; lo = hi; hi = tmp; }
+    }
+}
+TD int find_split(const int *codes, int first, int last)       // accel/LBvh.py:296-314
+{
+    int first_code = codes[first], last_code = codes[last];
+    int split = first;
+    if (first_code != last_code) {
+        int delta_node = common_upper_bits(first_code, last_code);
+        int stride = last - first;
+        for (;;) {
+            stride = (stride + 1) >> 1;
+            int middle = split + stride;
+            if (middle < last) {
+                int delta = common_upper_bits(first_code, codes[middle]);
+                if (delta > delta_node) split = middle;
+            }
+            if (stride <= 1) break;
+        }
+    }
+    return split;
+}
+
+// One thread per bvh node (accel/LBvh.py:389-450).  Thread i writes every word of row i
+// except `parent`, which is written by the parent's thread (root: -1), so that the
+// reference's separate init offload is not needed.
+__global__ void k_karras(SceneView s, const int *codes, const int *prims, float *bvh_node, int *parent, int *flag, int *subtree)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int n = s.n, N = 2 * n - 1;
+    if (i >= N) return;
+    float *nd = bvh_node + (size_t)i * NOD_VEC;
+    if (i == 0) { nd[3] = -1.0f; parent[0] = -1; }
+    flag[i] = 0;
+    if (i >= n - 1) {
+        nd[0] = 7.0f;            // float(int(float(int(-1) & (0xfffe|1))) & (0x0007|1)), UtilsFunc.py:232-243
+        nd[1] = -1.0f; nd[2] = -1.0f;
+        int prim = prims[i - (n - 1)];
+        nd[4] = (float)prim;
+        const int *pr = s.primitive + (size_t)prim * PRI_VEC;
+        v3 mn = V(0.0f, 0.0f, 0.0f), mx = mn;
+        if (pr[0] == PRIMITIVE_TRI) {
+            v3 v1 = vtx_pos(s, pr[1]), v2 = vtx_pos(s, pr[1] + 1), v3_ = vtx_pos(s, pr[1] + 2);
+            mn = v1; mx = v1;
+            mn.x = minf(minf(mn.x, v2.x), v3_.x); mx.x = maxf(maxf(mx.x, v2.x), v3_.x);
+            mn.y = minf(minf(mn.y, v2.y), v3_.y); mx.y = maxf(maxf(mx.y, v2.y), v3_.y);
+            mn.z = minf(minf(mn.z, v2.z), v3_.z); mx.z = maxf(maxf(mx.z, v2.z), v3_.z);
+        } else {
+            const float *sh = s.shape + (size_t)pr[1] * SHA_VEC;
+            if ((int)sh[0] == SHAPE_SPHERE) {
+                float r = sh[4];
+                mn = V(sh[1] + -r, sh[2] + -r, sh[3] + -r);
+                mx = V(sh[1] + r, sh[2] + r, sh[3] + r);
+            }
+        }
+        nd[5] = mn.x; nd[6] = mn.y; nd[7] = mn.z; nd[8] = mx.x; nd[9] = mx.y; nd[10] = mx.z;
+        subtree[i] = 1;
+    } else {
+        nd[0] = 65534.0f;        // float(int(-1) & 0xfffe)
+        nd[4] = -1.0f;
+        nd[5] = nd[6] = nd[7] = INF_VALUE;
+        nd[8] = nd[9] = nd[10] = -INF_VALUE;
+        int lo, hi;
+        determine_range(codes, n, i, lo, hi);
+        int split = find_split(codes, lo, hi);
+        int left = split, right = split + 1;
+        if ((lo < hi ? lo : hi) == split) left += n - 1;
+        if ((lo > hi ? lo : hi) == split + 1) right += n - 1;
+        nd[1] = (float)left; nd[2] = (float)right;
+        bvh_node[(size_t)left * NOD_VEC + 3] = (float)i;  parent[left] = i;
+        bvh_node[(size_t)right * NOD_VEC + 3] = (float)i; parent[right] = i;
+        subtree[i] = 0;
+    }
+}
+
+// Bottom-up refit: one thread per leaf climbs; the second thread to arrive at a node owns it.
+// Hand-off follows the guide's counter form: plain stores -> agent release fence (+ explicit
+// vmcnt drain) -> relaxed agent atomic; the owner does an agent acquire fence before reading
+// the children's rows.
+__global__ void k_refit(int n, float *bvh_node, const int *parent, int *flag, int *subtree, int *done)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int cur = parent[(n - 1) + i];
+    while (cur >= 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        int old = __hip_atomic_fetch_add(&flag[cur], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == 0) return;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        float *nd = bvh_node + (size_t)cur * NOD_VEC;
+        int l = (int)nd[1], r = (int)nd[2];
+        const float *ln = bvh_node + (size_t)l * NOD_VEC, *rn = bvh_node + (size_t)r * NOD_VEC;
+        // sc1 loads: served from L2 / memory, never from a stale L1 line
+        float lb[6], rb[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            lb[k] = __hip_atomic_load(&ln[5 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            rb[k] = __hip_atomic_load(&rn[5 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        int ls = __hip_atomic_load(&subtree[l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int rs = __hip_atomic_load(&subtree[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            __hip_atomic_store(&nd[5 + k], minf(lb[k], rb[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&nd[8 + k], maxf(lb[3 + k], rb[3 + k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __hip_atomic_store(&subtree[cur], ls + rs + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        atomicAdd(done, 1);
+        cur = parent[cur];
+    }
+}
+
+// DFS pre-order slot of node i = depth(i) + sum over ancestors entered through their right
+// child of the left sibling's subtree size (accel/LBvh.py:138-161: left first, right's slot
+// stored in the parent's word 1, left implicit at slot+1).
+__global__ void k_flatten(int n, const float *bvh_node, const int *parent, const int *subtree, float *compact, int *leaf_compact)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int N = 2 * n - 1;
+    if (i >= N) return;
+    int off = 0, cur = i;
+    while (true) {
+        int p = parent[cur];
+        if (p < 0) break;
+        const float *pn = bvh_node + (size_t)p * NOD_VEC;
+        int pl = (int)pn[1];
+        off += 1;
+        if (cur != pl) off += subtree[pl];
+        cur = p;
+    }
+    const float *nd = bvh_node + (size_t)i * NOD_VEC;
+    float *cn = compact + (size_t)off * CPN_VEC;
+    cn[0] = nd[0];
+    if ((((int)nd[0]) & 1) == 1) {
+        cn[1] = nd[4];
+        leaf_compact[(int)nd[4]] = off;
+    } else {
+        int l = (int)nd[1];
+        cn[1] = (float)(off + 1 + subtree[l]);
+    }
+#pragma unroll
+    for (int k = 0; k < 6; k++) cn[2 + k] = nd[5 + k];
+    cn[8] = 0.0f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Traversal layout
+// ---------------------------------------------------------------------------------------------
+TD int child_code(SceneView s, const float *cn, int idx)
+{
+    if ((((int)cn[0]) & 1) == 1) {
+        int prim = (int)cn[1];
+        int is_shape = (s.primitive[(size_t)prim * PRI_VEC] == PRIMITIVE_TRI) ? 0 : 1;
+        return ~(prim | (is_shape << 30));
+    }
+    return idx;
+}
+__global__ void k_wnodes(SceneView s, int N, const float *compact, float4 *wnode, float pad)
+{
+    int o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= N) return;
+    const float *cn = compact + (size_t)o * CPN_VEC;
+    if ((((int)cn[0]) & 1) == 1) return;
+    int li = o + 1, ri = (int)cn[1];
+    const float *lc = compact + (size_t)li * CPN_VEC, *rc = compact + (size_t)ri * CPN_VEC;
+    int cl = child_code(s, lc, li), cr = child_code(s, rc, ri);
+    float lp = cl < 0 ? pad : 0.0f, rp = cr < 0 ? pad : 0.0f;
+    float4 *w = wnode + (size_t)o * 4;
+    w[0] = make_float4(lc[2] - lp, lc[3] - lp, lc[4] - lp, lc[5] + lp);
+    w[1] = make_float4(lc[6] + lp, lc[7] + lp, rc[2] - rp, rc[3] - rp);
+    w[2] = make_float4(rc[4] - rp, rc[5] + rp, rc[6] + rp, rc[7] + rp);
+    w[3] = make_float4(__int_as_float(cl), __int_as_float(cr), 0.0f, 0.0f);
+}
+__global__ void k_tris(SceneView s, const int *leaf_compact, float4 *tri)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= s.n) return;
+    const int *pr = s.primitive + (size_t)i * PRI_VEC;
+    float4 *t = tri + (size_t)i * 3;
+    float lc = __int_as_float(leaf_compact[i]);
+    if (pr[0] == PRIMITIVE_TRI) {
+        v3 v0 = vtx_pos(s, pr[1]), v1 = vtx_pos(s, pr[1] + 1), v2 = vtx_pos(s, pr[1] + 2);
+        v3 E1 = v1 - v0, E2 = v2 - v0;
+        t[0] = make_float4(v0.x, v0.y, v0.z, lc);
+        t[1] = make_float4(E1.x, E1.y, E1.z, 0.0f);
+        t[2] = make_float4(E2.x, E2.y, E2.z, 0.0f);
+    } else {
+        const float *sh = s.shape + (size_t)pr[1] * SHA_VEC;
+        t[0] = make_float4(sh[1], sh[2], sh[3], lc);
+        t[1] = make_float4(sh[4], sh[0], 0.0f, 0.0f);
+        t[2] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Host driver
+// ---------------------------------------------------------------------------------------------
+int lbvh_build(tirt_ctx *c)
+{
+    TIRT_REQUIRE(c->n >= 1, "tirt_lbvh_build: no primitives uploaded");
+    const int n = c->n, N = 2 * n - 1;
+    hipStream_t st = c->stream;
+    c->built = false;
+    if (c->morton_unsorted.ensure(sizeof(int2) * (size_t)n)) return TIRT_ERR_HIP;
+    if (c->morton_sorted.ensure(sizeof(int2) * (size_t)n)) return TIRT_ERR_HIP;
+    if (c->keys_a.ensure(sizeof(int) * (size_t)n) || c->keys_b.ensure(sizeof(int) * (size_t)n) ||
+        c->vals_a.ensure(sizeof(int) * (size_t)n) || c->vals_b.ensure(sizeof(int) * (size_t)n)) return TIRT_ERR_HIP;
+    const int nblocks = (n + RS_TILE - 1) / RS_TILE;
+    if (c->hist.ensure(sizeof(int) * 256 * (size_t)nblocks)) return TIRT_ERR_HIP;
+    if (c->bvh_node.ensure(sizeof(float) * (size_t)N * NOD_VEC) || c->compact.ensure(sizeof(float) * (size_t)N * CPN_VEC)) return TIRT_ERR_HIP;
+    if (c->parent.ensure(sizeof(int) * (size_t)N) || c->flag.ensure(sizeof(int) * (size_t)N) ||
+        c->subtree.ensure(sizeof(int) * (size_t)N) || c->build_status.ensure(sizeof(int) * 4) ||
+        c->leaf_compact.ensure(sizeof(int) * (size_t)n)) return TIRT_ERR_HIP;
+    if (c->wnode.ensure(sizeof(float4) * 4 * (size_t)N) || c->tri.ensure(sizeof(float4) * 3 * (size_t)n)) return TIRT_ERR_HIP;
+
+    SceneView sv = scene_view(c);
+    const int B = 256;
+    TIRT_HIP(hipEventRecord(c->ev0, st));
+    hipLaunchKernelGGL(k_morton, dim3((n + B - 1) / B), dim3(B), 0, st, sv, c->bmin[0], c->bmin[1], c->bmin[2],
+                       c->bmax[0], c->bmax[1], c->bmax[2], c->morton_unsorted.as<int2>(), c->keys_a.as<int>(), c->vals_a.as<int>());
+    int *ka = c->keys_a.as<int>(), *kb = c->keys_b.as<int>(), *va = c->vals_a.as<int>(), *vb = c->vals_b.as<int>();
+    for (int shift = 0; shift < 30; shift += 8) {
+        hipLaunchKernelGGL(k_rs_hist, dim3(nblocks), dim3(RS_BLOCK), 0, st, ka, n, shift, c->hist.as<int>(), nblocks);
+        hipLaunchKernelGGL(k_rs_scan, dim3(1), dim3(1024), 0, st, c->hist.as<int>(), 256 * nblocks);
+        hipLaunchKernelGGL(k_rs_scatter, dim3(nblocks), dim3(RS_BLOCK), 0, st, ka, va, kb, vb, n, shift, c->hist.as<int>(), nblocks);
+        int *t = ka; ka = kb; kb = t; t = va; va = vb; vb = t;
+    }
+    // 4 passes: the sorted data is back in keys_a / vals_a
+    hipLaunchKernelGGL(k_pack_sorted, dim3((n + B - 1) / B), dim3(B), 0, st, ka, va, c->morton_sorted.as<int2>(), n);
+    TIRT_HIP(hipMemsetAsync(c->build_status.p, 0, sizeof(int) * 4, st));
+    hipLaunchKernelGGL(k_karras, dim3((N + B - 1) / B), dim3(B), 0, st, sv, ka, va, c->bvh_node.as<float>(),
+                       c->parent.as<int>(), c->flag.as<int>(), c->subtree.as<int>());
+    hipLaunchKernelGGL(k_refit, dim3((n + B - 1) / B), dim3(B), 0, st, n, c->bvh_node.as<float>(), c->parent.as<int>(),
+                       c->flag.as<int>(), c->subtree.as<int>(), c->build_status.as<int>());
+    hipLaunchKernelGGL(k_flatten, dim3((N + B - 1) / B), dim3(B), 0, st, n, c->bvh_node.as<float>(), c->parent.as<int>(),
+                       c->subtree.as<int>(), c->compact.as<float>(), c->leaf_compact.as<int>());
+    // root box + refit status back to the host (one small read; the reference does ~depth of them)
+    int done = 0; float root[11];
+    TIRT_HIP(hipMemcpyAsync(&done, c->build_status.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    TIRT_HIP(hipMemcpyAsync(root, c->bvh_node.p, sizeof(float) * NOD_VEC, hipMemcpyDeviceToHost, st));
+    TIRT_HIP(hipStreamSynchronize(st));
+    if (done != n - 1) {
+        set_error("tirt_lbvh_build: refit reached " + std::to_string(done) + " of " + std::to_string(n - 1) + " internal nodes");
+        return TIRT_ERR_BUILD;
+    }
+    for (int k = 0; k < 3; k++) { c->root_min[k] = root[5 + k]; c->root_max[k] = root[8 + k]; }
+    float ex = root[8] - root[5], ey = root[9] - root[6], ez = root[10] - root[7];
+    float diag = sqrtf(ex * ex + ey * ey + ez * ez);
+    float pad = 1.0e-4f * diag;
+    hipLaunchKernelGGL(k_wnodes, dim3((N + B - 1) / B), dim3(B), 0, st, sv, N, c->compact.as<float>(), c->wnode.as<float4>(), pad);
+    hipLaunchKernelGGL(k_tris, dim3((n + B - 1) / B), dim3(B), 0, st, sv, c->leaf_compact.as<int>(), c->tri.as<float4>());
+    if (n == 1) {
+        int prim = 0, is_shape = 0;
+        int pr0;
+        TIRT_HIP(hipMemcpyAsync(&pr0, c->primitive.p, sizeof(int), hipMemcpyDeviceToHost, st));
+        TIRT_HIP(hipStreamSynchronize(st));
+        is_shape = (pr0 == PRIMITIVE_TRI) ? 0 : 1;
+        c->root_code = ~(prim | (is_shape << 30));
+    } else c->root_code = 0;
+    TIRT_HIP(hipEventRecord(c->ev1, st));
+    TIRT_HIP(hipStreamSynchronize(st));
+    float ms = 0.0f;
+    TIRT_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    c->ms_build = ms;
+    TIRT_HIP(hipGetLastError());
+    c->built = true;
+    return TIRT_OK;
+}
+
+}  // namespace tirt

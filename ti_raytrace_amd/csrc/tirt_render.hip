@@ -1,0 +1,585 @@
+// tirt_render.hip -- BVH traversal + the PT_RGB wavefront pipeline.
+//
+// Reference path: integrator/PT_RGB.py:44-136 is ONE per-pixel megakernel that inlines
+// Scene.closet_hit (Scene.py:702-744, traversal stack in GLOBAL memory, exhaustive visit
+// order, no t-culling), the shading branch, Scene.closet_hit_shadow (:671-699) and the film
+// update.  Here the same arithmetic is split into a wavefront of kernels over struct-of-arrays
+// path state in HBM:
+//
+//   k_generate        camera rays                                   Camera.py:122-142
+//   k_trace<closest>  closest hit of every live path                Scene.py:702-744
+//   k_shade           light / glass / disney branch, NEE set-up,    integrator/PT_RGB.py:66-132
+//                     next ray, throughput; compacts live paths
+//                     into the next queue with wave ballots
+//   k_trace<shadow>   NEE visibility, adds the stored contribution  Scene.py:671-699, PT_RGB.py:104-109
+//   k_film            running-mean film update                      integrator/PT_RGB.py:134-136
+//
+// Traversal: one ray per lane, 64-byte two-child nodes (tirt_internal.h), traversal stack in
+// LDS ([entry][lane] layout: conflict-free) with a global-memory spill tail.  Two visiting
+// rules, same closest hit:
+//   EXHAUSTIVE  the reference's: every internal node whose box passes `slabs` has both
+//               children visited, leaves are intersected unconditionally.  Used for the
+//               N_box / N_leaf "algorithmic bytes" counts and as a parity cross-check.
+//   ORDERED     near child first, children whose entry distance exceeds the current hit
+//               (with a 1e-4 relative margin) are skipped, leaf children are pre-tested
+//               against their (slightly inflated) box.  Product default.
+// Exact-t ties are resolved as the reference's visit order does (it pops the right child
+// first and keeps the first-found candidate on `t < hit_t`): the candidate with the larger
+// compact-node index wins.
+#include "tirt_internal.h"
+
+namespace tirt {
+
+constexpr int TR_BLOCK = 256;
+constexpr int TR_LDS_DEPTH = 24;       // stack entries per lane kept in LDS (24 KB / block)
+constexpr int TR_GRID = 2048;          // 8 blocks per CU x 256 CUs; rays are grid-strided
+
+enum { KIND_CLOSEST = 0, KIND_SHADOW_ACC = 1 };
+
+struct TraceArgs {
+    BvhView bvh;
+    const float *ox, *oy, *oz, *dx, *dy, *dz;    // rays, indexed by slot
+    const int *queue;                            // slot list (nullptr: slot = index)
+    const int *count_ptr; int count_fixed;       // number of rays: *count_ptr if non-null
+    float *ht, *hu, *hv; int *hprim;             // KIND_CLOSEST outputs, indexed by slot
+    const int *sprim; const float *scr, *scg, *scb; float *rr, *rg, *rb;   // KIND_SHADOW_ACC
+    int *spill; int spill_depth;                 // global stack tail: [entry][global thread]
+    DevCounters *ctr; int2 *per_ray_counts;
+};
+
+struct Stack {
+    int *lds; int tid; int *spill; size_t gstride; size_t gtid; int cap; int sp; bool overflow;
+    TD void push(int x)
+    {
+        if (sp < TR_LDS_DEPTH) lds[sp * TR_BLOCK + tid] = x;
+        else if (sp < cap) spill[(size_t)(sp - TR_LDS_DEPTH) * gstride + gtid] = x;
+        else { overflow = true; return; }
+        sp++;
+    }
+    TD int pop()
+    {
+        sp--;
+        return (sp < TR_LDS_DEPTH) ? lds[sp * TR_BLOCK + tid] : spill[(size_t)(sp - TR_LDS_DEPTH) * gstride + gtid];
+    }
+};
+
+template <int MODE, bool COUNT>
+TD void traverse(const BvhView &b, v3 o, v3 d, Stack &stk, float &hit_t, float &hit_u, float &hit_v, int &hit_prim,
+                 unsigned &nbox, unsigned &nleaf)
+{
+    const RayCtx r = make_ray(o, d);
+    hit_t = INF_VALUE; hit_u = 0.0f; hit_v = 0.0f; hit_prim = -1;
+    int hit_leaf = -1;
+    nbox = 1; nleaf = 0;
+    int cur = b.root_code;
+    if (cur >= 0) {
+        float tn;
+        if (!slabs(r, b.root_min[0], b.root_min[1], b.root_min[2], b.root_max[0], b.root_max[1], b.root_max[2], tn)) return;
+    }
+    stk.sp = 0;
+    for (;;) {
+        if (cur >= 0) {
+            const float4 *w = b.wnode + (size_t)cur * 4;
+            const float4 q0 = w[0], q1 = w[1], q2 = w[2], q3 = w[3];
+            const int cl = __float_as_int(q3.x), cr = __float_as_int(q3.y);
+            if (COUNT) nbox += 2;
+            float tl, tr;
+            int pl = slabs(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tl);
+            int pr = slabs(r, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tr);
+            if (MODE == TIRT_TRAVERSE_EXHAUSTIVE) {
+                if (cl < 0) pl = 1;              // leaves are popped and intersected without a box test
+                if (cr < 0) pr = 1;
+            } else {
+                const float lim = hit_t * 1.0001f;
+                pl &= (tl <= lim) ? 1 : 0;
+                pr &= (tr <= lim) ? 1 : 0;
+            }
+            if (pl & pr) {
+                const bool swap = (MODE != TIRT_TRAVERSE_EXHAUSTIVE) && (tr < tl);
+                stk.push(swap ? cl : cr);
+                cur = swap ? cr : cl;
+                continue;
+            }
+            if (pl) { cur = cl; continue; }
+            if (pr) { cur = cr; continue; }
+        } else {
+            const int code = ~cur;
+            const int prim = code & 0x3fffffff;
+            const float4 *tp = b.tri + (size_t)prim * 3;
+            const float4 a = tp[0], e1 = tp[1], e2 = tp[2];
+            if (COUNT) nleaf += 1;
+            float t, u, v;
+            if (((code >> 30) & 1) == 0) {
+                t = intersect_tri_packed(o, d, V(a.x, a.y, a.z), V(e1.x, e1.y, e1.z), V(e2.x, e2.y, e2.z), u, v);
+            } else {
+                float cc; u = 0.0f; v = 0.0f;
+                t = ((int)e1.y == SHAPE_SPHERE) ? intersect_sphere(o, d, V(a.x, a.y, a.z), e1.x, cc) : INF_VALUE;
+            }
+            const int leaf = __float_as_int(a.w);
+            if ((t > 0.0f) & ((t < hit_t) | ((t == hit_t) & (leaf > hit_leaf)))) {
+                hit_t = t; hit_u = u; hit_v = v; hit_prim = prim; hit_leaf = leaf;
+            }
+        }
+        if (stk.sp == 0) break;
+        cur = stk.pop();
+    }
+}
+
+TD unsigned long long wave_sum(unsigned long long v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+template <int MODE, bool COUNT, int KIND>
+__global__ __launch_bounds__(TR_BLOCK) void k_trace(TraceArgs a)
+{
+    __shared__ int lds_stack[TR_LDS_DEPTH * TR_BLOCK];
+    const int count = a.count_ptr ? *a.count_ptr : a.count_fixed;
+    const int total = gridDim.x * TR_BLOCK;
+    const int gtid = blockIdx.x * TR_BLOCK + threadIdx.x;
+    Stack stk;
+    stk.lds = lds_stack; stk.tid = threadIdx.x; stk.spill = a.spill; stk.gstride = (size_t)total; stk.gtid = (size_t)gtid;
+    stk.cap = TR_LDS_DEPTH + a.spill_depth; stk.sp = 0; stk.overflow = false;
+    unsigned long long sum_box = 0, sum_leaf = 0, n_over = 0;
+    for (int q = gtid; q < count; q += total) {
+        const int slot = a.queue ? a.queue[q] : q;
+        const v3 o = V(a.ox[slot], a.oy[slot], a.oz[slot]);
+        const v3 d = V(a.dx[slot], a.dy[slot], a.dz[slot]);
+        float t, u, v; int prim; unsigned nbox, nleaf;
+        stk.overflow = false;
+        traverse<MODE, COUNT>(a.bvh, o, d, stk, t, u, v, prim, nbox, nleaf);
+        if (stk.overflow) n_over++;
+        if (KIND == KIND_CLOSEST) {
+            a.ht[slot] = t; a.hu[slot] = u; a.hv[slot] = v; a.hprim[slot] = prim;
+        } else {
+            if (prim == a.sprim[slot]) {                 // integrator/PT_RGB.py:105-109
+                a.rr[slot] = a.rr[slot] + a.scr[slot];
+                a.rg[slot] = a.rg[slot] + a.scg[slot];
+                a.rb[slot] = a.rb[slot] + a.scb[slot];
+            }
+        }
+        if (COUNT) {
+            sum_box += nbox; sum_leaf += nleaf;
+            if (a.per_ray_counts) a.per_ray_counts[q] = make_int2((int)nbox, (int)nleaf);
+        }
+    }
+    if (a.ctr) {
+        if (COUNT) {
+            sum_box = wave_sum(sum_box); sum_leaf = wave_sum(sum_leaf);
+            if ((threadIdx.x & 63) == 0 && (sum_box | sum_leaf)) {
+                atomicAdd(KIND == KIND_CLOSEST ? &a.ctr->box_closest : &a.ctr->box_shadow, sum_box);
+                atomicAdd(KIND == KIND_CLOSEST ? &a.ctr->leaf_closest : &a.ctr->leaf_shadow, sum_leaf);
+            }
+        }
+        if (n_over) atomicAdd(&a.ctr->stack_overflow, n_over);
+        if (gtid == 0) atomicAdd(KIND == KIND_CLOSEST ? &a.ctr->rays_closest : &a.ctr->rays_shadow, (unsigned long long)count);
+    }
+}
+
+template <int KIND>
+static void launch_trace(tirt_ctx *c, const TraceArgs &a, int flags, int grid)
+{
+    const bool exh = (flags & TIRT_TRAVERSE_EXHAUSTIVE) != 0, cnt = (flags & TIRT_COUNT_NODES) != 0;
+    dim3 g(grid), b(TR_BLOCK);
+    if (exh && cnt) hipLaunchKernelGGL((k_trace<TIRT_TRAVERSE_EXHAUSTIVE, true, KIND>), g, b, 0, c->stream, a);
+    else if (exh) hipLaunchKernelGGL((k_trace<TIRT_TRAVERSE_EXHAUSTIVE, false, KIND>), g, b, 0, c->stream, a);
+    else if (cnt) hipLaunchKernelGGL((k_trace<TIRT_TRAVERSE_ORDERED, true, KIND>), g, b, 0, c->stream, a);
+    else hipLaunchKernelGGL((k_trace<TIRT_TRAVERSE_ORDERED, false, KIND>), g, b, 0, c->stream, a);
+}
+
+static int ensure_spill(tirt_ctx *c, int stack_size, int &spill_depth)
+{
+    int cap = stack_size > 64 ? stack_size : 64;
+    spill_depth = cap - TR_LDS_DEPTH;
+    return c->spill.ensure(sizeof(int) * (size_t)spill_depth * TR_GRID * TR_BLOCK);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Batch entry points (Debug-integrator style closest hit on caller-supplied rays)
+// ---------------------------------------------------------------------------------------------
+__global__ void k_split_rays(const float *rays, int nr, float *ox, float *oy, float *oz, float *dx, float *dy, float *dz)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nr) return;
+    const float *r = rays + (size_t)i * 6;
+    ox[i] = r[0]; oy[i] = r[1]; oz[i] = r[2]; dx[i] = r[3]; dy[i] = r[4]; dz[i] = r[5];
+}
+__global__ void k_hit_attr(SceneView s, int nr, const float *ox, const float *oy, const float *oz, const float *dx, const float *dy,
+                           const float *dz, const float *ht, const float *hu, const float *hv, const int *hprim, float *out)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nr) return;
+    float *o = out + (size_t)i * 13;
+    o[0] = ht[i];
+    HitAttr h; h.pos = h.gnor = h.nor = h.tex = V(0.0f, 0.0f, 0.0f);
+    if (ht[i] < INF_VALUE) h = hit_attributes(s, V(ox[i], oy[i], oz[i]), V(dx[i], dy[i], dz[i]), hprim[i], ht[i], hu[i], hv[i]);
+    else { h.gnor = normalized(h.gnor); h.nor = normalized(h.nor); }     // reference normalises (0,0,0) on a miss
+    o[1] = h.pos.x; o[2] = h.pos.y; o[3] = h.pos.z;
+    o[4] = h.gnor.x; o[5] = h.gnor.y; o[6] = h.gnor.z;
+    o[7] = h.nor.x; o[8] = h.nor.y; o[9] = h.nor.z;
+    o[10] = h.tex.x; o[11] = h.tex.y; o[12] = h.tex.z;
+}
+
+int launch_trace_batch(tirt_ctx *c, const float *rays, int nr, int stack_size, int flags, bool shadow,
+                       float *out_f, int32_t *out_prim, int32_t *counts)
+{
+    TIRT_REQUIRE(c->built, "trace: LBVH not built");
+    TIRT_REQUIRE(nr >= 0, "trace: nr < 0");
+    if (nr == 0) return TIRT_OK;
+    if (ensure_counters(c)) return TIRT_ERR_HIP;
+    hipStream_t st = c->stream;
+    if (c->tr_rays.ensure(sizeof(float) * 6 * (size_t)nr)) return TIRT_ERR_HIP;
+    if (c->tr_out.ensure(sizeof(float) * (6 + 3 + 13) * (size_t)nr)) return TIRT_ERR_HIP;
+    if (c->tr_prim.ensure(sizeof(int) * (size_t)nr)) return TIRT_ERR_HIP;
+    if (c->tr_counts.ensure(sizeof(int2) * (size_t)nr)) return TIRT_ERR_HIP;
+    int spill_depth;
+    if (ensure_spill(c, stack_size, spill_depth)) return TIRT_ERR_HIP;
+    float *base = c->tr_out.as<float>();
+    float *ox = base, *oy = ox + nr, *oz = oy + nr, *dx = oz + nr, *dy = dx + nr, *dz = dy + nr;
+    float *ht = dz + nr, *hu = ht + nr, *hv = hu + nr, *attr = hv + nr;
+    TIRT_HIP(hipMemcpyAsync(c->tr_rays.p, rays, sizeof(float) * 6 * (size_t)nr, hipMemcpyHostToDevice, st));
+    const int B = 256;
+    hipLaunchKernelGGL(k_split_rays, dim3((nr + B - 1) / B), dim3(B), 0, st, c->tr_rays.as<float>(), nr, ox, oy, oz, dx, dy, dz);
+    TraceArgs a = {};
+    a.bvh = bvh_view(c);
+    a.ox = ox; a.oy = oy; a.oz = oz; a.dx = dx; a.dy = dy; a.dz = dz;
+    a.queue = nullptr; a.count_ptr = nullptr; a.count_fixed = nr;
+    a.ht = ht; a.hu = hu; a.hv = hv; a.hprim = c->tr_prim.as<int>();
+    a.spill = c->spill.as<int>(); a.spill_depth = spill_depth;
+    a.ctr = c->dev_counters.as<DevCounters>();
+    a.per_ray_counts = (flags & TIRT_COUNT_NODES) ? c->tr_counts.as<int2>() : nullptr;
+    int grid = (nr + TR_BLOCK - 1) / TR_BLOCK; if (grid > TR_GRID) grid = TR_GRID;
+    launch_trace<KIND_CLOSEST>(c, a, flags, grid);
+    if (!shadow) {
+        hipLaunchKernelGGL(k_hit_attr, dim3((nr + B - 1) / B), dim3(B), 0, st, scene_view(c), nr, ox, oy, oz, dx, dy, dz, ht, hu, hv,
+                           c->tr_prim.as<int>(), attr);
+        TIRT_HIP(hipMemcpyAsync(out_f, attr, sizeof(float) * 13 * (size_t)nr, hipMemcpyDeviceToHost, st));
+    } else {
+        TIRT_HIP(hipMemcpyAsync(out_f, ht, sizeof(float) * (size_t)nr, hipMemcpyDeviceToHost, st));
+    }
+    TIRT_HIP(hipMemcpyAsync(out_prim, c->tr_prim.p, sizeof(int) * (size_t)nr, hipMemcpyDeviceToHost, st));
+    if (counts && (flags & TIRT_COUNT_NODES))
+        TIRT_HIP(hipMemcpyAsync(counts, c->tr_counts.p, sizeof(int2) * (size_t)nr, hipMemcpyDeviceToHost, st));
+    TIRT_HIP(hipStreamSynchronize(st));
+    TIRT_HIP(hipGetLastError());
+    return TIRT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Wavefront PT_RGB
+// ---------------------------------------------------------------------------------------------
+struct TileMap { int tile_rank, tile_count, tile_size, H; };
+TD int local_to_pixel(const TileMap &m, int k)
+{
+    int lt = k / m.tile_size, within = k - lt * m.tile_size;
+    return (lt * m.tile_count + m.tile_rank) * m.tile_size + within;
+}
+
+__global__ void k_generate(PathState ps, CameraView cam, TileMap tm, int P, int S, uint32_t frame_begin, uint32_t seed,
+                           DevCounters *ctr)
+{
+    int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    int f = s / P, k = s - f * P;
+    int p = local_to_pixel(tm, k);
+    int i = p / tm.H, j = p - i * tm.H;
+    uint32_t frame = frame_begin + (uint32_t)f;
+    float jx = 0.0f, jy = 0.0f;
+    if (frame != 0) {                                    // Camera.py:135-137
+        jx = tm_rand(seed, (uint32_t)p, frame, TM_DIM_JX) - 0.5f;
+        jy = tm_rand(seed, (uint32_t)p, frame, TM_DIM_JY) - 0.5f;
+    }
+    v3 d = camera_ray_direction(cam, i, j, jx, jy);
+    ps.ox[s] = cam.eye[0]; ps.oy[s] = cam.eye[1]; ps.oz[s] = cam.eye[2];
+    ps.dx[s] = d.x; ps.dy[s] = d.y; ps.dz[s] = d.z;
+    ps.tr[s] = 1.0f; ps.tg[s] = 1.0f; ps.tb[s] = 1.0f;
+    ps.rr[s] = 0.0f; ps.rg[s] = 0.0f; ps.rb[s] = 0.0f;
+    ps.brdf_pdf[s] = 1.0f; ps.flags[s] = 1u;
+    if (s == 0) atomicAdd(&ctr->paths, (unsigned long long)S);
+}
+
+// wave-aggregated append: one atomic per wave
+TD int queue_slot(bool want, int *counter)
+{
+    unsigned long long mask = __ballot(want);
+    if (mask == 0ull) return -1;
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    const int leader = __ffsll((long long)mask) - 1;
+    if (lane == leader) base = atomicAdd(counter, __popcll(mask));
+    base = __shfl(base, leader, 64);
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    return want ? base + __popcll(mask & lt) : -1;
+}
+
+__global__ __launch_bounds__(256) void k_shade(PathState ps, SceneView sc, TileMap tm, int P, uint32_t frame_begin, uint32_t seed,
+                                             int bounce, const int *queue, const int *count_ptr, int count_fixed,
+                                             int *next_queue, int *next_count, int *shadow_queue, int *shadow_count,
+                                             DevCounters *ctr)
+{
+    const int count = count_ptr ? *count_ptr : count_fixed;
+    const int total = gridDim.x * blockDim.x;
+    const int rounds = (count + total - 1) / total;
+    unsigned long long n_shaded = 0;
+    for (int it = 0; it < rounds; it++) {
+        const int q = it * total + blockIdx.x * blockDim.x + threadIdx.x;
+        bool live = q < count, want_next = false, want_shadow = false;
+        int slot = 0;
+        if (live) {
+            slot = queue ? queue[q] : q;
+            const int f = slot / P, k = slot - f * P;
+            const uint32_t pixel = (uint32_t)local_to_pixel(tm, k);
+            const uint32_t frame = frame_begin + (uint32_t)f;
+            const uint32_t dim0 = TM_DIM_BOUNCE0 + TM_DIMS_PER_BOUNCE * (uint32_t)bounce;
+            const v3 origin = V(ps.ox[slot], ps.oy[slot], ps.oz[slot]);
+            const v3 direction = V(ps.dx[slot], ps.dy[slot], ps.dz[slot]);
+            const float t = ps.ht[slot];
+            v3 throughout = V(ps.tr[slot], ps.tg[slot], ps.tb[slot]);
+            v3 radiance = V(ps.rr[slot], ps.rg[slot], ps.rb[slot]);
+            float brdf_pdf = ps.brdf_pdf[slot];
+            int perfect_spec = (int)(ps.flags[slot] & 1u);
+            if (t < INF_VALUE) {
+                const int prim_id = ps.hprim[slot];
+                const HitAttr h = hit_attributes(sc, origin, direction, prim_id, t, ps.hu[slot], ps.hv[slot]);
+                const v3 normal = h.nor;
+                const v3 fnormal = normal * signf(dot(-direction, h.gnor));            // UtilsFunc.py:465-467
+                const int mat_id = sc.primitive[(size_t)prim_id * PRI_VEC + 2];
+                const float *m = sc.material + (size_t)mat_id * MAT_VEC;
+                const v3 mat_color = V(m[2], m[3], m[4]);
+                const int mat_type = (int)m[0];
+                if (mat_type == MAT_LIGHT) {                                           // PT_RGB.py:72-81
+                    const float fCosTheta = absf(dot(direction, h.gnor));
+                    if (perfect_spec == 1) {
+                        radiance = radiance + throughout * mat_color;
+                    } else {
+                        const float area = get_prim_area(sc, prim_id) * (float)sc.light_count;
+                        const float light_pdf = (t * t) / (area * fCosTheta);
+                        radiance = radiance + (throughout * power_heuristic(brdf_pdf, light_pdf)) * mat_color;
+                    }
+                } else {
+                    n_shaded++;
+                    const v3 reflect_color = srgb_to_lrgb(mat_color);
+                    v3 next_dir; float f_or_b = 1.0f, brdf = 1.0f;
+                    if (mat_type == MAT_GLASS) {                                       // PT_RGB.py:89-92
+                        perfect_spec = 1;
+                        next_dir = glass_sample(m, direction, normal, tm_rand(seed, pixel, frame, dim0 + TM_SLOT_GLASS), f_or_b);
+                        brdf = 1.0f; brdf_pdf = 1.0f;
+                    } else {
+                        perfect_spec = 0;
+                        // Scene.py:477-518 sample_li
+                        int lidx = (int)(tm_rand(seed, pixel, frame, dim0 + TM_SLOT_LIGHT) * (float)sc.light_count);
+                        if (lidx >= sc.light_count) lidx = sc.light_count - 1;
+                        const int light_prim = sc.light[lidx];
+                        const float ra = tm_rand(seed, pixel, frame, dim0 + TM_SLOT_LA);
+                        const float rb = tm_rand(seed, pixel, frame, dim0 + TM_SLOT_LB);
+                        v3 light_pos, light_normal;
+                        get_prim_random_point_normal(sc, light_prim, ra, rb, light_pos, light_normal);
+                        const int lmat = sc.primitive[(size_t)light_prim * PRI_VEC + 2];
+                        const float *lm = sc.material + (size_t)lmat * MAT_VEC;
+                        const v3 light_emission = V(lm[2], lm[3], lm[4]);
+                        const float light_area = get_prim_area(sc, light_prim);
+                        const float light_choice_pdf = 1.0f / ((float)sc.light_count * light_area);
+                        light_normal = normalized(light_normal);
+                        v3 light_dir = h.pos - light_pos;
+                        const float light_dist = norm(light_dir);
+                        light_dir = light_dir / light_dist;
+                        const float NdotL_surface = dot(fnormal, light_dir);            // PT_RGB.py:101-109
+                        const float NdotL_light = dot(light_normal, light_dir);
+                        if ((NdotL_surface < 0.0f) & (NdotL_light > 0.0f)) {
+                            want_shadow = true;
+                            float e_pdf;
+                            const float e_brdf = disney_evaluate_pdf(m, fnormal, -direction, -light_dir, e_pdf);
+                            const float light_pdf = light_dist * light_dist * light_choice_pdf / NdotL_light;
+                            v3 c = V(0.0f, 0.0f, 0.0f);
+                            int expect = -2;                       // never equals a primitive id
+                            if (e_pdf > 0.0f) {
+                                const float w = power_heuristic(light_pdf, e_pdf) / maxf(0.0001f, light_pdf);
+                                c = light_emission * w;
+                                c = c * throughout;
+                                c = c * reflect_color;
+                                c = c * e_brdf;
+                                c = c * absf(NdotL_surface);
+                                expect = prim_id;
+                            }
+                            ps.sox[slot] = light_pos.x; ps.soy[slot] = light_pos.y; ps.soz[slot] = light_pos.z;
+                            ps.sdx[slot] = light_dir.x; ps.sdy[slot] = light_dir.y; ps.sdz[slot] = light_dir.z;
+                            ps.scr[slot] = c.x; ps.scg[slot] = c.y; ps.scb[slot] = c.z;
+                            ps.sprim[slot] = expect;
+                        }
+                        next_dir = disney_sample(m, direction, fnormal, tm_rand(seed, pixel, frame, dim0 + TM_SLOT_LOBE),
+                                                 tm_rand(seed, pixel, frame, dim0 + TM_SLOT_R1),
+                                                 tm_rand(seed, pixel, frame, dim0 + TM_SLOT_R2));
+                        f_or_b = 1.0f;
+                        brdf = disney_evaluate_pdf(m, fnormal, -direction, next_dir, brdf_pdf);
+                        brdf *= absf(dot(normal, next_dir));
+                    }
+                    const v3 next_origin = offset_ray(h.pos, fnormal * signf(f_or_b));   // PT_RGB.py:115
+                    if (brdf_pdf > 0.0f) {
+                        bool alive = true;
+                        if (f_or_b < 0.0f) {                                             // PT_RGB.py:118-122
+                            const float extinction = m[6];
+                            const float R = tm_exp(-t / extinction);
+                            if (tm_rand(seed, pixel, frame, dim0 + TM_SLOT_EXT) >= R) alive = false;
+                        }
+                        if (alive) {
+                            throughout = throughout * (reflect_color * (brdf / brdf_pdf));
+                            want_next = true;
+                            ps.ox[slot] = next_origin.x; ps.oy[slot] = next_origin.y; ps.oz[slot] = next_origin.z;
+                            ps.dx[slot] = next_dir.x; ps.dy[slot] = next_dir.y; ps.dz[slot] = next_dir.z;
+                            ps.tr[slot] = throughout.x; ps.tg[slot] = throughout.y; ps.tb[slot] = throughout.z;
+                            ps.brdf_pdf[slot] = brdf_pdf;
+                            ps.flags[slot] = (uint32_t)perfect_spec;
+                        }
+                    }
+                }
+            } else {                                                                     // PT_RGB.py:127-132
+                const float dis = tm_sqrt(direction.x * direction.x + direction.z * direction.z);
+                const float tx = (tm_atan2(direction.z, direction.x) + PI_SCENE) / PI_SCENE / 2.0f;
+                const float ty = tm_atan2(direction.y, dis) / PI_SCENE + 0.5f;
+                const v3 e = srgb_to_lrgb(texture2d(sc, tx, ty));
+                radiance = radiance + (e * throughout) * sc.env_power;
+            }
+            ps.rr[slot] = radiance.x; ps.rg[slot] = radiance.y; ps.rb[slot] = radiance.z;
+        }
+        const int qs = queue_slot(want_shadow, shadow_count);
+        if (want_shadow) shadow_queue[qs] = slot;
+        const int qn = queue_slot(want_next, next_count);
+        if (want_next) next_queue[qn] = slot;
+    }
+    n_shaded = wave_sum(n_shaded);
+    if ((threadIdx.x & 63) == 0 && n_shaded) atomicAdd(&ctr->shaded, n_shaded);
+}
+
+// integrator/PT_RGB.py:134-136, frames applied in order
+__global__ void k_film(PathState ps, TileMap tm, int P, int F, uint32_t frame_begin, float *hdr)
+{
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= P) return;
+    int p = local_to_pixel(tm, k);
+    float *px = hdr + (size_t)p * 3;
+    float r = px[0], g = px[1], b = px[2];
+    for (int f = 0; f < F; f++) {
+        int s = f * P + k;
+        float frame = (float)(int)(frame_begin + (uint32_t)f);
+        float coff = 1.0f / (frame + 1.0f);
+        r = ps.rr[s] * coff + r * (1.0f - coff);
+        g = ps.rg[s] * coff + g * (1.0f - coff);
+        b = ps.rb[s] * coff + b * (1.0f - coff);
+    }
+    px[0] = r; px[1] = g; px[2] = b;
+}
+
+static int ensure_paths(tirt_ctx *c, size_t S, int max_depth)
+{
+    if (S > c->path_capacity || !c->path_mem.p) {
+        const int nwords = 28;
+        if (c->path_mem.ensure(sizeof(float) * nwords * S)) return TIRT_ERR_HIP;
+        if (c->queue_a.ensure(sizeof(int) * S) || c->queue_b.ensure(sizeof(int) * S) || c->queue_s.ensure(sizeof(int) * S)) return TIRT_ERR_HIP;
+        float *w = c->path_mem.as<float>();
+        PathState &p = c->ps;
+        auto nxt = [&]() { float *r = w; w += S; return r; };
+        p.ox = nxt(); p.oy = nxt(); p.oz = nxt(); p.dx = nxt(); p.dy = nxt(); p.dz = nxt();
+        p.ht = nxt(); p.hu = nxt(); p.hv = nxt(); p.hprim = (int *)nxt();
+        p.tr = nxt(); p.tg = nxt(); p.tb = nxt(); p.rr = nxt(); p.rg = nxt(); p.rb = nxt();
+        p.brdf_pdf = nxt(); p.flags = (uint32_t *)nxt();
+        p.sox = nxt(); p.soy = nxt(); p.soz = nxt(); p.sdx = nxt(); p.sdy = nxt(); p.sdz = nxt();
+        p.scr = nxt(); p.scg = nxt(); p.scb = nxt(); p.sprim = (int *)nxt();
+        c->path_capacity = S;
+    }
+    if (c->counters_mem.ensure(sizeof(int) * 2 * (size_t)(max_depth + 2))) return TIRT_ERR_HIP;
+    return 0;
+}
+
+int pt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed, int max_depth, int stack_size, int flags)
+{
+    TIRT_REQUIRE(c->built, "tirt_pt_rgb_render: LBVH not built");
+    TIRT_REQUIRE(c->cam_set, "tirt_pt_rgb_render: camera not set");
+    TIRT_REQUIRE(c->hdr.p && c->npix_local >= 0, "tirt_pt_rgb_render: film not created");
+    TIRT_REQUIRE(frame_count >= 0 && max_depth >= 1 && max_depth <= 4096, "tirt_pt_rgb_render: bad frame_count/max_depth");
+    if (frame_count == 0 || c->npix_local == 0) return TIRT_OK;
+    if (ensure_counters(c)) return TIRT_ERR_HIP;
+    hipStream_t st = c->stream;
+    const int P = (int)c->npix_local;
+    // frames per batch: keep <= ~4M paths in flight
+    int FB = (int)((4u << 20) / (size_t)P); if (FB < 1) FB = 1; if (FB > frame_count) FB = frame_count;
+    if (ensure_paths(c, (size_t)FB * P, max_depth)) return TIRT_ERR_HIP;
+    int spill_depth;
+    if (ensure_spill(c, stack_size, spill_depth)) return TIRT_ERR_HIP;
+    const SceneView sv = scene_view(c);
+    const BvhView bv = bvh_view(c);
+    const TileMap tm = {c->tile_rank, c->tile_count, c->tile_size, c->H};
+    DevCounters *ctr = c->dev_counters.as<DevCounters>();
+    int *cnt_path = c->counters_mem.as<int>();              // [max_depth+1]
+    int *cnt_shadow = cnt_path + (max_depth + 2);           // [max_depth]
+    const int B = 256;
+
+    hipEvent_t r0, r1;
+    TIRT_HIP(hipEventCreate(&r0)); TIRT_HIP(hipEventCreate(&r1));
+    TIRT_HIP(hipEventRecord(r0, st));
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> evc, evs, evh;     // closest / shadow / shade timing pairs
+    auto stamp = [&](std::vector<std::pair<hipEvent_t, hipEvent_t>> &v, bool begin) {
+        if (!c->time_kernels) return;
+        if (begin) { hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b); v.push_back({a, b}); (void)hipEventRecord(a, st); }
+        else (void)hipEventRecord(v.back().second, st);
+    };
+
+    for (int fb = 0; fb < frame_count; fb += FB) {
+        const int F = (frame_count - fb < FB) ? frame_count - fb : FB;
+        const int S = F * P;
+        const uint32_t f0 = frame_begin + (uint32_t)fb;
+        TIRT_HIP(hipMemsetAsync(c->counters_mem.p, 0, sizeof(int) * 2 * (size_t)(max_depth + 2), st));
+        hipLaunchKernelGGL(k_generate, dim3((S + B - 1) / B), dim3(B), 0, st, c->ps, c->cam, tm, P, S, f0, seed, ctr);
+        int *qcur = nullptr, *qnext = c->queue_a.as<int>(), *qother = c->queue_b.as<int>();
+        int grid_full = (S + TR_BLOCK - 1) / TR_BLOCK; if (grid_full > TR_GRID) grid_full = TR_GRID;
+        for (int b = 0; b < max_depth; b++) {
+            TraceArgs a = {};
+            a.bvh = bv;
+            a.ox = c->ps.ox; a.oy = c->ps.oy; a.oz = c->ps.oz; a.dx = c->ps.dx; a.dy = c->ps.dy; a.dz = c->ps.dz;
+            a.queue = qcur; a.count_ptr = (b == 0) ? nullptr : &cnt_path[b]; a.count_fixed = S;
+            a.ht = c->ps.ht; a.hu = c->ps.hu; a.hv = c->ps.hv; a.hprim = c->ps.hprim;
+            a.spill = c->spill.as<int>(); a.spill_depth = spill_depth; a.ctr = ctr; a.per_ray_counts = nullptr;
+            stamp(evc, true);
+            launch_trace<KIND_CLOSEST>(c, a, flags, grid_full);
+            stamp(evc, false);
+            c->launches_trace_closest++;
+
+            stamp(evh, true);
+            hipLaunchKernelGGL(k_shade, dim3(grid_full), dim3(B), 0, st, c->ps, sv, tm, P, f0, seed, b, qcur,
+                               (b == 0) ? (const int *)nullptr : (const int *)&cnt_path[b], S, qnext, &cnt_path[b + 1],
+                               c->queue_s.as<int>(), &cnt_shadow[b], ctr);
+            stamp(evh, false);
+            c->launches_shade++;
+
+            TraceArgs sa = {};
+            sa.bvh = bv;
+            sa.ox = c->ps.sox; sa.oy = c->ps.soy; sa.oz = c->ps.soz; sa.dx = c->ps.sdx; sa.dy = c->ps.sdy; sa.dz = c->ps.sdz;
+            sa.queue = c->queue_s.as<int>(); sa.count_ptr = &cnt_shadow[b]; sa.count_fixed = 0;
+            sa.sprim = c->ps.sprim; sa.scr = c->ps.scr; sa.scg = c->ps.scg; sa.scb = c->ps.scb;
+            sa.rr = c->ps.rr; sa.rg = c->ps.rg; sa.rb = c->ps.rb;
+            sa.spill = c->spill.as<int>(); sa.spill_depth = spill_depth; sa.ctr = ctr; sa.per_ray_counts = nullptr;
+            stamp(evs, true);
+            launch_trace<KIND_SHADOW_ACC>(c, sa, flags, grid_full);
+            stamp(evs, false);
+            c->launches_trace_shadow++;
+
+            qcur = qnext; qnext = qother; qother = qcur;
+        }
+        hipLaunchKernelGGL(k_film, dim3((P + B - 1) / B), dim3(B), 0, st, c->ps, tm, P, F, f0, c->hdr.as<float>());
+    }
+    TIRT_HIP(hipEventRecord(r1, st));
+    if (c->time_kernels) {
+        TIRT_HIP(hipStreamSynchronize(st));
+        auto drain = [&](std::vector<std::pair<hipEvent_t, hipEvent_t>> &v, double &acc) {
+            for (auto &pr : v) { float ms = 0; (void)hipEventElapsedTime(&ms, pr.first, pr.second); acc += ms; (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+            v.clear();
+        };
+        drain(evc, c->ms_trace_closest); drain(evs, c->ms_trace_shadow); drain(evh, c->ms_shade);
+    }
+    c->ev_pool.push_back({r0, r1});        // drained (and destroyed) by tirt_stats / tirt_stats_reset
+    TIRT_HIP(hipGetLastError());
+    return TIRT_OK;
+}
+
+}  // namespace tirt
