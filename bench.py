@@ -1,0 +1,231 @@
+#!/usr/bin/env python
+"""bench.py -- headline metric of BASELINE.json: Mrays/s (primary + secondary) of the PT_RGB
+ray loop on the synthetic 100k-triangle scene at 1024x1024 (configs[2]; 256 spp = the
+default 32 steps x 8 frames).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" = one pass of the hot path over one batch of pixel-samples: `--frames-per-step`
+(default 8) consecutive frames of the full 1024^2 film, i.e. 8.4 M paths.  With N > 1 the
+film is sharded by pixel tiles (linear pixel index, tiles of 4096, round-robin over ranks,
+replicated scene + BVH, no collective on the data path) and the tiles are summed into rank
+0's film with ONE RCCL reduce at the end -- total work is fixed, so "scaling" is "strong".
+A ray = one closet_hit or closet_hit_shadow call of the reference
+(integrator/PT_RGB.py:65,104); rays are counted by device counters.
+
+Timing: W untimed warm-up steps, then exactly K steps bracketed by barrier +
+torch.cuda.synchronize() + tirt_sync on both sides; MAX over ranks; rank 0 prints one JSON
+line.  Inputs (scene, BVH) are resident in HBM before the timed region.
+
+Extra objects:
+  roofline      dominant kernel = closest-hit traversal (k_trace).  achieved = ALGORITHMIC
+                bytes per launch / mean launch duration, both measured live: bytes from the
+                reference-semantics pop counts (32 B x N_box + 36 B x N_leaf + 48 B per ray,
+                SURVEY.md 8d) gathered by an untimed exhaustive counting pass over the same
+                frames, duration from HIP events on the library's stream around every
+                closest-hit launch of an untimed instrumented pass.
+  cpu_baseline  the CPU oracle (oracle/, a restatement of the reference algorithm: AoS rows,
+                exhaustive unordered traversal, per-pixel loop) on all host cores over a
+                bounded pixel sample of the same scene/frame ("kind": "port"; the reference's
+                own ti.cpu path cannot run: Taichi is not installable here).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--frames-per-step", type=int, default=8)
+    ap.add_argument("--size", type=int, default=1024)
+    ap.add_argument("--ntri", type=int, default=100000)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--tile-size", type=int, default=4096)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-sample-tiles", type=int, default=64, help="oracle renders 1/this of the pixels, 1 frame")
+    ap.add_argument("--save-png", default="")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("--gpus %d needs one process per GPU: launch with torch.distributed.run" % args.gpus)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from ti_raytrace_amd import scenes, _native
+    from ti_raytrace_amd import distributed as tdist
+
+    W = H = args.size
+    total_frames = (args.warmup + args.steps) * args.frames_per_step
+    ex = scenes.synthetic(W, H, max(total_frames, 4), ntri=args.ntri, device_id=local_rank, seed=args.seed,
+                          tile_rank=rank, tile_count=world, tile_size=args.tile_size)
+    t0 = time.time()
+    ex.build_scene()
+    ctx = ex.scene.ctx
+    ctx.sync()
+    build_wall = time.time() - t0
+    build_ms = ctx.stats()["ms_build"]
+    fps = args.frames_per_step
+
+    def barrier():
+        ctx.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def run_steps(k):
+        for _ in range(k):
+            ex.integrator.render_frames(fps)
+            ex.cam.update_frame(fps)
+
+    run_steps(args.warmup)
+    barrier()
+    ctx.stats_reset()
+    t_begin = time.perf_counter()
+    run_steps(args.steps)
+    film = tdist.reduce_film(ctx, W, H, dst=0)              # one RCCL reduce of the framebuffer (world > 1)
+    barrier()
+    elapsed = time.perf_counter() - t_begin
+    st = ctx.stats()
+
+    # MAX over ranks of the elapsed time, SUM over ranks of the rays
+    el_t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    rays_t = torch.tensor([float(st["rays_closest"]), float(st["rays_shadow"]), float(st["paths"])], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(el_t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(rays_t, op=dist.ReduceOp.SUM)
+    elapsed = float(el_t.item())
+    rays_closest, rays_shadow, paths = [float(x) for x in rays_t.tolist()]
+    mrays = (rays_closest + rays_shadow) / elapsed / 1e6
+
+    result = {
+        "metric": "Mrays/s (primary+secondary) at 1024^2 100k-tri",
+        "value": round(mrays, 3),
+        "unit": "Mrays/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed * 1e3 / max(args.steps, 1), 4),
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": "synthetic %d-tri random mesh (scene seed 1234, s=0.03), PT_RGB %dx%d, %d spp timed "
+                        "(%d steps x %d frames), max_depth 15, render seed %d" %
+                        (args.ntri, W, H, args.steps * fps, args.steps, fps, args.seed),
+            "parallelism": "pixel tiles of %d round-robin over %d GPU(s), replicated BVH, one RCCL film reduce" % (args.tile_size, world),
+            "traversal": "ordered+t-culled (bit-identical hits to the reference's exhaustive order)",
+        },
+        "rays": {"closest": int(rays_closest), "shadow": int(rays_shadow), "paths": int(paths),
+                 "rays_per_path": round((rays_closest + rays_shadow) / max(paths, 1.0), 3)},
+        "lbvh_build_ms": round(build_ms, 3),
+        "scene_setup_wall_s": round(build_wall, 3),
+    }
+
+    if rank == 0 and args.save_png:
+        from ti_raytrace_amd.Example import write_png
+        ctx.film_import_device(film.data_ptr()) if world > 1 else None
+        ctx.tone_map(0.5)
+        write_png(ctx.film_download(W, H, want_hdr=False, want_rgb=True)[1], args.save_png)
+
+    # ---- roofline for the dominant kernel (rank 0's shard, untimed extra passes) -----------------
+    if not args.no_roofline:
+        probe_frames = fps
+        f0 = ex.cam.frame
+        ctx.stats_reset()
+        ctx.pt_rgb_render(f0, probe_frames, args.seed, 15, 64, _native.TRAVERSE_EXHAUSTIVE | _native.COUNT_NODES)
+        ctx.sync()
+        c = ctx.stats()
+        alg_closest = 32.0 * c["box_closest"] + 36.0 * c["leaf_closest"] + 48.0 * c["rays_closest"]
+        alg_shadow = 32.0 * c["box_shadow"] + 36.0 * c["leaf_shadow"] + 48.0 * c["rays_shadow"]
+        ctx.stats_reset()
+        ctx.pt_rgb_render(f0, probe_frames, args.seed, 15, 64, _native.TRAVERSE_ORDERED | _native.COUNT_NODES)
+        ctx.sync()
+        co = ctx.stats()
+        ctx.set_option("time_kernels", 1)
+        ctx.stats_reset()
+        ctx.pt_rgb_render(f0, probe_frames, args.seed, 15, 64, 0)
+        ctx.sync()
+        t = ctx.stats()
+        ctx.set_option("time_kernels", 0)
+        n_launch = max(t["launches_trace_closest"], 1)
+        avg_ms = t["ms_trace_closest"] / n_launch
+        achieved = (alg_closest / n_launch) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        result["roofline"] = {
+            "bound": "hbm", "kernel": "k_trace<ordered,closest>",
+            "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+            "alg_bytes_per_launch": round(alg_closest / n_launch, 1),
+            "avg_launch_ms": round(avg_ms, 5), "launches": int(n_launch),
+            "alg_bytes_per_closest_ray": round(alg_closest / max(c["rays_closest"], 1), 1),
+            "alg_bytes_per_shadow_ray": round(alg_shadow / max(c["rays_shadow"], 1), 1),
+            "n_box_per_closest_ray": round(c["box_closest"] / max(c["rays_closest"], 1), 2),
+            "n_leaf_per_closest_ray": round(c["leaf_closest"] / max(c["rays_closest"], 1), 2),
+            "n_box_ordered_per_closest_ray": round(co["box_closest"] / max(co["rays_closest"], 1), 2),
+            "n_leaf_ordered_per_closest_ray": round(co["leaf_closest"] / max(co["rays_closest"], 1), 2),
+            "kernel_ms": {"trace_closest": round(t["ms_trace_closest"], 3), "trace_shadow": round(t["ms_trace_shadow"], 3),
+                          "shade": round(t["ms_shade"], 3), "render_total": round(t["ms_render"], 3)},
+            "whole_job_alg_GBps": round((alg_closest + alg_shadow + 260.0 * c["shaded"] + 24.0 * c["paths"]) /
+                                        max(t["ms_render"], 1e-9) / 1e6, 2),
+            "note": "the ~10 MB BVH is L2/Infinity-Cache resident: HBM traffic is far below the algorithmic bytes",
+        }
+
+    # ---- CPU baseline: oracle on the host cores, bounded sample (rank 0, N = 1 only) ---------------
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_api
+        orc = oracle_api.OracleScene(ex.scene, ex.cam)
+        tb = time.perf_counter()
+        orc.lbvh_build()
+        cpu_build_s = time.perf_counter() - tb
+        cores = os.cpu_count() or 1
+        tc = time.perf_counter()
+        _, ost = orc.render(W, H, 1, 1, seed=args.seed, tile_rank=0, tile_count=args.cpu_sample_tiles,
+                            tile_size=args.tile_size, nthreads=cores)
+        cpu_s = time.perf_counter() - tc
+        cpu_rays = ost["rays_closest"] + ost["rays_shadow"]
+        result["cpu_baseline"] = {
+            "value": round(cpu_rays / cpu_s / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "sample": "frame 1 of the same scene, 1/%d of the 1024^2 pixels (tiles of %d, every %dth tile) = %d paths, "
+                      "%d rays in %.2f s; CPU oracle LBVH build %.3f s" %
+                      (args.cpu_sample_tiles, args.tile_size, args.cpu_sample_tiles, ost["paths"], cpu_rays, cpu_s, cpu_build_s),
+        }
+
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -116,7 +116,8 @@ TD void traverse(const BvhView &b, v3 o, v3 d, Stack &stk, float &hit_t, float &
                 t = ((int)e1.y == SHAPE_SPHERE) ? intersect_sphere(o, d, V(a.x, a.y, a.z), e1.x, cc) : INF_VALUE;
             }
             const int leaf = __float_as_int(a.w);
-            if ((t > 0.0f) & ((t < hit_t) | ((t == hit_t) & (leaf > hit_leaf)))) {
+            // reference: accept iff 0 < t < hit_t (so never t >= INF_VALUE); equal-t candidates: see header
+            if ((t > 0.0f) & ((t < hit_t) | ((t == hit_t) & (hit_leaf >= 0) & (leaf > hit_leaf)))) {
                 hit_t = t; hit_u = u; hit_v = v; hit_prim = prim; hit_leaf = leaf;
             }
         }
