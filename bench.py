@@ -54,7 +54,7 @@ def parse():
     ap.add_argument("--tile-size", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--cpu-sample-tiles", type=int, default=64, help="oracle renders 1/this of the pixels, 1 frame")
+    ap.add_argument("--cpu-target-s", type=float, default=15.0, help="seconds of CPU-oracle work for cpu_baseline")
     ap.add_argument("--save-png", default="")
     return ap.parse_args()
 
@@ -208,17 +208,22 @@ def main():
         tb = time.perf_counter()
         orc.lbvh_build()
         cpu_build_s = time.perf_counter() - tb
-        cores = os.cpu_count() or 1
+        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        # probe 1/64 of one frame, then size the sample for ~15 s of CPU work (whole frames)
+        tp = time.perf_counter()
+        _, pst = orc.render(W, H, 1, 1, seed=args.seed, tile_rank=0, tile_count=64, tile_size=args.tile_size, nthreads=cores)
+        probe_s = max(time.perf_counter() - tp, 1e-3)
+        frame_s = probe_s * 64.0
+        nframes = int(min(max(args.cpu_target_s / frame_s, 1.0), 64.0))
         tc = time.perf_counter()
-        _, ost = orc.render(W, H, 1, 1, seed=args.seed, tile_rank=0, tile_count=args.cpu_sample_tiles,
-                            tile_size=args.tile_size, nthreads=cores)
+        _, ost = orc.render(W, H, 1, nframes, seed=args.seed, nthreads=cores)
         cpu_s = time.perf_counter() - tc
         cpu_rays = ost["rays_closest"] + ost["rays_shadow"]
         result["cpu_baseline"] = {
             "value": round(cpu_rays / cpu_s / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": "frame 1 of the same scene, 1/%d of the 1024^2 pixels (tiles of %d, every %dth tile) = %d paths, "
-                      "%d rays in %.2f s; CPU oracle LBVH build %.3f s" %
-                      (args.cpu_sample_tiles, args.tile_size, args.cpu_sample_tiles, ost["paths"], cpu_rays, cpu_s, cpu_build_s),
+            "sample": "frames 1..%d of the same scene at the full 1024^2 (%d paths, %d rays) in %.2f s on %d threads; "
+                      "CPU oracle LBVH build %.3f s (GPU %.3f ms)" %
+                      (nframes, ost["paths"], cpu_rays, cpu_s, cores, cpu_build_s, build_ms),
         }
 
     if rank == 0:
