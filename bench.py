@@ -1,13 +1,13 @@
 #!/usr/bin/env python
 """bench.py -- headline metric of BASELINE.json: Mrays/s (primary + secondary) of the PT_RGB
 ray loop on the synthetic 100k-triangle scene at 1024x1024 (configs[2]; 256 spp = the
-default 32 steps x 8 frames).
+default 8 steps x 32 frames).
 
   python bench.py --gpus N --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" = one pass of the hot path over one batch of pixel-samples: `--frames-per-step`
-(default 8) consecutive frames of the full 1024^2 film, i.e. 8.4 M paths.  With N > 1 the
+(default 32) consecutive frames of the full 1024^2 film, i.e. 33.5 M paths (one wavefront batch).  With N > 1 the
 film is sharded by pixel tiles (linear pixel index, tiles of 4096, round-robin over ranks,
 replicated scene + BVH, no collective on the data path) and the tiles are summed into rank
 0's film with ONE RCCL reduce at the end -- total work is fixed, so "scaling" is "strong".
@@ -45,9 +45,9 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=32)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--frames-per-step", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--frames-per-step", type=int, default=32)
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--ntri", type=int, default=100000)
     ap.add_argument("--seed", type=int, default=1)

@@ -62,7 +62,9 @@ int tirt_create(int device_id, tirt_ctx **out);
 void tirt_destroy(tirt_ctx *ctx);
 int tirt_sync(tirt_ctx *ctx);
 /* options: "time_kernels" (0/1) -- bracket every trace/shade launch with HIP events on the
- * ctx stream so that tirt_stats reports per-kernel time (bench/roofline only) */
+ *            ctx stream so that tirt_stats reports per-kernel time (bench/roofline only)
+ *          "batch_paths" -- pixel-samples kept in flight per wavefront batch (default 32 Mi,
+ *            112 B of HBM each) */
 int tirt_set_option(tirt_ctx *ctx, const char *name, double value);
 
 /* Scene.setup_data_gpu field uploads (reference Scene.py:299-308).

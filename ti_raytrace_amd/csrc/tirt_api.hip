@@ -228,6 +228,10 @@ int tirt_set_option(tirt_ctx *c, const char *name, double value)
     CTX(c);
     TIRT_REQUIRE(name, "tirt_set_option: null name");
     if (!strcmp(name, "time_kernels")) { c->time_kernels = value != 0.0; return TIRT_OK; }
+    if (!strcmp(name, "batch_paths")) {
+        TIRT_REQUIRE(value >= 1.0 && value <= 1.0e9, "tirt_set_option: batch_paths out of range");
+        c->batch_paths = (size_t)value; return TIRT_OK;
+    }
     set_error(std::string("tirt_set_option: unknown option ") + name);
     return TIRT_ERR_ARG;
 }

@@ -91,6 +91,25 @@ TD int slabs(const RayCtx &r, float mnx, float mny, float mnz, float mxx, float 
     tnear = tmin;
     return ret;
 }
+// Branch-free form for rays with |d| >= 1e-6 on every axis (all but axis-parallel rays).
+// Same products and the same min/max selections as slab_axis, so tmin/tmax are the same
+// floats; tmin only grows and tmax only shrinks across the axes, so the reference's
+// per-axis `tmin > tmax` checks are equivalent to the single check at the end (no NaN can
+// arise: 1/d is finite).
+TD bool ray_has_parallel_axis(const RayCtx &r)
+{ return (absf(r.dx) < 0.000001f) || (absf(r.dy) < 0.000001f) || (absf(r.dz) < 0.000001f); }
+TD int slabs_fast(const RayCtx &r, float mnx, float mny, float mnz, float mxx, float mxy, float mxz, float &tnear)
+{
+    const float ax = (mnx - r.ox) * r.idx, bx = (mxx - r.ox) * r.idx;
+    const float ay = (mny - r.oy) * r.idy, by = (mxy - r.oy) * r.idy;
+    const float az = (mnz - r.oz) * r.idz, bz = (mxz - r.oz) * r.idz;
+    const float tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)),
+                                       __builtin_fmaxf(__builtin_fminf(az, bz), 0.0f));
+    const float tmax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)),
+                                       __builtin_fminf(__builtin_fmaxf(az, bz), INF_VALUE));
+    tnear = tmin;
+    return (tmin > tmax) ? 0 : 1;
+}
 
 // ---- Scene.py:603-638 intersect_tri on a packed (v0, E1 = v1-v0, E2 = v2-v0) triangle ------------
 TD float intersect_tri_packed(v3 origin, v3 direction, v3 v0, v3 E1, v3 E2, float &u, float &v)

@@ -70,6 +70,7 @@ struct PathState {
     float *brdf_pdf; uint32_t *flags;           // bit0 perfect_spec
     float *sox, *soy, *soz, *sdx, *sdy, *sdz;    // shadow ray (origin on the light)
     float *scr, *scg, *scb; int *sprim;         // contribution if sprim is the closest hit
+    float *sdist;                               // distance light point -> shaded point
 };
 
 struct DevCounters {          // lives in device memory; accumulated by the kernels
@@ -111,6 +112,7 @@ struct tirt_ctx {
 
     // wavefront state
     size_t path_capacity = 0;
+    size_t batch_paths = (size_t)32 << 20;         // option "batch_paths"
     tirt::DevBuf path_mem, queue_a, queue_b, queue_s, counters_mem, spill;
     tirt::PathState ps;
 

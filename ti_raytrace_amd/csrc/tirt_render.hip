@@ -42,89 +42,19 @@ struct TraceArgs {
     const int *queue;                            // slot list (nullptr: slot = index)
     const int *count_ptr; int count_fixed;       // number of rays: *count_ptr if non-null
     float *ht, *hu, *hv; int *hprim;             // KIND_CLOSEST outputs, indexed by slot
-    const int *sprim; const float *scr, *scg, *scb; float *rr, *rg, *rb;   // KIND_SHADOW_ACC
+    const int *sprim; const float *sdist, *scr, *scg, *scb; float *rr, *rg, *rb;   // KIND_SHADOW_ACC
     int *spill; int spill_depth;                 // global stack tail: [entry][global thread]
+    int *fetch;                                  // ray-fetch cursor of this launch (zero on entry)
     DevCounters *ctr; int2 *per_ray_counts;
 };
 
-struct Stack {
-    int *lds; int tid; int *spill; size_t gstride; size_t gtid; int cap; int sp; bool overflow;
-    TD void push(int x)
-    {
-        if (sp < TR_LDS_DEPTH) lds[sp * TR_BLOCK + tid] = x;
-        else if (sp < cap) spill[(size_t)(sp - TR_LDS_DEPTH) * gstride + gtid] = x;
-        else { overflow = true; return; }
-        sp++;
-    }
-    TD int pop()
-    {
-        sp--;
-        return (sp < TR_LDS_DEPTH) ? lds[sp * TR_BLOCK + tid] : spill[(size_t)(sp - TR_LDS_DEPTH) * gstride + gtid];
-    }
-};
-
-template <int MODE, bool COUNT>
-TD void traverse(const BvhView &b, v3 o, v3 d, Stack &stk, float &hit_t, float &hit_u, float &hit_v, int &hit_prim,
-                 unsigned &nbox, unsigned &nleaf)
-{
-    const RayCtx r = make_ray(o, d);
-    hit_t = INF_VALUE; hit_u = 0.0f; hit_v = 0.0f; hit_prim = -1;
-    int hit_leaf = -1;
-    nbox = 1; nleaf = 0;
-    int cur = b.root_code;
-    if (cur >= 0) {
-        float tn;
-        if (!slabs(r, b.root_min[0], b.root_min[1], b.root_min[2], b.root_max[0], b.root_max[1], b.root_max[2], tn)) return;
-    }
-    stk.sp = 0;
-    for (;;) {
-        if (cur >= 0) {
-            const float4 *w = b.wnode + (size_t)cur * 4;
-            const float4 q0 = w[0], q1 = w[1], q2 = w[2], q3 = w[3];
-            const int cl = __float_as_int(q3.x), cr = __float_as_int(q3.y);
-            if (COUNT) nbox += 2;
-            float tl, tr;
-            int pl = slabs(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tl);
-            int pr = slabs(r, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tr);
-            if (MODE == TIRT_TRAVERSE_EXHAUSTIVE) {
-                if (cl < 0) pl = 1;              // leaves are popped and intersected without a box test
-                if (cr < 0) pr = 1;
-            } else {
-                const float lim = hit_t * 1.0001f;
-                pl &= (tl <= lim) ? 1 : 0;
-                pr &= (tr <= lim) ? 1 : 0;
-            }
-            if (pl & pr) {
-                const bool swap = (MODE != TIRT_TRAVERSE_EXHAUSTIVE) && (tr < tl);
-                stk.push(swap ? cl : cr);
-                cur = swap ? cr : cl;
-                continue;
-            }
-            if (pl) { cur = cl; continue; }
-            if (pr) { cur = cr; continue; }
-        } else {
-            const int code = ~cur;
-            const int prim = code & 0x3fffffff;
-            const float4 *tp = b.tri + (size_t)prim * 3;
-            const float4 a = tp[0], e1 = tp[1], e2 = tp[2];
-            if (COUNT) nleaf += 1;
-            float t, u, v;
-            if (((code >> 30) & 1) == 0) {
-                t = intersect_tri_packed(o, d, V(a.x, a.y, a.z), V(e1.x, e1.y, e1.z), V(e2.x, e2.y, e2.z), u, v);
-            } else {
-                float cc; u = 0.0f; v = 0.0f;
-                t = ((int)e1.y == SHAPE_SPHERE) ? intersect_sphere(o, d, V(a.x, a.y, a.z), e1.x, cc) : INF_VALUE;
-            }
-            const int leaf = __float_as_int(a.w);
-            // reference: accept iff 0 < t < hit_t (so never t >= INF_VALUE); equal-t candidates: see header
-            if ((t > 0.0f) & ((t < hit_t) | ((t == hit_t) & (hit_leaf >= 0) & (leaf > hit_leaf)))) {
-                hit_t = t; hit_u = u; hit_v = v; hit_prim = prim; hit_leaf = leaf;
-            }
-        }
-        if (stk.sp == 0) break;
-        cur = stk.pop();
-    }
-}
+// Persistent waves with ray re-fetch ("while-while" traversal): every wave keeps pulling rays
+// from the queue through one wave-aggregated atomic whenever at least TR_REFILL_MIN of its 64
+// lanes are idle, so that a few long rays do not leave the other lanes of the wave parked
+// (a one-ray-per-lane loop measured 15 % VALU lane utilisation on this workload).  Inner-node
+// steps and triangle tests run in separate loops so that lanes doing the same thing run together.
+constexpr int TR_REFILL_MIN = 20;
+constexpr int TR_SENT = (int)0x80000000;      // "stack empty": never a node index nor a leaf code
 
 TD unsigned long long wave_sum(unsigned long long v)
 {
@@ -137,39 +67,153 @@ template <int MODE, bool COUNT, int KIND>
 __global__ __launch_bounds__(TR_BLOCK) void k_trace(TraceArgs a)
 {
     __shared__ int lds_stack[TR_LDS_DEPTH * TR_BLOCK];
+    constexpr bool SHADOW = (KIND == KIND_SHADOW_ACC);
+    constexpr bool BOUNDED = SHADOW && (MODE != TIRT_TRAVERSE_EXHAUSTIVE);
     const int count = a.count_ptr ? *a.count_ptr : a.count_fixed;
-    const int total = gridDim.x * TR_BLOCK;
-    const int gtid = blockIdx.x * TR_BLOCK + threadIdx.x;
-    Stack stk;
-    stk.lds = lds_stack; stk.tid = threadIdx.x; stk.spill = a.spill; stk.gstride = (size_t)total; stk.gtid = (size_t)gtid;
-    stk.cap = TR_LDS_DEPTH + a.spill_depth; stk.sp = 0; stk.overflow = false;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const size_t gstride = (size_t)gridDim.x * TR_BLOCK, gtid = (size_t)blockIdx.x * TR_BLOCK + tid;
+    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const int cap = TR_LDS_DEPTH + a.spill_depth;
+    const BvhView &b = a.bvh;
+
+    // per-lane ray state
+    bool have = false, par = false, overflow = false;
+    int slot = 0, q = 0, cur = TR_SENT, sp = 0, hit_prim = -1, hit_leaf = -1, expect = -3;
+    float hit_t = INF_VALUE, hit_u = 0.0f, hit_v = 0.0f, cull_far = 3.0e38f, settle = -1.0f;
+    unsigned nbox = 0, nleaf = 0;
+    RayCtx r = {};
+    bool exhausted = false;
     unsigned long long sum_box = 0, sum_leaf = 0, n_over = 0;
-    for (int q = gtid; q < count; q += total) {
-        const int slot = a.queue ? a.queue[q] : q;
-        const v3 o = V(a.ox[slot], a.oy[slot], a.oz[slot]);
-        const v3 d = V(a.dx[slot], a.dy[slot], a.dz[slot]);
-        float t, u, v; int prim; unsigned nbox, nleaf;
-        stk.overflow = false;
-        traverse<MODE, COUNT>(a.bvh, o, d, stk, t, u, v, prim, nbox, nleaf);
-        if (stk.overflow) n_over++;
-        if (KIND == KIND_CLOSEST) {
-            a.ht[slot] = t; a.hu[slot] = u; a.hv[slot] = v; a.hprim[slot] = prim;
-        } else {
-            if (prim == a.sprim[slot]) {                 // integrator/PT_RGB.py:105-109
+
+#define TR_PUSH(x)                                                                                   \
+    do {                                                                                             \
+        const int x__ = (x);                                                                         \
+        if (sp < TR_LDS_DEPTH) { lds_stack[sp * TR_BLOCK + tid] = x__; sp++; }                       \
+        else if (sp < cap) { a.spill[(size_t)(sp - TR_LDS_DEPTH) * gstride + gtid] = x__; sp++; }    \
+        else overflow = true;                                                                        \
+    } while (0)
+#define TR_POP(dst)                                                                                  \
+    do {                                                                                             \
+        if (sp == 0) dst = TR_SENT;                                                                  \
+        else {                                                                                       \
+            sp--;                                                                                    \
+            if (sp < TR_LDS_DEPTH) dst = lds_stack[sp * TR_BLOCK + tid];                            \
+            else dst = a.spill[(size_t)(sp - TR_LDS_DEPTH) * gstride + gtid];                        \
+        }                                                                                            \
+    } while (0)
+
+    for (;;) {
+        // ---- refill idle lanes -------------------------------------------------------------
+        const unsigned long long idle = __ballot(!have);
+        if (idle != 0ull && !exhausted && (__popcll(idle) >= TR_REFILL_MIN || idle == ~0ull)) {
+            const int n_idle = __popcll(idle);
+            const int leader = __ffsll((long long)idle) - 1;
+            int base = 0;
+            if (lane == leader) base = atomicAdd(a.fetch, n_idle);
+            base = __shfl(base, leader, 64);
+            if (base + n_idle >= count) exhausted = true;
+            const int my = base + __popcll(idle & lt_mask);
+            if (!have && my < count) {
+                q = my;
+                slot = a.queue ? a.queue[my] : my;
+                const v3 o = V(a.ox[slot], a.oy[slot], a.oz[slot]);
+                const v3 d = V(a.dx[slot], a.dy[slot], a.dz[slot]);
+                r = make_ray(o, d);
+                par = ray_has_parallel_axis(r);
+                hit_t = INF_VALUE; hit_u = 0.0f; hit_v = 0.0f; hit_prim = -1; hit_leaf = -1;
+                nbox = 1; nleaf = 0; sp = 0; overflow = false;
+                if (BOUNDED) {
+                    const float t_bound = a.sdist[slot];
+                    expect = a.sprim[slot];
+                    cull_far = t_bound * 1.01f; settle = t_bound * 0.99f;
+                } else if (SHADOW) expect = a.sprim[slot];
+                cur = b.root_code;
+                if (cur >= 0) {
+                    float tn;
+                    if (!slabs(r, b.root_min[0], b.root_min[1], b.root_min[2], b.root_max[0], b.root_max[1], b.root_max[2], tn)) cur = TR_SENT;
+                }
+                have = true;
+            }
+        }
+        if (__ballot(have) == 0ull) break;
+
+        // ---- inner nodes: until this lane reaches a leaf or runs out of stack ---------------
+        while (have && cur >= 0) {
+            const float4 *w = b.wnode + (size_t)cur * 4;
+            const float4 q0 = w[0], q1 = w[1], q2 = w[2], q3 = w[3];
+            const int cl = __float_as_int(q3.x), cr = __float_as_int(q3.y);
+            if (COUNT) nbox += 2;
+            float tl, tr;
+            int pl, pr;
+            if (!par) {
+                pl = slabs_fast(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tl);
+                pr = slabs_fast(r, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tr);
+            } else {
+                pl = slabs(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tl);
+                pr = slabs(r, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tr);
+            }
+            if (MODE == TIRT_TRAVERSE_EXHAUSTIVE) {
+                if (cl < 0) pl = 1;              // leaves are popped and intersected without a box test
+                if (cr < 0) pr = 1;
+            } else {
+                const float lim = minf(hit_t * 1.0001f, cull_far);
+                pl &= (tl <= lim) ? 1 : 0;
+                pr &= (tr <= lim) ? 1 : 0;
+            }
+            if (pl & pr) {
+                const bool swap = (MODE != TIRT_TRAVERSE_EXHAUSTIVE) && (tr < tl);
+                TR_PUSH(swap ? cl : cr);
+                cur = swap ? cr : cl;
+            } else if (pl) cur = cl;
+            else if (pr) cur = cr;
+            else TR_POP(cur);
+        }
+
+        // ---- leaf: one primitive test ---------------------------------------------------------
+        if (have && cur != TR_SENT) {
+            const int code = ~cur;
+            const int prim = code & 0x3fffffff;
+            const float4 *tp = b.tri + (size_t)prim * 3;
+            const float4 ta = tp[0], e1 = tp[1], e2 = tp[2];
+            if (COUNT) nleaf += 1;
+            const v3 o = V(r.ox, r.oy, r.oz), d = V(r.dx, r.dy, r.dz);
+            float t, u, v;
+            if (((code >> 30) & 1) == 0) {
+                t = intersect_tri_packed(o, d, V(ta.x, ta.y, ta.z), V(e1.x, e1.y, e1.z), V(e2.x, e2.y, e2.z), u, v);
+            } else {
+                float cc; u = 0.0f; v = 0.0f;
+                t = ((int)e1.y == SHAPE_SPHERE) ? intersect_sphere(o, d, V(ta.x, ta.y, ta.z), e1.x, cc) : INF_VALUE;
+            }
+            const int leaf = __float_as_int(ta.w);
+            TR_POP(cur);
+            // reference: accept iff 0 < t < hit_t (so never t >= INF_VALUE); equal-t candidates: see header
+            if ((t > 0.0f) & ((t < hit_t) | ((t == hit_t) & (hit_leaf >= 0) & (leaf > hit_leaf)))) {
+                hit_t = t; hit_u = u; hit_v = v; hit_prim = prim; hit_leaf = leaf;
+                if (BOUNDED && prim != expect && t < settle) cur = TR_SENT;      // answer settled: "occluded"
+            }
+        }
+
+        // ---- finished rays write back and free their lane ---------------------------------------
+        if (have && cur == TR_SENT) {
+            if (KIND == KIND_CLOSEST) {
+                a.ht[slot] = hit_t; a.hu[slot] = hit_u; a.hv[slot] = hit_v; a.hprim[slot] = hit_prim;
+            } else if (hit_prim == expect) {                 // integrator/PT_RGB.py:105-109
                 a.rr[slot] = a.rr[slot] + a.scr[slot];
                 a.rg[slot] = a.rg[slot] + a.scg[slot];
                 a.rb[slot] = a.rb[slot] + a.scb[slot];
             }
-        }
-        if (COUNT) {
-            sum_box += nbox; sum_leaf += nleaf;
-            if (a.per_ray_counts) a.per_ray_counts[q] = make_int2((int)nbox, (int)nleaf);
+            if (COUNT) {
+                sum_box += nbox; sum_leaf += nleaf;
+                if (a.per_ray_counts) a.per_ray_counts[q] = make_int2((int)nbox, (int)nleaf);
+            }
+            if (overflow) n_over++;
+            have = false;
         }
     }
     if (a.ctr) {
         if (COUNT) {
             sum_box = wave_sum(sum_box); sum_leaf = wave_sum(sum_leaf);
-            if ((threadIdx.x & 63) == 0 && (sum_box | sum_leaf)) {
+            if (lane == 0 && (sum_box | sum_leaf)) {
                 atomicAdd(KIND == KIND_CLOSEST ? &a.ctr->box_closest : &a.ctr->box_shadow, sum_box);
                 atomicAdd(KIND == KIND_CLOSEST ? &a.ctr->leaf_closest : &a.ctr->leaf_shadow, sum_leaf);
             }
@@ -251,6 +295,9 @@ int launch_trace_batch(tirt_ctx *c, const float *rays, int nr, int stack_size, i
     a.spill = c->spill.as<int>(); a.spill_depth = spill_depth;
     a.ctr = c->dev_counters.as<DevCounters>();
     a.per_ray_counts = (flags & TIRT_COUNT_NODES) ? c->tr_counts.as<int2>() : nullptr;
+    if (c->counters_mem.ensure(sizeof(int) * 4 * 18)) return TIRT_ERR_HIP;
+    TIRT_HIP(hipMemsetAsync(c->counters_mem.p, 0, sizeof(int), st));
+    a.fetch = c->counters_mem.as<int>();
     int grid = (nr + TR_BLOCK - 1) / TR_BLOCK; if (grid > TR_GRID) grid = TR_GRID;
     launch_trace<KIND_CLOSEST>(c, a, flags, grid);
     if (!shadow) {
@@ -408,6 +455,7 @@ __global__ __launch_bounds__(256) void k_shade(PathState ps, SceneView sc, TileM
                             ps.sdx[slot] = light_dir.x; ps.sdy[slot] = light_dir.y; ps.sdz[slot] = light_dir.z;
                             ps.scr[slot] = c.x; ps.scg[slot] = c.y; ps.scb[slot] = c.z;
                             ps.sprim[slot] = expect;
+                            ps.sdist[slot] = light_dist;
                         }
                         next_dir = disney_sample(m, direction, fnormal, tm_rand(seed, pixel, frame, dim0 + TM_SLOT_LOBE),
                                                  tm_rand(seed, pixel, frame, dim0 + TM_SLOT_R1),
@@ -475,7 +523,7 @@ __global__ void k_film(PathState ps, TileMap tm, int P, int F, uint32_t frame_be
 static int ensure_paths(tirt_ctx *c, size_t S, int max_depth)
 {
     if (S > c->path_capacity || !c->path_mem.p) {
-        const int nwords = 28;
+        const int nwords = 29;
         if (c->path_mem.ensure(sizeof(float) * nwords * S)) return TIRT_ERR_HIP;
         if (c->queue_a.ensure(sizeof(int) * S) || c->queue_b.ensure(sizeof(int) * S) || c->queue_s.ensure(sizeof(int) * S)) return TIRT_ERR_HIP;
         float *w = c->path_mem.as<float>();
@@ -486,10 +534,10 @@ static int ensure_paths(tirt_ctx *c, size_t S, int max_depth)
         p.tr = nxt(); p.tg = nxt(); p.tb = nxt(); p.rr = nxt(); p.rg = nxt(); p.rb = nxt();
         p.brdf_pdf = nxt(); p.flags = (uint32_t *)nxt();
         p.sox = nxt(); p.soy = nxt(); p.soz = nxt(); p.sdx = nxt(); p.sdy = nxt(); p.sdz = nxt();
-        p.scr = nxt(); p.scg = nxt(); p.scb = nxt(); p.sprim = (int *)nxt();
+        p.scr = nxt(); p.scg = nxt(); p.scb = nxt(); p.sprim = (int *)nxt(); p.sdist = nxt();
         c->path_capacity = S;
     }
-    if (c->counters_mem.ensure(sizeof(int) * 2 * (size_t)(max_depth + 2))) return TIRT_ERR_HIP;
+    if (c->counters_mem.ensure(sizeof(int) * 4 * (size_t)(max_depth + 2))) return TIRT_ERR_HIP;
     return 0;
 }
 
@@ -503,8 +551,9 @@ int pt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed,
     if (ensure_counters(c)) return TIRT_ERR_HIP;
     hipStream_t st = c->stream;
     const int P = (int)c->npix_local;
-    // frames per batch: keep <= ~4M paths in flight
-    int FB = (int)((4u << 20) / (size_t)P); if (FB < 1) FB = 1; if (FB > frame_count) FB = frame_count;
+    // frames per batch: up to batch_paths pixel-samples in flight (the per-bounce launches of a
+    // batch end in a latency-bound tail of a few long rays, so bigger batches amortise it)
+    int FB = (int)(c->batch_paths / (size_t)P); if (FB < 1) FB = 1; if (FB > frame_count) FB = frame_count;
     if (ensure_paths(c, (size_t)FB * P, max_depth)) return TIRT_ERR_HIP;
     int spill_depth;
     if (ensure_spill(c, stack_size, spill_depth)) return TIRT_ERR_HIP;
@@ -514,6 +563,7 @@ int pt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed,
     DevCounters *ctr = c->dev_counters.as<DevCounters>();
     int *cnt_path = c->counters_mem.as<int>();              // [max_depth+1]
     int *cnt_shadow = cnt_path + (max_depth + 2);           // [max_depth]
+    int *fetch_c = cnt_shadow + (max_depth + 2), *fetch_s = fetch_c + (max_depth + 2);   // ray-fetch cursors
     const int B = 256;
 
     hipEvent_t r0, r1;
@@ -530,7 +580,7 @@ int pt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed,
         const int F = (frame_count - fb < FB) ? frame_count - fb : FB;
         const int S = F * P;
         const uint32_t f0 = frame_begin + (uint32_t)fb;
-        TIRT_HIP(hipMemsetAsync(c->counters_mem.p, 0, sizeof(int) * 2 * (size_t)(max_depth + 2), st));
+        TIRT_HIP(hipMemsetAsync(c->counters_mem.p, 0, sizeof(int) * 4 * (size_t)(max_depth + 2), st));
         hipLaunchKernelGGL(k_generate, dim3((S + B - 1) / B), dim3(B), 0, st, c->ps, c->cam, tm, P, S, f0, seed, ctr);
         int *qcur = nullptr, *qnext = c->queue_a.as<int>(), *qother = c->queue_b.as<int>();
         int grid_full = (S + TR_BLOCK - 1) / TR_BLOCK; if (grid_full > TR_GRID) grid_full = TR_GRID;
@@ -541,6 +591,7 @@ int pt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed,
             a.queue = qcur; a.count_ptr = (b == 0) ? nullptr : &cnt_path[b]; a.count_fixed = S;
             a.ht = c->ps.ht; a.hu = c->ps.hu; a.hv = c->ps.hv; a.hprim = c->ps.hprim;
             a.spill = c->spill.as<int>(); a.spill_depth = spill_depth; a.ctr = ctr; a.per_ray_counts = nullptr;
+            a.fetch = &fetch_c[b];
             stamp(evc, true);
             launch_trace<KIND_CLOSEST>(c, a, flags, grid_full);
             stamp(evc, false);
@@ -557,9 +608,10 @@ int pt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed,
             sa.bvh = bv;
             sa.ox = c->ps.sox; sa.oy = c->ps.soy; sa.oz = c->ps.soz; sa.dx = c->ps.sdx; sa.dy = c->ps.sdy; sa.dz = c->ps.sdz;
             sa.queue = c->queue_s.as<int>(); sa.count_ptr = &cnt_shadow[b]; sa.count_fixed = 0;
-            sa.sprim = c->ps.sprim; sa.scr = c->ps.scr; sa.scg = c->ps.scg; sa.scb = c->ps.scb;
+            sa.sprim = c->ps.sprim; sa.sdist = c->ps.sdist; sa.scr = c->ps.scr; sa.scg = c->ps.scg; sa.scb = c->ps.scb;
             sa.rr = c->ps.rr; sa.rg = c->ps.rg; sa.rb = c->ps.rb;
             sa.spill = c->spill.as<int>(); sa.spill_depth = spill_depth; sa.ctr = ctr; sa.per_ray_counts = nullptr;
+            sa.fetch = &fetch_s[b];
             stamp(evs, true);
             launch_trace<KIND_SHADOW_ACC>(c, sa, flags, grid_full);
             stamp(evs, false);
