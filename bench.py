@@ -56,6 +56,7 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-target-s", type=float, default=15.0, help="seconds of CPU-oracle work for cpu_baseline")
     ap.add_argument("--save-png", default="")
+    ap.add_argument("--opt", action="append", default=[], help="name=value passed to tirt_set_option (tuning)")
     return ap.parse_args()
 
 
@@ -89,6 +90,9 @@ def main():
     t0 = time.time()
     ex.build_scene()
     ctx = ex.scene.ctx
+    for kv in args.opt:
+        k, v = kv.split("=")
+        ctx.set_option(k, float(v))
     ctx.sync()
     build_wall = time.time() - t0
     build_ms = ctx.stats()["ms_build"]
@@ -195,6 +199,11 @@ def main():
             "n_leaf_ordered_per_closest_ray": round(co["leaf_closest"] / max(co["rays_closest"], 1), 2),
             "kernel_ms": {"trace_closest": round(t["ms_trace_closest"], 3), "trace_shadow": round(t["ms_trace_shadow"], 3),
                           "shade": round(t["ms_shade"], 3), "render_total": round(t["ms_render"], 3)},
+            "wave_diag_ordered": {"node_iters_per_ray": round(co["diag_it_node"] * 64.0 / max(co["rays_closest"] + co["rays_shadow"], 1), 2),
+                                  "node_lane_util": round(co["diag_lanes_node"] / max(co["diag_it_node"] * 64.0, 1), 4),
+                                  "leaf_iters_per_ray": round(co["diag_it_leaf"] * 64.0 / max(co["rays_closest"] + co["rays_shadow"], 1), 2),
+                                  "leaf_lane_util": round(co["diag_lanes_leaf"] / max(co["diag_it_leaf"] * 64.0, 1), 4),
+                                  "refills_per_wave_ray": round(co["diag_refills"] * 64.0 / max(co["rays_closest"] + co["rays_shadow"], 1), 3)},
             "whole_job_alg_GBps": round((alg_closest + alg_shadow + 260.0 * c["shaded"] + 24.0 * c["paths"]) /
                                         max(t["ms_render"], 1e-9) / 1e6, 2),
             "note": "the ~10 MB BVH is L2/Infinity-Cache resident: HBM traffic is far below the algorithmic bytes",

@@ -51,6 +51,9 @@ typedef struct {
     uint64_t launches_trace_closest;
     uint64_t launches_trace_shadow;
     uint64_t launches_shade;
+    /* wave-occupancy diagnostics of the traversal kernels (TIRT_COUNT_NODES only): per-wave
+     * loop trips and the number of busy lanes summed over those trips (64 = full wave) */
+    uint64_t diag_it_node, diag_lanes_node, diag_it_leaf, diag_lanes_leaf, diag_refills, diag_it_outer;
 } tirt_stats_t;
 
 const char *tirt_last_error(void);

@@ -27,7 +27,8 @@ class Stats(C.Structure):
         (n, C.c_double) for n in ("ms_build", "ms_render", "ms_trace_closest",
                                   "ms_trace_shadow", "ms_shade")] + [
         (n, C.c_uint64) for n in ("launches_trace_closest", "launches_trace_shadow",
-                                  "launches_shade")]
+                                  "launches_shade", "diag_it_node", "diag_lanes_node", "diag_it_leaf",
+                                  "diag_lanes_leaf", "diag_refills", "diag_it_outer")]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

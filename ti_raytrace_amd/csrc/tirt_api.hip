@@ -232,6 +232,10 @@ int tirt_set_option(tirt_ctx *c, const char *name, double value)
         TIRT_REQUIRE(value >= 1.0 && value <= 1.0e9, "tirt_set_option: batch_paths out of range");
         c->batch_paths = (size_t)value; return TIRT_OK;
     }
+    if (!strcmp(name, "trace_lds_depth")) { TIRT_REQUIRE(value >= 1 && value <= 64, "trace_lds_depth: 1..64"); c->tr_lds_depth = (int)value; return TIRT_OK; }
+    if (!strcmp(name, "trace_refill_min")) { TIRT_REQUIRE(value >= 1 && value <= 64, "trace_refill_min: 1..64"); c->tr_refill_min = (int)value; return TIRT_OK; }
+    if (!strcmp(name, "trace_node_min")) { TIRT_REQUIRE(value >= 1 && value <= 64, "trace_node_min: 1..64"); c->tr_node_min = (int)value; return TIRT_OK; }
+    if (!strcmp(name, "trace_grid")) { TIRT_REQUIRE(value >= 1 && value <= 4096, "trace_grid: 1..4096"); c->tr_grid = (int)value; return TIRT_OK; }
     set_error(std::string("tirt_set_option: unknown option ") + name);
     return TIRT_ERR_ARG;
 }
@@ -473,6 +477,8 @@ int tirt_stats(tirt_ctx *c, tirt_stats_t *out)
     out->box_closest = h.box_closest; out->leaf_closest = h.leaf_closest;
     out->box_shadow = h.box_shadow; out->leaf_shadow = h.leaf_shadow;
     out->shaded = h.shaded; out->paths = h.paths; out->stack_overflow = h.stack_overflow;
+    out->diag_it_node = h.it_node; out->diag_lanes_node = h.lanes_node; out->diag_it_leaf = h.it_leaf;
+    out->diag_lanes_leaf = h.lanes_leaf; out->diag_refills = h.refills; out->diag_it_outer = h.it_outer;
     out->ms_build = c->ms_build; out->ms_render = c->ms_render;
     out->ms_trace_closest = c->ms_trace_closest; out->ms_trace_shadow = c->ms_trace_shadow; out->ms_shade = c->ms_shade;
     out->launches_trace_closest = c->launches_trace_closest; out->launches_trace_shadow = c->launches_trace_shadow;

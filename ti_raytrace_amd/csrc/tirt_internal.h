@@ -76,6 +76,8 @@ struct PathState {
 struct DevCounters {          // lives in device memory; accumulated by the kernels
     unsigned long long rays_closest, rays_shadow, box_closest, leaf_closest, box_shadow, leaf_shadow;
     unsigned long long shaded, paths, stack_overflow;
+    // wave-occupancy diagnostics of k_trace (TIRT_COUNT_NODES only): loop trips and busy lanes
+    unsigned long long it_node, lanes_node, it_leaf, lanes_leaf, refills, it_outer;
 };
 
 }  // namespace tirt
@@ -113,6 +115,8 @@ struct tirt_ctx {
     // wavefront state
     size_t path_capacity = 0;
     size_t batch_paths = (size_t)32 << 20;         // option "batch_paths"
+    // traversal tunables (options "trace_lds_depth", "trace_refill_min", "trace_node_min", "trace_grid")
+    int tr_lds_depth = 24, tr_refill_min = 36, tr_node_min = 12, tr_grid = 1536;
     tirt::DevBuf path_mem, queue_a, queue_b, queue_s, counters_mem, spill;
     tirt::PathState ps;
 

@@ -31,8 +31,7 @@
 namespace tirt {
 
 constexpr int TR_BLOCK = 256;
-constexpr int TR_LDS_DEPTH = 24;       // stack entries per lane kept in LDS (24 KB / block)
-constexpr int TR_GRID = 2048;          // 8 blocks per CU x 256 CUs; rays are grid-strided
+constexpr int TR_GRID_MAX = 4096;      // upper bound on persistent blocks (sizes the spill buffer)
 
 enum { KIND_CLOSEST = 0, KIND_SHADOW_ACC = 1 };
 
@@ -45,6 +44,9 @@ struct TraceArgs {
     const int *sprim; const float *sdist, *scr, *scg, *scb; float *rr, *rg, *rb;   // KIND_SHADOW_ACC
     int *spill; int spill_depth;                 // global stack tail: [entry][global thread]
     int *fetch;                                  // ray-fetch cursor of this launch (zero on entry)
+    int lds_depth;                               // stack entries per lane kept in LDS
+    int refill_min;                              // re-fetch rays when this many lanes of a wave are idle
+    int node_min;                                // leave the inner-node loop below this many busy lanes
     DevCounters *ctr; int2 *per_ray_counts;
 };
 
@@ -53,7 +55,6 @@ struct TraceArgs {
 // lanes are idle, so that a few long rays do not leave the other lanes of the wave parked
 // (a one-ray-per-lane loop measured 15 % VALU lane utilisation on this workload).  Inner-node
 // steps and triangle tests run in separate loops so that lanes doing the same thing run together.
-constexpr int TR_REFILL_MIN = 20;
 constexpr int TR_SENT = (int)0x80000000;      // "stack empty": never a node index nor a leaf code
 
 TD unsigned long long wave_sum(unsigned long long v)
@@ -63,10 +64,14 @@ TD unsigned long long wave_sum(unsigned long long v)
     return v;
 }
 
+#ifndef TR_MIN_WAVES
+#define TR_MIN_WAVES 6
+#endif
 template <int MODE, bool COUNT, int KIND>
-__global__ __launch_bounds__(TR_BLOCK) void k_trace(TraceArgs a)
+__global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
 {
-    __shared__ int lds_stack[TR_LDS_DEPTH * TR_BLOCK];
+    extern __shared__ __attribute__((aligned(16))) int lds_stack[];      // [lds_depth][TR_BLOCK]
+    const int TR_LDS_DEPTH = a.lds_depth;
     constexpr bool SHADOW = (KIND == KIND_SHADOW_ACC);
     constexpr bool BOUNDED = SHADOW && (MODE != TIRT_TRAVERSE_EXHAUSTIVE);
     const int count = a.count_ptr ? *a.count_ptr : a.count_fixed;
@@ -83,7 +88,9 @@ __global__ __launch_bounds__(TR_BLOCK) void k_trace(TraceArgs a)
     unsigned nbox = 0, nleaf = 0;
     RayCtx r = {};
     bool exhausted = false;
+    bool wave_par = false;                      // any lane of the wave holds an axis-parallel ray (rare)
     unsigned long long sum_box = 0, sum_leaf = 0, n_over = 0;
+    unsigned long long d_it_node = 0, d_lanes_node = 0, d_it_leaf = 0, d_lanes_leaf = 0, d_refills = 0, d_outer = 0;
 
 #define TR_PUSH(x)                                                                                   \
     do {                                                                                             \
@@ -105,8 +112,9 @@ __global__ __launch_bounds__(TR_BLOCK) void k_trace(TraceArgs a)
     for (;;) {
         // ---- refill idle lanes -------------------------------------------------------------
         const unsigned long long idle = __ballot(!have);
-        if (idle != 0ull && !exhausted && (__popcll(idle) >= TR_REFILL_MIN || idle == ~0ull)) {
+        if (idle != 0ull && !exhausted && (__popcll(idle) >= a.refill_min || idle == ~0ull)) {
             const int n_idle = __popcll(idle);
+            if (COUNT) d_refills++;
             const int leader = __ffsll((long long)idle) - 1;
             int base = 0;
             if (lane == leader) base = atomicAdd(a.fetch, n_idle);
@@ -136,16 +144,28 @@ __global__ __launch_bounds__(TR_BLOCK) void k_trace(TraceArgs a)
             }
         }
         if (__ballot(have) == 0ull) break;
+        wave_par = __ballot(have && par) != 0ull;
+        if (COUNT) d_outer++;
 
-        // ---- inner nodes: until this lane reaches a leaf or runs out of stack ---------------
-        while (have && cur >= 0) {
+        // ---- inner nodes.  Lanes that reached a leaf (or finished) wait here; the loop goes on
+        // while at least node_min lanes still have inner-node work, or nobody is waiting at all.
+        for (;;) {
+            const bool act = have && cur >= 0;
+            const int n_act = __popcll(__ballot(act));
+            if (n_act == 0) break;
+            if (n_act < a.node_min && __ballot(have && cur < 0) != 0ull) break;
+            if (COUNT) { d_it_node++; d_lanes_node += (unsigned long long)n_act; }
+            if (!act) continue;
             const float4 *w = b.wnode + (size_t)cur * 4;
             const float4 q0 = w[0], q1 = w[1], q2 = w[2], q3 = w[3];
             const int cl = __float_as_int(q3.x), cr = __float_as_int(q3.y);
             if (COUNT) nbox += 2;
             float tl, tr;
             int pl, pr;
-            if (!par) {
+            if (!wave_par) {
+                pl = slabs_fast(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tl);
+                pr = slabs_fast(r, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tr);
+            } else if (!par) {
                 pl = slabs_fast(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tl);
                 pr = slabs_fast(r, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tr);
             } else {
@@ -170,7 +190,11 @@ __global__ __launch_bounds__(TR_BLOCK) void k_trace(TraceArgs a)
         }
 
         // ---- leaf: one primitive test ---------------------------------------------------------
-        if (have && cur != TR_SENT) {
+        if (COUNT) {
+            const int n_l = __popcll(__ballot(have && cur < 0 && cur != TR_SENT));
+            if (n_l) { d_it_leaf++; d_lanes_leaf += (unsigned long long)n_l; }
+        }
+        if (have && cur < 0 && cur != TR_SENT) {
             const int code = ~cur;
             const int prim = code & 0x3fffffff;
             const float4 *tp = b.tri + (size_t)prim * 3;
@@ -218,6 +242,11 @@ __global__ __launch_bounds__(TR_BLOCK) void k_trace(TraceArgs a)
                 atomicAdd(KIND == KIND_CLOSEST ? &a.ctr->leaf_closest : &a.ctr->leaf_shadow, sum_leaf);
             }
         }
+        if (COUNT && lane == 0) {
+            atomicAdd(&a.ctr->it_node, d_it_node); atomicAdd(&a.ctr->lanes_node, d_lanes_node);
+            atomicAdd(&a.ctr->it_leaf, d_it_leaf); atomicAdd(&a.ctr->lanes_leaf, d_lanes_leaf);
+            atomicAdd(&a.ctr->refills, d_refills); atomicAdd(&a.ctr->it_outer, d_outer);
+        }
         if (n_over) atomicAdd(&a.ctr->stack_overflow, n_over);
         if (gtid == 0) atomicAdd(KIND == KIND_CLOSEST ? &a.ctr->rays_closest : &a.ctr->rays_shadow, (unsigned long long)count);
     }
@@ -228,18 +257,22 @@ static void launch_trace(tirt_ctx *c, const TraceArgs &a, int flags, int grid)
 {
     const bool exh = (flags & TIRT_TRAVERSE_EXHAUSTIVE) != 0, cnt = (flags & TIRT_COUNT_NODES) != 0;
     dim3 g(grid), b(TR_BLOCK);
-    if (exh && cnt) hipLaunchKernelGGL((k_trace<TIRT_TRAVERSE_EXHAUSTIVE, true, KIND>), g, b, 0, c->stream, a);
-    else if (exh) hipLaunchKernelGGL((k_trace<TIRT_TRAVERSE_EXHAUSTIVE, false, KIND>), g, b, 0, c->stream, a);
-    else if (cnt) hipLaunchKernelGGL((k_trace<TIRT_TRAVERSE_ORDERED, true, KIND>), g, b, 0, c->stream, a);
-    else hipLaunchKernelGGL((k_trace<TIRT_TRAVERSE_ORDERED, false, KIND>), g, b, 0, c->stream, a);
+    const size_t lds = sizeof(int) * (size_t)a.lds_depth * TR_BLOCK;
+    if (exh && cnt) hipLaunchKernelGGL((k_trace<TIRT_TRAVERSE_EXHAUSTIVE, true, KIND>), g, b, lds, c->stream, a);
+    else if (exh) hipLaunchKernelGGL((k_trace<TIRT_TRAVERSE_EXHAUSTIVE, false, KIND>), g, b, lds, c->stream, a);
+    else if (cnt) hipLaunchKernelGGL((k_trace<TIRT_TRAVERSE_ORDERED, true, KIND>), g, b, lds, c->stream, a);
+    else hipLaunchKernelGGL((k_trace<TIRT_TRAVERSE_ORDERED, false, KIND>), g, b, lds, c->stream, a);
 }
 
 static int ensure_spill(tirt_ctx *c, int stack_size, int &spill_depth)
 {
     int cap = stack_size > 64 ? stack_size : 64;
-    spill_depth = cap - TR_LDS_DEPTH;
-    return c->spill.ensure(sizeof(int) * (size_t)spill_depth * TR_GRID * TR_BLOCK);
+    spill_depth = cap - c->tr_lds_depth;
+    if (spill_depth < 0) spill_depth = 0;
+    return c->spill.ensure(sizeof(int) * (size_t)(spill_depth > 0 ? spill_depth : 1) * TR_GRID_MAX * TR_BLOCK);
 }
+static void fill_tunables(const tirt_ctx *c, TraceArgs &a)
+{ a.lds_depth = c->tr_lds_depth; a.refill_min = c->tr_refill_min; a.node_min = c->tr_node_min; }
 
 // ---------------------------------------------------------------------------------------------
 // Batch entry points (Debug-integrator style closest hit on caller-supplied rays)
@@ -298,7 +331,8 @@ int launch_trace_batch(tirt_ctx *c, const float *rays, int nr, int stack_size, i
     if (c->counters_mem.ensure(sizeof(int) * 4 * 18)) return TIRT_ERR_HIP;
     TIRT_HIP(hipMemsetAsync(c->counters_mem.p, 0, sizeof(int), st));
     a.fetch = c->counters_mem.as<int>();
-    int grid = (nr + TR_BLOCK - 1) / TR_BLOCK; if (grid > TR_GRID) grid = TR_GRID;
+    fill_tunables(c, a);
+    int grid = (nr + TR_BLOCK - 1) / TR_BLOCK; if (grid > c->tr_grid) grid = c->tr_grid;
     launch_trace<KIND_CLOSEST>(c, a, flags, grid);
     if (!shadow) {
         hipLaunchKernelGGL(k_hit_attr, dim3((nr + B - 1) / B), dim3(B), 0, st, scene_view(c), nr, ox, oy, oz, dx, dy, dz, ht, hu, hv,
@@ -583,7 +617,7 @@ int pt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed,
         TIRT_HIP(hipMemsetAsync(c->counters_mem.p, 0, sizeof(int) * 4 * (size_t)(max_depth + 2), st));
         hipLaunchKernelGGL(k_generate, dim3((S + B - 1) / B), dim3(B), 0, st, c->ps, c->cam, tm, P, S, f0, seed, ctr);
         int *qcur = nullptr, *qnext = c->queue_a.as<int>(), *qother = c->queue_b.as<int>();
-        int grid_full = (S + TR_BLOCK - 1) / TR_BLOCK; if (grid_full > TR_GRID) grid_full = TR_GRID;
+        int grid_full = (S + TR_BLOCK - 1) / TR_BLOCK; if (grid_full > c->tr_grid) grid_full = c->tr_grid;
         for (int b = 0; b < max_depth; b++) {
             TraceArgs a = {};
             a.bvh = bv;
@@ -592,6 +626,7 @@ int pt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed,
             a.ht = c->ps.ht; a.hu = c->ps.hu; a.hv = c->ps.hv; a.hprim = c->ps.hprim;
             a.spill = c->spill.as<int>(); a.spill_depth = spill_depth; a.ctr = ctr; a.per_ray_counts = nullptr;
             a.fetch = &fetch_c[b];
+            fill_tunables(c, a);
             stamp(evc, true);
             launch_trace<KIND_CLOSEST>(c, a, flags, grid_full);
             stamp(evc, false);
@@ -612,6 +647,7 @@ int pt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed,
             sa.rr = c->ps.rr; sa.rg = c->ps.rg; sa.rb = c->ps.rb;
             sa.spill = c->spill.as<int>(); sa.spill_depth = spill_depth; sa.ctr = ctr; sa.per_ray_counts = nullptr;
             sa.fetch = &fetch_s[b];
+            fill_tunables(c, sa);
             stamp(evs, true);
             launch_trace<KIND_SHADOW_ACC>(c, sa, flags, grid_full);
             stamp(evs, false);
