@@ -47,6 +47,13 @@ def test_bit_exact(ctx, fn, name, gen):
     assert same.all(), "%s: %d / %d differ, first %r" % (name, (~same).sum(), x.size, x[~same][:4])
 
 
+def test_sincos_matches_separate_calls(ctx):
+    x = np.random.RandomState(5).uniform(-7, 7, 100000).astype(np.float32)
+    z = np.zeros_like(x)
+    assert np.array_equal(ctx.kat_math(10, x, z).view(np.uint32), host_math(0, x, z).view(np.uint32))
+    assert np.array_equal(ctx.kat_math(11, x, z).view(np.uint32), host_math(1, x, z).view(np.uint32))
+
+
 def test_special_values(ctx):
     x = np.array([0.0, -0.001, 1.0, 0.0, np.inf, -1.0, 4.0], np.float32)
     y = np.array([2.4, 5.0, 0.0, 0.0, 2.0, 0.5, 0.5], np.float32)

@@ -14,6 +14,7 @@ SceneView scene_view(const tirt_ctx *c)
     SceneView s;
     s.vertex = c->vertex.as<float>(); s.primitive = c->primitive.as<int>(); s.material = c->material.as<float>();
     s.shape = c->shape.as<float>(); s.light = c->light.as<int>(); s.env = c->env.as<int>();
+    s.mat_lrgb = c->mat_lrgb.as<float>();
     s.n = c->n; s.light_count = c->light_count; s.env_w = c->env_w; s.env_h = c->env_h; s.env_power = c->env_power;
     return s;
 }
@@ -31,6 +32,22 @@ int ensure_counters(tirt_ctx *c)
         if (c->dev_counters.ensure(sizeof(DevCounters))) return TIRT_ERR_HIP;
         TIRT_HIP(hipMemsetAsync(c->dev_counters.p, 0, sizeof(DevCounters), c->stream));
     }
+    return 0;
+}
+
+// ---- per-material srgb_to_lrgb(colour) table (integrator/PT_RGB.py:86 evaluates it per path vertex) ----
+__global__ void k_material_lrgb(const float *material, int nm, float *out)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nm) return;
+    const float *m = material + (size_t)i * MAT_VEC;
+    v3 c = srgb_to_lrgb(V(m[2], m[3], m[4]));
+    out[3 * i] = c.x; out[3 * i + 1] = c.y; out[3 * i + 2] = c.z;
+}
+static int refresh_material_table(tirt_ctx *c)
+{
+    if (c->mat_lrgb.ensure(sizeof(float) * 3 * (size_t)c->nm)) return TIRT_ERR_HIP;
+    hipLaunchKernelGGL(k_material_lrgb, dim3((c->nm + 63) / 64), dim3(64), 0, c->stream, c->material.as<float>(), c->nm, c->mat_lrgb.as<float>());
     return 0;
 }
 
@@ -120,6 +137,8 @@ __global__ void k_kat_math(int fn, const float *x, const float *y, float *out, i
         case 7: r = tm_sqrt(x[i]); break;
         case 8: r = x[i] / y[i]; break;
         case 9: r = tm_rand(tm_f2u(x[i]), tm_f2u(y[i]), 3u, 5u); break;
+        case 10: { float sn, cs; tm_sincos(x[i], &sn, &cs); r = sn; } break;
+        case 11: { float sn, cs; tm_sincos(x[i], &sn, &cs); r = cs; } break;
     }
     out[i] = r;
 }
@@ -200,7 +219,7 @@ void tirt_destroy(tirt_ctx *c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     drain_render_events(c);
-    DevBuf *bufs[] = {&c->vertex, &c->primitive, &c->material, &c->shape, &c->light, &c->env, &c->morton_unsorted, &c->keys_a,
+    DevBuf *bufs[] = {&c->vertex, &c->primitive, &c->material, &c->shape, &c->light, &c->env, &c->mat_lrgb, &c->morton_unsorted, &c->keys_a,
                       &c->keys_b, &c->vals_a, &c->vals_b, &c->hist, &c->morton_sorted, &c->bvh_node, &c->compact, &c->parent,
                       &c->flag, &c->subtree, &c->build_status, &c->leaf_compact, &c->wnode, &c->tri, &c->hdr, &c->rgb,
                       &c->path_mem, &c->queue_a, &c->queue_b, &c->queue_s, &c->counters_mem, &c->spill, &c->tr_rays,
@@ -265,6 +284,7 @@ int tirt_scene_upload(tirt_ctx *c, const float *vertex, int nv, const int32_t *p
     if (upload(c->light, light, sizeof(int) * (size_t)nl, st)) return TIRT_ERR_HIP;
     c->nv = nv; c->n = n; c->nm = nm; c->ns = ns; c->nl = nl; c->light_count = light_count;
     for (int k = 0; k < 3; k++) { c->bmin[k] = bmin[k]; c->bmax[k] = bmax[k]; }
+    if (refresh_material_table(c)) return TIRT_ERR_HIP;
     if (!c->env.p) {        // default: 1x1 black (Scene.py:295-296 loads image/black.png)
         int32_t z = 0;
         if (upload(c->env, &z, sizeof(int32_t), st)) return TIRT_ERR_HIP;
@@ -279,6 +299,7 @@ int tirt_material_upload(tirt_ctx *c, const float *material, int nm)
     CTX(c);
     TIRT_REQUIRE(material && nm == c->nm, "tirt_material_upload: material count differs from the uploaded scene");
     if (upload(c->material, material, sizeof(float) * 10 * (size_t)nm, c->stream)) return TIRT_ERR_HIP;
+    if (refresh_material_table(c)) return TIRT_ERR_HIP;
     TIRT_HIP(hipStreamSynchronize(c->stream));
     return TIRT_OK;
 }

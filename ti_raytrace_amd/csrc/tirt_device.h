@@ -51,6 +51,7 @@ struct SceneView {
     const float *shape;      // [ns*10]
     const int *light;        // [nl]
     const int *env;          // [w*h]
+    const float *mat_lrgb;   // [nm*3] srgb_to_lrgb(material colour), filled on device at upload
     int n, light_count, env_w, env_h;
     float env_power;
 };
@@ -208,8 +209,9 @@ TD v3 cosine_sample_hemisphere(float u1, float u2)
     float r = tm_sqrt(u1);
     float phi = two_pi * u2;
     v3 p;
-    p.x = r * tm_cos(phi);
-    p.y = r * tm_sin(phi);
+    float sn, cs; tm_sincos(phi, &sn, &cs);
+    p.x = r * cs;
+    p.y = r * sn;
     p.z = tm_sqrt(maxf(0.0f, 1.0f - p.x * p.x - p.y * p.y));
     return normalized(p);
 }
@@ -272,7 +274,7 @@ TD v3 disney_sample(const float *m, v3 dir, v3 N, float probability, float r1, f
         float phi = r1 * 2.0f * PI_UF;
         float cosTheta = tm_sqrt((1.0f - r2) / (1.0f + (specularAlpha * specularAlpha - 1.0f) * r2));
         float sinTheta = tm_sqrt(1.0f - (cosTheta * cosTheta));
-        float sinPhi = tm_sin(phi), cosPhi = tm_cos(phi);
+        float sinPhi, cosPhi; tm_sincos(phi, &sinPhi, &cosPhi);
         v3 half = V(sinTheta * cosPhi, sinTheta * sinPhi, cosTheta);
         half = inverse_transform(half, N);
         next_dir = reflect_(dir, half);
@@ -354,7 +356,8 @@ TD v3 uniform_sample_sphere(float u1, float u2)
     float z = 1.0f - 2.0f * u1;
     float r = tm_sqrt(clampf(1.0f - z * z, 0.0f, 1.0f));
     float phi = two_pi * u2;
-    return V(r * tm_cos(phi), r * tm_sin(phi), z);
+    float sn, cs; tm_sincos(phi, &sn, &cs);
+    return V(r * cs, r * sn, z);
 }
 // ---- Scene.py:381-420 ------------------------------------------------------------------------------------
 TD void get_prim_random_point_normal(const SceneView &s, int index, float a, float b, v3 &pos, v3 &nor)

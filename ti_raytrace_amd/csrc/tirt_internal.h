@@ -90,7 +90,7 @@ struct tirt_ctx {
     // scene (Scene.py fields)
     int nv = 0, n = 0, nm = 0, ns = 0, nl = 0, light_count = 0;
     float bmin[3] = {0, 0, 0}, bmax[3] = {0, 0, 0};
-    tirt::DevBuf vertex, primitive, material, shape, light, env;
+    tirt::DevBuf vertex, primitive, material, shape, light, env, mat_lrgb;
     int env_w = 0, env_h = 0; float env_power = 0.0f;
 
     // LBVH (accel/LBvh.py fields)

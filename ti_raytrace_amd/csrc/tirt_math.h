@@ -182,6 +182,18 @@ TM_HD float tm_cos(float x)
     return (float)(((q + 1) & 2) ? -v : v);
 }
 
+/* sin and cos of the same angle from ONE range reduction; bit-identical to tm_sin / tm_cos */
+TM_HD void tm_sincos(float x, float *s, float *c)
+{
+    if (x != x || x > 1.0e6f || x < -1.0e6f) { *s = tm_nan(); *c = tm_nan(); return; }
+    double r; int q = tm_reduce((double)x, &r) & 3;
+    double ks = tm_ksin(r), kc = tm_kcos(r);
+    double sv = (q & 1) ? kc : ks;
+    double cv = (q & 1) ? ks : kc;
+    *s = (float)((q & 2) ? -sv : sv);
+    *c = (float)(((q + 1) & 2) ? -cv : cv);
+}
+
 /* ---- atan / atan2 / acos ------------------------------------------------------------ */
 /* atan of z in [0,1]: table of atan(k/8) + odd series on the residual */
 TM_HD double tm_atan01(double z)

@@ -396,7 +396,10 @@ TD int queue_slot(bool want, int *counter)
     return want ? base + __popcll(mask & lt) : -1;
 }
 
-__global__ __launch_bounds__(256) void k_shade(PathState ps, SceneView sc, TileMap tm, int P, uint32_t frame_begin, uint32_t seed,
+#ifndef SH_MIN_WAVES
+#define SH_MIN_WAVES 3
+#endif
+__global__ __launch_bounds__(256, SH_MIN_WAVES) void k_shade(PathState ps, SceneView sc, TileMap tm, int P, uint32_t frame_begin, uint32_t seed,
                                              int bounce, const int *queue, const int *count_ptr, int count_fixed,
                                              int *next_queue, int *next_count, int *shadow_queue, int *shadow_count,
                                              DevCounters *ctr)
@@ -442,7 +445,8 @@ __global__ __launch_bounds__(256) void k_shade(PathState ps, SceneView sc, TileM
                     }
                 } else {
                     n_shaded++;
-                    const v3 reflect_color = srgb_to_lrgb(mat_color);
+                    // UF.srgb_to_lrgb(material colour) (PT_RGB.py:86): per-material table filled by the same device function
+                    const v3 reflect_color = V(sc.mat_lrgb[mat_id * 3], sc.mat_lrgb[mat_id * 3 + 1], sc.mat_lrgb[mat_id * 3 + 2]);
                     v3 next_dir; float f_or_b = 1.0f, brdf = 1.0f;
                     if (mat_type == MAT_GLASS) {                                       // PT_RGB.py:89-92
                         perfect_spec = 1;
