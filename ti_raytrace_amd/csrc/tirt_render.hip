@@ -140,6 +140,12 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
                     float tn;
                     if (!slabs(r, b.root_min[0], b.root_min[1], b.root_min[2], b.root_max[0], b.root_max[1], b.root_max[2], tn)) cur = TR_SENT;
                 }
+                // A ray with a NaN component passes every `slabs` test (all comparisons are false)
+                // and fails every primitive test, in the reference as well: it walks the whole tree
+                // and misses.  Same result, without the walk (ordered mode; the exhaustive mode keeps the walk).  (NaN shading normals come from
+                // process_normal's acos of a dot product just above 1, Scene.py:377.)
+                if (MODE != TIRT_TRAVERSE_EXHAUSTIVE &&
+                    !((o.x == o.x) & (o.y == o.y) & (o.z == o.z) & (d.x == d.x) & (d.y == d.y) & (d.z == d.z))) cur = TR_SENT;
                 have = true;
             }
         }
