@@ -182,13 +182,18 @@ def main():
         ctx.sync()
         t = ctx.stats()
         ctx.set_option("time_kernels", 0)
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if os.path.exists(tpath) and args.size == 1024 and args.ntri == 100000 and fps == 32 and world == 1:
+            tj = json.load(open(tpath)).get("k_trace<ordered,closest>", {})
+            traffic, traffic_src = tj.get("hbm_bytes_per_launch"), tj.get("source")
         n_launch = max(t["launches_trace_closest"], 1)
         avg_ms = t["ms_trace_closest"] / n_launch
         achieved = (alg_closest / n_launch) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         result["roofline"] = {
             "bound": "hbm", "kernel": "k_trace<ordered,closest>",
             "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
             "alg_bytes_per_launch": round(alg_closest / n_launch, 1),
             "avg_launch_ms": round(avg_ms, 5), "launches": int(n_launch),
             "alg_bytes_per_closest_ray": round(alg_closest / max(c["rays_closest"], 1), 1),

@@ -1,9 +1,10 @@
+# rocprofv3 passes on the GPU box (each counter group in its own run, as gpurun requires):
+#   bash tools/pmc_passes.sh <tag>      -> gpurun_out/<tag>_*/...
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
-B="python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline"
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/pmc_sq -- $B > $R/gpurun_out/pmc_sq.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $R/gpurun_out/pmc_sq2 -- $B > $R/gpurun_out/pmc_sq2.log 2>&1
-rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum --output-format csv -d $R/gpurun_out/pmc_tcc -- $B > $R/gpurun_out/pmc_tcc.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc_fetch -- $B > $R/gpurun_out/pmc_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc_write -- $B > $R/gpurun_out/pmc_write.log 2>&1
-find $R/gpurun_out -name "*counter_collection.csv" | head
+R=$GRAFT_REPO_ROOT; T=${1:-pmc}
+B="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline"
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${T}_stats -- $B > $R/gpurun_out/${T}_stats.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/${T}_sq -- $B > $R/gpurun_out/${T}_sq.log 2>&1
+rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum --output-format csv -d $R/gpurun_out/${T}_tcc -- $B > $R/gpurun_out/${T}_tcc.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/${T}_fetch -- $B > $R/gpurun_out/${T}_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/${T}_write -- $B > $R/gpurun_out/${T}_write.log 2>&1
