@@ -38,6 +38,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # one HW queue per render lane; before HIP initialises
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
@@ -56,6 +57,7 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-target-s", type=float, default=15.0, help="seconds of CPU-oracle work for cpu_baseline")
     ap.add_argument("--save-png", default="")
+    ap.add_argument("--emulate-world", type=int, default=0, help="render only rank 0's tiles of an N-rank job (scaling study on one GPU)")
     ap.add_argument("--opt", action="append", default=[], help="name=value passed to tirt_set_option (tuning)")
     return ap.parse_args()
 
@@ -86,7 +88,8 @@ def main():
     W = H = args.size
     total_frames = (args.warmup + args.steps) * args.frames_per_step
     ex = scenes.synthetic(W, H, max(total_frames, 4), ntri=args.ntri, device_id=local_rank, seed=args.seed,
-                          tile_rank=rank, tile_count=world, tile_size=args.tile_size)
+                          tile_rank=rank, tile_count=(args.emulate_world if args.emulate_world > 0 and world == 1 else world),
+                          tile_size=args.tile_size)
     t0 = time.time()
     ex.build_scene()
     ctx = ex.scene.ctx
@@ -176,7 +179,7 @@ def main():
         ctx.pt_rgb_render(f0, probe_frames, args.seed, 15, 64, _native.TRAVERSE_ORDERED | _native.COUNT_NODES)
         ctx.sync()
         co = ctx.stats()
-        ctx.set_option("time_kernels", 1)
+        ctx.set_option("time_kernels", 1)            # per-kernel HIP events; runs the batches on ONE lane (no overlap)
         ctx.stats_reset()
         ctx.pt_rgb_render(f0, probe_frames, args.seed, 15, 64, 0)
         ctx.sync()

@@ -66,6 +66,9 @@ void tirt_destroy(tirt_ctx *ctx);
 int tirt_sync(tirt_ctx *ctx);
 /* options: "time_kernels" (0/1) -- bracket every trace/shade launch with HIP events on the
  *            ctx stream so that tirt_stats reports per-kernel time (bench/roofline only)
+ *            (also confines the batches to one lane so that kernel times are not overlapped)
+ *          "overlap_lanes" (1..8, default 4) -- wavefront batches in flight on separate streams
+ *          "trace_lds_depth" / "trace_refill_min" / "trace_node_min" / "trace_grid" -- traversal tuning
  *          "batch_paths" -- pixel-samples kept in flight per wavefront batch (default 32 Mi,
  *            112 B of HBM each) */
 int tirt_set_option(tirt_ctx *ctx, const char *name, double value);

@@ -5,6 +5,13 @@ Modules keep the reference's names: ``SceneData``, ``Scene``, ``Camera``, ``LBvh
 The compute path is ``csrc/libtirt.so`` (hand-written HIP for gfx950) behind the C-ABI of
 ``include/tirt.h``; see DESIGN.md / INTEGRATION.md.
 """
+import os as _os
+
+# The render lanes (4 concurrent wavefront batches, see DESIGN.md) want one hardware queue each;
+# the ROCm runtime multiplexes streams onto GPU_MAX_HW_QUEUES (default 4) queues.  Must be set
+# before the HIP runtime initialises, hence here; an explicit user setting wins.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 from . import SceneData, UtilsFunc, Texture, Camera, LBvh, Scene, PT_RGB, Example  # noqa: F401
 
 __all__ = ["SceneData", "UtilsFunc", "Texture", "Camera", "LBvh", "Scene", "PT_RGB", "Example"]

@@ -26,6 +26,12 @@ BvhView bvh_view(const tirt_ctx *c)
     b.root_code = c->root_code;
     return b;
 }
+int sync_all(tirt_ctx *c)
+{
+    for (Lane &L : c->lanes) if (L.stream) TIRT_HIP(hipStreamSynchronize(L.stream));
+    TIRT_HIP(hipStreamSynchronize(c->stream));
+    return 0;
+}
 int ensure_counters(tirt_ctx *c)
 {
     if (!c->dev_counters.p) {
@@ -208,6 +214,11 @@ int tirt_create(int device_id, tirt_ctx **out)
     TIRT_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     TIRT_HIP(hipEventCreate(&c->ev0));
     TIRT_HIP(hipEventCreate(&c->ev1));
+    TIRT_HIP(hipEventCreateWithFlags(&c->ev_main, hipEventDisableTiming));
+    for (Lane &L : c->lanes) {
+        TIRT_HIP(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+        TIRT_HIP(hipEventCreateWithFlags(&L.film_done, hipEventDisableTiming));
+    }
     memset(&c->cam, 0, sizeof(c->cam));
     *out = c;
     return TIRT_OK;
@@ -217,18 +228,29 @@ void tirt_destroy(tirt_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    (void)sync_all(c);
     drain_render_events(c);
     DevBuf *bufs[] = {&c->vertex, &c->primitive, &c->material, &c->shape, &c->light, &c->env, &c->mat_lrgb, &c->morton_unsorted, &c->keys_a,
                       &c->keys_b, &c->vals_a, &c->vals_b, &c->hist, &c->morton_sorted, &c->bvh_node, &c->compact, &c->parent,
                       &c->flag, &c->subtree, &c->build_status, &c->leaf_compact, &c->wnode, &c->tri, &c->hdr, &c->rgb,
-                      &c->path_mem, &c->queue_a, &c->queue_b, &c->queue_s, &c->counters_mem, &c->spill, &c->tr_rays,
+                      &c->counters_mem, &c->spill, &c->tr_rays,
                       &c->tr_out, &c->tr_prim, &c->tr_counts, &c->dev_counters};
     for (DevBuf *b : bufs) b->release();
+    for (Lane &L : c->lanes) {
+        DevBuf *lb[] = {&L.path_mem, &L.queue_a, &L.queue_b, &L.queue_s, &L.counters_mem, &L.spill};
+        for (DevBuf *b : lb) b->release();
+        if (L.film_done) (void)hipEventDestroy(L.film_done);
+        if (L.stream) (void)hipStreamDestroy(L.stream);
+    }
+    if (c->ev_main) (void)hipEventDestroy(c->ev_main);
     (void)hipEventDestroy(c->ev0); (void)hipEventDestroy(c->ev1);
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
+
+// film readers/writers on the main stream run after the last film update of the render lanes
+#define AFTER_RENDER(c)                                                            \
+    do { if ((c)->last_film) TIRT_HIP(hipStreamWaitEvent((c)->stream, (c)->last_film, 0)); } while (0)
 
 #define CTX(c)                                                                     \
     TIRT_REQUIRE(c, "null context");                                               \
@@ -237,7 +259,7 @@ void tirt_destroy(tirt_ctx *c)
 int tirt_sync(tirt_ctx *c)
 {
     CTX(c);
-    TIRT_HIP(hipStreamSynchronize(c->stream));
+    if (sync_all(c)) return TIRT_ERR_HIP;
     TIRT_HIP(hipGetLastError());
     return TIRT_OK;
 }
@@ -247,6 +269,7 @@ int tirt_set_option(tirt_ctx *c, const char *name, double value)
     CTX(c);
     TIRT_REQUIRE(name, "tirt_set_option: null name");
     if (!strcmp(name, "time_kernels")) { c->time_kernels = value != 0.0; return TIRT_OK; }
+    if (!strcmp(name, "overlap_lanes")) { TIRT_REQUIRE(value >= 1.0 && value <= (double)TIRT_MAX_LANES, "overlap_lanes: 1..8"); if (sync_all(c)) return TIRT_ERR_HIP; c->n_lanes = (int)value; return TIRT_OK; }
     if (!strcmp(name, "batch_paths")) {
         TIRT_REQUIRE(value >= 1.0 && value <= 1.0e9, "tirt_set_option: batch_paths out of range");
         c->batch_paths = (size_t)value; return TIRT_OK;
@@ -399,6 +422,7 @@ int tirt_camera_set(tirt_ctx *c, const float view[16], const float view_inv[16],
 int tirt_film_create(tirt_ctx *c, int W, int H, int tile_rank, int tile_count, int tile_size)
 {
     CTX(c);
+    AFTER_RENDER(c);
     TIRT_REQUIRE(W >= 1 && H >= 1 && (long long)W * H < (1ll << 30), "tirt_film_create: bad size");
     TIRT_REQUIRE(tile_count >= 1 && tile_rank >= 0 && tile_rank < tile_count && tile_size >= 1, "tirt_film_create: bad tiling");
     const long NP = (long)W * H;
@@ -419,6 +443,7 @@ int tirt_film_create(tirt_ctx *c, int W, int H, int tile_rank, int tile_count, i
 int tirt_film_clear(tirt_ctx *c)
 {
     CTX(c);
+    AFTER_RENDER(c);
     TIRT_REQUIRE(c->hdr.p, "tirt_film_clear: film not created");
     TIRT_HIP(hipMemsetAsync(c->hdr.p, 0, sizeof(float) * 3 * (size_t)c->W * c->H, c->stream));
     TIRT_HIP(hipMemsetAsync(c->rgb.p, 0, sizeof(float) * 3 * (size_t)c->W * c->H, c->stream));
@@ -434,6 +459,7 @@ int tirt_pt_rgb_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint3
 int tirt_tone_map(tirt_ctx *c, float exposure)
 {
     CTX(c);
+    AFTER_RENDER(c);
     TIRT_REQUIRE(c->hdr.p, "tirt_tone_map: film not created");
     long nvals = 3l * c->W * c->H;
     hipLaunchKernelGGL(k_tone_map, dim3((unsigned)((nvals + 255) / 256)), dim3(256), 0, c->stream, c->hdr.as<float>(), c->rgb.as<float>(), nvals, exposure);
@@ -444,6 +470,7 @@ int tirt_tone_map(tirt_ctx *c, float exposure)
 int tirt_film_download(tirt_ctx *c, float *hdr, float *rgb)
 {
     CTX(c);
+    AFTER_RENDER(c);
     TIRT_REQUIRE(c->hdr.p, "tirt_film_download: film not created");
     size_t bytes = sizeof(float) * 3 * (size_t)c->W * c->H;
     if (hdr) TIRT_HIP(hipMemcpyAsync(hdr, c->hdr.p, bytes, hipMemcpyDeviceToHost, c->stream));
@@ -456,6 +483,7 @@ int tirt_film_download(tirt_ctx *c, float *hdr, float *rgb)
 int tirt_film_export_device(tirt_ctx *c, void *dev_dst)
 {
     CTX(c);
+    AFTER_RENDER(c);
     TIRT_REQUIRE(c->hdr.p && dev_dst, "tirt_film_export_device: film not created");
     TIRT_HIP(hipMemcpyAsync(dev_dst, c->hdr.p, sizeof(float) * 3 * (size_t)c->W * c->H, hipMemcpyDeviceToDevice, c->stream));
     TIRT_HIP(hipStreamSynchronize(c->stream));
@@ -465,6 +493,7 @@ int tirt_film_export_device(tirt_ctx *c, void *dev_dst)
 int tirt_film_import_device(tirt_ctx *c, const void *dev_src)
 {
     CTX(c);
+    AFTER_RENDER(c);
     TIRT_REQUIRE(c->hdr.p && dev_src, "tirt_film_import_device: film not created");
     TIRT_HIP(hipMemcpyAsync(c->hdr.p, dev_src, sizeof(float) * 3 * (size_t)c->W * c->H, hipMemcpyDeviceToDevice, c->stream));
     TIRT_HIP(hipStreamSynchronize(c->stream));
@@ -491,6 +520,7 @@ int tirt_stats(tirt_ctx *c, tirt_stats_t *out)
     TIRT_REQUIRE(out, "tirt_stats: null");
     if (ensure_counters(c)) return TIRT_ERR_HIP;
     DevCounters h;
+    if (sync_all(c)) return TIRT_ERR_HIP;
     TIRT_HIP(hipMemcpyAsync(&h, c->dev_counters.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
     TIRT_HIP(hipStreamSynchronize(c->stream));
     drain_render_events(c);
@@ -511,7 +541,7 @@ int tirt_stats_reset(tirt_ctx *c)
 {
     CTX(c);
     if (ensure_counters(c)) return TIRT_ERR_HIP;
-    TIRT_HIP(hipStreamSynchronize(c->stream));
+    if (sync_all(c)) return TIRT_ERR_HIP;
     drain_render_events(c);
     TIRT_HIP(hipMemsetAsync(c->dev_counters.p, 0, sizeof(DevCounters), c->stream));
     TIRT_HIP(hipStreamSynchronize(c->stream));

@@ -80,6 +80,18 @@ struct DevCounters {          // lives in device memory; accumulated by the kern
     unsigned long long it_node, lanes_node, it_leaf, lanes_leaf, refills, it_outer;
 };
 
+// One in-flight wavefront batch: its own stream, path state, queues and counters.  Two lanes
+// alternate, so that the latency-bound tail of one batch (a few long rays per bounce) overlaps
+// with the bulk of the next one.
+#define TIRT_MAX_LANES 8
+struct Lane {
+    hipStream_t stream = nullptr;
+    hipEvent_t film_done = nullptr; bool film_recorded = false;
+    size_t path_capacity = 0;
+    DevBuf path_mem, queue_a, queue_b, queue_s, counters_mem, spill;
+    PathState ps;
+};
+
 }  // namespace tirt
 
 struct tirt_ctx {
@@ -113,12 +125,15 @@ struct tirt_ctx {
     tirt::DevBuf hdr, rgb;
 
     // wavefront state
-    size_t path_capacity = 0;
+    tirt::Lane lanes[TIRT_MAX_LANES];
+    int n_lanes = 4;                               // option "overlap_lanes" (1..TIRT_MAX_LANES)
+    unsigned lane_cursor = 0;
+    hipEvent_t ev_main = nullptr;
+    hipEvent_t last_film = nullptr;               // film_done of the most recent batch (any lane)
     size_t batch_paths = (size_t)32 << 20;         // option "batch_paths"
     // traversal tunables (options "trace_lds_depth", "trace_refill_min", "trace_node_min", "trace_grid")
     int tr_lds_depth = 24, tr_refill_min = 36, tr_node_min = 12, tr_grid = 1536;
-    tirt::DevBuf path_mem, queue_a, queue_b, queue_s, counters_mem, spill;
-    tirt::PathState ps;
+    tirt::DevBuf counters_mem, spill;            // used by the batch trace entry points (main stream)
 
     // batch trace scratch
     tirt::DevBuf tr_rays, tr_out, tr_prim, tr_counts;
@@ -139,4 +154,5 @@ int launch_trace_batch(tirt_ctx *c, const float *rays, int nr, int stack_size, i
                        float *out_f, int32_t *out_prim, int32_t *counts);
 int pt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed, int max_depth, int stack_size, int flags);
 int ensure_counters(tirt_ctx *c);
+int sync_all(tirt_ctx *c);
 }  // namespace tirt

@@ -259,23 +259,23 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
 }
 
 template <int KIND>
-static void launch_trace(tirt_ctx *c, const TraceArgs &a, int flags, int grid)
+static void launch_trace(hipStream_t stream, const TraceArgs &a, int flags, int grid)
 {
     const bool exh = (flags & TIRT_TRAVERSE_EXHAUSTIVE) != 0, cnt = (flags & TIRT_COUNT_NODES) != 0;
     dim3 g(grid), b(TR_BLOCK);
     const size_t lds = sizeof(int) * (size_t)a.lds_depth * TR_BLOCK;
-    if (exh && cnt) hipLaunchKernelGGL((k_trace<TIRT_TRAVERSE_EXHAUSTIVE, true, KIND>), g, b, lds, c->stream, a);
-    else if (exh) hipLaunchKernelGGL((k_trace<TIRT_TRAVERSE_EXHAUSTIVE, false, KIND>), g, b, lds, c->stream, a);
-    else if (cnt) hipLaunchKernelGGL((k_trace<TIRT_TRAVERSE_ORDERED, true, KIND>), g, b, lds, c->stream, a);
-    else hipLaunchKernelGGL((k_trace<TIRT_TRAVERSE_ORDERED, false, KIND>), g, b, lds, c->stream, a);
+    if (exh && cnt) hipLaunchKernelGGL((k_trace<TIRT_TRAVERSE_EXHAUSTIVE, true, KIND>), g, b, lds, stream, a);
+    else if (exh) hipLaunchKernelGGL((k_trace<TIRT_TRAVERSE_EXHAUSTIVE, false, KIND>), g, b, lds, stream, a);
+    else if (cnt) hipLaunchKernelGGL((k_trace<TIRT_TRAVERSE_ORDERED, true, KIND>), g, b, lds, stream, a);
+    else hipLaunchKernelGGL((k_trace<TIRT_TRAVERSE_ORDERED, false, KIND>), g, b, lds, stream, a);
 }
 
-static int ensure_spill(tirt_ctx *c, int stack_size, int &spill_depth)
+static int ensure_spill(tirt_ctx *c, DevBuf &spill, int stack_size, int &spill_depth)
 {
     int cap = stack_size > 64 ? stack_size : 64;
     spill_depth = cap - c->tr_lds_depth;
     if (spill_depth < 0) spill_depth = 0;
-    return c->spill.ensure(sizeof(int) * (size_t)(spill_depth > 0 ? spill_depth : 1) * TR_GRID_MAX * TR_BLOCK);
+    return spill.ensure(sizeof(int) * (size_t)(spill_depth > 0 ? spill_depth : 1) * TR_GRID_MAX * TR_BLOCK);
 }
 static void fill_tunables(const tirt_ctx *c, TraceArgs &a)
 { a.lds_depth = c->tr_lds_depth; a.refill_min = c->tr_refill_min; a.node_min = c->tr_node_min; }
@@ -319,7 +319,7 @@ int launch_trace_batch(tirt_ctx *c, const float *rays, int nr, int stack_size, i
     if (c->tr_prim.ensure(sizeof(int) * (size_t)nr)) return TIRT_ERR_HIP;
     if (c->tr_counts.ensure(sizeof(int2) * (size_t)nr)) return TIRT_ERR_HIP;
     int spill_depth;
-    if (ensure_spill(c, stack_size, spill_depth)) return TIRT_ERR_HIP;
+    if (ensure_spill(c, c->spill, stack_size, spill_depth)) return TIRT_ERR_HIP;
     float *base = c->tr_out.as<float>();
     float *ox = base, *oy = ox + nr, *oz = oy + nr, *dx = oz + nr, *dy = dx + nr, *dz = dy + nr;
     float *ht = dz + nr, *hu = ht + nr, *hv = hu + nr, *attr = hv + nr;
@@ -339,7 +339,7 @@ int launch_trace_batch(tirt_ctx *c, const float *rays, int nr, int stack_size, i
     a.fetch = c->counters_mem.as<int>();
     fill_tunables(c, a);
     int grid = (nr + TR_BLOCK - 1) / TR_BLOCK; if (grid > c->tr_grid) grid = c->tr_grid;
-    launch_trace<KIND_CLOSEST>(c, a, flags, grid);
+    launch_trace<KIND_CLOSEST>(st, a, flags, grid);
     if (!shadow) {
         hipLaunchKernelGGL(k_hit_attr, dim3((nr + B - 1) / B), dim3(B), 0, st, scene_view(c), nr, ox, oy, oz, dx, dy, dz, ht, hu, hv,
                            c->tr_prim.as<int>(), attr);
@@ -564,14 +564,14 @@ __global__ void k_film(PathState ps, TileMap tm, int P, int F, uint32_t frame_be
     px[0] = r; px[1] = g; px[2] = b;
 }
 
-static int ensure_paths(tirt_ctx *c, size_t S, int max_depth)
+static int ensure_paths(Lane &L, size_t S, int max_depth)
 {
-    if (S > c->path_capacity || !c->path_mem.p) {
+    if (S > L.path_capacity || !L.path_mem.p) {
         const int nwords = 29;
-        if (c->path_mem.ensure(sizeof(float) * nwords * S)) return TIRT_ERR_HIP;
-        if (c->queue_a.ensure(sizeof(int) * S) || c->queue_b.ensure(sizeof(int) * S) || c->queue_s.ensure(sizeof(int) * S)) return TIRT_ERR_HIP;
-        float *w = c->path_mem.as<float>();
-        PathState &p = c->ps;
+        if (L.path_mem.ensure(sizeof(float) * nwords * S)) return TIRT_ERR_HIP;
+        if (L.queue_a.ensure(sizeof(int) * S) || L.queue_b.ensure(sizeof(int) * S) || L.queue_s.ensure(sizeof(int) * S)) return TIRT_ERR_HIP;
+        float *w = L.path_mem.as<float>();
+        PathState &p = L.ps;
         auto nxt = [&]() { float *r = w; w += S; return r; };
         p.ox = nxt(); p.oy = nxt(); p.oz = nxt(); p.dx = nxt(); p.dy = nxt(); p.dz = nxt();
         p.ht = nxt(); p.hu = nxt(); p.hv = nxt(); p.hprim = (int *)nxt();
@@ -579,9 +579,9 @@ static int ensure_paths(tirt_ctx *c, size_t S, int max_depth)
         p.brdf_pdf = nxt(); p.flags = (uint32_t *)nxt();
         p.sox = nxt(); p.soy = nxt(); p.soz = nxt(); p.sdx = nxt(); p.sdy = nxt(); p.sdz = nxt();
         p.scr = nxt(); p.scg = nxt(); p.scb = nxt(); p.sprim = (int *)nxt(); p.sdist = nxt();
-        c->path_capacity = S;
+        L.path_capacity = S;
     }
-    if (c->counters_mem.ensure(sizeof(int) * 4 * (size_t)(max_depth + 2))) return TIRT_ERR_HIP;
+    if (L.counters_mem.ensure(sizeof(int) * 4 * (size_t)(max_depth + 2))) return TIRT_ERR_HIP;
     return 0;
 }
 
@@ -593,90 +593,102 @@ int pt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed,
     TIRT_REQUIRE(frame_count >= 0 && max_depth >= 1 && max_depth <= 4096, "tirt_pt_rgb_render: bad frame_count/max_depth");
     if (frame_count == 0 || c->npix_local == 0) return TIRT_OK;
     if (ensure_counters(c)) return TIRT_ERR_HIP;
-    hipStream_t st = c->stream;
     const int P = (int)c->npix_local;
     // frames per batch: up to batch_paths pixel-samples in flight (the per-bounce launches of a
     // batch end in a latency-bound tail of a few long rays, so bigger batches amortise it)
     int FB = (int)(c->batch_paths / (size_t)P); if (FB < 1) FB = 1; if (FB > frame_count) FB = frame_count;
-    if (ensure_paths(c, (size_t)FB * P, max_depth)) return TIRT_ERR_HIP;
-    int spill_depth;
-    if (ensure_spill(c, stack_size, spill_depth)) return TIRT_ERR_HIP;
     const SceneView sv = scene_view(c);
     const BvhView bv = bvh_view(c);
     const TileMap tm = {c->tile_rank, c->tile_count, c->tile_size, c->H};
     DevCounters *ctr = c->dev_counters.as<DevCounters>();
-    int *cnt_path = c->counters_mem.as<int>();              // [max_depth+1]
-    int *cnt_shadow = cnt_path + (max_depth + 2);           // [max_depth]
-    int *fetch_c = cnt_shadow + (max_depth + 2), *fetch_s = fetch_c + (max_depth + 2);   // ray-fetch cursors
     const int B = 256;
-
-    hipEvent_t r0, r1;
-    TIRT_HIP(hipEventCreate(&r0)); TIRT_HIP(hipEventCreate(&r1));
-    TIRT_HIP(hipEventRecord(r0, st));
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> evc, evs, evh;     // closest / shadow / shade timing pairs
-    auto stamp = [&](std::vector<std::pair<hipEvent_t, hipEvent_t>> &v, bool begin) {
-        if (!c->time_kernels) return;
-        if (begin) { hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b); v.push_back({a, b}); (void)hipEventRecord(a, st); }
-        else (void)hipEventRecord(v.back().second, st);
-    };
+    // everything queued on the main stream (uploads, film clear, tone map) precedes the lanes' work
+    TIRT_HIP(hipEventRecord(c->ev_main, c->stream));
+    const int n_lanes = c->time_kernels ? 1 : c->n_lanes;
 
     for (int fb = 0; fb < frame_count; fb += FB) {
+        Lane &L = c->lanes[n_lanes == 1 ? 0 : (c->lane_cursor++ % (unsigned)n_lanes)];
+        hipStream_t st = L.stream;
         const int F = (frame_count - fb < FB) ? frame_count - fb : FB;
         const int S = F * P;
         const uint32_t f0 = frame_begin + (uint32_t)fb;
-        TIRT_HIP(hipMemsetAsync(c->counters_mem.p, 0, sizeof(int) * 4 * (size_t)(max_depth + 2), st));
-        hipLaunchKernelGGL(k_generate, dim3((S + B - 1) / B), dim3(B), 0, st, c->ps, c->cam, tm, P, S, f0, seed, ctr);
-        int *qcur = nullptr, *qnext = c->queue_a.as<int>(), *qother = c->queue_b.as<int>();
+        if (ensure_paths(L, (size_t)S, max_depth)) return TIRT_ERR_HIP;
+        int spill_depth;
+        if (ensure_spill(c, L.spill, stack_size, spill_depth)) return TIRT_ERR_HIP;
+        int *cnt_path = L.counters_mem.as<int>();               // [max_depth+2] live paths per bounce
+        int *cnt_shadow = cnt_path + (max_depth + 2);           // shadow rays per bounce
+        int *fetch_c = cnt_shadow + (max_depth + 2), *fetch_s = fetch_c + (max_depth + 2);   // ray-fetch cursors
+
+        TIRT_HIP(hipStreamWaitEvent(st, c->ev_main, 0));
+        hipEvent_t r0, r1;
+        TIRT_HIP(hipEventCreate(&r0)); TIRT_HIP(hipEventCreate(&r1));
+        TIRT_HIP(hipEventRecord(r0, st));
+        std::vector<std::pair<hipEvent_t, hipEvent_t>> evc, evs, evh;     // closest / shadow / shade timing pairs
+        auto stamp = [&](std::vector<std::pair<hipEvent_t, hipEvent_t>> &v, bool begin) {
+            if (!c->time_kernels) return;
+            if (begin) { hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b); v.push_back({a, b}); (void)hipEventRecord(a, st); }
+            else (void)hipEventRecord(v.back().second, st);
+        };
+
+        TIRT_HIP(hipMemsetAsync(L.counters_mem.p, 0, sizeof(int) * 4 * (size_t)(max_depth + 2), st));
+        hipLaunchKernelGGL(k_generate, dim3((S + B - 1) / B), dim3(B), 0, st, L.ps, c->cam, tm, P, S, f0, seed, ctr);
+        int *qcur = nullptr, *qnext = L.queue_a.as<int>(), *qother = L.queue_b.as<int>();
         int grid_full = (S + TR_BLOCK - 1) / TR_BLOCK; if (grid_full > c->tr_grid) grid_full = c->tr_grid;
         for (int b = 0; b < max_depth; b++) {
             TraceArgs a = {};
             a.bvh = bv;
-            a.ox = c->ps.ox; a.oy = c->ps.oy; a.oz = c->ps.oz; a.dx = c->ps.dx; a.dy = c->ps.dy; a.dz = c->ps.dz;
+            a.ox = L.ps.ox; a.oy = L.ps.oy; a.oz = L.ps.oz; a.dx = L.ps.dx; a.dy = L.ps.dy; a.dz = L.ps.dz;
             a.queue = qcur; a.count_ptr = (b == 0) ? nullptr : &cnt_path[b]; a.count_fixed = S;
-            a.ht = c->ps.ht; a.hu = c->ps.hu; a.hv = c->ps.hv; a.hprim = c->ps.hprim;
-            a.spill = c->spill.as<int>(); a.spill_depth = spill_depth; a.ctr = ctr; a.per_ray_counts = nullptr;
+            a.ht = L.ps.ht; a.hu = L.ps.hu; a.hv = L.ps.hv; a.hprim = L.ps.hprim;
+            a.spill = L.spill.as<int>(); a.spill_depth = spill_depth; a.ctr = ctr; a.per_ray_counts = nullptr;
             a.fetch = &fetch_c[b];
             fill_tunables(c, a);
             stamp(evc, true);
-            launch_trace<KIND_CLOSEST>(c, a, flags, grid_full);
+            launch_trace<KIND_CLOSEST>(st, a, flags, grid_full);
             stamp(evc, false);
             c->launches_trace_closest++;
 
             stamp(evh, true);
-            hipLaunchKernelGGL(k_shade, dim3(grid_full), dim3(B), 0, st, c->ps, sv, tm, P, f0, seed, b, qcur,
+            hipLaunchKernelGGL(k_shade, dim3(grid_full), dim3(B), 0, st, L.ps, sv, tm, P, f0, seed, b, qcur,
                                (b == 0) ? (const int *)nullptr : (const int *)&cnt_path[b], S, qnext, &cnt_path[b + 1],
-                               c->queue_s.as<int>(), &cnt_shadow[b], ctr);
+                               L.queue_s.as<int>(), &cnt_shadow[b], ctr);
             stamp(evh, false);
             c->launches_shade++;
 
             TraceArgs sa = {};
             sa.bvh = bv;
-            sa.ox = c->ps.sox; sa.oy = c->ps.soy; sa.oz = c->ps.soz; sa.dx = c->ps.sdx; sa.dy = c->ps.sdy; sa.dz = c->ps.sdz;
-            sa.queue = c->queue_s.as<int>(); sa.count_ptr = &cnt_shadow[b]; sa.count_fixed = 0;
-            sa.sprim = c->ps.sprim; sa.sdist = c->ps.sdist; sa.scr = c->ps.scr; sa.scg = c->ps.scg; sa.scb = c->ps.scb;
-            sa.rr = c->ps.rr; sa.rg = c->ps.rg; sa.rb = c->ps.rb;
-            sa.spill = c->spill.as<int>(); sa.spill_depth = spill_depth; sa.ctr = ctr; sa.per_ray_counts = nullptr;
+            sa.ox = L.ps.sox; sa.oy = L.ps.soy; sa.oz = L.ps.soz; sa.dx = L.ps.sdx; sa.dy = L.ps.sdy; sa.dz = L.ps.sdz;
+            sa.queue = L.queue_s.as<int>(); sa.count_ptr = &cnt_shadow[b]; sa.count_fixed = 0;
+            sa.sprim = L.ps.sprim; sa.sdist = L.ps.sdist; sa.scr = L.ps.scr; sa.scg = L.ps.scg; sa.scb = L.ps.scb;
+            sa.rr = L.ps.rr; sa.rg = L.ps.rg; sa.rb = L.ps.rb;
+            sa.spill = L.spill.as<int>(); sa.spill_depth = spill_depth; sa.ctr = ctr; sa.per_ray_counts = nullptr;
             sa.fetch = &fetch_s[b];
             fill_tunables(c, sa);
             stamp(evs, true);
-            launch_trace<KIND_SHADOW_ACC>(c, sa, flags, grid_full);
+            launch_trace<KIND_SHADOW_ACC>(st, sa, flags, grid_full);
             stamp(evs, false);
             c->launches_trace_shadow++;
 
             qcur = qnext; qnext = qother; qother = qcur;
         }
-        hipLaunchKernelGGL(k_film, dim3((P + B - 1) / B), dim3(B), 0, st, c->ps, tm, P, F, f0, c->hdr.as<float>());
+        // the running mean is order dependent: this batch's film update follows the previous batch's
+        if (c->last_film) TIRT_HIP(hipStreamWaitEvent(st, c->last_film, 0));
+        hipLaunchKernelGGL(k_film, dim3((P + B - 1) / B), dim3(B), 0, st, L.ps, tm, P, F, f0, c->hdr.as<float>());
+        TIRT_HIP(hipEventRecord(L.film_done, st));
+        L.film_recorded = true;
+        c->last_film = L.film_done;
+        TIRT_HIP(hipEventRecord(r1, st));
+        if (c->time_kernels) {
+            TIRT_HIP(hipStreamSynchronize(st));
+            auto drain = [&](std::vector<std::pair<hipEvent_t, hipEvent_t>> &v, double &acc) {
+                for (auto &pr : v) { float ms = 0; (void)hipEventElapsedTime(&ms, pr.first, pr.second); acc += ms; (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+                v.clear();
+            };
+            drain(evc, c->ms_trace_closest); drain(evs, c->ms_trace_shadow); drain(evh, c->ms_shade);
+        }
+        c->ev_pool.push_back({r0, r1});        // drained (and destroyed) by tirt_stats / tirt_stats_reset
     }
-    TIRT_HIP(hipEventRecord(r1, st));
-    if (c->time_kernels) {
-        TIRT_HIP(hipStreamSynchronize(st));
-        auto drain = [&](std::vector<std::pair<hipEvent_t, hipEvent_t>> &v, double &acc) {
-            for (auto &pr : v) { float ms = 0; (void)hipEventElapsedTime(&ms, pr.first, pr.second); acc += ms; (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
-            v.clear();
-        };
-        drain(evc, c->ms_trace_closest); drain(evs, c->ms_trace_shadow); drain(evh, c->ms_shade);
-    }
-    c->ev_pool.push_back({r0, r1});        // drained (and destroyed) by tirt_stats / tirt_stats_reset
+    // main-stream consumers of the film (tone map, downloads, clear) wait for c->last_film themselves
     TIRT_HIP(hipGetLastError());
     return TIRT_OK;
 }
