@@ -151,3 +151,51 @@ def test_cornell_full_config_matches_reference_out_png(gpu_ctx_ok):
     r = rel_l2(ours, ref)
     print("cornell 512^2 x512 vs out.png: mean err %s, block rel-L2 %.4f" % (np.round(mean_err, 4), r))
     assert (mean_err < 0.01).all() and r < 0.02
+
+
+def test_full_size_ordered_equals_reference_order(gpu_ctx_ok):
+    """BASELINE config 3 at its full 1024^2 size (4 frames): the product's ordered, t-culled
+    traversal and the reference's exhaustive visiting order (verified against the oracle at
+    reduced size above) produce the same film bit for bit, the same ray counts, and the
+    2-lane / 4-lane batch overlap does not change a bit either."""
+    W = H = 1024
+    ex = scenes.synthetic(W, H, 8, device_id=0)
+    ex.build_scene()
+    ctx = ex.scene.ctx
+    films, rays = [], []
+    for flags, lanes, batch in ((0, 4, 1 << 20), (_native.TRAVERSE_EXHAUSTIVE, 1, 32 << 20), (0, 1, 32 << 20)):
+        ctx.set_option("overlap_lanes", lanes)
+        ctx.set_option("batch_paths", batch)          # 1 Mi paths per batch -> 4 batches rotate over the lanes
+        ctx.film_clear(); ctx.stats_reset()
+        ctx.pt_rgb_render(0, 4, 1, 15, 64, flags)
+        films.append(ctx.film_download(W, H)[0])
+        st = ctx.stats()
+        rays.append((st["rays_closest"], st["rays_shadow"], st["shaded"], st["paths"]))
+        assert st["stack_overflow"] == 0
+    assert np.array_equal(films[0], films[1]) and np.array_equal(films[0], films[2])
+    assert rays[0] == rays[1] == rays[2]
+    assert np.isfinite(films[0]).all() and films[0].mean() > 0
+
+
+def test_abi_error_behaviour(gpu_ctx_ok):
+    """Call-order and argument errors come back as negative codes with a message, never a crash."""
+    ctx = _native.Context(0)
+    with pytest.raises(_native.TirtError, match="not built"):
+        ctx.pt_rgb_render(0, 1, 1)
+    with pytest.raises(_native.TirtError, match="no primitives"):
+        ctx.lbvh_build()
+    v = np.zeros((3, 9), np.float32); m = np.zeros((1, 10), np.float32); s = np.zeros((1, 10), np.float32)
+    good = np.array([[1, 0, 0]], np.int32)
+    for bad in (np.array([[1, 1, 0]], np.int32), np.array([[1, 0, 5]], np.int32), np.array([[2, 3, 0]], np.int32)):
+        with pytest.raises(_native.TirtError, match="out of range"):
+            ctx.scene_upload(v, bad, m, s, np.zeros(1, np.int32), 0, np.zeros(3), np.ones(3))
+    with pytest.raises(_native.TirtError, match="out of range"):
+        ctx.scene_upload(v, good, m, s, np.array([7], np.int32), 1, np.zeros(3), np.ones(3))
+    ctx.scene_upload(v, good, m, s, np.zeros(1, np.int32), 0, np.zeros(3), np.ones(3))
+    with pytest.raises(_native.TirtError, match="bad size"):
+        ctx.film_create(0, 16)
+    with pytest.raises(_native.TirtError, match="unknown option"):
+        ctx.set_option("nonsense", 1)
+    with pytest.raises(_native.TirtError):
+        _native.Context(9999)
+    ctx.close()
