@@ -61,16 +61,26 @@ struct BvhView {
     int root_code;
 };
 
-// Per-path wavefront state, struct-of-arrays in HBM (capacity = paths per batch).
-struct PathState {
+// Wavefront state, struct-of-arrays in HBM.  Live paths are kept DENSE: every bounce the shade
+// kernel writes the surviving paths' state into the other PathSoA at consecutive indices
+// (wave-ballot compaction), so the trace and shade kernels stream their inputs with fully
+// coalesced 4-byte-per-lane accesses instead of gathering through a slot list.
+struct PathSoA {
     float *ox, *oy, *oz, *dx, *dy, *dz;          // current ray
-    float *ht, *hu, *hv; int *hprim;            // closest hit of the current ray
     float *tr, *tg, *tb;                         // throughput
-    float *rr, *rg, *rb;                         // radiance of this pixel-sample
+    float *rr, *rg, *rb;                         // radiance so far
     float *brdf_pdf; uint32_t *flags;           // bit0 perfect_spec
-    float *sox, *soy, *soz, *sdx, *sdy, *sdz;    // shadow ray (origin on the light)
+    int *slot;                                   // path id = frame_in_batch * P + local pixel
+};
+struct PathState {
+    PathSoA st[2];                               // ping-pong: bounce b reads st[b&1], writes st[(b+1)&1]
+    float *ht, *hu, *hv; int *hprim;            // closest hit of ray q (written by trace, read by shade)
+    float *sox, *soy, *soz, *sdx, *sdy, *sdz;    // shadow rays (dense, origin on the light)
     float *scr, *scg, *scb; int *sprim;         // contribution if sprim is the closest hit
     float *sdist;                               // distance light point -> shaded point
+    int *sdst;                                   // where the contribution goes: >= 0 index in the next
+                                                 // PathSoA (path continues), < 0: ~slot in the final radiance
+    float *fr, *fg, *fb;                         // final radiance per path id (read by k_film)
 };
 
 struct DevCounters {          // lives in device memory; accumulated by the kernels

@@ -37,11 +37,11 @@ enum { KIND_CLOSEST = 0, KIND_SHADOW_ACC = 1 };
 
 struct TraceArgs {
     BvhView bvh;
-    const float *ox, *oy, *oz, *dx, *dy, *dz;    // rays, indexed by slot
-    const int *queue;                            // slot list (nullptr: slot = index)
+    const float *ox, *oy, *oz, *dx, *dy, *dz;    // rays, dense: ray q at index q
     const int *count_ptr; int count_fixed;       // number of rays: *count_ptr if non-null
-    float *ht, *hu, *hv; int *hprim;             // KIND_CLOSEST outputs, indexed by slot
-    const int *sprim; const float *sdist, *scr, *scg, *scb; float *rr, *rg, *rb;   // KIND_SHADOW_ACC
+    float *ht, *hu, *hv; int *hprim;             // KIND_CLOSEST outputs, index q
+    // KIND_SHADOW_ACC: contribution of ray q goes to (rr,rg,rb)[sdst[q]] or (fr,fg,fb)[~sdst[q]]
+    const int *sprim, *sdst; const float *sdist, *scr, *scg, *scb; float *rr, *rg, *rb, *fr, *fg, *fb;
     int *spill; int spill_depth;                 // global stack tail: [entry][global thread]
     int *fetch;                                  // ray-fetch cursor of this launch (zero on entry)
     int lds_depth;                               // stack entries per lane kept in LDS
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
 
     // per-lane ray state
     bool have = false, par = false, overflow = false;
-    int slot = 0, q = 0, cur = TR_SENT, sp = 0, hit_prim = -1, hit_leaf = -1, expect = -3;
+    int q = 0, cur = TR_SENT, sp = 0, hit_prim = -1, hit_leaf = -1, expect = -3;
     float hit_t = INF_VALUE, hit_u = 0.0f, hit_v = 0.0f, cull_far = 3.0e38f, settle = -1.0f;
     unsigned nbox = 0, nleaf = 0;
     RayCtx r = {};
@@ -123,18 +123,17 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
             const int my = base + __popcll(idle & lt_mask);
             if (!have && my < count) {
                 q = my;
-                slot = a.queue ? a.queue[my] : my;
-                const v3 o = V(a.ox[slot], a.oy[slot], a.oz[slot]);
-                const v3 d = V(a.dx[slot], a.dy[slot], a.dz[slot]);
+                const v3 o = V(a.ox[q], a.oy[q], a.oz[q]);
+                const v3 d = V(a.dx[q], a.dy[q], a.dz[q]);
                 r = make_ray(o, d);
                 par = ray_has_parallel_axis(r);
                 hit_t = INF_VALUE; hit_u = 0.0f; hit_v = 0.0f; hit_prim = -1; hit_leaf = -1;
                 nbox = 1; nleaf = 0; sp = 0; overflow = false;
                 if (BOUNDED) {
-                    const float t_bound = a.sdist[slot];
-                    expect = a.sprim[slot];
+                    const float t_bound = a.sdist[q];
+                    expect = a.sprim[q];
                     cull_far = t_bound * 1.01f; settle = t_bound * 0.99f;
-                } else if (SHADOW) expect = a.sprim[slot];
+                } else if (SHADOW) expect = a.sprim[q];
                 cur = b.root_code;
                 if (cur >= 0) {
                     float tn;
@@ -226,11 +225,13 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
         // ---- finished rays write back and free their lane ---------------------------------------
         if (have && cur == TR_SENT) {
             if (KIND == KIND_CLOSEST) {
-                a.ht[slot] = hit_t; a.hu[slot] = hit_u; a.hv[slot] = hit_v; a.hprim[slot] = hit_prim;
+                a.ht[q] = hit_t; a.hu[q] = hit_u; a.hv[q] = hit_v; a.hprim[q] = hit_prim;
             } else if (hit_prim == expect) {                 // integrator/PT_RGB.py:105-109
-                a.rr[slot] = a.rr[slot] + a.scr[slot];
-                a.rg[slot] = a.rg[slot] + a.scg[slot];
-                a.rb[slot] = a.rb[slot] + a.scb[slot];
+                const int dst = a.sdst[q];
+                float *pr = dst >= 0 ? a.rr + dst : a.fr + ~dst;
+                float *pg = dst >= 0 ? a.rg + dst : a.fg + ~dst;
+                float *pb = dst >= 0 ? a.rb + dst : a.fb + ~dst;
+                *pr = *pr + a.scr[q]; *pg = *pg + a.scg[q]; *pb = *pb + a.scb[q];
             }
             if (COUNT) {
                 sum_box += nbox; sum_leaf += nleaf;
@@ -329,7 +330,7 @@ int launch_trace_batch(tirt_ctx *c, const float *rays, int nr, int stack_size, i
     TraceArgs a = {};
     a.bvh = bvh_view(c);
     a.ox = ox; a.oy = oy; a.oz = oz; a.dx = dx; a.dy = dy; a.dz = dz;
-    a.queue = nullptr; a.count_ptr = nullptr; a.count_fixed = nr;
+    a.count_ptr = nullptr; a.count_fixed = nr;
     a.ht = ht; a.hu = hu; a.hv = hv; a.hprim = c->tr_prim.as<int>();
     a.spill = c->spill.as<int>(); a.spill_depth = spill_depth;
     a.ctr = c->dev_counters.as<DevCounters>();
@@ -365,7 +366,7 @@ TD int local_to_pixel(const TileMap &m, int k)
     return (lt * m.tile_count + m.tile_rank) * m.tile_size + within;
 }
 
-__global__ void k_generate(PathState ps, CameraView cam, TileMap tm, int P, int S, uint32_t frame_begin, uint32_t seed,
+__global__ void k_generate(PathSoA ps, CameraView cam, TileMap tm, int P, int S, uint32_t frame_begin, uint32_t seed,
                            DevCounters *ctr)
 {
     int s = blockIdx.x * blockDim.x + threadIdx.x;
@@ -384,7 +385,7 @@ __global__ void k_generate(PathState ps, CameraView cam, TileMap tm, int P, int 
     ps.dx[s] = d.x; ps.dy[s] = d.y; ps.dz[s] = d.z;
     ps.tr[s] = 1.0f; ps.tg[s] = 1.0f; ps.tb[s] = 1.0f;
     ps.rr[s] = 0.0f; ps.rg[s] = 0.0f; ps.rb[s] = 0.0f;
-    ps.brdf_pdf[s] = 1.0f; ps.flags[s] = 1u;
+    ps.brdf_pdf[s] = 1.0f; ps.flags[s] = 1u; ps.slot[s] = s;
     if (s == 0) atomicAdd(&ctr->paths, (unsigned long long)S);
 }
 
@@ -405,10 +406,10 @@ TD int queue_slot(bool want, int *counter)
 #ifndef SH_MIN_WAVES
 #define SH_MIN_WAVES 3
 #endif
-__global__ __launch_bounds__(256, SH_MIN_WAVES) void k_shade(PathState ps, SceneView sc, TileMap tm, int P, uint32_t frame_begin, uint32_t seed,
-                                             int bounce, const int *queue, const int *count_ptr, int count_fixed,
-                                             int *next_queue, int *next_count, int *shadow_queue, int *shadow_count,
-                                             DevCounters *ctr)
+__global__ __launch_bounds__(256, SH_MIN_WAVES) void k_shade(PathState ps, PathSoA in, PathSoA out, SceneView sc, TileMap tm, int P,
+                                                           uint32_t frame_begin, uint32_t seed, int bounce, int last_bounce,
+                                                           const int *count_ptr, int count_fixed, int *next_count,
+                                                           int *shadow_count, DevCounters *ctr)
 {
     const int count = count_ptr ? *count_ptr : count_fixed;
     const int total = gridDim.x * blockDim.x;
@@ -418,22 +419,25 @@ __global__ __launch_bounds__(256, SH_MIN_WAVES) void k_shade(PathState ps, Scene
         const int q = it * total + blockIdx.x * blockDim.x + threadIdx.x;
         bool live = q < count, want_next = false, want_shadow = false;
         int slot = 0;
+        v3 radiance = V(0.0f, 0.0f, 0.0f), next_o = radiance, next_d = radiance, next_thr = radiance;
+        v3 sh_o = radiance, sh_d = radiance, sh_c = radiance;
+        float next_pdf = 0.0f, sh_dist = 0.0f; int next_spec = 0, sh_expect = -2;
         if (live) {
-            slot = queue ? queue[q] : q;
+            slot = in.slot[q];
             const int f = slot / P, k = slot - f * P;
             const uint32_t pixel = (uint32_t)local_to_pixel(tm, k);
             const uint32_t frame = frame_begin + (uint32_t)f;
             const uint32_t dim0 = TM_DIM_BOUNCE0 + TM_DIMS_PER_BOUNCE * (uint32_t)bounce;
-            const v3 origin = V(ps.ox[slot], ps.oy[slot], ps.oz[slot]);
-            const v3 direction = V(ps.dx[slot], ps.dy[slot], ps.dz[slot]);
-            const float t = ps.ht[slot];
-            v3 throughout = V(ps.tr[slot], ps.tg[slot], ps.tb[slot]);
-            v3 radiance = V(ps.rr[slot], ps.rg[slot], ps.rb[slot]);
-            float brdf_pdf = ps.brdf_pdf[slot];
-            int perfect_spec = (int)(ps.flags[slot] & 1u);
+            const v3 origin = V(in.ox[q], in.oy[q], in.oz[q]);
+            const v3 direction = V(in.dx[q], in.dy[q], in.dz[q]);
+            const float t = ps.ht[q];
+            v3 throughout = V(in.tr[q], in.tg[q], in.tb[q]);
+            radiance = V(in.rr[q], in.rg[q], in.rb[q]);
+            float brdf_pdf = in.brdf_pdf[q];
+            int perfect_spec = (int)(in.flags[q] & 1u);
             if (t < INF_VALUE) {
-                const int prim_id = ps.hprim[slot];
-                const HitAttr h = hit_attributes(sc, origin, direction, prim_id, t, ps.hu[slot], ps.hv[slot]);
+                const int prim_id = ps.hprim[q];
+                const HitAttr h = hit_attributes(sc, origin, direction, prim_id, t, ps.hu[q], ps.hv[q]);
                 const v3 normal = h.nor;
                 const v3 fnormal = normal * signf(dot(-direction, h.gnor));            // UtilsFunc.py:465-467
                 const int mat_id = sc.primitive[(size_t)prim_id * PRI_VEC + 2];
@@ -495,11 +499,7 @@ __global__ __launch_bounds__(256, SH_MIN_WAVES) void k_shade(PathState ps, Scene
                                 c = c * absf(NdotL_surface);
                                 expect = prim_id;
                             }
-                            ps.sox[slot] = light_pos.x; ps.soy[slot] = light_pos.y; ps.soz[slot] = light_pos.z;
-                            ps.sdx[slot] = light_dir.x; ps.sdy[slot] = light_dir.y; ps.sdz[slot] = light_dir.z;
-                            ps.scr[slot] = c.x; ps.scg[slot] = c.y; ps.scb[slot] = c.z;
-                            ps.sprim[slot] = expect;
-                            ps.sdist[slot] = light_dist;
+                            sh_o = light_pos; sh_d = light_dir; sh_c = c; sh_expect = expect; sh_dist = light_dist;
                         }
                         next_dir = disney_sample(m, direction, fnormal, tm_rand(seed, pixel, frame, dim0 + TM_SLOT_LOBE),
                                                  tm_rand(seed, pixel, frame, dim0 + TM_SLOT_R1),
@@ -518,12 +518,9 @@ __global__ __launch_bounds__(256, SH_MIN_WAVES) void k_shade(PathState ps, Scene
                         }
                         if (alive) {
                             throughout = throughout * (reflect_color * (brdf / brdf_pdf));
-                            want_next = true;
-                            ps.ox[slot] = next_origin.x; ps.oy[slot] = next_origin.y; ps.oz[slot] = next_origin.z;
-                            ps.dx[slot] = next_dir.x; ps.dy[slot] = next_dir.y; ps.dz[slot] = next_dir.z;
-                            ps.tr[slot] = throughout.x; ps.tg[slot] = throughout.y; ps.tb[slot] = throughout.z;
-                            ps.brdf_pdf[slot] = brdf_pdf;
-                            ps.flags[slot] = (uint32_t)perfect_spec;
+                            want_next = !last_bounce;      // depth reaches MAX_DEPTH after the last bounce: the loop ends
+                            next_o = next_origin; next_d = next_dir; next_thr = throughout;
+                            next_pdf = brdf_pdf; next_spec = perfect_spec;
                         }
                     }
                 }
@@ -534,12 +531,28 @@ __global__ __launch_bounds__(256, SH_MIN_WAVES) void k_shade(PathState ps, Scene
                 const v3 e = srgb_to_lrgb(texture2d(sc, tx, ty));
                 radiance = radiance + (e * throughout) * sc.env_power;
             }
-            ps.rr[slot] = radiance.x; ps.rg[slot] = radiance.y; ps.rb[slot] = radiance.z;
+        }
+        // dense compaction: survivors go to consecutive indices of the other PathSoA, finished
+        // paths deposit their radiance in the per-path final array, shadow rays get their own
+        // dense list with the address their contribution must be added to
+        const int qn = queue_slot(want_next, next_count);
+        if (want_next) {
+            out.ox[qn] = next_o.x; out.oy[qn] = next_o.y; out.oz[qn] = next_o.z;
+            out.dx[qn] = next_d.x; out.dy[qn] = next_d.y; out.dz[qn] = next_d.z;
+            out.tr[qn] = next_thr.x; out.tg[qn] = next_thr.y; out.tb[qn] = next_thr.z;
+            out.rr[qn] = radiance.x; out.rg[qn] = radiance.y; out.rb[qn] = radiance.z;
+            out.brdf_pdf[qn] = next_pdf; out.flags[qn] = (uint32_t)next_spec; out.slot[qn] = slot;
+        } else if (live) {
+            ps.fr[slot] = radiance.x; ps.fg[slot] = radiance.y; ps.fb[slot] = radiance.z;
         }
         const int qs = queue_slot(want_shadow, shadow_count);
-        if (want_shadow) shadow_queue[qs] = slot;
-        const int qn = queue_slot(want_next, next_count);
-        if (want_next) next_queue[qn] = slot;
+        if (want_shadow) {
+            ps.sox[qs] = sh_o.x; ps.soy[qs] = sh_o.y; ps.soz[qs] = sh_o.z;
+            ps.sdx[qs] = sh_d.x; ps.sdy[qs] = sh_d.y; ps.sdz[qs] = sh_d.z;
+            ps.scr[qs] = sh_c.x; ps.scg[qs] = sh_c.y; ps.scb[qs] = sh_c.z;
+            ps.sprim[qs] = sh_expect; ps.sdist[qs] = sh_dist;
+            ps.sdst[qs] = want_next ? qn : ~slot;
+        }
     }
     n_shaded = wave_sum(n_shaded);
     if ((threadIdx.x & 63) == 0 && n_shaded) atomicAdd(&ctr->shaded, n_shaded);
@@ -557,9 +570,9 @@ __global__ void k_film(PathState ps, TileMap tm, int P, int F, uint32_t frame_be
         int s = f * P + k;
         float frame = (float)(int)(frame_begin + (uint32_t)f);
         float coff = 1.0f / (frame + 1.0f);
-        r = ps.rr[s] * coff + r * (1.0f - coff);
-        g = ps.rg[s] * coff + g * (1.0f - coff);
-        b = ps.rb[s] * coff + b * (1.0f - coff);
+        r = ps.fr[s] * coff + r * (1.0f - coff);
+        g = ps.fg[s] * coff + g * (1.0f - coff);
+        b = ps.fb[s] * coff + b * (1.0f - coff);
     }
     px[0] = r; px[1] = g; px[2] = b;
 }
@@ -567,18 +580,21 @@ __global__ void k_film(PathState ps, TileMap tm, int P, int F, uint32_t frame_be
 static int ensure_paths(Lane &L, size_t S, int max_depth)
 {
     if (S > L.path_capacity || !L.path_mem.p) {
-        const int nwords = 29;
+        const int nwords = 2 * 15 + 4 + 12 + 3;
         if (L.path_mem.ensure(sizeof(float) * nwords * S)) return TIRT_ERR_HIP;
-        if (L.queue_a.ensure(sizeof(int) * S) || L.queue_b.ensure(sizeof(int) * S) || L.queue_s.ensure(sizeof(int) * S)) return TIRT_ERR_HIP;
         float *w = L.path_mem.as<float>();
         PathState &p = L.ps;
         auto nxt = [&]() { float *r = w; w += S; return r; };
-        p.ox = nxt(); p.oy = nxt(); p.oz = nxt(); p.dx = nxt(); p.dy = nxt(); p.dz = nxt();
+        for (int k = 0; k < 2; k++) {
+            PathSoA &q = p.st[k];
+            q.ox = nxt(); q.oy = nxt(); q.oz = nxt(); q.dx = nxt(); q.dy = nxt(); q.dz = nxt();
+            q.tr = nxt(); q.tg = nxt(); q.tb = nxt(); q.rr = nxt(); q.rg = nxt(); q.rb = nxt();
+            q.brdf_pdf = nxt(); q.flags = (uint32_t *)nxt(); q.slot = (int *)nxt();
+        }
         p.ht = nxt(); p.hu = nxt(); p.hv = nxt(); p.hprim = (int *)nxt();
-        p.tr = nxt(); p.tg = nxt(); p.tb = nxt(); p.rr = nxt(); p.rg = nxt(); p.rb = nxt();
-        p.brdf_pdf = nxt(); p.flags = (uint32_t *)nxt();
         p.sox = nxt(); p.soy = nxt(); p.soz = nxt(); p.sdx = nxt(); p.sdy = nxt(); p.sdz = nxt();
-        p.scr = nxt(); p.scg = nxt(); p.scb = nxt(); p.sprim = (int *)nxt(); p.sdist = nxt();
+        p.scr = nxt(); p.scg = nxt(); p.scb = nxt(); p.sprim = (int *)nxt(); p.sdist = nxt(); p.sdst = (int *)nxt();
+        p.fr = nxt(); p.fg = nxt(); p.fb = nxt();
         L.path_capacity = S;
     }
     if (L.counters_mem.ensure(sizeof(int) * 4 * (size_t)(max_depth + 2))) return TIRT_ERR_HIP;
@@ -631,14 +647,14 @@ int pt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed,
         };
 
         TIRT_HIP(hipMemsetAsync(L.counters_mem.p, 0, sizeof(int) * 4 * (size_t)(max_depth + 2), st));
-        hipLaunchKernelGGL(k_generate, dim3((S + B - 1) / B), dim3(B), 0, st, L.ps, c->cam, tm, P, S, f0, seed, ctr);
-        int *qcur = nullptr, *qnext = L.queue_a.as<int>(), *qother = L.queue_b.as<int>();
+        hipLaunchKernelGGL(k_generate, dim3((S + B - 1) / B), dim3(B), 0, st, L.ps.st[0], c->cam, tm, P, S, f0, seed, ctr);
         int grid_full = (S + TR_BLOCK - 1) / TR_BLOCK; if (grid_full > c->tr_grid) grid_full = c->tr_grid;
         for (int b = 0; b < max_depth; b++) {
             TraceArgs a = {};
             a.bvh = bv;
-            a.ox = L.ps.ox; a.oy = L.ps.oy; a.oz = L.ps.oz; a.dx = L.ps.dx; a.dy = L.ps.dy; a.dz = L.ps.dz;
-            a.queue = qcur; a.count_ptr = (b == 0) ? nullptr : &cnt_path[b]; a.count_fixed = S;
+            const PathSoA &in = L.ps.st[b & 1], &out = L.ps.st[(b + 1) & 1];
+            a.ox = in.ox; a.oy = in.oy; a.oz = in.oz; a.dx = in.dx; a.dy = in.dy; a.dz = in.dz;
+            a.count_ptr = (b == 0) ? nullptr : &cnt_path[b]; a.count_fixed = S;
             a.ht = L.ps.ht; a.hu = L.ps.hu; a.hv = L.ps.hv; a.hprim = L.ps.hprim;
             a.spill = L.spill.as<int>(); a.spill_depth = spill_depth; a.ctr = ctr; a.per_ray_counts = nullptr;
             a.fetch = &fetch_c[b];
@@ -649,18 +665,18 @@ int pt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed,
             c->launches_trace_closest++;
 
             stamp(evh, true);
-            hipLaunchKernelGGL(k_shade, dim3(grid_full), dim3(B), 0, st, L.ps, sv, tm, P, f0, seed, b, qcur,
-                               (b == 0) ? (const int *)nullptr : (const int *)&cnt_path[b], S, qnext, &cnt_path[b + 1],
-                               L.queue_s.as<int>(), &cnt_shadow[b], ctr);
+            hipLaunchKernelGGL(k_shade, dim3(grid_full), dim3(B), 0, st, L.ps, in, out, sv, tm, P, f0, seed, b,
+                               (b == max_depth - 1) ? 1 : 0, (b == 0) ? (const int *)nullptr : (const int *)&cnt_path[b], S,
+                               &cnt_path[b + 1], &cnt_shadow[b], ctr);
             stamp(evh, false);
             c->launches_shade++;
 
             TraceArgs sa = {};
             sa.bvh = bv;
             sa.ox = L.ps.sox; sa.oy = L.ps.soy; sa.oz = L.ps.soz; sa.dx = L.ps.sdx; sa.dy = L.ps.sdy; sa.dz = L.ps.sdz;
-            sa.queue = L.queue_s.as<int>(); sa.count_ptr = &cnt_shadow[b]; sa.count_fixed = 0;
-            sa.sprim = L.ps.sprim; sa.sdist = L.ps.sdist; sa.scr = L.ps.scr; sa.scg = L.ps.scg; sa.scb = L.ps.scb;
-            sa.rr = L.ps.rr; sa.rg = L.ps.rg; sa.rb = L.ps.rb;
+            sa.count_ptr = &cnt_shadow[b]; sa.count_fixed = 0;
+            sa.sprim = L.ps.sprim; sa.sdst = L.ps.sdst; sa.sdist = L.ps.sdist; sa.scr = L.ps.scr; sa.scg = L.ps.scg; sa.scb = L.ps.scb;
+            sa.rr = out.rr; sa.rg = out.rg; sa.rb = out.rb; sa.fr = L.ps.fr; sa.fg = L.ps.fg; sa.fb = L.ps.fb;
             sa.spill = L.spill.as<int>(); sa.spill_depth = spill_depth; sa.ctr = ctr; sa.per_ray_counts = nullptr;
             sa.fetch = &fetch_s[b];
             fill_tunables(c, sa);
@@ -669,7 +685,6 @@ int pt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed,
             stamp(evs, false);
             c->launches_trace_shadow++;
 
-            qcur = qnext; qnext = qother; qother = qcur;
         }
         // the running mean is order dependent: this batch's film update follows the previous batch's
         if (c->last_film) TIRT_HIP(hipStreamWaitEvent(st, c->last_film, 0));
