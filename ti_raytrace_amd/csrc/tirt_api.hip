@@ -286,6 +286,7 @@ int tirt_scene_upload(tirt_ctx *c, const float *vertex, int nv, const int32_t *p
                       const float *shape, int ns, const int32_t *light, int nl, int light_count, const float bmin[3], const float bmax[3])
 {
     CTX(c);
+    if (sync_all(c)) return TIRT_ERR_HIP;      // scene data must not change under batches still in flight
     TIRT_REQUIRE(n >= 1 && nv >= 0 && nm >= 1 && ns >= 1 && nl >= 1, "tirt_scene_upload: need n,nm,ns,nl >= 1");
     TIRT_REQUIRE(vertex && primitive && material && shape && light && bmin && bmax, "tirt_scene_upload: null pointer");
     TIRT_REQUIRE(light_count >= 0 && light_count <= nl, "tirt_scene_upload: light_count out of range");
@@ -320,6 +321,7 @@ int tirt_scene_upload(tirt_ctx *c, const float *vertex, int nv, const int32_t *p
 int tirt_material_upload(tirt_ctx *c, const float *material, int nm)
 {
     CTX(c);
+    if (sync_all(c)) return TIRT_ERR_HIP;      // scene data must not change under batches still in flight
     TIRT_REQUIRE(material && nm == c->nm, "tirt_material_upload: material count differs from the uploaded scene");
     if (upload(c->material, material, sizeof(float) * 10 * (size_t)nm, c->stream)) return TIRT_ERR_HIP;
     if (refresh_material_table(c)) return TIRT_ERR_HIP;
@@ -330,6 +332,7 @@ int tirt_material_upload(tirt_ctx *c, const float *material, int nm)
 int tirt_env_upload(tirt_ctx *c, const int32_t *rgb_packed, int w, int h, float power)
 {
     CTX(c);
+    if (sync_all(c)) return TIRT_ERR_HIP;      // scene data must not change under batches still in flight
     TIRT_REQUIRE(rgb_packed && w >= 1 && h >= 1, "tirt_env_upload: bad image");
     if (upload(c->env, rgb_packed, sizeof(int32_t) * (size_t)w * h, c->stream)) return TIRT_ERR_HIP;
     c->env_w = w; c->env_h = h; c->env_power = power;
@@ -340,6 +343,7 @@ int tirt_env_upload(tirt_ctx *c, const int32_t *rgb_packed, int w, int h, float 
 int tirt_lbvh_build(tirt_ctx *c)
 {
     CTX(c);
+    if (sync_all(c)) return TIRT_ERR_HIP;      // scene data must not change under batches still in flight
     return lbvh_build(c);
 }
 
@@ -367,6 +371,7 @@ int tirt_morton_download(tirt_ctx *c, int32_t *out)
 int tirt_process_normal(tirt_ctx *c, const int32_t *vertex_index)
 {
     CTX(c);
+    if (sync_all(c)) return TIRT_ERR_HIP;      // scene data must not change under batches still in flight
     TIRT_REQUIRE(c->built && vertex_index, "tirt_process_normal: LBVH not built");
     if (c->nv == 0) return TIRT_OK;
     for (int i = 0; i < c->nv; i++) TIRT_REQUIRE(vertex_index[i] >= 0 && vertex_index[i] < c->n, "tirt_process_normal: vertex_index out of range");
