@@ -118,6 +118,11 @@ int tirt_film_clear(tirt_ctx *ctx);
 int tirt_pt_rgb_render(tirt_ctx *ctx, uint32_t frame_begin, int frame_count, uint32_t seed,
                        int max_depth, int stack_size, int flags);
 
+/* BDPT.render x frame_count (integrator/BDPT_RGB.py:595-642): eye + light sub-paths, all
+ * connections up to MAX_DEPTH 5 with MIS, light-tracing splats; same film, camera and tiling as
+ * PT_RGB (with tiles, every context accumulates splats into its full-size film: sum-reduce). */
+int tirt_bdpt_rgb_render(tirt_ctx *ctx, uint32_t frame_begin, int frame_count, uint32_t seed);
+
 /* UtilsFunc.tone_map(exposure, hdr, rgb_film) (UtilsFunc.py:583-586) */
 int tirt_tone_map(tirt_ctx *ctx, float exposure);
 /* field.to_numpy(): either pointer may be NULL */

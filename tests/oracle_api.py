@@ -61,6 +61,11 @@ def load(libm=False):
         L.orc_pt_rgb_render.argtypes = [_vp, C.c_int, C.c_int, C.c_uint32, C.c_int, C.c_uint32, C.c_int, C.c_int,
                                         _f32p, C.c_long, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int,
                                         C.POINTER(OrcStats)]
+        L.orc_bdpt_create.restype = _vp
+        L.orc_bdpt_create.argtypes = [C.c_int, C.c_int, _f32p]
+        L.orc_bdpt_destroy.argtypes = [_vp]
+        L.orc_bdpt_render.restype = C.c_int
+        L.orc_bdpt_render.argtypes = [_vp, _vp, C.c_uint32, C.c_int, C.c_uint32, C.c_int, _f32p, _f32p, C.POINTER(OrcStats)]
         L.orc_tone_map.argtypes = [C.c_float, _f32p, _f32p, C.c_long]
         L.orc_total_area.restype = C.c_float
         L.orc_total_area.argtypes = [_vp]
@@ -172,6 +177,18 @@ class OracleScene:
                                  hdr.reshape(-1), p_begin, p_end, tile_rank, tile_count, tile_size,
                                  nthreads, C.byref(st))
         return hdr, st.as_dict()
+
+    def bdpt_render(self, cam, W, H, frame_begin, frame_count, seed=1, stack_size=64, hdr=None, state=None):
+        """BDPT_RGB.render x frame_count.  Returns (hdr, stats, state); pass `state` back to continue
+        with the persistent per-pixel vertex arrays of the previous frames."""
+        if hdr is None:
+            hdr = np.zeros((W, H, 3), np.float32)
+        if state is None:
+            state = self.L.orc_bdpt_create(W, H, np.ascontiguousarray(cam.view_np[0].reshape(-1), np.float32))
+        rad = np.zeros((W, H, 3), np.float32)
+        st = OrcStats()
+        self.L.orc_bdpt_render(self.h, state, frame_begin, frame_count, seed, stack_size, rad.reshape(-1), hdr.reshape(-1), C.byref(st))
+        return hdr, st.as_dict(), state
 
     def tone_map(self, exposure, hdr):
         out = np.zeros_like(hdr)

@@ -12,6 +12,6 @@ import os as _os
 # before the HIP runtime initialises, hence here; an explicit user setting wins.
 _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
-from . import SceneData, UtilsFunc, Texture, Camera, LBvh, Scene, PT_RGB, Example  # noqa: F401
+from . import SceneData, UtilsFunc, Texture, Camera, LBvh, Scene, PT_RGB, BDPT_RGB, Example  # noqa: F401
 
-__all__ = ["SceneData", "UtilsFunc", "Texture", "Camera", "LBvh", "Scene", "PT_RGB", "Example"]
+__all__ = ["SceneData", "UtilsFunc", "Texture", "Camera", "LBvh", "Scene", "PT_RGB", "BDPT_RGB", "Example"]

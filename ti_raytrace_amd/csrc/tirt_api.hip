@@ -234,7 +234,7 @@ void tirt_destroy(tirt_ctx *c)
                       &c->keys_b, &c->vals_a, &c->vals_b, &c->hist, &c->morton_sorted, &c->bvh_node, &c->compact, &c->parent,
                       &c->flag, &c->subtree, &c->build_status, &c->leaf_compact, &c->wnode, &c->tri, &c->hdr, &c->rgb,
                       &c->counters_mem, &c->spill, &c->tr_rays,
-                      &c->tr_out, &c->tr_prim, &c->tr_counts, &c->dev_counters};
+                      &c->tr_out, &c->tr_prim, &c->tr_counts, &c->dev_counters, &c->bdpt_px, &c->bdpt_rad};
     for (DevBuf *b : bufs) b->release();
     for (Lane &L : c->lanes) {
         DevBuf *lb[] = {&L.path_mem, &L.queue_a, &L.queue_b, &L.queue_s, &L.counters_mem, &L.spill};
@@ -439,6 +439,7 @@ int tirt_film_create(tirt_ctx *c, int W, int H, int tile_rank, int tile_count, i
         local += end - beg;
     }
     c->npix_local = local;
+    c->bdpt_px.release();                        // BDPT vertex arrays belong to the film: start from zeros
     TIRT_HIP(hipMemsetAsync(c->hdr.p, 0, sizeof(float) * 3 * (size_t)NP, c->stream));
     TIRT_HIP(hipMemsetAsync(c->rgb.p, 0, sizeof(float) * 3 * (size_t)NP, c->stream));
     TIRT_HIP(hipStreamSynchronize(c->stream));
@@ -450,6 +451,7 @@ int tirt_film_clear(tirt_ctx *c)
     CTX(c);
     AFTER_RENDER(c);
     TIRT_REQUIRE(c->hdr.p, "tirt_film_clear: film not created");
+    if (c->bdpt_px.p) TIRT_HIP(hipMemsetAsync(c->bdpt_px.p, 0, c->bdpt_px.bytes, c->stream));
     TIRT_HIP(hipMemsetAsync(c->hdr.p, 0, sizeof(float) * 3 * (size_t)c->W * c->H, c->stream));
     TIRT_HIP(hipMemsetAsync(c->rgb.p, 0, sizeof(float) * 3 * (size_t)c->W * c->H, c->stream));
     return TIRT_OK;
@@ -459,6 +461,12 @@ int tirt_pt_rgb_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint3
 {
     CTX(c);
     return pt_render(c, frame_begin, frame_count, seed, max_depth, stack_size, flags);
+}
+
+int tirt_bdpt_rgb_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed)
+{
+    CTX(c);
+    return bdpt_render(c, frame_begin, frame_count, seed);
 }
 
 int tirt_tone_map(tirt_ctx *c, float exposure)

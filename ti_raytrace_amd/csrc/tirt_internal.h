@@ -83,6 +83,14 @@ struct PathState {
     float *fr, *fg, *fb;                         // final radiance per path id (read by k_film)
 };
 
+// pixel-tile shard of this context: local pixel k -> linear pixel index
+struct TileMap { int tile_rank, tile_count, tile_size, H; };
+TD int local_to_pixel(const TileMap &m, int k)
+{
+    int lt = k / m.tile_size, within = k - lt * m.tile_size;
+    return (lt * m.tile_count + m.tile_rank) * m.tile_size + within;
+}
+
 struct DevCounters {          // lives in device memory; accumulated by the kernels
     unsigned long long rays_closest, rays_shadow, box_closest, leaf_closest, box_shadow, leaf_shadow;
     unsigned long long shaded, paths, stack_overflow;
@@ -145,6 +153,9 @@ struct tirt_ctx {
     int tr_lds_depth = 24, tr_refill_min = 36, tr_node_min = 12, tr_grid = 1536;
     tirt::DevBuf counters_mem, spill;            // used by the batch trace entry points (main stream)
 
+    // BDPT_RGB: persistent per-pixel vertex arrays + per-frame radiance (splat target)
+    tirt::DevBuf bdpt_px, bdpt_rad;
+
     // batch trace scratch
     tirt::DevBuf tr_rays, tr_out, tr_prim, tr_counts;
 
@@ -163,6 +174,7 @@ int lbvh_build(tirt_ctx *c);
 int launch_trace_batch(tirt_ctx *c, const float *rays, int nr, int stack_size, int flags, bool shadow,
                        float *out_f, int32_t *out_prim, int32_t *counts);
 int pt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed, int max_depth, int stack_size, int flags);
+int bdpt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed);
 int ensure_counters(tirt_ctx *c);
 int sync_all(tirt_ctx *c);
 }  // namespace tirt

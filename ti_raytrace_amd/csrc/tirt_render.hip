@@ -359,13 +359,6 @@ int launch_trace_batch(tirt_ctx *c, const float *rays, int nr, int stack_size, i
 // ---------------------------------------------------------------------------------------------
 // Wavefront PT_RGB
 // ---------------------------------------------------------------------------------------------
-struct TileMap { int tile_rank, tile_count, tile_size, H; };
-TD int local_to_pixel(const TileMap &m, int k)
-{
-    int lt = k / m.tile_size, within = k - lt * m.tile_size;
-    return (lt * m.tile_count + m.tile_rank) * m.tile_size + within;
-}
-
 __global__ void k_generate(PathSoA ps, CameraView cam, TileMap tm, int P, int S, uint32_t frame_begin, uint32_t seed,
                            DevCounters *ctr)
 {

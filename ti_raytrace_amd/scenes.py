@@ -7,7 +7,7 @@ import os
 
 import numpy as np
 
-from . import Example, PT_RGB
+from . import Example, PT_RGB, BDPT_RGB
 from . import SceneData as SCD
 
 ASSETS = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "assets")
@@ -50,6 +50,25 @@ class single_model(Example.example):
         self.scene.process_normal()
         self.scene.total_area()
         self.frame_camera(0.8)
+
+
+class veach_bdpt(Example.example):
+    """example/veach_bdpt.py:12-35 (BASELINE config 5): bdpt.obj, BDPT_RGB, smooth normals,
+    camera at 0.5 x |diagonal|."""
+
+    def __init__(self, imgSizeX, imgSizeY, sample_count, device_id=None, integrator="bdpt", **kwargs):
+        Example.example.__init__(self, imgSizeX, imgSizeY, sample_count, device_id)
+        self.scene.add_obj(asset("model", "bdpt.obj"))
+        if integrator == "bdpt":
+            self.integrator = BDPT_RGB.BDPT(imgSizeX, imgSizeY, self.cam, self.scene, 64, **kwargs)
+        else:
+            self.integrator = PT_RGB.PathTrace(imgSizeX, imgSizeY, self.cam, self.scene, 64, **kwargs)
+
+    def build_scene(self):
+        Example.example.build_scene(self)
+        self.scene.process_normal()
+        self.scene.total_area()
+        self.frame_camera(0.5)
 
 
 # ---- synthetic scene -------------------------------------------------------------------------

@@ -1,4 +1,4 @@
-"""Runs BASELINE.json configs 1-3 on one GPU and prints one JSON line per config
+"""Runs BASELINE.json configs 1-3 and 5 on one GPU and prints one JSON line per config
 (Mrays/s, ray counts, LBVH build ms); writes tone-mapped PNGs to gpurun_out/."""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -32,10 +32,13 @@ def run(name, ex, spp, batch):
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["1", "2", "3"]
+    which = sys.argv[1:] or ["1", "2", "3", "5"]
     if "1" in which:
         run("cfg1_cornell_512_512spp", scenes.cornell_box(512, 512, 512, device_id=0), 512, 64)
     if "2" in which:
         run("cfg2_teapot_1024_64spp", scenes.single_model(1024, 1024, 64, device_id=0), 64, 16)
+    if "5" in which:
+        run("cfg5_veach_bdpt_512_64spp", scenes.veach_bdpt(512, 512, 64, device_id=0), 64, 8)
+        run("cfg5_veach_pt_512_64spp", scenes.veach_bdpt(512, 512, 64, device_id=0, integrator="pt"), 64, 32)
     if "3" in which:
         run("cfg3_synth100k_1024_256spp", scenes.synthetic(1024, 1024, 256, device_id=0), 256, 32)
