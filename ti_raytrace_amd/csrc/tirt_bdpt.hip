@@ -137,7 +137,7 @@ TD bsample bd_sample(const SceneView &s, v3 dir, v3 normal, v3 fnormal, int mat_
     return r;
 }
 
-struct BdCtx { SceneView sc; BvhView bvh; CameraView cam; BdView bv; uint32_t seed; unsigned long long *rays_closest, *rays_shadow; };
+struct BdCtx { SceneView sc; BvhView bvh; CameraView cam; BdView bv; uint32_t seed; unsigned long long *rays_closest, *rays_shadow, *paths; };
 
 // BDPT_RGB.py:103-198
 TD int bd_eye_path(const BdCtx &c, bpixel *P, int i, int j, uint32_t frame, unsigned &n_closest)
@@ -528,6 +528,7 @@ __global__ __launch_bounds__(64) void k_bdpt_pixel(BdCtx c, bpixel *px, float *r
     }
     atomicAdd(c.rays_closest, (unsigned long long)n_closest);
     atomicAdd(c.rays_shadow, (unsigned long long)n_shadow);
+    atomicAdd(c.paths, 1ull);
 }
 
 // BDPT_RGB.py:639-642
@@ -556,7 +557,7 @@ int bdpt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t see
     for (int k = 0; k < 12; k++) bc.bv.view[k] = c->view[k];
     bc.bv.W = c->W; bc.bv.H = c->H;
     DevCounters *ctr = c->dev_counters.as<DevCounters>();
-    bc.rays_closest = &ctr->rays_closest; bc.rays_shadow = &ctr->rays_shadow;
+    bc.rays_closest = &ctr->rays_closest; bc.rays_shadow = &ctr->rays_shadow; bc.paths = &ctr->paths;
     const TileMap tm = {c->tile_rank, c->tile_count, c->tile_size, c->H};
     const int P = (int)c->npix_local;
     hipStream_t st = c->stream;
