@@ -93,3 +93,19 @@ def test_render_is_deterministic_and_tile_independent():
     h2, _ = o.render(W, H, 0, 2)
     h3, _ = o.render(W, H, 2, 1, hdr=h2.copy())
     assert np.array_equal(h3, full)
+
+
+def test_bdpt_oracle_is_deterministic_and_stateful():
+    """BDPT restatement (BASELINE config 5): finite, reproducible, and rendering frames 0..2 in one
+    call equals 2 + 1 frames with the persistent per-pixel vertex state handed over."""
+    W = H = 20
+    ex = host_only(scenes.cornell_box(W, H, 4))
+    o = oa.OracleScene(ex.scene, ex.cam)
+    o.lbvh_build()
+    a, st, _ = o.bdpt_render(ex.cam, W, H, 0, 3)
+    b, _, _ = o.bdpt_render(ex.cam, W, H, 0, 3)
+    assert np.array_equal(a, b) and np.isfinite(a).all() and a.mean() > 0.05
+    assert st["rays_closest"] > 0 and st["rays_shadow"] > 0
+    h2, _, state = o.bdpt_render(ex.cam, W, H, 0, 2)
+    h3, _, _ = o.bdpt_render(ex.cam, W, H, 2, 1, hdr=h2.copy(), state=state)
+    assert np.array_equal(h3, a)
