@@ -78,8 +78,11 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    force_dist = os.environ.get("TIRT_FORCE_DIST", "0") == "1"      # exercise the RCCL path with one rank (self-test)
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from ti_raytrace_amd import scenes, _native
@@ -104,7 +107,7 @@ def main():
     def barrier():
         ctx.sync()
         torch.cuda.synchronize()
-        if world > 1:
+        if world > 1 or force_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -114,11 +117,12 @@ def main():
             ex.cam.update_frame(fps)
 
     run_steps(args.warmup)
+    tdist.warmup(ctx, W, H, force=force_dist)
     barrier()
     ctx.stats_reset()
     t_begin = time.perf_counter()
     run_steps(args.steps)
-    film = tdist.reduce_film(ctx, W, H, dst=0)              # one RCCL reduce of the framebuffer (world > 1)
+    film = tdist.reduce_film(ctx, W, H, dst=0, force=force_dist)   # one RCCL reduce of the framebuffer (world > 1)
     barrier()
     elapsed = time.perf_counter() - t_begin
     st = ctx.stats()
@@ -245,7 +249,7 @@ def main():
 
     if rank == 0:
         print(json.dumps(result))
-    if world > 1:
+    if world > 1 or force_dist:
         dist.destroy_process_group()
 
 

@@ -615,15 +615,19 @@ int pt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed,
     TIRT_HIP(hipEventRecord(c->ev_main, c->stream));
     const int n_lanes = c->time_kernels ? 1 : c->n_lanes;
 
+    // all lanes get their buffers up front (an allocation inside a later call would stall the pipeline)
+    int spill_depth = 0;
+    for (int k = 0; k < n_lanes; k++) {
+        if (ensure_paths(c->lanes[k], (size_t)FB * P, max_depth)) return TIRT_ERR_HIP;
+        if (ensure_spill(c, c->lanes[k].spill, stack_size, spill_depth)) return TIRT_ERR_HIP;
+    }
+
     for (int fb = 0; fb < frame_count; fb += FB) {
         Lane &L = c->lanes[n_lanes == 1 ? 0 : (c->lane_cursor++ % (unsigned)n_lanes)];
         hipStream_t st = L.stream;
         const int F = (frame_count - fb < FB) ? frame_count - fb : FB;
         const int S = F * P;
         const uint32_t f0 = frame_begin + (uint32_t)fb;
-        if (ensure_paths(L, (size_t)S, max_depth)) return TIRT_ERR_HIP;
-        int spill_depth;
-        if (ensure_spill(c, L.spill, stack_size, spill_depth)) return TIRT_ERR_HIP;
         int *cnt_path = L.counters_mem.as<int>();               // [max_depth+2] live paths per bounce
         int *cnt_shadow = cnt_path + (max_depth + 2);           // shadow rays per bounce
         int *fetch_c = cnt_shadow + (max_depth + 2), *fetch_s = fetch_c + (max_depth + 2);   // ray-fetch cursors

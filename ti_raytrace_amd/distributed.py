@@ -26,26 +26,38 @@ def local_pixel_count(W, H, rank, world, tile_size):
     return total
 
 
-def reduce_film_tensor(film, dst=0):
+def reduce_film_tensor(film, dst=0, force=False):
     """Sum-reduce a film tensor (any device/backend) onto ``dst``; no-op without a process group."""
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force):
         dist.reduce(film, dst=dst, op=dist.ReduceOp.SUM)
     return film
 
 
-def reduce_film(ctx, W, H, dst=0):
+def warmup(ctx, W, H, force=False):
+    """Creates the RCCL communicator and runs one film-sized reduce on a scratch tensor, so that the
+    first real reduce does not pay for communicator set-up."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force)):
+        return
+    t = torch.zeros((W, H, 3), dtype=torch.float32, device=torch.device("cuda", ctx.device_id))
+    dist.reduce(t, dst=0, op=dist.ReduceOp.SUM)
+    torch.cuda.synchronize()
+
+
+def reduce_film(ctx, W, H, dst=0, force=False):
     """Export this rank's hdr film into a torch CUDA tensor (device-to-device copy through the
     C-ABI), reduce it over RCCL onto ``dst`` and, on ``dst``, import the sum back as the
     context's film.  Returns the tensor (None when running on a single GPU)."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+    if not (dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force)):
         return None
     film = torch.empty((W, H, 3), dtype=torch.float32, device=torch.device("cuda", ctx.device_id))
     ctx.film_export_device(film.data_ptr())
     torch.cuda.synchronize()
-    reduce_film_tensor(film, dst)
+    reduce_film_tensor(film, dst, force)
     torch.cuda.synchronize()
     if dist.get_rank() == dst:
         ctx.film_import_device(film.data_ptr())
