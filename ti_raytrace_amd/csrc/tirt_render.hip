@@ -154,44 +154,57 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
 
         // ---- inner nodes.  Lanes that reached a leaf (or finished) wait here; the loop goes on
         // while at least node_min lanes still have inner-node work, or nobody is waiting at all.
+        // (idle lanes keep cur == TR_SENT, so `cur >= 0` alone means "has inner-node work".)
         for (;;) {
-            const bool act = have && cur >= 0;
+            const bool act = cur >= 0;
             const int n_act = __popcll(__ballot(act));
             if (n_act == 0) break;
             if (n_act < a.node_min && __ballot(have && cur < 0) != 0ull) break;
             if (COUNT) { d_it_node++; d_lanes_node += (unsigned long long)n_act; }
-            if (!act) continue;
-            const float4 *w = b.wnode + (size_t)cur * 4;
-            const float4 q0 = w[0], q1 = w[1], q2 = w[2], q3 = w[3];
-            const int cl = __float_as_int(q3.x), cr = __float_as_int(q3.y);
-            if (COUNT) nbox += 2;
-            float tl, tr;
-            int pl, pr;
-            if (!wave_par) {
-                pl = slabs_fast(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tl);
-                pr = slabs_fast(r, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tr);
-            } else if (!par) {
-                pl = slabs_fast(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tl);
-                pr = slabs_fast(r, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tr);
-            } else {
-                pl = slabs(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tl);
-                pr = slabs(r, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tr);
+            if (act) {
+                const float4 *w = b.wnode + (size_t)cur * 4;
+                const float4 q0 = w[0], q1 = w[1], q2 = w[2], q3 = w[3];
+                const int cl = __float_as_int(q3.x), cr = __float_as_int(q3.y);
+                if (COUNT) nbox += 2;
+                float tl, tr;
+                int pl, pr;
+                if (!wave_par || !par) {
+                    pl = slabs_fast(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tl);
+                    pr = slabs_fast(r, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tr);
+                } else {
+                    pl = slabs(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tl);
+                    pr = slabs(r, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tr);
+                }
+                bool hl, hr;
+                if (MODE == TIRT_TRAVERSE_EXHAUSTIVE) {
+                    hl = (pl != 0) | (cl < 0);           // leaves are popped and intersected without a box test
+                    hr = (pr != 0) | (cr < 0);
+                } else {
+                    const float lim = minf(hit_t * 1.0001f, cull_far);
+                    hl = (pl != 0) & (tl <= lim);
+                    hr = (pr != 0) & (tr <= lim);
+                }
+                const bool both = hl & hr, any = hl | hr;
+                const bool swap = (MODE != TIRT_TRAVERSE_EXHAUSTIVE) & both & (tr < tl);
+                const int nearc = hl ? (swap ? cr : cl) : cr;      // the child to continue with when any
+                const int farc = swap ? cl : cr;                   // pushed when both
+                // stack traffic: two flat predicated regions; the global spill tail (sp >= LDS depth:
+                // trees deeper than the LDS stack) is a wave-uniform cold path
+                if (__ballot((both && sp >= TR_LDS_DEPTH) || (!any && sp > TR_LDS_DEPTH)) != 0ull) {
+                    if (both) TR_PUSH(farc);
+                    if (!any) TR_POP(cur); else cur = nearc;
+                } else {
+                    if (both) { lds_stack[sp * TR_BLOCK + tid] = farc; sp++; }
+                    int next = nearc;
+                    if (!any) {
+                        const bool empty = sp == 0;
+                        sp = empty ? 0 : sp - 1;
+                        const int top = lds_stack[sp * TR_BLOCK + tid];
+                        next = empty ? TR_SENT : top;
+                    }
+                    cur = next;
+                }
             }
-            if (MODE == TIRT_TRAVERSE_EXHAUSTIVE) {
-                if (cl < 0) pl = 1;              // leaves are popped and intersected without a box test
-                if (cr < 0) pr = 1;
-            } else {
-                const float lim = minf(hit_t * 1.0001f, cull_far);
-                pl &= (tl <= lim) ? 1 : 0;
-                pr &= (tr <= lim) ? 1 : 0;
-            }
-            if (pl & pr) {
-                const bool swap = (MODE != TIRT_TRAVERSE_EXHAUSTIVE) && (tr < tl);
-                TR_PUSH(swap ? cl : cr);
-                cur = swap ? cr : cl;
-            } else if (pl) cur = cl;
-            else if (pr) cur = cr;
-            else TR_POP(cur);
         }
 
         // ---- leaf: one primitive test ---------------------------------------------------------
