@@ -235,7 +235,8 @@ def main():
         _, pst = orc.render(W, H, 1, 1, seed=args.seed, tile_rank=0, tile_count=64, tile_size=args.tile_size, nthreads=cores)
         probe_s = max(time.perf_counter() - tp, 1e-3)
         frame_s = probe_s * 64.0
-        nframes = int(min(max(args.cpu_target_s / frame_s, 1.0), 64.0))
+        # (the probe over-estimates on many-core hosts: thread start-up dominates its 16k paths)
+        nframes = int(min(max(round(1.7 * args.cpu_target_s / frame_s), 1.0), 16.0))
         tc = time.perf_counter()
         _, ost = orc.render(W, H, 1, nframes, seed=args.seed, nthreads=cores)
         cpu_s = time.perf_counter() - tc
