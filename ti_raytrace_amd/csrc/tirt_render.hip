@@ -33,7 +33,7 @@ namespace tirt {
 constexpr int TR_BLOCK = 256;
 constexpr int TR_GRID_MAX = 4096;      // upper bound on persistent blocks (sizes the spill buffer)
 
-enum { KIND_CLOSEST = 0, KIND_SHADOW_ACC = 1 };
+enum { KIND_CLOSEST = 0, KIND_SHADOW_ACC = 1, KIND_MIXED = 2 };   // MIXED: closest rays of bounce b + shadow rays of bounce b-1 in one launch
 
 struct TraceArgs {
     BvhView bvh;
@@ -43,6 +43,8 @@ struct TraceArgs {
     // KIND_SHADOW_ACC: contribution of ray q goes to (rr,rg,rb)[sdst[q]] or (fr,fg,fb)[~sdst[q]]
     const int *sprim, *sdst; const float *sdist, *scr, *scg, *scb; float *rr, *rg, *rb, *fr, *fg, *fb;
     int *spill; int spill_depth;                 // global stack tail: [entry][global thread]
+    // KIND_MIXED: the shadow rays live in their own arrays; indices [count, count + scount) are shadow rays
+    const float *sox, *soy, *soz, *sdx, *sdy, *sdz; const int *scount_ptr;
     int *fetch;                                  // ray-fetch cursor of this launch (zero on entry)
     int lds_depth;                               // stack entries per lane kept in LDS
     int refill_min;                              // re-fetch rays when this many lanes of a wave are idle
@@ -72,9 +74,11 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) int lds_stack[];      // [lds_depth][TR_BLOCK]
     const int TR_LDS_DEPTH = a.lds_depth;
-    constexpr bool SHADOW = (KIND == KIND_SHADOW_ACC);
-    constexpr bool BOUNDED = SHADOW && (MODE != TIRT_TRAVERSE_EXHAUSTIVE);
-    const int count = a.count_ptr ? *a.count_ptr : a.count_fixed;
+    constexpr bool MAY_SHADOW = (KIND != KIND_CLOSEST);
+    constexpr bool BOUNDED = MAY_SHADOW && (MODE != TIRT_TRAVERSE_EXHAUSTIVE);
+    const int count_c = (KIND == KIND_SHADOW_ACC) ? 0 : (a.count_ptr ? *a.count_ptr : a.count_fixed);
+    const int count_s = (KIND == KIND_CLOSEST) ? 0 : (KIND == KIND_MIXED ? *a.scount_ptr : (a.count_ptr ? *a.count_ptr : a.count_fixed));
+    const int count = count_c + count_s;
     const int tid = threadIdx.x, lane = tid & 63;
     const size_t gstride = (size_t)gridDim.x * TR_BLOCK, gtid = (size_t)blockIdx.x * TR_BLOCK + tid;
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
@@ -82,14 +86,14 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
     const BvhView &b = a.bvh;
 
     // per-lane ray state
-    bool have = false, par = false, overflow = false;
+    bool have = false, par = false, overflow = false, is_sh = (KIND == KIND_SHADOW_ACC);
     int q = 0, cur = TR_SENT, sp = 0, hit_prim = -1, hit_leaf = -1, expect = -3;
     float hit_t = INF_VALUE, hit_u = 0.0f, hit_v = 0.0f, cull_far = 3.0e38f, settle = -1.0f;
     unsigned nbox = 0, nleaf = 0;
     RayCtx r = {};
     bool exhausted = false;
     bool wave_par = false;                      // any lane of the wave holds an axis-parallel ray (rare)
-    unsigned long long sum_box = 0, sum_leaf = 0, n_over = 0;
+    unsigned long long sum_box = 0, sum_leaf = 0, sum_box_s = 0, sum_leaf_s = 0, n_over = 0;
     unsigned long long d_it_node = 0, d_lanes_node = 0, d_it_leaf = 0, d_lanes_leaf = 0, d_refills = 0, d_outer = 0;
 
 #define TR_PUSH(x)                                                                                   \
@@ -123,17 +127,19 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
             const int my = base + __popcll(idle & lt_mask);
             if (!have && my < count) {
                 q = my;
-                const v3 o = V(a.ox[q], a.oy[q], a.oz[q]);
-                const v3 d = V(a.dx[q], a.dy[q], a.dz[q]);
+                if (KIND == KIND_MIXED) { is_sh = my >= count_c; if (is_sh) q = my - count_c; }
+                const bool mixed_sh = (KIND == KIND_MIXED) && is_sh;
+                const v3 o = mixed_sh ? V(a.sox[q], a.soy[q], a.soz[q]) : V(a.ox[q], a.oy[q], a.oz[q]);
+                const v3 d = mixed_sh ? V(a.sdx[q], a.sdy[q], a.sdz[q]) : V(a.dx[q], a.dy[q], a.dz[q]);
                 r = make_ray(o, d);
                 par = ray_has_parallel_axis(r);
                 hit_t = INF_VALUE; hit_u = 0.0f; hit_v = 0.0f; hit_prim = -1; hit_leaf = -1;
                 nbox = 1; nleaf = 0; sp = 0; overflow = false;
-                if (BOUNDED) {
-                    const float t_bound = a.sdist[q];
+                cull_far = 3.0e38f; settle = -1.0f; expect = -3;
+                if (MAY_SHADOW && is_sh) {
                     expect = a.sprim[q];
-                    cull_far = t_bound * 1.01f; settle = t_bound * 0.99f;
-                } else if (SHADOW) expect = a.sprim[q];
+                    if (BOUNDED) { const float t_bound = a.sdist[q]; cull_far = t_bound * 1.01f; settle = t_bound * 0.99f; }
+                }
                 cur = b.root_code;
                 if (cur >= 0) {
                     float tn;
@@ -237,7 +243,7 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
 
         // ---- finished rays write back and free their lane ---------------------------------------
         if (have && cur == TR_SENT) {
-            if (KIND == KIND_CLOSEST) {
+            if (!(MAY_SHADOW && is_sh)) {
                 a.ht[q] = hit_t; a.hu[q] = hit_u; a.hv[q] = hit_v; a.hprim[q] = hit_prim;
             } else if (hit_prim == expect) {                 // integrator/PT_RGB.py:105-109
                 const int dst = a.sdst[q];
@@ -247,7 +253,8 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
                 *pr = *pr + a.scr[q]; *pg = *pg + a.scg[q]; *pb = *pb + a.scb[q];
             }
             if (COUNT) {
-                sum_box += nbox; sum_leaf += nleaf;
+                if (MAY_SHADOW && is_sh) { sum_box_s += nbox; sum_leaf_s += nleaf; }
+                else { sum_box += nbox; sum_leaf += nleaf; }
                 if (a.per_ray_counts) a.per_ray_counts[q] = make_int2((int)nbox, (int)nleaf);
             }
             if (overflow) n_over++;
@@ -257,10 +264,9 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
     if (a.ctr) {
         if (COUNT) {
             sum_box = wave_sum(sum_box); sum_leaf = wave_sum(sum_leaf);
-            if (lane == 0 && (sum_box | sum_leaf)) {
-                atomicAdd(KIND == KIND_CLOSEST ? &a.ctr->box_closest : &a.ctr->box_shadow, sum_box);
-                atomicAdd(KIND == KIND_CLOSEST ? &a.ctr->leaf_closest : &a.ctr->leaf_shadow, sum_leaf);
-            }
+            sum_box_s = wave_sum(sum_box_s); sum_leaf_s = wave_sum(sum_leaf_s);
+            if (lane == 0 && (sum_box | sum_leaf)) { atomicAdd(&a.ctr->box_closest, sum_box); atomicAdd(&a.ctr->leaf_closest, sum_leaf); }
+            if (lane == 0 && (sum_box_s | sum_leaf_s)) { atomicAdd(&a.ctr->box_shadow, sum_box_s); atomicAdd(&a.ctr->leaf_shadow, sum_leaf_s); }
         }
         if (COUNT && lane == 0) {
             atomicAdd(&a.ctr->it_node, d_it_node); atomicAdd(&a.ctr->lanes_node, d_lanes_node);
@@ -268,7 +274,10 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
             atomicAdd(&a.ctr->refills, d_refills); atomicAdd(&a.ctr->it_outer, d_outer);
         }
         if (n_over) atomicAdd(&a.ctr->stack_overflow, n_over);
-        if (gtid == 0) atomicAdd(KIND == KIND_CLOSEST ? &a.ctr->rays_closest : &a.ctr->rays_shadow, (unsigned long long)count);
+        if (gtid == 0) {
+            if (count_c) atomicAdd(&a.ctr->rays_closest, (unsigned long long)count_c);
+            if (count_s) atomicAdd(&a.ctr->rays_shadow, (unsigned long long)count_s);
+        }
     }
 }
 
@@ -660,17 +669,24 @@ int pt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed,
         hipLaunchKernelGGL(k_generate, dim3((S + B - 1) / B), dim3(B), 0, st, L.ps.st[0], c->cam, tm, P, S, f0, seed, ctr);
         int grid_full = (S + TR_BLOCK - 1) / TR_BLOCK; if (grid_full > c->tr_grid) grid_full = c->tr_grid;
         for (int b = 0; b < max_depth; b++) {
+            const PathSoA &in = L.ps.st[b & 1], &out = L.ps.st[(b + 1) & 1];
+            // closest hits of bounce b, together with the NEE shadow rays of bounce b-1 (they add into
+            // `in`'s radiance, which nothing reads before shade(b)): one launch instead of two
             TraceArgs a = {};
             a.bvh = bv;
-            const PathSoA &in = L.ps.st[b & 1], &out = L.ps.st[(b + 1) & 1];
             a.ox = in.ox; a.oy = in.oy; a.oz = in.oz; a.dx = in.dx; a.dy = in.dy; a.dz = in.dz;
             a.count_ptr = (b == 0) ? nullptr : &cnt_path[b]; a.count_fixed = S;
             a.ht = L.ps.ht; a.hu = L.ps.hu; a.hv = L.ps.hv; a.hprim = L.ps.hprim;
             a.spill = L.spill.as<int>(); a.spill_depth = spill_depth; a.ctr = ctr; a.per_ray_counts = nullptr;
             a.fetch = &fetch_c[b];
+            a.sox = L.ps.sox; a.soy = L.ps.soy; a.soz = L.ps.soz; a.sdx = L.ps.sdx; a.sdy = L.ps.sdy; a.sdz = L.ps.sdz;
+            a.sprim = L.ps.sprim; a.sdst = L.ps.sdst; a.sdist = L.ps.sdist; a.scr = L.ps.scr; a.scg = L.ps.scg; a.scb = L.ps.scb;
+            a.rr = in.rr; a.rg = in.rg; a.rb = in.rb; a.fr = L.ps.fr; a.fg = L.ps.fg; a.fb = L.ps.fb;
+            a.scount_ptr = (b == 0) ? nullptr : &cnt_shadow[b - 1];
             fill_tunables(c, a);
             stamp(evc, true);
-            launch_trace<KIND_CLOSEST>(st, a, flags, grid_full);
+            if (b == 0) launch_trace<KIND_CLOSEST>(st, a, flags, grid_full);
+            else launch_trace<KIND_MIXED>(st, a, flags, grid_full);
             stamp(evc, false);
             c->launches_trace_closest++;
 
@@ -681,20 +697,21 @@ int pt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed,
             stamp(evh, false);
             c->launches_shade++;
 
-            TraceArgs sa = {};
-            sa.bvh = bv;
-            sa.ox = L.ps.sox; sa.oy = L.ps.soy; sa.oz = L.ps.soz; sa.dx = L.ps.sdx; sa.dy = L.ps.sdy; sa.dz = L.ps.sdz;
-            sa.count_ptr = &cnt_shadow[b]; sa.count_fixed = 0;
-            sa.sprim = L.ps.sprim; sa.sdst = L.ps.sdst; sa.sdist = L.ps.sdist; sa.scr = L.ps.scr; sa.scg = L.ps.scg; sa.scb = L.ps.scb;
-            sa.rr = out.rr; sa.rg = out.rg; sa.rb = out.rb; sa.fr = L.ps.fr; sa.fg = L.ps.fg; sa.fb = L.ps.fb;
-            sa.spill = L.spill.as<int>(); sa.spill_depth = spill_depth; sa.ctr = ctr; sa.per_ray_counts = nullptr;
-            sa.fetch = &fetch_s[b];
-            fill_tunables(c, sa);
-            stamp(evs, true);
-            launch_trace<KIND_SHADOW_ACC>(st, sa, flags, grid_full);
-            stamp(evs, false);
-            c->launches_trace_shadow++;
-
+            if (b == max_depth - 1) {          // the last bounce's shadow rays have no closest-hit launch to ride on
+                TraceArgs sa = {};
+                sa.bvh = bv;
+                sa.ox = L.ps.sox; sa.oy = L.ps.soy; sa.oz = L.ps.soz; sa.dx = L.ps.sdx; sa.dy = L.ps.sdy; sa.dz = L.ps.sdz;
+                sa.count_ptr = &cnt_shadow[b]; sa.count_fixed = 0;
+                sa.sprim = L.ps.sprim; sa.sdst = L.ps.sdst; sa.sdist = L.ps.sdist; sa.scr = L.ps.scr; sa.scg = L.ps.scg; sa.scb = L.ps.scb;
+                sa.rr = out.rr; sa.rg = out.rg; sa.rb = out.rb; sa.fr = L.ps.fr; sa.fg = L.ps.fg; sa.fb = L.ps.fb;
+                sa.spill = L.spill.as<int>(); sa.spill_depth = spill_depth; sa.ctr = ctr; sa.per_ray_counts = nullptr;
+                sa.fetch = &fetch_s[b];
+                fill_tunables(c, sa);
+                stamp(evs, true);
+                launch_trace<KIND_SHADOW_ACC>(st, sa, flags, grid_full);
+                stamp(evs, false);
+                c->launches_trace_shadow++;
+            }
         }
         // the running mean is order dependent: this batch's film update follows the previous batch's
         if (c->last_film) TIRT_HIP(hipStreamWaitEvent(st, c->last_film, 0));
