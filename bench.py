@@ -192,7 +192,7 @@ def main():
         traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tpath) and args.size == 1024 and args.ntri == 100000 and fps == 32 and world == 1:
-            tj = json.load(open(tpath)).get("k_trace<ordered,closest>", {})
+            tj = json.load(open(tpath)).get("k_trace", {})
             traffic, traffic_src = tj.get("hbm_bytes_per_launch"), tj.get("source")
         # dominant kernel = k_trace (closest hits of bounce b + NEE shadow rays of bounce b-1 share a launch)
         n_launch = max(t["launches_trace_closest"] + t["launches_trace_shadow"], 1)
