@@ -69,6 +69,9 @@ int tirt_sync(tirt_ctx *ctx);
  *            (also confines the batches to one lane so that kernel times are not overlapped)
  *          "overlap_lanes" (1..8, default 4) -- wavefront batches in flight on separate streams
  *          "trace_lds_depth" / "trace_refill_min" / "trace_node_min" / "trace_grid" -- traversal tuning
+ *          "merge_paths" -- consecutive tirt_pt_rgb_render calls over contiguous frames are merged
+ *            until this many pixel-samples are pending (default 8 Mi; 0 submits every call at once);
+ *            every other entry point submits what is pending first
  *          "batch_paths" -- pixel-samples kept in flight per wavefront batch (default 32 Mi,
  *            112 B of HBM each) */
 int tirt_set_option(tirt_ctx *ctx, const char *name, double value);
@@ -114,7 +117,7 @@ int tirt_film_clear(tirt_ctx *ctx);
 
 /* PathTrace.render x frame_count (integrator/PT_RGB.py:44-136), frames frame_begin ..
  * frame_begin+frame_count-1 accumulated into hdr as the running mean of :134-136.
- * Asynchronous on the ctx stream. */
+ * Asynchronous, and possibly deferred: see option "merge_paths". */
 int tirt_pt_rgb_render(tirt_ctx *ctx, uint32_t frame_begin, int frame_count, uint32_t seed,
                        int max_depth, int stack_size, int flags);
 

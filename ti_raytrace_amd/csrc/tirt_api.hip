@@ -26,8 +26,15 @@ BvhView bvh_view(const tirt_ctx *c)
     b.root_code = c->root_code;
     return b;
 }
+int flush_pending(tirt_ctx *c)
+{
+    if (!c->pend.valid) return 0;
+    c->pend.valid = false;
+    return pt_render(c, c->pend.begin, c->pend.count, c->pend.seed, c->pend.max_depth, c->pend.stack_size, c->pend.flags);
+}
 int sync_all(tirt_ctx *c)
 {
+    if (int rc = flush_pending(c)) return rc;
     for (Lane &L : c->lanes) if (L.stream) TIRT_HIP(hipStreamSynchronize(L.stream));
     TIRT_HIP(hipStreamSynchronize(c->stream));
     return 0;
@@ -252,9 +259,13 @@ void tirt_destroy(tirt_ctx *c)
 #define AFTER_RENDER(c)                                                            \
     do { if ((c)->last_film) TIRT_HIP(hipStreamWaitEvent((c)->stream, (c)->last_film, 0)); } while (0)
 
-#define CTX(c)                                                                     \
+#define CTX_NOFLUSH(c)                                                             \
     TIRT_REQUIRE(c, "null context");                                               \
     TIRT_HIP(hipSetDevice((c)->device))
+// every entry point except tirt_pt_rgb_render first submits the render calls still pending
+#define CTX(c)                                                                     \
+    CTX_NOFLUSH(c);                                                                \
+    do { if (int rc__ = flush_pending(c)) return rc__; } while (0)
 
 int tirt_sync(tirt_ctx *c)
 {
@@ -270,6 +281,7 @@ int tirt_set_option(tirt_ctx *c, const char *name, double value)
     TIRT_REQUIRE(name, "tirt_set_option: null name");
     if (!strcmp(name, "time_kernels")) { c->time_kernels = value != 0.0; return TIRT_OK; }
     if (!strcmp(name, "overlap_lanes")) { TIRT_REQUIRE(value >= 1.0 && value <= (double)TIRT_MAX_LANES, "overlap_lanes: 1..8"); if (sync_all(c)) return TIRT_ERR_HIP; c->n_lanes = (int)value; return TIRT_OK; }
+    if (!strcmp(name, "merge_paths")) { TIRT_REQUIRE(value >= 0.0 && value <= 1.0e9, "merge_paths out of range"); c->merge_paths = (size_t)value; return TIRT_OK; }
     if (!strcmp(name, "batch_paths")) {
         TIRT_REQUIRE(value >= 1.0 && value <= 1.0e9, "tirt_set_option: batch_paths out of range");
         c->batch_paths = (size_t)value; return TIRT_OK;
@@ -459,8 +471,23 @@ int tirt_film_clear(tirt_ctx *c)
 
 int tirt_pt_rgb_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed, int max_depth, int stack_size, int flags)
 {
-    CTX(c);
-    return pt_render(c, frame_begin, frame_count, seed, max_depth, stack_size, flags);
+    CTX_NOFLUSH(c);
+    TIRT_REQUIRE(c->built, "tirt_pt_rgb_render: LBVH not built");
+    TIRT_REQUIRE(c->cam_set, "tirt_pt_rgb_render: camera not set");
+    TIRT_REQUIRE(c->hdr.p && c->npix_local >= 0, "tirt_pt_rgb_render: film not created");
+    TIRT_REQUIRE(frame_count >= 0 && max_depth >= 1 && max_depth <= 4096, "tirt_pt_rgb_render: bad frame_count/max_depth");
+    if (frame_count == 0) return TIRT_OK;
+    auto &p = c->pend;
+    if (p.valid && p.begin + (uint32_t)p.count == frame_begin && p.seed == seed && p.max_depth == max_depth &&
+        p.stack_size == stack_size && p.flags == flags) {
+        p.count += frame_count;
+    } else {
+        if (int rc = flush_pending(c)) return rc;
+        p.valid = true; p.begin = frame_begin; p.count = frame_count; p.seed = seed;
+        p.max_depth = max_depth; p.stack_size = stack_size; p.flags = flags;
+    }
+    if ((size_t)p.count * (size_t)(c->npix_local > 0 ? c->npix_local : 1) >= c->merge_paths) return flush_pending(c);
+    return TIRT_OK;
 }
 
 int tirt_bdpt_rgb_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed)

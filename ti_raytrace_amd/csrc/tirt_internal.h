@@ -149,6 +149,11 @@ struct tirt_ctx {
     hipEvent_t ev_main = nullptr;
     hipEvent_t last_film = nullptr;               // film_done of the most recent batch (any lane)
     size_t batch_paths = (size_t)32 << 20;         // option "batch_paths"
+    // deferred submission: consecutive tirt_pt_rgb_render calls over contiguous frames are merged until
+    // merge_paths pixel-samples are pending (small calls -- one frame at a time, or the 1/N-size shards
+    // of a multi-GPU job -- then run as one efficient batch); any other API call flushes first
+    size_t merge_paths = (size_t)8 << 20;          // option "merge_paths" (0 = submit every call at once)
+    struct { bool valid = false; uint32_t begin = 0; int count = 0; uint32_t seed = 0; int max_depth = 0, stack_size = 0, flags = 0; } pend;
     // traversal tunables (options "trace_lds_depth", "trace_refill_min", "trace_node_min", "trace_grid")
     int tr_lds_depth = 24, tr_refill_min = 36, tr_node_min = 12, tr_grid = 1536;
     tirt::DevBuf counters_mem, spill;            // used by the batch trace entry points (main stream)
@@ -177,4 +182,5 @@ int pt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed,
 int bdpt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed);
 int ensure_counters(tirt_ctx *c);
 int sync_all(tirt_ctx *c);
+int flush_pending(tirt_ctx *c);
 }  // namespace tirt

@@ -638,9 +638,18 @@ int pt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed,
     const int n_lanes = c->time_kernels ? 1 : c->n_lanes;
 
     // all lanes get their buffers up front (an allocation inside a later call would stall the pipeline)
+    // sized for what deferred submission can merge later (merge_paths + one call), so that a bigger
+    // merged batch does not re-allocate in the middle of a job; small films skip the head-room
     int spill_depth = 0;
+    size_t cap = (size_t)FB * P;
+    if (c->merge_paths > 0 && P >= 65536) {
+        size_t want = c->merge_paths + (size_t)frame_count * P;
+        if (want > c->batch_paths) want = c->batch_paths;
+        want = (want / P) * P;
+        if (want > cap) cap = want;
+    }
     for (int k = 0; k < n_lanes; k++) {
-        if (ensure_paths(c->lanes[k], (size_t)FB * P, max_depth)) return TIRT_ERR_HIP;
+        if (ensure_paths(c->lanes[k], cap, max_depth)) return TIRT_ERR_HIP;
         if (ensure_spill(c, c->lanes[k].spill, stack_size, spill_depth)) return TIRT_ERR_HIP;
     }
 
