@@ -27,7 +27,8 @@ struct BdView { float view[12]; int W, H; };
 
 // ---- plain traversal (ordered, t-culled; same hit as the reference's exhaustive order) ------------
 struct SimpleHit { float t, u, v; int prim; };
-TD SimpleHit trace_simple(const BvhView &b, v3 o, v3 d)
+constexpr int BD_BLOCK = 64, BD_STACK = 64;
+TD SimpleHit trace_simple(const BvhView &b, v3 o, v3 d, int *stack /* LDS, [entry][lane] */)
 {
     SimpleHit h; h.t = INF_VALUE; h.u = 0.0f; h.v = 0.0f; h.prim = -1;
     int hit_leaf = -1;
@@ -38,21 +39,23 @@ TD SimpleHit trace_simple(const BvhView &b, v3 o, v3 d)
         float tn;
         if (!slabs(r, b.root_min[0], b.root_min[1], b.root_min[2], b.root_max[0], b.root_max[1], b.root_max[2], tn)) return h;
     }
-    int stack[64]; int sp = 0;
+    int sp = 0;
+    const bool par = ray_has_parallel_axis(r);
     for (;;) {
         if (cur >= 0) {
             const float4 *w = b.wnode + (size_t)cur * 4;
             const float4 q0 = w[0], q1 = w[1], q2 = w[2], q3 = w[3];
             const int cl = __float_as_int(q3.x), cr = __float_as_int(q3.y);
             float tl, tr;
-            int pl = slabs(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tl);
-            int pr = slabs(r, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tr);
+            int pl, pr;
+            if (!par) { pl = slabs_fast(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tl); pr = slabs_fast(r, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tr); }
+            else { pl = slabs(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tl); pr = slabs(r, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tr); }
             const float lim = h.t * 1.0001f;
             pl &= (tl <= lim) ? 1 : 0;
             pr &= (tr <= lim) ? 1 : 0;
             if (pl & pr) {
                 const bool swap = tr < tl;
-                if (sp < 64) stack[sp++] = swap ? cl : cr;
+                if (sp < BD_STACK) { stack[sp * BD_BLOCK] = swap ? cl : cr; sp++; }
                 cur = swap ? cr : cl;
                 continue;
             }
@@ -70,7 +73,7 @@ TD SimpleHit trace_simple(const BvhView &b, v3 o, v3 d)
             if ((t > 0.0f) & ((t < h.t) | ((t == h.t) & (hit_leaf >= 0) & (leaf > hit_leaf)))) { h.t = t; h.u = u; h.v = v; h.prim = prim; hit_leaf = leaf; }
         }
         if (sp == 0) break;
-        cur = stack[--sp];
+        sp--; cur = stack[sp * BD_BLOCK];
     }
     return h;
 }
@@ -137,7 +140,7 @@ TD bsample bd_sample(const SceneView &s, v3 dir, v3 normal, v3 fnormal, int mat_
     return r;
 }
 
-struct BdCtx { SceneView sc; BvhView bvh; CameraView cam; BdView bv; uint32_t seed; unsigned long long *rays_closest, *rays_shadow, *paths; };
+struct BdCtx { SceneView sc; BvhView bvh; CameraView cam; BdView bv; uint32_t seed; unsigned long long *rays_closest, *rays_shadow, *paths; int *stack; };
 
 // BDPT_RGB.py:103-198
 TD int bd_eye_path(const BdCtx &c, bpixel *P, int i, int j, uint32_t frame, unsigned &n_closest)
@@ -153,7 +156,7 @@ TD int bd_eye_path(const BdCtx &c, bpixel *P, int i, int j, uint32_t frame, unsi
     float pdfFwd = 1.0f, pdfRev = 0.0f;
     v3 beta = V(1.0f, 1.0f, 1.0f);
     while (depth < BD_EYE_MAX) {
-        const SimpleHit sh = trace_simple(c.bvh, origin, dir);
+        const SimpleHit sh = trace_simple(c.bvh, origin, dir, c.stack);
         n_closest++;
         if (sh.t < INF_VALUE) {
             const HitAttr h = hit_attributes(c.sc, origin, dir, sh.prim, sh.t, sh.u, sh.v);
@@ -232,7 +235,7 @@ TD int bd_light_path(const BdCtx &c, bpixel *P, int i, int j, uint32_t frame, un
     v3 beta = (emission / light_pdf) * absf(dot(lnor, ldir));
     v3 origin = lpos, dir = ldir;
     while (depth < BD_LIGHT_MAX) {
-        const SimpleHit sh = trace_simple(c.bvh, origin, dir);
+        const SimpleHit sh = trace_simple(c.bvh, origin, dir, c.stack);
         n_closest++;
         if (sh.t < INF_VALUE) {
             const HitAttr h = hit_attributes(s, origin, dir, sh.prim, sh.t, sh.u, sh.v);
@@ -414,7 +417,7 @@ TD v3 bd_connect_path(const BdCtx &c, bpixel *P, int i, int j, int e, int l, uin
         const v3 snormal = light[l - 1].snormal;
         const float NdotL = dot(wi, snormal);
         if ((nu >= 0) & (light[l - 1].delta != 1) & (NdotL < 0.0f) & (light[l - 1].type == VERTEX_SURFACE)) {
-            const SimpleHit sh = trace_simple(c.bvh, origin, wi);
+            const SimpleHit sh = trace_simple(c.bvh, origin, wi, c.stack);
             n_shadow++;
             if (sh.prim == prim) {
                 float pdf;
@@ -445,7 +448,7 @@ TD v3 bd_connect_path(const BdCtx &c, bpixel *P, int i, int j, int e, int l, uin
             wi = wi / light_dist;
             const float NdotLl = dot(wi, light_normal);
             const float NdotLe = dot(wi, eye[e - 1].snormal);
-            const SimpleHit sh = trace_simple(c.bvh, surface, -wi);
+            const SimpleHit sh = trace_simple(c.bvh, surface, -wi, c.stack);
             n_shadow++;
             if ((sh.prim == light_prim) & (sh.t > EPS_UF)) {
                 const float light_pdf = light_choice_pdf;
@@ -470,7 +473,7 @@ TD v3 bd_connect_path(const BdCtx &c, bpixel *P, int i, int j, int e, int l, uin
             const float dist = norm(dir);
             dir = dir / dist;
             const float NdotLl = dot(dir, light[l - 1].snormal), NdotLe = dot(dir, eye[e - 1].snormal);
-            const SimpleHit sh = trace_simple(c.bvh, surfaceL, dir);
+            const SimpleHit sh = trace_simple(c.bvh, surfaceL, dir, c.stack);
             n_shadow++;
             if ((sh.prim == primE) & (sh.t > EPS_UF)) {
                 float lpdf, epdf;
@@ -504,8 +507,10 @@ __global__ void k_bdpt_clear(bpixel *px, float *radiance, long npix)
 }
 
 // BDPT_RGB.py:617-637: one thread per owned pixel
-__global__ __launch_bounds__(64) void k_bdpt_pixel(BdCtx c, bpixel *px, float *radiance, TileMap tm, int P_local, uint32_t frame)
+__global__ __launch_bounds__(BD_BLOCK) void k_bdpt_pixel(BdCtx c, bpixel *px, float *radiance, TileMap tm, int P_local, uint32_t frame)
 {
+    __shared__ int lds_stack[BD_STACK * BD_BLOCK];
+    c.stack = lds_stack + threadIdx.x;
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= P_local) return;
     const int p = local_to_pixel(tm, k);
@@ -553,7 +558,7 @@ int bdpt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t see
     }
     if (c->bdpt_rad.ensure(sizeof(float) * 3 * (size_t)NP)) return TIRT_ERR_HIP;
     BdCtx bc;
-    bc.sc = scene_view(c); bc.bvh = bvh_view(c); bc.cam = c->cam; bc.seed = seed;
+    bc.sc = scene_view(c); bc.bvh = bvh_view(c); bc.cam = c->cam; bc.seed = seed; bc.stack = nullptr;
     for (int k = 0; k < 12; k++) bc.bv.view[k] = c->view[k];
     bc.bv.W = c->W; bc.bv.H = c->H;
     DevCounters *ctr = c->dev_counters.as<DevCounters>();
@@ -564,7 +569,7 @@ int bdpt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t see
     for (int f = 0; f < frame_count; f++) {
         const uint32_t frame = frame_begin + (uint32_t)f;
         hipLaunchKernelGGL(k_bdpt_clear, dim3((unsigned)((NP + 255) / 256)), dim3(256), 0, st, c->bdpt_px.as<bpixel>(), c->bdpt_rad.as<float>(), NP);
-        if (P > 0) hipLaunchKernelGGL(k_bdpt_pixel, dim3((P + 63) / 64), dim3(64), 0, st, bc, c->bdpt_px.as<bpixel>(), c->bdpt_rad.as<float>(), tm, P, frame);
+        if (P > 0) hipLaunchKernelGGL(k_bdpt_pixel, dim3((P + BD_BLOCK - 1) / BD_BLOCK), dim3(BD_BLOCK), 0, st, bc, c->bdpt_px.as<bpixel>(), c->bdpt_rad.as<float>(), tm, P, frame);
         const float coff = 1.0f / ((float)(int)frame + 1.0f);
         hipLaunchKernelGGL(k_bdpt_film, dim3((unsigned)((3 * NP + 255) / 256)), dim3(256), 0, st, c->bdpt_rad.as<float>(), c->hdr.as<float>(), 3 * NP, coff);
     }
