@@ -17,6 +17,8 @@ def bits_equal(a, b):
 
 def check_scene(ex, W, H, extra_rays=None, max_rays=40000):
     ex.build_scene()
+    if not ex.cam.view_inv_np.any():          # plain Example.example: nobody framed the camera yet
+        ex.frame_camera(0.8)
     o = oa.OracleScene(ex.scene, ex.cam)
     o.lbvh_build()
     rays = oa.camera_rays(ex.cam, W, H)
@@ -88,3 +90,39 @@ def test_headline_100k_primary_rays(gpu_ctx_ok):
     n, frac, cnt = check_scene(ex, 256, 256, max_rays=30000)
     print("100k scene: hit fraction %.3f, exhaustive N_box %.1f N_leaf %.1f per primary ray" % (frac, cnt[0], cnt[1]))
     assert 0.3 < frac < 0.95
+
+
+def test_deep_duplicate_chain_uses_the_spill_stack(gpu_ctx_ok):
+    """48 triangles with the same centroid (one Morton code) form a 48-deep chain under the
+    reference's duplicate rule (accel/LBvh.py:240-251): deeper than the 24-entry LDS stack, so the
+    global spill tail of the traversal stack is exercised.  Hits must still equal the oracle's."""
+    from ti_raytrace_amd import Example, PT_RGB
+    from ti_raytrace_amd import SceneData as SCD
+    W = H = 48
+    ex = Example.example(W, H, 4, 0)
+    mat = SCD.Material(); mat.type = SCD.MAT_DISNEY; mat.setRough(0.5); mat.setColor([0.8, 0.8, 0.8, 1.0]); mat.alebdoTex = -1
+    r = np.random.RandomState(11)
+    tris = []
+    for k in range(48):                       # nested, slightly tilted triangles around the origin: centroid exactly (0,0,0)
+        a = r.uniform(0.3, 1.0); th = r.uniform(0, 2 * np.pi); tilt = r.uniform(-0.3, 0.3)
+        p = np.array([[np.cos(th + 2 * np.pi * j / 3) * a, np.sin(th + 2 * np.pi * j / 3) * a, 0.0] for j in range(3)])
+        p[:, 2] = tilt * p[:, 0]
+        p -= p.mean(axis=0, keepdims=True)
+        tris.append(p)
+    for k in range(40):                       # some ordinary geometry around it
+        c = r.uniform(-1.5, 1.5, size=3); tris.append(c[None, :] + r.uniform(-0.2, 0.2, size=(3, 3)))
+    ex.scene.add_mesh(np.asarray(tris), mat)
+    ex.add_sphere_light(pos=(0.0, 3.0, 0.0), radius=0.5, emission=30.0)
+    ex.integrator = PT_RGB.PathTrace(W, H, ex.cam, ex.scene, 64)
+    n, frac, cnt = check_scene(ex, W, H, random_rays(4000, -1.5, 1.5, 5))
+    o = oa.OracleScene(ex.scene, ex.cam); o.lbvh_build()
+    codes = o.lbvh_get()[0][:, 0]
+    runs = np.diff(np.flatnonzero(np.diff(codes) != 0)).max()
+    assert runs >= 40                        # the chain exists
+    st = ex.scene.ctx.stats()
+    assert st["stack_overflow"] == 0
+    # and the image still matches
+    ex.integrator.render_frames(2)
+    got = ex.integrator.hdr.to_numpy()
+    want, ost = o.render(W, H, 0, 2, seed=ex.integrator.seed)
+    assert ost["overflow"] == 0 and np.array_equal(got, want)
