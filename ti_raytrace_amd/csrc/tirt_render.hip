@@ -738,6 +738,18 @@ int pt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed,
             drain(evc, c->ms_trace_closest); drain(evs, c->ms_trace_shadow); drain(evh, c->ms_shade);
         }
         c->ev_pool.push_back({r0, r1});        // drained (and destroyed) by tirt_stats / tirt_stats_reset
+        if (c->ev_pool.size() > 64) {          // long render loops that never ask for stats: retire finished pairs
+            size_t keep = 0;
+            for (auto &pr : c->ev_pool) {
+                if (hipEventQuery(pr.second) == hipSuccess) {
+                    float ms = 0.0f;
+                    if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) c->ms_render += ms;
+                    (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second);
+                } else c->ev_pool[keep++] = pr;
+            }
+            c->ev_pool.resize(keep);
+            (void)hipGetLastError();           // hipEventQuery's hipErrorNotReady is not an error
+        }
     }
     // main-stream consumers of the film (tone map, downloads, clear) wait for c->last_film themselves
     TIRT_HIP(hipGetLastError());
