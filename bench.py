@@ -138,7 +138,7 @@ def main():
     mrays = (rays_closest + rays_shadow) / elapsed / 1e6
 
     result = {
-        "metric": "Mrays/s (primary+secondary) at 1024^2 100k-tri",
+        "metric": "Mrays/s (primary+secondary) at 1024\u00b2 100k-tri, 1/2/4/8 GPU + HBM GB/s",
         "value": round(mrays, 3),
         "unit": "Mrays/s",
         "n_gpus": world,
@@ -203,6 +203,7 @@ def main():
             "bound": "hbm", "kernel": "k_trace<ordered> (closest-hit + NEE shadow rays)",
             "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
+            "hbm_GBps_measured": (round(traffic / (avg_ms * 1e-3) / 1e9, 1) if (traffic and avg_ms > 0) else None),
             "alg_bytes_per_launch": round(alg_trace / n_launch, 1),
             "avg_launch_ms": round(avg_ms, 5), "launches": int(n_launch),
             "alg_bytes_per_closest_ray": round(alg_closest / max(c["rays_closest"], 1), 1),
