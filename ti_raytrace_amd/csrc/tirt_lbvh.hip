@@ -273,24 +273,24 @@ __global__ void k_karras(SceneView s, const int *codes, const int *prims, float 
 }
 
 // Bottom-up refit: one thread per leaf climbs; the second thread to arrive at a node owns it.
-// Hand-off follows the guide's counter form: plain stores -> agent release fence (+ explicit
-// vmcnt drain) -> relaxed agent atomic; the owner does an agent acquire fence before reading
-// the children's rows.
+// Hand-off without cache-wide fences (a release fence per climbing step writes back the whole L2:
+// 15 ms of the 19.7 ms build at 4 M primitives): every word another thread will read is written
+// with an agent-scope (sc1, write-through) store, the stores are drained with `s_waitcnt vmcnt(0)`
+// before the arrival counter is bumped, and the owner reads its children's rows with agent-scope
+// (sc1, L1-bypassing) loads -- the guide's "drained sc1 payload -> sc1 flag" recipe
+// (MI355X_MICROARCH.md, row handoff-flag).  Leaf rows come from the previous kernel.
 __global__ void k_refit(int n, float *bvh_node, const int *parent, int *flag, int *subtree, int *done)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     int cur = parent[(n - 1) + i];
     while (cur >= 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this thread's sc1 stores of the node below have landed
         int old = __hip_atomic_fetch_add(&flag[cur], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (old == 0) return;
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         float *nd = bvh_node + (size_t)cur * NOD_VEC;
-        int l = (int)nd[1], r = (int)nd[2];
+        int l = (int)nd[1], r = (int)nd[2];                     // written by k_karras (previous launch)
         const float *ln = bvh_node + (size_t)l * NOD_VEC, *rn = bvh_node + (size_t)r * NOD_VEC;
-        // sc1 loads: served from L2 / memory, never from a stale L1 line
         float lb[6], rb[6];
 #pragma unroll
         for (int k = 0; k < 6; k++) {
