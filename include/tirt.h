@@ -68,7 +68,8 @@ int tirt_sync(tirt_ctx *ctx);
  *            ctx stream so that tirt_stats reports per-kernel time (bench/roofline only)
  *            (also confines the batches to one lane so that kernel times are not overlapped)
  *          "overlap_lanes" (1..8, default 4) -- wavefront batches in flight on separate streams
- *          "trace_lds_depth" / "trace_refill_min" / "trace_node_min" / "trace_grid" -- traversal tuning
+ *          "trace_lds_depth" / "trace_refill_min" / "trace_node_min" / "trace_grid" / "trace_slices" /
+ *          "shade_grid" -- kernel tuning
  *          "merge_paths" -- consecutive tirt_pt_rgb_render calls over contiguous frames are merged
  *            until this many pixel-samples are pending (default 8 Mi; 0 submits every call at once);
  *            every other entry point submits what is pending first

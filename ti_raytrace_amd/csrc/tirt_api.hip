@@ -289,6 +289,13 @@ int tirt_set_option(tirt_ctx *c, const char *name, double value)
     if (!strcmp(name, "trace_lds_depth")) { TIRT_REQUIRE(value >= 1 && value <= 64, "trace_lds_depth: 1..64"); c->tr_lds_depth = (int)value; return TIRT_OK; }
     if (!strcmp(name, "trace_refill_min")) { TIRT_REQUIRE(value >= 1 && value <= 64, "trace_refill_min: 1..64"); c->tr_refill_min = (int)value; return TIRT_OK; }
     if (!strcmp(name, "trace_node_min")) { TIRT_REQUIRE(value >= 1 && value <= 64, "trace_node_min: 1..64"); c->tr_node_min = (int)value; return TIRT_OK; }
+    if (!strcmp(name, "trace_slices")) {
+        const int iv = (int)value;
+        TIRT_REQUIRE(iv >= 1 && iv <= 64 && (iv & (iv - 1)) == 0, "trace_slices: power of two, 1..64");
+        int l = 0; while ((1 << l) < iv) l++;
+        c->tr_slice_log2 = l; return TIRT_OK;
+    }
+    if (!strcmp(name, "shade_grid")) { TIRT_REQUIRE(value >= 1 && value <= 65536, "shade_grid: 1..65536"); c->sh_grid = (int)value; return TIRT_OK; }
     if (!strcmp(name, "trace_grid")) { TIRT_REQUIRE(value >= 1 && value <= 4096, "trace_grid: 1..4096"); c->tr_grid = (int)value; return TIRT_OK; }
     set_error(std::string("tirt_set_option: unknown option ") + name);
     return TIRT_ERR_ARG;

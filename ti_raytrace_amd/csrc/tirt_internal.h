@@ -154,8 +154,9 @@ struct tirt_ctx {
     // of a multi-GPU job -- then run as one efficient batch); any other API call flushes first
     size_t merge_paths = (size_t)8 << 20;          // option "merge_paths" (0 = submit every call at once)
     struct { bool valid = false; uint32_t begin = 0; int count = 0; uint32_t seed = 0; int max_depth = 0, stack_size = 0, flags = 0; } pend;
-    // traversal tunables (options "trace_lds_depth", "trace_refill_min", "trace_node_min", "trace_grid")
-    int tr_lds_depth = 24, tr_refill_min = 36, tr_node_min = 12, tr_grid = 1536;
+    // traversal tunables (options "trace_lds_depth", "trace_refill_min", "trace_node_min", "trace_grid",
+    // "trace_slices" = number of ray-fetch cursors, "shade_grid" = persistent blocks of k_shade)
+    int tr_lds_depth = 24, tr_refill_min = 36, tr_node_min = 12, tr_grid = 1536, tr_slice_log2 = 5, sh_grid = 512;
     tirt::DevBuf counters_mem, spill;            // used by the batch trace entry points (main stream)
 
     // BDPT_RGB: persistent per-pixel vertex arrays + per-frame radiance (splat target)

@@ -45,7 +45,12 @@ struct TraceArgs {
     int *spill; int spill_depth;                 // global stack tail: [entry][global thread]
     // KIND_MIXED: the shadow rays live in their own arrays; indices [count, count + scount) are shadow rays
     const float *sox, *soy, *soz, *sdx, *sdy, *sdz; const int *scount_ptr;
-    int *fetch;                                  // ray-fetch cursor of this launch (zero on entry)
+    // ray-fetch cursors of this launch (zero on entry).  Same-address device atomics retire at one per
+    // ~11 ns on MI355X (tools/micro/atomic_rate.hip), which would cap a single cursor at ~3 Grays/s, so
+    // the queue is cut into 2^slice_log2 interleaved slices (64-ray chunks, chunk c belongs to slice
+    // c mod S), each with its own cursor in its own 128-byte line; a wave drains its home slice and
+    // then moves on to the next one.
+    int *fetch; int slice_log2;
     int lds_depth;                               // stack entries per lane kept in LDS
     int refill_min;                              // re-fetch rays when this many lanes of a wave are idle
     int node_min;                                // leave the inner-node loop below this many busy lanes
@@ -57,6 +62,8 @@ struct TraceArgs {
 // lanes are idle, so that a few long rays do not leave the other lanes of the wave parked
 // (a one-ray-per-lane loop measured 15 % VALU lane utilisation on this workload).  Inner-node
 // steps and triangle tests run in separate loops so that lanes doing the same thing run together.
+constexpr int TR_FETCH_STRIDE = 32;           // ints between two slice cursors (one 128-byte line each)
+constexpr int TR_SLICES_MAX = 64;
 constexpr int TR_SENT = (int)0x80000000;      // "stack empty": never a node index nor a leaf code
 
 TD unsigned long long wave_sum(unsigned long long v)
@@ -92,6 +99,9 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
     unsigned nbox = 0, nleaf = 0;
     RayCtx r = {};
     bool exhausted = false;
+    const int S_LOG = a.slice_log2, S_MASK = (1 << S_LOG) - 1;
+    int home = (int)((blockIdx.x * (TR_BLOCK / 64) + (tid >> 6)) & S_MASK), tried = 0;      // wave-uniform
+    const int full_chunks = count >> 6;
     bool wave_par = false;                      // any lane of the wave holds an axis-parallel ray (rare)
     unsigned long long sum_box = 0, sum_leaf = 0, sum_box_s = 0, sum_leaf_s = 0, n_over = 0;
     unsigned long long d_it_node = 0, d_lanes_node = 0, d_it_leaf = 0, d_lanes_leaf = 0, d_refills = 0, d_outer = 0;
@@ -120,11 +130,18 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
             const int n_idle = __popcll(idle);
             if (COUNT) d_refills++;
             const int leader = __ffsll((long long)idle) - 1;
+            // rays of slice `home`: its 64-ray chunks are the global chunks home, home + S, home + 2S, ...
+            const int len = (((full_chunks >> S_LOG) + (home < (full_chunks & S_MASK) ? 1 : 0)) << 6) +
+                            (home == (full_chunks & S_MASK) ? (count & 63) : 0);
             int base = 0;
-            if (lane == leader) base = atomicAdd(a.fetch, n_idle);
+            if (lane == leader) base = atomicAdd(a.fetch + home * TR_FETCH_STRIDE, n_idle);
             base = __shfl(base, leader, 64);
-            if (base + n_idle >= count) exhausted = true;
-            const int my = base + __popcll(idle & lt_mask);
+            const int v = base + __popcll(idle & lt_mask);                // index within the slice
+            const int my = v < len ? (((((v >> 6) << S_LOG) + home) << 6) | (v & 63)) : count;
+            if (base + n_idle >= len) {                                    // slice drained: move on
+                home = (home + 1) & S_MASK;
+                if (++tried > S_MASK) exhausted = true;
+            }
             if (!have && my < count) {
                 q = my;
                 if (KIND == KIND_MIXED) { is_sh = my >= count_c; if (is_sh) q = my - count_c; }
@@ -154,7 +171,7 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
                 have = true;
             }
         }
-        if (__ballot(have) == 0ull) break;
+        if (__ballot(have) == 0ull) { if (exhausted) break; continue; }
         wave_par = __ballot(have && par) != 0ull;
         if (COUNT) d_outer++;
 
@@ -301,7 +318,7 @@ static int ensure_spill(tirt_ctx *c, DevBuf &spill, int stack_size, int &spill_d
     return spill.ensure(sizeof(int) * (size_t)(spill_depth > 0 ? spill_depth : 1) * TR_GRID_MAX * TR_BLOCK);
 }
 static void fill_tunables(const tirt_ctx *c, TraceArgs &a)
-{ a.lds_depth = c->tr_lds_depth; a.refill_min = c->tr_refill_min; a.node_min = c->tr_node_min; }
+{ a.lds_depth = c->tr_lds_depth; a.refill_min = c->tr_refill_min; a.node_min = c->tr_node_min; a.slice_log2 = c->tr_slice_log2; }
 
 // ---------------------------------------------------------------------------------------------
 // Batch entry points (Debug-integrator style closest hit on caller-supplied rays)
@@ -357,8 +374,8 @@ int launch_trace_batch(tirt_ctx *c, const float *rays, int nr, int stack_size, i
     a.spill = c->spill.as<int>(); a.spill_depth = spill_depth;
     a.ctr = c->dev_counters.as<DevCounters>();
     a.per_ray_counts = (flags & TIRT_COUNT_NODES) ? c->tr_counts.as<int2>() : nullptr;
-    if (c->counters_mem.ensure(sizeof(int) * 4 * 18)) return TIRT_ERR_HIP;
-    TIRT_HIP(hipMemsetAsync(c->counters_mem.p, 0, sizeof(int), st));
+    if (c->counters_mem.ensure(sizeof(int) * TR_FETCH_STRIDE * TR_SLICES_MAX)) return TIRT_ERR_HIP;
+    TIRT_HIP(hipMemsetAsync(c->counters_mem.p, 0, sizeof(int) * TR_FETCH_STRIDE * TR_SLICES_MAX, st));
     a.fetch = c->counters_mem.as<int>();
     fill_tunables(c, a);
     int grid = (nr + TR_BLOCK - 1) / TR_BLOCK; if (grid > c->tr_grid) grid = c->tr_grid;
@@ -404,28 +421,22 @@ __global__ void k_generate(PathSoA ps, CameraView cam, TileMap tm, int P, int S,
     if (s == 0) atomicAdd(&ctr->paths, (unsigned long long)S);
 }
 
-// wave-aggregated append: one atomic per wave
-TD int queue_slot(bool want, int *counter)
-{
-    unsigned long long mask = __ballot(want);
-    if (mask == 0ull) return -1;
-    const int lane = threadIdx.x & 63;
-    int base = 0;
-    const int leader = __ffsll((long long)mask) - 1;
-    if (lane == leader) base = atomicAdd(counter, __popcll(mask));
-    base = __shfl(base, leader, 64);
-    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    return want ? base + __popcll(mask & lt) : -1;
-}
-
-#ifndef SH_MIN_WAVES
-#define SH_MIN_WAVES 3
+// Block size of k_shade.  The survivors / shadow rays of a block are appended with ONE 64-bit atomic per
+// block and round (low word: next-bounce paths, high word: shadow rays): same-address device atomics
+// retire at ~11 ns each on MI355X, so one atomic per wave and queue (2 x 524k per 33.5 M paths)
+// bounded the kernel at ~6 ms; per 512-thread block it is 65k.
+#ifndef SH_BLOCK
+#define SH_BLOCK 512
 #endif
-__global__ __launch_bounds__(256, SH_MIN_WAVES) void k_shade(PathState ps, PathSoA in, PathSoA out, SceneView sc, TileMap tm, int P,
-                                                           uint32_t frame_begin, uint32_t seed, int bounce, int last_bounce,
-                                                           const int *count_ptr, int count_fixed, int *next_count,
-                                                           int *shadow_count, DevCounters *ctr)
+__global__ __launch_bounds__(SH_BLOCK) void k_shade(PathState ps, PathSoA in, PathSoA out, SceneView sc, TileMap tm, int P,
+                                                   uint32_t frame_begin, uint32_t seed, int bounce, int last_bounce,
+                                                   const int *count_ptr, int count_fixed, unsigned long long *append_ctr,
+                                                   DevCounters *ctr)
 {
+    __shared__ unsigned s_wcnt[2][SH_BLOCK / 64];
+    __shared__ unsigned long long s_base[2];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     const int count = count_ptr ? *count_ptr : count_fixed;
     const int total = gridDim.x * blockDim.x;
     const int rounds = (count + total - 1) / total;
@@ -550,7 +561,23 @@ __global__ __launch_bounds__(256, SH_MIN_WAVES) void k_shade(PathState ps, PathS
         // dense compaction: survivors go to consecutive indices of the other PathSoA, finished
         // paths deposit their radiance in the per-path final array, shadow rays get their own
         // dense list with the address their contribution must be added to
-        const int qn = queue_slot(want_next, next_count);
+        const int par = it & 1;
+        const unsigned long long nmask = __ballot(want_next), smask = __ballot(want_shadow);
+        if (lane == 0) s_wcnt[par][wid] = (unsigned)__popcll(nmask) | ((unsigned)__popcll(smask) << 16);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned tn = 0, tsd = 0;
+#pragma unroll
+            for (int w = 0; w < SH_BLOCK / 64; w++) { tn += s_wcnt[par][w] & 0xffffu; tsd += s_wcnt[par][w] >> 16; }
+            s_base[par] = (tn | tsd) ? atomicAdd(append_ctr, (unsigned long long)tn | ((unsigned long long)tsd << 32)) : 0ull;
+        }
+        __syncthreads();
+        unsigned pn = 0, psd = 0;
+#pragma unroll
+        for (int w = 0; w < SH_BLOCK / 64; w++) if (w < wid) { pn += s_wcnt[par][w] & 0xffffu; psd += s_wcnt[par][w] >> 16; }
+        const unsigned long long bb = s_base[par];
+        const int qn = (int)(unsigned)(bb & 0xffffffffull) + (int)pn + __popcll(nmask & lt_mask);
+        const int qs = (int)(unsigned)(bb >> 32) + (int)psd + __popcll(smask & lt_mask);
         if (want_next) {
             out.ox[qn] = next_o.x; out.oy[qn] = next_o.y; out.oz[qn] = next_o.z;
             out.dx[qn] = next_d.x; out.dy[qn] = next_d.y; out.dz[qn] = next_d.z;
@@ -560,7 +587,6 @@ __global__ __launch_bounds__(256, SH_MIN_WAVES) void k_shade(PathState ps, PathS
         } else if (live) {
             ps.fr[slot] = radiance.x; ps.fg[slot] = radiance.y; ps.fb[slot] = radiance.z;
         }
-        const int qs = queue_slot(want_shadow, shadow_count);
         if (want_shadow) {
             ps.sox[qs] = sh_o.x; ps.soy[qs] = sh_o.y; ps.soz[qs] = sh_o.z;
             ps.sdx[qs] = sh_d.x; ps.sdy[qs] = sh_d.y; ps.sdz[qs] = sh_d.z;
@@ -592,6 +618,13 @@ __global__ void k_film(PathState ps, TileMap tm, int P, int F, uint32_t frame_be
     px[0] = r; px[1] = g; px[2] = b;
 }
 
+// Per-batch device counters of a lane: one packed append counter per bounce (low word: paths that go on
+// to bounce b+1, high word: shadow rays of bounce b), each in its own 128-byte line, then the sliced
+// ray-fetch cursors of the max_depth + 1 traversal launches.
+constexpr size_t LINE = 128;
+static size_t lane_counter_bytes(int max_depth)
+{ return LINE * (size_t)(max_depth + 1) + sizeof(int) * TR_FETCH_STRIDE * TR_SLICES_MAX * (size_t)(max_depth + 1); }
+
 static int ensure_paths(Lane &L, size_t S, int max_depth)
 {
     if (S > L.path_capacity || !L.path_mem.p) {
@@ -612,7 +645,7 @@ static int ensure_paths(Lane &L, size_t S, int max_depth)
         p.fr = nxt(); p.fg = nxt(); p.fb = nxt();
         L.path_capacity = S;
     }
-    if (L.counters_mem.ensure(sizeof(int) * 4 * (size_t)(max_depth + 2))) return TIRT_ERR_HIP;
+    if (L.counters_mem.ensure(lane_counter_bytes(max_depth))) return TIRT_ERR_HIP;
     return 0;
 }
 
@@ -659,9 +692,11 @@ int pt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed,
         const int F = (frame_count - fb < FB) ? frame_count - fb : FB;
         const int S = F * P;
         const uint32_t f0 = frame_begin + (uint32_t)fb;
-        int *cnt_path = L.counters_mem.as<int>();               // [max_depth+2] live paths per bounce
-        int *cnt_shadow = cnt_path + (max_depth + 2);           // shadow rays per bounce
-        int *fetch_c = cnt_shadow + (max_depth + 2), *fetch_s = fetch_c + (max_depth + 2);   // ray-fetch cursors
+        char *cm = L.counters_mem.as<char>();
+        auto append_ctr = [&](int b) { return (unsigned long long *)(cm + LINE * (size_t)b); };
+        auto cnt_path = [&](int b) { return (const int *)append_ctr(b - 1); };           // live paths entering bounce b >= 1
+        auto cnt_shadow = [&](int b) { return (const int *)append_ctr(b) + 1; };         // shadow rays made by bounce b
+        auto fetch = [&](int launch) { return (int *)(cm + LINE * (size_t)(max_depth + 1)) + (size_t)launch * TR_FETCH_STRIDE * TR_SLICES_MAX; };
 
         TIRT_HIP(hipStreamWaitEvent(st, c->ev_main, 0));
         hipEvent_t r0, r1;
@@ -674,9 +709,10 @@ int pt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed,
             else (void)hipEventRecord(v.back().second, st);
         };
 
-        TIRT_HIP(hipMemsetAsync(L.counters_mem.p, 0, sizeof(int) * 4 * (size_t)(max_depth + 2), st));
+        TIRT_HIP(hipMemsetAsync(L.counters_mem.p, 0, lane_counter_bytes(max_depth), st));
         hipLaunchKernelGGL(k_generate, dim3((S + B - 1) / B), dim3(B), 0, st, L.ps.st[0], c->cam, tm, P, S, f0, seed, ctr);
         int grid_full = (S + TR_BLOCK - 1) / TR_BLOCK; if (grid_full > c->tr_grid) grid_full = c->tr_grid;
+        int grid_shade = (S + SH_BLOCK - 1) / SH_BLOCK; if (grid_shade > c->sh_grid) grid_shade = c->sh_grid;
         for (int b = 0; b < max_depth; b++) {
             const PathSoA &in = L.ps.st[b & 1], &out = L.ps.st[(b + 1) & 1];
             // closest hits of bounce b, together with the NEE shadow rays of bounce b-1 (they add into
@@ -684,14 +720,14 @@ int pt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed,
             TraceArgs a = {};
             a.bvh = bv;
             a.ox = in.ox; a.oy = in.oy; a.oz = in.oz; a.dx = in.dx; a.dy = in.dy; a.dz = in.dz;
-            a.count_ptr = (b == 0) ? nullptr : &cnt_path[b]; a.count_fixed = S;
+            a.count_ptr = (b == 0) ? nullptr : cnt_path(b); a.count_fixed = S;
             a.ht = L.ps.ht; a.hu = L.ps.hu; a.hv = L.ps.hv; a.hprim = L.ps.hprim;
             a.spill = L.spill.as<int>(); a.spill_depth = spill_depth; a.ctr = ctr; a.per_ray_counts = nullptr;
-            a.fetch = &fetch_c[b];
+            a.fetch = fetch(b);
             a.sox = L.ps.sox; a.soy = L.ps.soy; a.soz = L.ps.soz; a.sdx = L.ps.sdx; a.sdy = L.ps.sdy; a.sdz = L.ps.sdz;
             a.sprim = L.ps.sprim; a.sdst = L.ps.sdst; a.sdist = L.ps.sdist; a.scr = L.ps.scr; a.scg = L.ps.scg; a.scb = L.ps.scb;
             a.rr = in.rr; a.rg = in.rg; a.rb = in.rb; a.fr = L.ps.fr; a.fg = L.ps.fg; a.fb = L.ps.fb;
-            a.scount_ptr = (b == 0) ? nullptr : &cnt_shadow[b - 1];
+            a.scount_ptr = (b == 0) ? nullptr : cnt_shadow(b - 1);
             fill_tunables(c, a);
             stamp(evc, true);
             if (b == 0) launch_trace<KIND_CLOSEST>(st, a, flags, grid_full);
@@ -700,9 +736,9 @@ int pt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed,
             c->launches_trace_closest++;
 
             stamp(evh, true);
-            hipLaunchKernelGGL(k_shade, dim3(grid_full), dim3(B), 0, st, L.ps, in, out, sv, tm, P, f0, seed, b,
-                               (b == max_depth - 1) ? 1 : 0, (b == 0) ? (const int *)nullptr : (const int *)&cnt_path[b], S,
-                               &cnt_path[b + 1], &cnt_shadow[b], ctr);
+            hipLaunchKernelGGL(k_shade, dim3(grid_shade), dim3(SH_BLOCK), 0, st, L.ps, in, out, sv, tm, P, f0, seed, b,
+                               (b == max_depth - 1) ? 1 : 0, (b == 0) ? (const int *)nullptr : cnt_path(b), S,
+                               append_ctr(b), ctr);
             stamp(evh, false);
             c->launches_shade++;
 
@@ -710,11 +746,11 @@ int pt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed,
                 TraceArgs sa = {};
                 sa.bvh = bv;
                 sa.ox = L.ps.sox; sa.oy = L.ps.soy; sa.oz = L.ps.soz; sa.dx = L.ps.sdx; sa.dy = L.ps.sdy; sa.dz = L.ps.sdz;
-                sa.count_ptr = &cnt_shadow[b]; sa.count_fixed = 0;
+                sa.count_ptr = cnt_shadow(b); sa.count_fixed = 0;
                 sa.sprim = L.ps.sprim; sa.sdst = L.ps.sdst; sa.sdist = L.ps.sdist; sa.scr = L.ps.scr; sa.scg = L.ps.scg; sa.scb = L.ps.scb;
                 sa.rr = out.rr; sa.rg = out.rg; sa.rb = out.rb; sa.fr = L.ps.fr; sa.fg = L.ps.fg; sa.fb = L.ps.fb;
                 sa.spill = L.spill.as<int>(); sa.spill_depth = spill_depth; sa.ctr = ctr; sa.per_ray_counts = nullptr;
-                sa.fetch = &fetch_s[b];
+                sa.fetch = fetch(max_depth);
                 fill_tunables(c, sa);
                 stamp(evs, true);
                 launch_trace<KIND_SHADOW_ACC>(st, sa, flags, grid_full);
