@@ -286,7 +286,7 @@ int tirt_set_option(tirt_ctx *c, const char *name, double value)
         TIRT_REQUIRE(value >= 1.0 && value <= 1.0e9, "tirt_set_option: batch_paths out of range");
         c->batch_paths = (size_t)value; return TIRT_OK;
     }
-    if (!strcmp(name, "trace_lds_depth")) { TIRT_REQUIRE(value >= 1 && value <= 64, "trace_lds_depth: 1..64"); c->tr_lds_depth = (int)value; return TIRT_OK; }
+    if (!strcmp(name, "trace_lds_depth")) { TIRT_REQUIRE(value >= 10 && value <= 64, "trace_lds_depth: 10..64"); c->tr_lds_depth = (int)value; return TIRT_OK; }
     if (!strcmp(name, "trace_refill_min")) { TIRT_REQUIRE(value >= 1 && value <= 64, "trace_refill_min: 1..64"); c->tr_refill_min = (int)value; return TIRT_OK; }
     if (!strcmp(name, "trace_node_min")) { TIRT_REQUIRE(value >= 1 && value <= 64, "trace_node_min: 1..64"); c->tr_node_min = (int)value; return TIRT_OK; }
     if (!strcmp(name, "trace_slices")) {
