@@ -218,6 +218,7 @@ def main():
                                   "node_lane_util": round(co["diag_lanes_node"] / max(co["diag_it_node"] * 64.0, 1), 4),
                                   "leaf_iters_per_ray": round(co["diag_it_leaf"] * 64.0 / max(co["rays_closest"] + co["rays_shadow"], 1), 2),
                                   "leaf_lane_util": round(co["diag_lanes_leaf"] / max(co["diag_it_leaf"] * 64.0, 1), 4),
+                                  "top_node_visits_per_ray": round(co["diag_it_outer"] / max(co["rays_closest"] + co["rays_shadow"], 1), 2),
                                   "refills_per_wave_ray": round(co["diag_refills"] * 64.0 / max(co["rays_closest"] + co["rays_shadow"], 1), 3)},
             "whole_job_alg_GBps": round((alg_closest + alg_shadow + 260.0 * c["shaded"] + 24.0 * c["paths"]) /
                                         max(t["ms_render"], 1e-9) / 1e6, 2),

@@ -38,7 +38,7 @@ def check_scene(ex, W, H, extra_rays=None, max_rays=40000):
         if flags & _native.TRAVERSE_EXHAUSTIVE:
             assert np.array_equal(gcnt, wcnt), "N_box/N_leaf differ from the oracle's pop counts"
         elif gcnt is not None:
-            assert (gcnt[:, 0] <= wcnt[:, 0]).all()            # ordered traversal never visits more
+            assert (gcnt[:, 1] <= wcnt[:, 1]).all()            # ordered traversal never tests more primitives
     # shadow variant returns (t, prim) of the closest hit
     st, sp, _ = o.shadow_hit(rays)
     gt, gp, _ = ctx.trace_shadow(rays, 64, 0)

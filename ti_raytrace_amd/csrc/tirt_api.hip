@@ -21,7 +21,7 @@ SceneView scene_view(const tirt_ctx *c)
 BvhView bvh_view(const tirt_ctx *c)
 {
     BvhView b;
-    b.wnode = c->wnode.as<float4>(); b.tri = c->tri.as<float4>();
+    b.wnode = c->wnode.as<float4>(); b.qnode = c->qnode.as<float4>(); b.tri = c->tri.as<float4>();
     for (int k = 0; k < 3; k++) { b.root_min[k] = c->root_min[k]; b.root_max[k] = c->root_max[k]; }
     b.root_code = c->root_code;
     return b;
@@ -239,7 +239,7 @@ void tirt_destroy(tirt_ctx *c)
     drain_render_events(c);
     DevBuf *bufs[] = {&c->vertex, &c->primitive, &c->material, &c->shape, &c->light, &c->env, &c->mat_lrgb, &c->morton_unsorted, &c->keys_a,
                       &c->keys_b, &c->vals_a, &c->vals_b, &c->hist, &c->morton_sorted, &c->bvh_node, &c->compact, &c->parent,
-                      &c->flag, &c->subtree, &c->build_status, &c->leaf_compact, &c->wnode, &c->tri, &c->hdr, &c->rgb,
+                      &c->flag, &c->subtree, &c->build_status, &c->leaf_compact, &c->wnode, &c->tri, &c->qnode, &c->quad_flag, &c->quad_index, &c->quad_top, &c->qtop, &c->scan_tiles, &c->hdr, &c->rgb,
                       &c->counters_mem, &c->spill, &c->tr_rays,
                       &c->tr_out, &c->tr_prim, &c->tr_counts, &c->dev_counters, &c->bdpt_px, &c->bdpt_rad};
     for (DevBuf *b : bufs) b->release();
@@ -286,7 +286,7 @@ int tirt_set_option(tirt_ctx *c, const char *name, double value)
         TIRT_REQUIRE(value >= 1.0 && value <= 1.0e9, "tirt_set_option: batch_paths out of range");
         c->batch_paths = (size_t)value; return TIRT_OK;
     }
-    if (!strcmp(name, "trace_lds_depth")) { TIRT_REQUIRE(value >= 10 && value <= 64, "trace_lds_depth: 10..64"); c->tr_lds_depth = (int)value; return TIRT_OK; }
+    if (!strcmp(name, "trace_lds_depth")) { TIRT_REQUIRE(value >= 12 && value <= 64, "trace_lds_depth: 12..64"); c->tr_lds_depth = (int)value; return TIRT_OK; }
     if (!strcmp(name, "trace_refill_min")) { TIRT_REQUIRE(value >= 1 && value <= 64, "trace_refill_min: 1..64"); c->tr_refill_min = (int)value; return TIRT_OK; }
     if (!strcmp(name, "trace_node_min")) { TIRT_REQUIRE(value >= 1 && value <= 64, "trace_node_min: 1..64"); c->tr_node_min = (int)value; return TIRT_OK; }
     if (!strcmp(name, "trace_slices")) {

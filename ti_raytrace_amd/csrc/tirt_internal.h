@@ -54,8 +54,16 @@ struct DevBuf {
 // tri: one 48-byte record per primitive, indexed by primitive id:
 //   triangles: (v0.xyz, bits leaf_compact_index) (E1.xyz, 0) (E2.xyz, 0)
 //   spheres  : (centre.xyz, bits leaf_compact_index) (radius, 0, 0, 0) (0,0,0,0)
+// qnode: one 128-byte record per internal node at even depth (dense index in compact order), holding
+//   its up to four grandchildren: (q0 q1 q2) boxes of slots 0,1 laid out like wnode's, (q3 q4 q5) slots
+//   2,3, q6 = four codes (>= 0: qnode index, < 0: leaf as above, TR_EMPTY: unused slot), q7 unused.
+//   The ordered traversal walks these; wnode serves the exhaustive (reference-order) mode and BDPT.
+constexpr int TR_EMPTY = (int)0x80000001;
+constexpr int TR_TOP_LEVELS = 4;                         // levels of 4-wide nodes that get a breadth-first slot
+constexpr int TR_TOP_SLOTS = 85;                         // (4^TR_TOP_LEVELS - 1) / 3
 struct BvhView {
     const float4 *wnode;
+    const float4 *qnode;
     const float4 *tri;
     float root_min[3], root_max[3];
     int root_code;
@@ -132,6 +140,7 @@ struct tirt_ctx {
     tirt::DevBuf bvh_node, compact;               // f32 [N*11], [N*9]
     tirt::DevBuf parent, flag, subtree, build_status, leaf_compact;
     tirt::DevBuf wnode, tri;                      // traversal layout
+    tirt::DevBuf qnode, quad_flag, quad_index, quad_top, qtop, scan_tiles;   // 4-wide traversal nodes (ordered traversal)
     float root_min[3], root_max[3]; int root_code = 0;
 
     // camera

@@ -313,24 +313,34 @@ __global__ void k_refit(int n, float *bvh_node, const int *parent, int *flag, in
 // DFS pre-order slot of node i = depth(i) + sum over ancestors entered through their right
 // child of the left sibling's subtree size (accel/LBvh.py:138-161: left first, right's slot
 // stored in the parent's word 1, left implicit at slot+1).
-__global__ void k_flatten(int n, const float *bvh_node, const int *parent, const int *subtree, float *compact, int *leaf_compact)
+__global__ void k_flatten(int n, const float *bvh_node, const int *parent, const int *subtree, float *compact, int *leaf_compact,
+                          int *quad_flag, int *quad_top)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     int N = 2 * n - 1;
     if (i >= N) return;
-    int off = 0, cur = i;
+    int off = 0, cur = i, depth = 0;
+    unsigned path = 0;                       // bit k: the step k levels above the node went to a right child
     while (true) {
         int p = parent[cur];
         if (p < 0) break;
         const float *pn = bvh_node + (size_t)p * NOD_VEC;
         int pl = (int)pn[1];
-        off += 1;
+        if (cur != pl && depth < 32) path |= 1u << depth;
+        off += 1; depth += 1;
         if (cur != pl) off += subtree[pl];
         cur = p;
     }
     const float *nd = bvh_node + (size_t)i * NOD_VEC;
     float *cn = compact + (size_t)off * CPN_VEC;
     cn[0] = nd[0];
+    // internal nodes at even depth root the 4-wide traversal nodes (k_qnodes)
+    const bool is_quad = (((int)nd[0]) & 1) == 0 && (depth & 1) == 0;
+    quad_flag[off] = is_quad ? 1 : 0;
+    // the first TR_TOP_LEVELS levels of 4-wide nodes also get a breadth-first slot (heap numbering by
+    // path): the traversal kernel keeps those records in LDS
+    const int qd = depth >> 1;
+    quad_top[off] = (is_quad && qd < TR_TOP_LEVELS) ? (int)(((1u << (2 * qd)) - 1u) / 3u + path) : -1;
     if ((((int)nd[0]) & 1) == 1) {
         cn[1] = nd[4];
         leaf_compact[(int)nd[4]] = off;
@@ -393,13 +403,122 @@ __global__ void k_tris(SceneView s, const int *leaf_compact, float4 *tri)
 }
 
 // ---------------------------------------------------------------------------------------------
+// 4-wide traversal nodes for the ordered (product) traversal.  Every internal node at even depth
+// becomes one 128-byte record holding its (up to four) grandchildren: a child that is a leaf keeps its
+// slot, an internal child is replaced by its two children.  Boxes are the reference's own (leaf boxes
+// inflated by `pad`, as in k_wnodes); skipping the box test of the collapsed child changes no result:
+// a child box lies inside its parent's and `slabs` is monotone in the plane positions (fl(b - o) and
+// fl(x * (1/d)) are), so "grandchild passes" implies "child passes".
+//   q0 q1 q2 = boxes of slots 0,1 laid out like wnode's,  q3 q4 q5 = slots 2,3,  q6 = the four codes:
+//   >= 0 dense index of a 4-wide node, < 0 leaf (as in wnode), TR_EMPTY = unused slot (box never hit).
+// Records are numbered in compact (DFS) order by an exclusive scan of quad_flag.
+// ---------------------------------------------------------------------------------------------
+constexpr int SC_BLOCK = 256, SC_ITEMS = 8, SC_TILE = SC_BLOCK * SC_ITEMS;
+__global__ __launch_bounds__(SC_BLOCK) void k_scan_tiles(const int *in, int *out, int *tile_sum, int N)
+{
+    __shared__ int sh[SC_BLOCK];
+    const int base = blockIdx.x * SC_TILE + threadIdx.x * SC_ITEMS;
+    int v[SC_ITEMS], t = 0;
+#pragma unroll
+    for (int k = 0; k < SC_ITEMS; k++) { v[k] = (base + k < N) ? in[base + k] : 0; t += v[k]; }
+    sh[threadIdx.x] = t;
+    __syncthreads();
+    for (int o = 1; o < SC_BLOCK; o <<= 1) {
+        int x = (threadIdx.x >= o) ? sh[threadIdx.x - o] : 0;
+        __syncthreads();
+        sh[threadIdx.x] += x;
+        __syncthreads();
+    }
+    int run = sh[threadIdx.x] - t;
+#pragma unroll
+    for (int k = 0; k < SC_ITEMS; k++) { if (base + k < N) out[base + k] = run; run += v[k]; }
+    if (threadIdx.x == SC_BLOCK - 1) tile_sum[blockIdx.x] = sh[threadIdx.x];
+}
+__global__ __launch_bounds__(1024) void k_scan_tops(int *tile_sum, int nt)
+{
+    __shared__ int sh[1024];
+    __shared__ int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int b0 = 0; b0 < nt; b0 += 1024) {
+        const int i = b0 + threadIdx.x;
+        const int t = (i < nt) ? tile_sum[i] : 0;
+        sh[threadIdx.x] = t;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            int x = (threadIdx.x >= o) ? sh[threadIdx.x - o] : 0;
+            __syncthreads();
+            sh[threadIdx.x] += x;
+            __syncthreads();
+        }
+        if (i < nt) tile_sum[i] = carry + sh[threadIdx.x] - t;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += sh[1023];
+        __syncthreads();
+    }
+}
+__global__ void k_scan_add(int *out, const int *tile_sum, int N)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) out[i] += tile_sum[i / SC_TILE];
+}
+
+struct QSlot { float mn[3], mx[3]; int code; };
+TD QSlot quad_slot(SceneView s, const float *compact, const int *quad_index, int idx, float pad)
+{
+    const float *cn = compact + (size_t)idx * CPN_VEC;
+    QSlot q;
+    const bool leaf = (((int)cn[0]) & 1) == 1;
+    q.code = leaf ? child_code(s, cn, idx) : quad_index[idx];
+    const float p = leaf ? pad : 0.0f;
+    for (int k = 0; k < 3; k++) { q.mn[k] = cn[2 + k] - p; q.mx[k] = cn[5 + k] + p; }
+    return q;
+}
+TD QSlot quad_empty()
+{
+    QSlot q; q.code = TR_EMPTY;
+    for (int k = 0; k < 3; k++) { q.mn[k] = 3.0e38f; q.mx[k] = 3.0e38f; }   // (3e38 - o) * (1/d) = +-inf on both planes: never hit
+    return q;
+}
+__global__ void k_qnodes(SceneView s, int N, const float *compact, const int *quad_flag, const int *quad_index, const int *quad_top,
+                         float4 *qnode, float4 *qtop, float pad)
+{
+    int o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= N || !quad_flag[o]) return;
+    const float *cn = compact + (size_t)o * CPN_VEC;
+    const int child[2] = {o + 1, (int)cn[1]};
+    QSlot sl[4];
+    for (int c = 0; c < 2; c++) {
+        const float *cc = compact + (size_t)child[c] * CPN_VEC;
+        if ((((int)cc[0]) & 1) == 1) { sl[2 * c] = quad_slot(s, compact, quad_index, child[c], pad); sl[2 * c + 1] = quad_empty(); }
+        else {
+            sl[2 * c] = quad_slot(s, compact, quad_index, child[c] + 1, pad);
+            sl[2 * c + 1] = quad_slot(s, compact, quad_index, (int)cc[1], pad);
+        }
+    }
+    float4 *w = qnode + (size_t)quad_index[o] * 8;
+    for (int h = 0; h < 2; h++) {
+        const QSlot &a = sl[2 * h], &b = sl[2 * h + 1];
+        w[3 * h + 0] = make_float4(a.mn[0], a.mn[1], a.mn[2], a.mx[0]);
+        w[3 * h + 1] = make_float4(a.mx[1], a.mx[2], b.mn[0], b.mn[1]);
+        w[3 * h + 2] = make_float4(b.mn[2], b.mx[0], b.mx[1], b.mx[2]);
+    }
+    w[6] = make_float4(__int_as_float(sl[0].code), __int_as_float(sl[1].code), __int_as_float(sl[2].code), __int_as_float(sl[3].code));
+    w[7] = make_float4(__int_as_float(quad_top[o]), 0.0f, 0.0f, 0.0f);
+    if (quad_top[o] >= 0) {                  // copy for the LDS-resident top of the tree
+        float4 *t = qtop + (size_t)quad_top[o] * 8;
+        for (int k = 0; k < 8; k++) t[k] = w[k];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Host driver
 // ---------------------------------------------------------------------------------------------
 int lbvh_build(tirt_ctx *c)
 {
     TIRT_REQUIRE(c->n >= 1, "tirt_lbvh_build: no primitives uploaded");
     const int n = c->n, N = 2 * n - 1;
-    hipStream_t st = c->stream;
+    hipStream_t st = c->stream, st0 = st;
     c->built = false;
     if (c->morton_unsorted.ensure(sizeof(int2) * (size_t)n)) return TIRT_ERR_HIP;
     if (c->morton_sorted.ensure(sizeof(int2) * (size_t)n)) return TIRT_ERR_HIP;
@@ -412,6 +531,13 @@ int lbvh_build(tirt_ctx *c)
         c->subtree.ensure(sizeof(int) * (size_t)N) || c->build_status.ensure(sizeof(int) * 4) ||
         c->leaf_compact.ensure(sizeof(int) * (size_t)n)) return TIRT_ERR_HIP;
     if (c->wnode.ensure(sizeof(float4) * 4 * (size_t)N) || c->tri.ensure(sizeof(float4) * 3 * (size_t)n)) return TIRT_ERR_HIP;
+    // 4-wide nodes: one per internal node at even depth (< n of them); indices are used as 32-bit byte offsets / 128
+    TIRT_REQUIRE(n <= (1 << 24), "tirt_lbvh_build: more than 16 Mi primitives");
+    const int n_tiles = (N + SC_TILE - 1) / SC_TILE;
+    if (c->qnode.ensure(sizeof(float4) * 8 * (size_t)n) || c->quad_flag.ensure(sizeof(int) * (size_t)N) ||
+        c->quad_index.ensure(sizeof(int) * (size_t)N) || c->scan_tiles.ensure(sizeof(int) * (size_t)n_tiles) ||
+        c->quad_top.ensure(sizeof(int) * (size_t)N) || c->qtop.ensure(sizeof(float4) * 8 * TR_TOP_SLOTS)) return TIRT_ERR_HIP;
+    TIRT_HIP(hipMemsetAsync(c->qtop.p, 0, sizeof(float4) * 8 * TR_TOP_SLOTS, st0));
 
     SceneView sv = scene_view(c);
     const int B = 256;
@@ -433,7 +559,10 @@ int lbvh_build(tirt_ctx *c)
     hipLaunchKernelGGL(k_refit, dim3((n + B - 1) / B), dim3(B), 0, st, n, c->bvh_node.as<float>(), c->parent.as<int>(),
                        c->flag.as<int>(), c->subtree.as<int>(), c->build_status.as<int>());
     hipLaunchKernelGGL(k_flatten, dim3((N + B - 1) / B), dim3(B), 0, st, n, c->bvh_node.as<float>(), c->parent.as<int>(),
-                       c->subtree.as<int>(), c->compact.as<float>(), c->leaf_compact.as<int>());
+                       c->subtree.as<int>(), c->compact.as<float>(), c->leaf_compact.as<int>(), c->quad_flag.as<int>(), c->quad_top.as<int>());
+    hipLaunchKernelGGL(k_scan_tiles, dim3(n_tiles), dim3(SC_BLOCK), 0, st, c->quad_flag.as<int>(), c->quad_index.as<int>(), c->scan_tiles.as<int>(), N);
+    hipLaunchKernelGGL(k_scan_tops, dim3(1), dim3(1024), 0, st, c->scan_tiles.as<int>(), n_tiles);
+    hipLaunchKernelGGL(k_scan_add, dim3((N + B - 1) / B), dim3(B), 0, st, c->quad_index.as<int>(), c->scan_tiles.as<int>(), N);
     // root box + refit status back to the host (one small read; the reference does ~depth of them)
     int done = 0; float root[11];
     TIRT_HIP(hipMemcpyAsync(&done, c->build_status.p, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -449,6 +578,8 @@ int lbvh_build(tirt_ctx *c)
     float pad = 1.0e-4f * diag;
     hipLaunchKernelGGL(k_wnodes, dim3((N + B - 1) / B), dim3(B), 0, st, sv, N, c->compact.as<float>(), c->wnode.as<float4>(), pad);
     hipLaunchKernelGGL(k_tris, dim3((n + B - 1) / B), dim3(B), 0, st, sv, c->leaf_compact.as<int>(), c->tri.as<float4>());
+    hipLaunchKernelGGL(k_qnodes, dim3((N + B - 1) / B), dim3(B), 0, st, sv, N, c->compact.as<float>(), c->quad_flag.as<int>(),
+                       c->quad_index.as<int>(), c->quad_top.as<int>(), c->qnode.as<float4>(), c->qtop.as<float4>(), pad);
     if (n == 1) {
         int prim = 0, is_shape = 0;
         int pr0;

@@ -123,7 +123,7 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
     // entry below the bottom.
     constexpr unsigned ENTRY = TR_BLOCK * 4u;
     const unsigned sa_bottom = (unsigned)(size_t)(lds_int *)lds_stack + (unsigned)tid * 4u;
-    const unsigned sa_hi = (unsigned)(TR_LDS_DEPTH - 1) * ENTRY + sa_bottom;     // top entry of the LDS part
+    const unsigned sa_hi = (unsigned)(TR_LDS_DEPTH - 3) * ENTRY + sa_bottom;     // a step pushes up to three entries: page out at this fill level
     unsigned sa = sa_bottom;
     int paged = 0;                              // pages of this lane's stack that live in the spill buffer
 #define LDS_AT(addr) (*(lds_int *)(size_t)(addr))
@@ -198,7 +198,6 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
         }
         if (ballot64(have) == 0ull) { if (exhausted) break; continue; }
         wave_par = ballot64(have && par) != 0ull;
-        if (COUNT) d_outer++;
 
         // ---- inner nodes.  Lanes that reached a leaf (or finished) wait here; the loop goes on
         // while at least node_min lanes still have inner-node work, or nobody is waiting at all.
@@ -215,39 +214,13 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
             if (wave_any((int)sa >= (int)sa_hi)) break;        // a lane's LDS stack is full: page out below (cold)
             if (COUNT) { d_it_node++; d_lanes_node += (unsigned long long)n_act; }
             if (act) {
-                const float4 *w = (const float4 *)((const char *)b.wnode + ((unsigned)cur << 6));
-                const float4 q0 = w[0], q1 = w[1], q2 = w[2], q3 = w[3];
-                const int cl = __float_as_int(q3.x), cr = __float_as_int(q3.y);
-                if (COUNT) nbox += 2;
-                // the part of a step after the two box tests: near child first, far child pushed, pop on a double miss
-#define TR_DESCEND(hl, hr, tl, tr)                                                                   \
-                do {                                                                                 \
-                    const bool both__ = (hl) && (hr);                                                \
-                    const bool swap__ = (MODE != TIRT_TRAVERSE_EXHAUSTIVE) && both__ && ((tr) < (tl)); \
-                    const int farc__ = swap__ ? cl : cr;                                             \
-                    int next__ = ((hl) && !swap__) ? cl : cr;                                        \
-                    if (both__) { sa += ENTRY; LDS_AT(sa) = farc__; }                                \
-                    if (!((hl) || (hr))) TR_POP(next__);                                             \
-                    cur = next__;                                                                    \
-                } while (0)
-                if (MODE != TIRT_TRAVERSE_EXHAUSTIVE && !wave_par) {
-                    // (plane - o) * (1/d) for the 12 planes; q0..q2 hold them as
-                    // (Lmn.x Lmn.y)(Lmn.z Lmx.x)(Lmx.y Lmx.z)(Rmn.x Rmn.y)(Rmn.z Rmx.x)(Rmx.y Rmx.z)
-                    // (v_pk_add/mul_f32 on these pairs measured 4 % slower than the scalar instructions)
-                    const f2 a0 = {(q0.x - r.ox) * r.idx, (q0.y - r.oy) * r.idy}, a1 = {(q0.z - r.oz) * r.idz, (q0.w - r.ox) * r.idx}, a2 = {(q1.x - r.oy) * r.idy, (q1.y - r.oz) * r.idz};
-                    const f2 b0 = {(q1.z - r.ox) * r.idx, (q1.w - r.oy) * r.idy}, b1 = {(q2.x - r.oz) * r.idz, (q2.y - r.ox) * r.idx}, b2 = {(q2.z - r.oy) * r.idy, (q2.w - r.oz) * r.idz};
-                    const float tl = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(a0.x, a1.y), __builtin_fminf(a0.y, a2.x)),
-                                                     __builtin_fmaxf(__builtin_fminf(a1.x, a2.y), 0.0f));
-                    const float fl = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(a0.x, a1.y), __builtin_fmaxf(a0.y, a2.x)),
-                                                     __builtin_fminf(__builtin_fmaxf(a1.x, a2.y), lim));
-                    const float tr = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(b0.x, b1.y), __builtin_fminf(b0.y, b2.x)),
-                                                     __builtin_fmaxf(__builtin_fminf(b1.x, b2.y), 0.0f));
-                    const float fr = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(b0.x, b1.y), __builtin_fmaxf(b0.y, b2.x)),
-                                                     __builtin_fminf(__builtin_fmaxf(b1.x, b2.y), lim));
-                    // box hit (tmin <= min(tmax, INF)) and entry not beyond the cull distance
-                    TR_DESCEND(tl <= fl, tr <= fr, tl, tr);
-                } else {
-                    // exhaustive mode, or some lane of the wave holds an axis-parallel ray: reference form
+                if (MODE == TIRT_TRAVERSE_EXHAUSTIVE) {
+                    // reference order on the two-child nodes: both children of every box that passes
+                    // `slabs`, leaves without a box test, right child first (left is pushed)
+                    const float4 *w = (const float4 *)((const char *)b.wnode + ((unsigned)cur << 6));
+                    const float4 q0 = w[0], q1 = w[1], q2 = w[2], q3 = w[3];
+                    const int cl = __float_as_int(q3.x), cr = __float_as_int(q3.y);
+                    if (COUNT) nbox += 2;
                     float tl, tr;
                     int pl, pr;
                     if (!par) {
@@ -257,15 +230,63 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
                         pl = slabs(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tl);
                         pr = slabs(r, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tr);
                     }
-                    bool hl, hr;
-                    if (MODE == TIRT_TRAVERSE_EXHAUSTIVE) {
-                        hl = (pl != 0) || (cl < 0);          // leaves are popped and intersected without a box test
-                        hr = (pr != 0) || (cr < 0);
-                    } else {
-                        hl = (pl != 0) && (tl <= lim);
-                        hr = (pr != 0) && (tr <= lim);
+                    const bool hl = (pl != 0) || (cl < 0), hr = (pr != 0) || (cr < 0);
+                    if (hl && hr) { sa += ENTRY; LDS_AT(sa) = cr; }
+                    int next = hl ? cl : cr;
+                    if (!(hl || hr)) TR_POP(next);
+                    cur = next;
+                } else {
+                    // ordered mode on the 4-wide nodes: four box tests, children visited near to far
+                    const float4 *w = (const float4 *)((const char *)b.qnode + ((unsigned)cur << 7));
+                    const float4 q0 = w[0], q1 = w[1], q2 = w[2], q3 = w[3], q4 = w[4], q5 = w[5], q6 = w[6];
+                    int c0 = __float_as_int(q6.x), c1 = __float_as_int(q6.y), c2 = __float_as_int(q6.z), c3 = __float_as_int(q6.w);
+                    if (COUNT) { nbox += 4; if (__float_as_int(w[7].x) >= 0) d_outer++; }
+                    constexpr float MISS = 3.0e38f;
+                    float d0, d1, d2, d3;                // entry distance of a hit box, MISS otherwise
+                    // box hit (tmin <= min(tmax, INF)) and entry not beyond the cull distance: tmin <= min(tmax, lim)
+#define TR_QBOX(mnx, mny, mnz, mxx, mxy, mxz, dist)                                                  \
+                    do {                                                                             \
+                        const float ax__ = ((mnx) - r.ox) * r.idx, bx__ = ((mxx) - r.ox) * r.idx;    \
+                        const float ay__ = ((mny) - r.oy) * r.idy, by__ = ((mxy) - r.oy) * r.idy;    \
+                        const float az__ = ((mnz) - r.oz) * r.idz, bz__ = ((mxz) - r.oz) * r.idz;    \
+                        const float tn__ = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax__, bx__), __builtin_fminf(ay__, by__)), \
+                                                           __builtin_fmaxf(__builtin_fminf(az__, bz__), 0.0f));                       \
+                        const float tf__ = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax__, bx__), __builtin_fmaxf(ay__, by__)), \
+                                                           __builtin_fminf(__builtin_fmaxf(az__, bz__), lim));                        \
+                        dist = (tn__ <= tf__) ? tn__ : MISS;                                         \
+                    } while (0)
+#define TR_QBOX_REF(mnx, mny, mnz, mxx, mxy, mxz, dist)                                              \
+                    do {                                                                             \
+                        float tn__;                                                                  \
+                        const int p__ = par ? slabs(r, mnx, mny, mnz, mxx, mxy, mxz, tn__) : slabs_fast(r, mnx, mny, mnz, mxx, mxy, mxz, tn__); \
+                        dist = ((p__ != 0) && (tn__ <= lim)) ? tn__ : MISS;                          \
+                    } while (0)
+                    if (!wave_par) {
+                        TR_QBOX(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, d0);
+                        TR_QBOX(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, d1);
+                        TR_QBOX(q3.x, q3.y, q3.z, q3.w, q4.x, q4.y, d2);
+                        TR_QBOX(q4.z, q4.w, q5.x, q5.y, q5.z, q5.w, d3);
+                    } else {                             // some lane of the wave holds an axis-parallel ray: reference form
+                        TR_QBOX_REF(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, d0);
+                        TR_QBOX_REF(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, d1);
+                        TR_QBOX_REF(q3.x, q3.y, q3.z, q3.w, q4.x, q4.y, d2);
+                        TR_QBOX_REF(q4.z, q4.w, q5.x, q5.y, q5.z, q5.w, d3);
                     }
-                    TR_DESCEND(hl, hr, tl, tr);
+                    // sort the four (distance, child) pairs: misses end up last
+#define TR_CE(da, ca, db, cb)                                                                        \
+                    do {                                                                             \
+                        const bool s__ = (db) < (da);                                                \
+                        const float lo__ = s__ ? (db) : (da), hi__ = s__ ? (da) : (db);              \
+                        const int clo__ = s__ ? (cb) : (ca), chi__ = s__ ? (ca) : (cb);              \
+                        da = lo__; db = hi__; ca = clo__; cb = chi__;                                \
+                    } while (0)
+                    TR_CE(d0, c0, d1, c1); TR_CE(d2, c2, d3, c3); TR_CE(d0, c0, d2, c2); TR_CE(d1, c1, d3, c3); TR_CE(d1, c1, d2, c2);
+                    if (d3 < MISS) { sa += ENTRY; LDS_AT(sa) = c3; }
+                    if (d2 < MISS) { sa += ENTRY; LDS_AT(sa) = c2; }
+                    if (d1 < MISS) { sa += ENTRY; LDS_AT(sa) = c1; }
+                    int next = c0;
+                    if (!(d0 < MISS)) TR_POP(next);
+                    cur = next;
                 }
             }
         }
@@ -336,10 +357,11 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
             if (lane == 0 && (sum_box | sum_leaf)) { atomicAdd(&a.ctr->box_closest, sum_box); atomicAdd(&a.ctr->leaf_closest, sum_leaf); }
             if (lane == 0 && (sum_box_s | sum_leaf_s)) { atomicAdd(&a.ctr->box_shadow, sum_box_s); atomicAdd(&a.ctr->leaf_shadow, sum_leaf_s); }
         }
+        if (COUNT) { d_outer = wave_sum(d_outer); if (lane == 0) atomicAdd(&a.ctr->it_outer, d_outer); }   // lane-visits of LDS-resident (top) nodes
         if (COUNT && lane == 0) {
             atomicAdd(&a.ctr->it_node, d_it_node); atomicAdd(&a.ctr->lanes_node, d_lanes_node);
             atomicAdd(&a.ctr->it_leaf, d_it_leaf); atomicAdd(&a.ctr->lanes_leaf, d_lanes_leaf);
-            atomicAdd(&a.ctr->refills, d_refills); atomicAdd(&a.ctr->it_outer, d_outer);
+            atomicAdd(&a.ctr->refills, d_refills);
         }
         if (n_over) atomicAdd(&a.ctr->stack_overflow, n_over);
         if (gtid == 0) {
