@@ -199,6 +199,8 @@ def main():
         alg_trace = alg_closest + alg_shadow
         avg_ms = (t["ms_trace_closest"] + t["ms_trace_shadow"]) / n_launch
         achieved = (alg_trace / n_launch) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        gather_bytes = (112.0 / 4.0 * (co["box_closest"] + co["box_shadow"]) + 48.0 * (co["leaf_closest"] + co["leaf_shadow"]) +
+                        24.0 * (co["rays_closest"] + co["rays_shadow"]))
         result["roofline"] = {
             "bound": "hbm", "kernel": "k_trace<ordered> (closest-hit + NEE shadow rays)",
             "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -220,9 +222,16 @@ def main():
                                   "leaf_lane_util": round(co["diag_lanes_leaf"] / max(co["diag_it_leaf"] * 64.0, 1), 4),
                                   "top_node_visits_per_ray": round(co["diag_it_outer"] / max(co["rays_closest"] + co["rays_shadow"], 1), 2),
                                   "refills_per_wave_ray": round(co["diag_refills"] * 64.0 / max(co["rays_closest"] + co["rays_shadow"], 1), 3)},
+            # what actually limits the kernel: 16-byte-per-lane gathers of node / triangle records through the L1
+            # (TA/TD) path -- measured ceiling for scattered 64-byte records on MI355X (tools/micro/gather_rate.hip):
+            # 14.0 TB/s from an L2-resident array, 7.7 TB/s from an 8 MB one; rocprofv3: TA busy 94 % (profiles/)
+            "l1_gather": {"GBps": round(gather_bytes / n_launch / (avg_ms * 1e-3) / 1e9, 1) if avg_ms > 0 else None,
+                          "bytes_per_launch": round(gather_bytes / n_launch, 1),
+                          "measured_ceiling_GBps": {"l2_resident_records": 14000.0, "8MB_working_set": 7700.0},
+                          "def": "112 B per 4-wide node visit + 48 B per primitive test + 24 B per ray, ordered traversal counts"},
             "whole_job_alg_GBps": round((alg_closest + alg_shadow + 260.0 * c["shaded"] + 24.0 * c["paths"]) /
                                         max(t["ms_render"], 1e-9) / 1e6, 2),
-            "note": "the ~10 MB BVH is L2/Infinity-Cache resident: HBM traffic is far below the algorithmic bytes",
+            "note": "the ~11 MB traversal data is L2/Infinity-Cache resident: HBM traffic is far below the algorithmic bytes; the kernel is bound by the L1 gather path (see l1_gather)",
         }
 
     # ---- CPU baseline: oracle on the host cores, bounded sample (rank 0, N = 1 only) ---------------

@@ -21,9 +21,10 @@ SceneView scene_view(const tirt_ctx *c)
 BvhView bvh_view(const tirt_ctx *c)
 {
     BvhView b;
-    b.wnode = c->wnode.as<float4>(); b.qnode = c->qnode.as<float4>(); b.tri = c->tri.as<float4>();
+    b.wnode = c->wnode.as<float4>(); b.qnode = c->qnode.as<float4>(); b.qtop = c->qtop.as<float4>(); b.tri = c->tri.as<float4>();
     for (int k = 0; k < 3; k++) { b.root_min[k] = c->root_min[k]; b.root_max[k] = c->root_max[k]; }
     b.root_code = c->root_code;
+    b.root_qcode = c->root_code >= 0 ? TR_TOP_BIT : c->root_code;
     return b;
 }
 int flush_pending(tirt_ctx *c)

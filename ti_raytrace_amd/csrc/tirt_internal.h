@@ -61,12 +61,15 @@ struct DevBuf {
 constexpr int TR_EMPTY = (int)0x80000001;
 constexpr int TR_TOP_LEVELS = 4;                         // levels of 4-wide nodes that get a breadth-first slot
 constexpr int TR_TOP_SLOTS = 85;                         // (4^TR_TOP_LEVELS - 1) / 3
+constexpr int TR_TOP_BIT = 1 << 29;                      // child code of a 4-wide node that lives in the LDS-resident top: TR_TOP_BIT | slot
 struct BvhView {
     const float4 *wnode;
     const float4 *qnode;
     const float4 *tri;
+    const float4 *qtop;           // the first TR_TOP_LEVELS levels of qnode in breadth-first slots (copied to LDS by k_trace)
     float root_min[3], root_max[3];
-    int root_code;
+    int root_code;                // two-child layout: compact index 0, or the leaf code of a one-primitive scene
+    int root_qcode;               // 4-wide layout: TR_TOP_BIT | 0, or the same leaf code
 };
 
 // Wavefront state, struct-of-arrays in HBM.  Live paths are kept DENSE: every bounce the shade
@@ -165,7 +168,7 @@ struct tirt_ctx {
     struct { bool valid = false; uint32_t begin = 0; int count = 0; uint32_t seed = 0; int max_depth = 0, stack_size = 0, flags = 0; } pend;
     // traversal tunables (options "trace_lds_depth", "trace_refill_min", "trace_node_min", "trace_grid",
     // "trace_slices" = number of ray-fetch cursors, "shade_grid" = persistent blocks of k_shade)
-    int tr_lds_depth = 24, tr_refill_min = 36, tr_node_min = 12, tr_grid = 1536, tr_slice_log2 = 5, sh_grid = 512;
+    int tr_lds_depth = 24, tr_refill_min = 20, tr_node_min = 28, tr_grid = 1536, tr_slice_log2 = 5, sh_grid = 512;
     tirt::DevBuf counters_mem, spill;            // used by the batch trace entry points (main stream)
 
     // BDPT_RGB: persistent per-pixel vertex arrays + per-frame radiance (splat target)

@@ -410,7 +410,8 @@ __global__ void k_tris(SceneView s, const int *leaf_compact, float4 *tri)
 // a child box lies inside its parent's and `slabs` is monotone in the plane positions (fl(b - o) and
 // fl(x * (1/d)) are), so "grandchild passes" implies "child passes".
 //   q0 q1 q2 = boxes of slots 0,1 laid out like wnode's,  q3 q4 q5 = slots 2,3,  q6 = the four codes:
-//   >= 0 dense index of a 4-wide node, < 0 leaf (as in wnode), TR_EMPTY = unused slot (box never hit).
+//   >= 0 a 4-wide node (dense index, or TR_TOP_BIT | breadth-first slot for the first TR_TOP_LEVELS levels,
+//   which k_trace keeps in LDS), < 0 leaf (as in wnode), TR_EMPTY = unused slot (box never hit).
 // Records are numbered in compact (DFS) order by an exclusive scan of quad_flag.
 // ---------------------------------------------------------------------------------------------
 constexpr int SC_BLOCK = 256, SC_ITEMS = 8, SC_TILE = SC_BLOCK * SC_ITEMS;
@@ -464,12 +465,12 @@ __global__ void k_scan_add(int *out, const int *tile_sum, int N)
 }
 
 struct QSlot { float mn[3], mx[3]; int code; };
-TD QSlot quad_slot(SceneView s, const float *compact, const int *quad_index, int idx, float pad)
+TD QSlot quad_slot(SceneView s, const float *compact, const int *quad_index, const int *quad_top, int idx, float pad)
 {
     const float *cn = compact + (size_t)idx * CPN_VEC;
     QSlot q;
     const bool leaf = (((int)cn[0]) & 1) == 1;
-    q.code = leaf ? child_code(s, cn, idx) : quad_index[idx];
+    q.code = leaf ? child_code(s, cn, idx) : (quad_top[idx] >= 0 ? (TR_TOP_BIT | quad_top[idx]) : quad_index[idx]);
     const float p = leaf ? pad : 0.0f;
     for (int k = 0; k < 3; k++) { q.mn[k] = cn[2 + k] - p; q.mx[k] = cn[5 + k] + p; }
     return q;
@@ -490,10 +491,10 @@ __global__ void k_qnodes(SceneView s, int N, const float *compact, const int *qu
     QSlot sl[4];
     for (int c = 0; c < 2; c++) {
         const float *cc = compact + (size_t)child[c] * CPN_VEC;
-        if ((((int)cc[0]) & 1) == 1) { sl[2 * c] = quad_slot(s, compact, quad_index, child[c], pad); sl[2 * c + 1] = quad_empty(); }
+        if ((((int)cc[0]) & 1) == 1) { sl[2 * c] = quad_slot(s, compact, quad_index, quad_top, child[c], pad); sl[2 * c + 1] = quad_empty(); }
         else {
-            sl[2 * c] = quad_slot(s, compact, quad_index, child[c] + 1, pad);
-            sl[2 * c + 1] = quad_slot(s, compact, quad_index, (int)cc[1], pad);
+            sl[2 * c] = quad_slot(s, compact, quad_index, quad_top, child[c] + 1, pad);
+            sl[2 * c + 1] = quad_slot(s, compact, quad_index, quad_top, (int)cc[1], pad);
         }
     }
     float4 *w = qnode + (size_t)quad_index[o] * 8;
