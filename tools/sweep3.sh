@@ -1,0 +1,7 @@
+R=${GRAFT_REPO_ROOT:-.}
+cd $R; timeout 900 python -m pytest tests -x -q -m gpu 2>&1 | tail -2
+run() { timeout 300 python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline "$@" 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print('%8.1f Mrays/s' % d['value'], '$*')"; }
+run; run
+for nm in 20 28 36; do for rm in 12 20 28; do run --opt trace_node_min=$nm --opt trace_refill_min=$rm; done; done
+run --opt trace_lds_depth=20
+run --opt trace_grid=1280
