@@ -11,9 +11,11 @@ OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 
 os.makedirs(OUT, exist_ok=True)
 
 
-def run(name, ex, spp, batch):
+def run(name, ex, spp, batch, warm=True):
     t0 = time.perf_counter(); ex.build_scene(); ctx = ex.scene.ctx; ctx.sync(); t_build = time.perf_counter() - t0
-    ex.integrator.render_frames(min(batch, 4)); ex.cam.update_frame(min(batch, 4)); ctx.sync()       # warm-up frames count
+    # warm-up: one full batch (allocates the lanes' buffers), then start over from frame 0 on a cleared film
+    if warm:
+        ex.integrator.render_frames(batch); ctx.sync(); ctx.film_clear(); ctx.sync()
     ctx.stats_reset(); t0 = time.perf_counter()
     while ex.cam.frame < spp:
         k = min(batch, spp - ex.cam.frame); ex.integrator.render_frames(k); ex.cam.update_frame(k)
@@ -38,7 +40,7 @@ if __name__ == "__main__":
     if "2" in which:
         run("cfg2_teapot_1024_64spp", scenes.single_model(1024, 1024, 64, device_id=0), 64, 16)
     if "5" in which:
-        run("cfg5_veach_bdpt_512_64spp", scenes.veach_bdpt(512, 512, 64, device_id=0), 64, 8)
+        run("cfg5_veach_bdpt_512_64spp", scenes.veach_bdpt(512, 512, 64, device_id=0), 64, 8, warm=False)   # BDPT keeps per-pixel state across frames
         run("cfg5_veach_pt_512_64spp", scenes.veach_bdpt(512, 512, 64, device_id=0, integrator="pt"), 64, 32)
     if "3" in which:
         run("cfg3_synth100k_1024_256spp", scenes.synthetic(1024, 1024, 256, device_id=0), 256, 32)
