@@ -126,3 +126,32 @@ def test_deep_duplicate_chain_uses_the_spill_stack(gpu_ctx_ok):
     got = ex.integrator.hdr.to_numpy()
     want, ost = o.render(W, H, 0, 2, seed=ex.integrator.seed)
     assert ost["overflow"] == 0 and np.array_equal(got, want)
+
+
+def test_stack_paging_with_a_minimal_lds_stack(gpu_ctx_ok):
+    """trace_lds_depth=12 leaves 8 usable LDS entries before a lane pages its oldest 8 entries out to the
+    global spill buffer (and back in when it pops the sentinel): on the 100k scene that happens all the
+    time.  Hits, in both visiting modes, and a rendered film must not change."""
+    ex = scenes.synthetic(128, 128, 4, device_id=0)
+    ex.build_scene()
+    ctx = ex.scene.ctx
+    rays = np.concatenate([oa.camera_rays(ex.cam, 128, 128), random_rays(20000, -0.2, 1.2, 7)], axis=0)
+    ref_t, ref_p, _ = ctx.trace_closest(rays, 64, 0)
+    ex.integrator.render_frames(2)
+    ref_film = ex.integrator.hdr.to_numpy().copy()
+    ctx.film_clear()
+    ctx.set_option("trace_lds_depth", 12)
+    for flags in (0, _native.TRAVERSE_EXHAUSTIVE):
+        got_t, got_p, _ = ctx.trace_closest(rays, 64, flags)
+        assert np.array_equal(got_p, ref_p) and bits_equal(got_t, ref_t).all()
+    ex.integrator.render_frames(2)
+    assert np.array_equal(ex.integrator.hdr.to_numpy(), ref_film)
+    assert ctx.stats()["stack_overflow"] == 0
+    ctx.set_option("trace_lds_depth", 24)
+
+
+def test_four_wide_nodes_on_unbalanced_trees(gpu_ctx_ok):
+    """Scenes whose LBVH has leaves at every depth parity (2, 3, 5, 6, 7, 9 primitives): empty slots,
+    leaf children next to collapsed ones, a root whose child is a leaf."""
+    for n in (2, 3, 5, 6, 7, 9, 17):
+        check_scene(tiny_scene(n, seed=20 + n, W=24, H=24, spread=0.6, device_id=0), 24, 24, random_rays(800, -2, 3, n))
