@@ -34,33 +34,44 @@ TD SimpleHit trace_simple(const BvhView &b, v3 o, v3 d, int *stack /* LDS, [entr
     int hit_leaf = -1;
     const RayCtx r = make_ray(o, d);
     if (!((o.x == o.x) & (o.y == o.y) & (o.z == o.z) & (d.x == d.x) & (d.y == d.y) & (d.z == d.z))) return h;   // NaN ray: misses
-    int cur = b.root_code;
+    int cur = b.root_qcode;
     if (cur >= 0) {
         float tn;
         if (!slabs(r, b.root_min[0], b.root_min[1], b.root_min[2], b.root_max[0], b.root_max[1], b.root_max[2], tn)) return h;
     }
     int sp = 0;
     const bool par = ray_has_parallel_axis(r);
+    constexpr float MISS = 3.0e38f;
     for (;;) {
         if (cur >= 0) {
-            const float4 *w = b.wnode + (size_t)cur * 4;
-            const float4 q0 = w[0], q1 = w[1], q2 = w[2], q3 = w[3];
-            const int cl = __float_as_int(q3.x), cr = __float_as_int(q3.y);
-            float tl, tr;
-            int pl, pr;
-            if (!par) { pl = slabs_fast(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tl); pr = slabs_fast(r, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tr); }
-            else { pl = slabs(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tl); pr = slabs(r, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tr); }
-            const float lim = h.t * 1.0001f;
-            pl &= (tl <= lim) ? 1 : 0;
-            pr &= (tr <= lim) ? 1 : 0;
-            if (pl & pr) {
-                const bool swap = tr < tl;
-                if (sp < BD_STACK) { stack[sp * BD_BLOCK] = swap ? cl : cr; sp++; }
-                cur = swap ? cr : cl;
-                continue;
-            }
-            if (pl) { cur = cl; continue; }
-            if (pr) { cur = cr; continue; }
+            // 4-wide node (tirt_internal.h): the first levels are addressed by breadth-first slot in qtop
+            const float4 *w = (cur & TR_TOP_BIT) ? b.qtop + (size_t)(cur & 0xffff) * 8 : b.qnode + (size_t)cur * 8;
+            const float4 q0 = w[0], q1 = w[1], q2 = w[2], q3 = w[3], q4 = w[4], q5 = w[5], q6 = w[6];
+            int c0 = __float_as_int(q6.x), c1 = __float_as_int(q6.y), c2 = __float_as_int(q6.z), c3 = __float_as_int(q6.w);
+            const float lim = minf(h.t * 1.0001f, INF_VALUE);
+            float d0, d1, d2, d3;
+#define BD_QBOX(mnx, mny, mnz, mxx, mxy, mxz, dist)                                                  \
+            do {                                                                                     \
+                float tn__;                                                                          \
+                const int p__ = par ? slabs(r, mnx, mny, mnz, mxx, mxy, mxz, tn__) : slabs_fast(r, mnx, mny, mnz, mxx, mxy, mxz, tn__); \
+                dist = ((p__ != 0) && (tn__ <= lim)) ? tn__ : MISS;                                  \
+            } while (0)
+            BD_QBOX(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, d0);
+            BD_QBOX(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, d1);
+            BD_QBOX(q3.x, q3.y, q3.z, q3.w, q4.x, q4.y, d2);
+            BD_QBOX(q4.z, q4.w, q5.x, q5.y, q5.z, q5.w, d3);
+#define BD_CE(da, ca, db, cb)                                                                        \
+            do {                                                                                     \
+                const bool s__ = (db) < (da);                                                        \
+                const float lo__ = s__ ? (db) : (da), hi__ = s__ ? (da) : (db);                      \
+                const int clo__ = s__ ? (cb) : (ca), chi__ = s__ ? (ca) : (cb);                      \
+                da = lo__; db = hi__; ca = clo__; cb = chi__;                                        \
+            } while (0)
+            BD_CE(d0, c0, d1, c1); BD_CE(d2, c2, d3, c3); BD_CE(d0, c0, d2, c2); BD_CE(d1, c1, d3, c3); BD_CE(d1, c1, d2, c2);
+            if (d3 < MISS && sp < BD_STACK) { stack[sp * BD_BLOCK] = c3; sp++; }
+            if (d2 < MISS && sp < BD_STACK) { stack[sp * BD_BLOCK] = c2; sp++; }
+            if (d1 < MISS && sp < BD_STACK) { stack[sp * BD_BLOCK] = c1; sp++; }
+            if (d0 < MISS) { cur = c0; continue; }
         } else {
             const int code = ~cur;
             const int prim = code & 0x3fffffff;
