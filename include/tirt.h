@@ -71,7 +71,7 @@ int tirt_sync(tirt_ctx *ctx);
  *          "trace_lds_depth" / "trace_refill_min" / "trace_node_min" / "trace_grid" / "trace_slices" /
  *          "shade_grid" -- kernel tuning
  *          "merge_paths" -- consecutive tirt_pt_rgb_render calls over contiguous frames are merged
- *            until this many pixel-samples are pending (default 8 Mi; 0 submits every call at once);
+ *            until this many pixel-samples are pending (default 32 Mi = one full batch; 0 submits every call at once);
  *            every other entry point submits what is pending first
  *          "batch_paths" -- pixel-samples kept in flight per wavefront batch (default 32 Mi,
  *            112 B of HBM each) */

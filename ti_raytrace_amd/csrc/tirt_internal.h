@@ -164,7 +164,7 @@ struct tirt_ctx {
     // deferred submission: consecutive tirt_pt_rgb_render calls over contiguous frames are merged until
     // merge_paths pixel-samples are pending (small calls -- one frame at a time, or the 1/N-size shards
     // of a multi-GPU job -- then run as one efficient batch); any other API call flushes first
-    size_t merge_paths = (size_t)8 << 20;          // option "merge_paths" (0 = submit every call at once)
+    size_t merge_paths = (size_t)32 << 20;         // option "merge_paths" (0 = submit every call at once)
     struct { bool valid = false; uint32_t begin = 0; int count = 0; uint32_t seed = 0; int max_depth = 0, stack_size = 0, flags = 0; } pend;
     // traversal tunables (options "trace_lds_depth", "trace_refill_min", "trace_node_min", "trace_grid",
     // "trace_slices" = number of ray-fetch cursors, "shade_grid" = persistent blocks of k_shade)
