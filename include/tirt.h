@@ -157,6 +157,22 @@ int tirt_kat_math(tirt_ctx *ctx, int fn, const float *x, const float *y, float *
  * in: [n*in_stride] out: [n*out_stride] */
 int tirt_kat_brdf(tirt_ctx *ctx, int which, const float *in, int in_stride, float *out, int out_stride, int n);
 
+/* ---- native Wavefront OBJ/MTL ingest (host only; no device, no context) -----------------------------
+ * Replaces the reference's use of the third-party PyWavefront 1.3.3 package in Scene.add_obj
+ * (Scene.py:66-127: `pywavefront.Wavefront(filename)`, `scene.materials[name].vertices / vertex_format /
+ * diffuse / emissive / transparency / optical_density / shininess`): materials in first-appearance order,
+ * ONE interleaved float list per material (fan-triangulated faces in file order), vertex format chosen
+ * by the material's first face.
+ *   params[19] = diffuse rgba, ambient rgba, specular rgba, emissive rgba, transparency, optical_density, shininess
+ *   vertex_format: 4 "V3F", 5 "T2F_V3F", 6 "N3F_V3F", 7 "T2F_N3F_V3F", 0 when the material owns no face */
+typedef struct tirt_obj tirt_obj;
+int tirt_obj_load(const char *path, tirt_obj **out);
+void tirt_obj_free(tirt_obj *obj);
+int tirt_obj_material_count(const tirt_obj *obj);
+int tirt_obj_material_info(const tirt_obj *obj, int index, char *name, int name_cap, double *params, int *vertex_format,
+                           int *is_default, long long *n_floats);
+int tirt_obj_material_vertices(const tirt_obj *obj, int index, double *out, long long n_floats);
+
 #ifdef __cplusplus
 }
 #endif

@@ -73,6 +73,12 @@ SIGNATURES = {
     "tirt_stats_reset": (C.c_int, [_vp]),
     "tirt_kat_math": (C.c_int, [_vp, C.c_int, _f32p, _f32p, _f32p, C.c_int]),
     "tirt_kat_brdf": (C.c_int, [_vp, C.c_int, _f32p, C.c_int, _f32p, C.c_int, C.c_int]),
+    "tirt_obj_load": (C.c_int, [C.c_char_p, C.POINTER(_vp)]),
+    "tirt_obj_free": (None, [_vp]),
+    "tirt_obj_material_count": (C.c_int, [_vp]),
+    "tirt_obj_material_info": (C.c_int, [_vp, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int),
+                                         C.POINTER(C.c_int), C.POINTER(C.c_longlong)]),
+    "tirt_obj_material_vertices": (C.c_int, [_vp, C.c_int, np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS"), C.c_longlong]),
 }
 
 _lib = None
