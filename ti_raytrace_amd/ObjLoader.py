@@ -18,7 +18,7 @@ The reference's committed ``nodelist.txt`` pins the material order + grouping fo
 ``cornell_box.obj`` (tests/test_oracle_golden.py); the fan order is unpinned.
 
 ``Wavefront(path)`` parses with the native reader of libtirt.so (``tirt_obj_load``,
-csrc/tirt_obj.hip: host C++, 3-7x faster: Teapot.obj 0.13 s -> 0.04 s); ``Wavefront(path, native=False)`` runs
+csrc/tirt_obj.hip: host C++, 3-7x faster: Teapot.obj 0.13 s -> 0.03 s); ``Wavefront(path, native=False)`` runs
 the pure-Python parser below, which tests/test_host.py uses as the checker of the native one
 (same materials, same doubles).
 """
