@@ -70,6 +70,8 @@ int tirt_sync(tirt_ctx *ctx);
  *          "overlap_lanes" (1..8, default 4) -- wavefront batches in flight on separate streams
  *          "trace_lds_depth" / "trace_refill_min" / "trace_node_min" / "trace_grid" / "trace_slices" /
  *          "shade_grid" -- kernel tuning
+ *          "bdpt_bounded" (0/1, default 1) -- BDPT connection rays are cut off at their target distance (same
+ *            visibility answers as the full closest-hit query; 0 = reference-style full query, for cross-checks)
  *          "merge_paths" -- consecutive tirt_pt_rgb_render calls over contiguous frames are merged
  *            until this many pixel-samples are pending (default 32 Mi = one full batch; 0 submits every call at once);
  *            every other entry point submits what is pending first

@@ -290,6 +290,7 @@ int tirt_set_option(tirt_ctx *c, const char *name, double value)
     if (!strcmp(name, "trace_lds_depth")) { TIRT_REQUIRE(value >= 12 && value <= 64, "trace_lds_depth: 12..64"); c->tr_lds_depth = (int)value; return TIRT_OK; }
     if (!strcmp(name, "trace_refill_min")) { TIRT_REQUIRE(value >= 1 && value <= 64, "trace_refill_min: 1..64"); c->tr_refill_min = (int)value; return TIRT_OK; }
     if (!strcmp(name, "trace_node_min")) { TIRT_REQUIRE(value >= 1 && value <= 64, "trace_node_min: 1..64"); c->tr_node_min = (int)value; return TIRT_OK; }
+    if (!strcmp(name, "bdpt_bounded")) { c->bdpt_bounded = value != 0.0 ? 1 : 0; return TIRT_OK; }
     if (!strcmp(name, "trace_slices")) {
         const int iv = (int)value;
         TIRT_REQUIRE(iv >= 1 && iv <= 64 && (iv & (iv - 1)) == 0, "trace_slices: power of two, 1..64");

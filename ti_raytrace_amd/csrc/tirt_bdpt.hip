@@ -28,8 +28,13 @@ struct BdView { float view[12]; int W, H; };
 // ---- plain traversal (ordered, t-culled; same hit as the reference's exhaustive order) ------------
 struct SimpleHit { float t, u, v; int prim; };
 constexpr int BD_BLOCK = 64, BD_STACK = 64;
-TD SimpleHit trace_simple(const BvhView &b, v3 o, v3 d, int *stack /* LDS, [entry][lane] */)
+// With expect >= -1 and t_bound > 0 the ray is a connection test ("is `expect` the closest hit, about t_bound
+// away?"): nodes beyond 1.01 x t_bound are skipped and a hit on another primitive before 0.99 x t_bound ends
+// the walk -- same yes/no (and the same t when yes) as the full closest-hit query, as in k_trace's shadow rays.
+TD SimpleHit trace_simple(const BvhView &b, v3 o, v3 d, int *stack /* LDS, [entry][lane] */, int expect = -3, float t_bound = -1.0f)
 {
+    const bool bounded = t_bound > 0.0f;
+    const float cull_far = bounded ? t_bound * 1.01f : 3.0e38f, settle = bounded ? t_bound * 0.99f : -1.0f;
     SimpleHit h; h.t = INF_VALUE; h.u = 0.0f; h.v = 0.0f; h.prim = -1;
     int hit_leaf = -1;
     const RayCtx r = make_ray(o, d);
@@ -48,7 +53,7 @@ TD SimpleHit trace_simple(const BvhView &b, v3 o, v3 d, int *stack /* LDS, [entr
             const float4 *w = (cur & TR_TOP_BIT) ? b.qtop + (size_t)(cur & 0xffff) * 8 : b.qnode + (size_t)cur * 8;
             const float4 q0 = w[0], q1 = w[1], q2 = w[2], q3 = w[3], q4 = w[4], q5 = w[5], q6 = w[6];
             int c0 = __float_as_int(q6.x), c1 = __float_as_int(q6.y), c2 = __float_as_int(q6.z), c3 = __float_as_int(q6.w);
-            const float lim = minf(h.t * 1.0001f, INF_VALUE);
+            const float lim = minf(minf(h.t * 1.0001f, cull_far), INF_VALUE);
             float d0, d1, d2, d3;
 #define BD_QBOX(mnx, mny, mnz, mxx, mxy, mxz, dist)                                                  \
             do {                                                                                     \
@@ -81,7 +86,10 @@ TD SimpleHit trace_simple(const BvhView &b, v3 o, v3 d, int *stack /* LDS, [entr
             if (((code >> 30) & 1) == 0) t = intersect_tri_packed(o, d, V(ta.x, ta.y, ta.z), V(e1.x, e1.y, e1.z), V(e2.x, e2.y, e2.z), u, v);
             else { float cc; u = 0.0f; v = 0.0f; t = ((int)e1.y == SHAPE_SPHERE) ? intersect_sphere(o, d, V(ta.x, ta.y, ta.z), e1.x, cc) : INF_VALUE; }
             const int leaf = __float_as_int(ta.w);
-            if ((t > 0.0f) & ((t < h.t) | ((t == h.t) & (hit_leaf >= 0) & (leaf > hit_leaf)))) { h.t = t; h.u = u; h.v = v; h.prim = prim; hit_leaf = leaf; }
+            if ((t > 0.0f) & ((t < h.t) | ((t == h.t) & (hit_leaf >= 0) & (leaf > hit_leaf)))) {
+                h.t = t; h.u = u; h.v = v; h.prim = prim; hit_leaf = leaf;
+                if (bounded && prim != expect && t < settle) return h;          // occluded: the answer is settled
+            }
         }
         if (sp == 0) break;
         sp--; cur = stack[sp * BD_BLOCK];
@@ -151,7 +159,7 @@ TD bsample bd_sample(const SceneView &s, v3 dir, v3 normal, v3 fnormal, int mat_
     return r;
 }
 
-struct BdCtx { SceneView sc; BvhView bvh; CameraView cam; BdView bv; uint32_t seed; unsigned long long *rays_closest, *rays_shadow, *paths; int *stack; };
+struct BdCtx { SceneView sc; BvhView bvh; CameraView cam; BdView bv; uint32_t seed; unsigned long long *rays_closest, *rays_shadow, *paths; int *stack; int bounded; };
 
 // BDPT_RGB.py:103-198
 TD int bd_eye_path(const BdCtx &c, bpixel *P, int i, int j, uint32_t frame, unsigned &n_closest)
@@ -428,7 +436,7 @@ TD v3 bd_connect_path(const BdCtx &c, bpixel *P, int i, int j, int e, int l, uin
         const v3 snormal = light[l - 1].snormal;
         const float NdotL = dot(wi, snormal);
         if ((nu >= 0) & (light[l - 1].delta != 1) & (NdotL < 0.0f) & (light[l - 1].type == VERTEX_SURFACE)) {
-            const SimpleHit sh = trace_simple(c.bvh, origin, wi, c.stack);
+            const SimpleHit sh = trace_simple(c.bvh, origin, wi, c.stack, c.bounded ? prim : -3, c.bounded ? norm(surface - origin) : -1.0f);
             n_shadow++;
             if (sh.prim == prim) {
                 float pdf;
@@ -459,7 +467,7 @@ TD v3 bd_connect_path(const BdCtx &c, bpixel *P, int i, int j, int e, int l, uin
             wi = wi / light_dist;
             const float NdotLl = dot(wi, light_normal);
             const float NdotLe = dot(wi, eye[e - 1].snormal);
-            const SimpleHit sh = trace_simple(c.bvh, surface, -wi, c.stack);
+            const SimpleHit sh = trace_simple(c.bvh, surface, -wi, c.stack, c.bounded ? light_prim : -3, c.bounded ? light_dist : -1.0f);
             n_shadow++;
             if ((sh.prim == light_prim) & (sh.t > EPS_UF)) {
                 const float light_pdf = light_choice_pdf;
@@ -484,7 +492,7 @@ TD v3 bd_connect_path(const BdCtx &c, bpixel *P, int i, int j, int e, int l, uin
             const float dist = norm(dir);
             dir = dir / dist;
             const float NdotLl = dot(dir, light[l - 1].snormal), NdotLe = dot(dir, eye[e - 1].snormal);
-            const SimpleHit sh = trace_simple(c.bvh, surfaceL, dir, c.stack);
+            const SimpleHit sh = trace_simple(c.bvh, surfaceL, dir, c.stack, c.bounded ? primE : -3, c.bounded ? dist : -1.0f);
             n_shadow++;
             if ((sh.prim == primE) & (sh.t > EPS_UF)) {
                 float lpdf, epdf;
@@ -569,7 +577,7 @@ int bdpt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t see
     }
     if (c->bdpt_rad.ensure(sizeof(float) * 3 * (size_t)NP)) return TIRT_ERR_HIP;
     BdCtx bc;
-    bc.sc = scene_view(c); bc.bvh = bvh_view(c); bc.cam = c->cam; bc.seed = seed; bc.stack = nullptr;
+    bc.sc = scene_view(c); bc.bvh = bvh_view(c); bc.cam = c->cam; bc.seed = seed; bc.stack = nullptr; bc.bounded = c->bdpt_bounded;
     for (int k = 0; k < 12; k++) bc.bv.view[k] = c->view[k];
     bc.bv.W = c->W; bc.bv.H = c->H;
     DevCounters *ctr = c->dev_counters.as<DevCounters>();

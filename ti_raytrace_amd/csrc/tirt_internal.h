@@ -173,6 +173,7 @@ struct tirt_ctx {
 
     // BDPT_RGB: persistent per-pixel vertex arrays + per-frame radiance (splat target)
     tirt::DevBuf bdpt_px, bdpt_rad;
+    int bdpt_bounded = 1;                          // option "bdpt_bounded": connection rays stop at their target distance
 
     // batch trace scratch
     tirt::DevBuf tr_rays, tr_out, tr_prim, tr_counts;
