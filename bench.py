@@ -261,10 +261,21 @@ def main():
                       (nframes, ost["paths"], cpu_rays, cpu_s, cores, cpu_build_s, build_ms),
         }
 
-    if rank == 0:
-        print(json.dumps(result))
     if world > 1 or force_dist:
         dist.destroy_process_group()
+    # RCCL writes its version banner to C stdio (block-buffered when piped): push it out first so that the JSON
+    # line is the LAST line on stdout
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+        try:
+            sys.stdout.flush(); os._exit(0)      # nothing (library teardown chatter) may follow the JSON line
+        except Exception:
+            pass
 
 
 if __name__ == "__main__":

@@ -534,7 +534,7 @@ __global__ __launch_bounds__(BD_BLOCK) void k_bdpt_pixel(BdCtx c, bpixel *px, fl
     if (k >= P_local) return;
     const int p = local_to_pixel(tm, k);
     const int i = p / c.bv.H, j = p - i * c.bv.H;
-    bpixel *P = px + p;
+    bpixel *P = px + p;                     // (working on a private copy of the 1.7 KB state measured 4 % slower)
     unsigned n_closest = 0, n_shadow = 0;
     const int eye_depth = bd_eye_path(c, P, i, j, frame, n_closest);
     const int light_depth = bd_light_path(c, P, i, j, frame, n_closest);
