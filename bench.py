@@ -261,21 +261,22 @@ def main():
                       (nframes, ost["paths"], cpu_rays, cpu_s, cores, cpu_build_s, build_ms),
         }
 
-    if world > 1 or force_dist:
-        dist.destroy_process_group()
-    # RCCL writes its version banner to C stdio (block-buffered when piped): push it out first so that the JSON
-    # line is the LAST line on stdout
-    try:
-        import ctypes
-        ctypes.CDLL(None).fflush(None)
-    except Exception:
-        pass
-    if rank == 0:
-        print(json.dumps(result), flush=True)
+    # RCCL writes its version banner to C stdio (block-buffered when piped): every rank pushes its buffer out, then
+    # rank 0 prints the JSON line as the LAST line on stdout and all ranks leave without teardown chatter
+    def flush_c():
         try:
-            sys.stdout.flush(); os._exit(0)      # nothing (library teardown chatter) may follow the JSON line
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
         except Exception:
             pass
+    flush_c(); sys.stdout.flush()
+    if world > 1 or force_dist:
+        dist.barrier()
+        torch.cuda.synchronize()
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    sys.stdout.flush(); sys.stderr.flush()
+    os._exit(0)
 
 
 if __name__ == "__main__":
