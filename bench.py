@@ -264,7 +264,8 @@ def main():
         }
 
     # RCCL writes its version banner to C stdio (block-buffered when piped): every rank pushes its buffer out, then
-    # rank 0 prints the JSON line as the LAST line on stdout and all ranks leave without teardown chatter
+    # rank 0 prints the JSON line as the LAST line on stdout (no os._exit here: rocprofv3 writes its output from
+    # exit handlers of this process)
     def flush_c():
         try:
             import ctypes
@@ -278,7 +279,8 @@ def main():
     if rank == 0:
         print(json.dumps(result), flush=True)
     sys.stdout.flush(); sys.stderr.flush()
-    os._exit(0)
+    if world > 1 or force_dist:
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
