@@ -245,7 +245,7 @@ void tirt_destroy(tirt_ctx *c)
                       &c->tr_out, &c->tr_prim, &c->tr_counts, &c->dev_counters, &c->bdpt_px, &c->bdpt_rad};
     for (DevBuf *b : bufs) b->release();
     for (Lane &L : c->lanes) {
-        DevBuf *lb[] = {&L.path_mem, &L.queue_a, &L.queue_b, &L.queue_s, &L.counters_mem, &L.spill};
+        DevBuf *lb[] = {&L.path_mem, &L.counters_mem, &L.spill};
         for (DevBuf *b : lb) b->release();
         if (L.film_done) (void)hipEventDestroy(L.film_done);
         if (L.stream) (void)hipStreamDestroy(L.stream);

@@ -57,7 +57,7 @@ struct DevBuf {
 // qnode: one 128-byte record per internal node at even depth (dense index in compact order), holding
 //   its up to four grandchildren: (q0 q1 q2) boxes of slots 0,1 laid out like wnode's, (q3 q4 q5) slots
 //   2,3, q6 = four codes (>= 0: qnode index, < 0: leaf as above, TR_EMPTY: unused slot), q7 unused.
-//   The ordered traversal walks these; wnode serves the exhaustive (reference-order) mode and BDPT.
+//   The ordered traversal and BDPT walk these; wnode serves the exhaustive (reference-order) mode.
 constexpr int TR_EMPTY = (int)0x80000001;
 constexpr int TR_TOP_LEVELS = 4;                         // levels of 4-wide nodes that get a breadth-first slot
 constexpr int TR_TOP_SLOTS = 85;                         // (4^TR_TOP_LEVELS - 1) / 3
@@ -109,7 +109,7 @@ struct DevCounters {          // lives in device memory; accumulated by the kern
     unsigned long long it_node, lanes_node, it_leaf, lanes_leaf, refills, it_outer;
 };
 
-// One in-flight wavefront batch: its own stream, path state, queues and counters.  Two lanes
+// One in-flight wavefront batch: its own stream, path state, queues and counters.  The lanes
 // alternate, so that the latency-bound tail of one batch (a few long rays per bounce) overlaps
 // with the bulk of the next one.
 #define TIRT_MAX_LANES 8
@@ -117,7 +117,7 @@ struct Lane {
     hipStream_t stream = nullptr;
     hipEvent_t film_done = nullptr; bool film_recorded = false;
     size_t path_capacity = 0;
-    DevBuf path_mem, queue_a, queue_b, queue_s, counters_mem, spill;
+    DevBuf path_mem, counters_mem, spill;
     PathState ps;
 };
 

@@ -10,19 +10,20 @@
 //   k_trace<closest>  closest hit of every live path                Scene.py:702-744
 //   k_shade           light / glass / disney branch, NEE set-up,    integrator/PT_RGB.py:66-132
 //                     next ray, throughput; compacts live paths
-//                     into the next queue with wave ballots
+//                     into the next dense state (ballots + one
+//                     packed atomic per block)
 //   k_trace<shadow>   NEE visibility, adds the stored contribution  Scene.py:671-699, PT_RGB.py:104-109
 //   k_film            running-mean film update                      integrator/PT_RGB.py:134-136
 //
-// Traversal: one ray per lane, 64-byte two-child nodes (tirt_internal.h), traversal stack in
-// LDS ([entry][lane] layout: conflict-free) with a global-memory spill tail.  Two visiting
-// rules, same closest hit:
-//   EXHAUSTIVE  the reference's: every internal node whose box passes `slabs` has both
-//               children visited, leaves are intersected unconditionally.  Used for the
-//               N_box / N_leaf "algorithmic bytes" counts and as a parity cross-check.
-//   ORDERED     near child first, children whose entry distance exceeds the current hit
-//               (with a 1e-4 relative margin) are skipped, leaf children are pre-tested
-//               against their (slightly inflated) box.  Product default.
+// Traversal: persistent waves, one ray per lane with re-fetch, traversal stack in LDS ([entry][lane]
+// layout: conflict-free) with a paged global-memory spill buffer.  Two visiting rules, same closest hit:
+//   EXHAUSTIVE  the reference's, on the 64-byte two-child nodes: every internal node whose box
+//               passes `slabs` has both children visited, leaves are intersected unconditionally.
+//               Used for the N_box / N_leaf "algorithmic bytes" counts and as a parity cross-check.
+//   ORDERED     on the 128-byte 4-wide nodes (tirt_internal.h; top four levels in LDS): children
+//               near to far, children whose entry distance exceeds the current hit (with a 1e-4
+//               relative margin) are skipped, leaf children are pre-tested against their
+//               (slightly inflated) box.  Product default.
 // Exact-t ties are resolved as the reference's visit order does (it pops the right child
 // first and keeps the first-found candidate on `t < hit_t`): the candidate with the larger
 // compact-node index wins.
