@@ -9,11 +9,11 @@ for sub in "abcdefg":
     if not cc or not kt:
         continue
     dur = collections.defaultdict(float); nl = collections.defaultdict(int)
-    for r in csv.DictReader(open(kt[0])):
+    for r in csv.DictReader(open(max(kt, key=os.path.getmtime))):
         k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("tirt::", "")
         dur[k] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9; nl[k] += 1
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
-    for r in csv.DictReader(open(cc[0])):
+    for r in csv.DictReader(open(max(cc, key=os.path.getmtime))):
         k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("tirt::", "")
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
     for k, v in sorted(agg.items()):

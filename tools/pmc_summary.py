@@ -15,14 +15,14 @@ def load(sub):
     fs = glob.glob(os.path.join(root, "%s_%s" % (tag, sub), "**", "*counter_collection.csv"), recursive=True)
     agg = collections.defaultdict(lambda: collections.defaultdict(float)); calls = collections.defaultdict(set)
     if fs:
-        for r in csv.DictReader(open(fs[0])):
+        for r in csv.DictReader(open(max(fs, key=os.path.getmtime))):
             k = short(r["Kernel_Name"]); agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); calls[k].add(r["Dispatch_Id"])
     return agg, calls
 
 
 fs = glob.glob(os.path.join(root, tag + "_stats", "**", "*kernel_stats.csv"), recursive=True)
 if fs:
-    for r in csv.DictReader(open(fs[0])):
+    for r in csv.DictReader(open(max(fs, key=os.path.getmtime))):
         k = short(r["Name"])
         out[k].update({"calls": int(r["Calls"]), "avg_us": round(float(r["AverageNs"]) / 1e3, 2), "total_ms": round(float(r["TotalDurationNs"]) / 1e6, 3),
                        "pct": float(r["Percentage"])})
