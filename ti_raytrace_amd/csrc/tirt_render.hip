@@ -720,11 +720,12 @@ constexpr size_t LINE = 128;
 static size_t lane_counter_bytes(int max_depth)
 { return LINE * (size_t)(max_depth + 1) + sizeof(int) * TR_FETCH_STRIDE * TR_SLICES_MAX * (size_t)(max_depth + 1); }
 
+constexpr int PATH_WORDS = 2 * 15 + 4 + 12 + 3;      // two PathSoA + hit record + shadow ray + final radiance
+static size_t path_state_bytes(size_t S) { return sizeof(float) * PATH_WORDS * S; }
 static int ensure_paths(Lane &L, size_t S, int max_depth)
 {
     if (S > L.path_capacity || !L.path_mem.p) {
-        const int nwords = 2 * 15 + 4 + 12 + 3;
-        if (L.path_mem.ensure(sizeof(float) * nwords * S)) return TIRT_ERR_HIP;
+        if (L.path_mem.ensure(path_state_bytes(S))) return TIRT_ERR_HIP;
         float *w = L.path_mem.as<float>();
         PathState &p = L.ps;
         auto nxt = [&]() { float *r = w; w += S; return r; };
@@ -763,7 +764,7 @@ int pt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed,
     const int B = 256;
     // everything queued on the main stream (uploads, film clear, tone map) precedes the lanes' work
     TIRT_HIP(hipEventRecord(c->ev_main, c->stream));
-    const int n_lanes = c->time_kernels ? 1 : c->n_lanes;
+    int n_lanes = c->time_kernels ? 1 : c->n_lanes;
 
     // all lanes get their buffers up front (an allocation inside a later call would stall the pipeline)
     // sized for what deferred submission can merge later (merge_paths + one call), so that a bigger
@@ -777,6 +778,11 @@ int pt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed,
         if (want > cap) cap = want;
     }
     for (int k = 0; k < n_lanes; k++) {
+        // very large films (196 B per path and lane): use fewer lanes rather than run out of HBM
+        if (k > 0 && cap > c->lanes[k].path_capacity) {
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b < path_state_bytes(cap) + ((size_t)2 << 30)) { n_lanes = k; break; }
+        }
         if (ensure_paths(c->lanes[k], cap, max_depth)) return TIRT_ERR_HIP;
         if (ensure_spill(c, c->lanes[k].spill, stack_size, spill_depth)) return TIRT_ERR_HIP;
     }
