@@ -645,6 +645,12 @@ __global__ __launch_bounds__(SH_BLOCK) void k_shade(PathState ps, PathSoA in, Pa
                         }
                     }
                 }
+            } else if (sc.env_power == 0.0f && (direction.x - direction.x == 0.0f) && (direction.y - direction.y == 0.0f) &&
+                       (direction.z - direction.z == 0.0f)) {
+                // black environment (PT_RGB.py:127-132 with env_power == 0): for a finite direction the lookup returns a
+                // finite e >= 0, so (e * throughput) * 0 is +-0 with throughput's sign, or NaN where throughput is not
+                // finite -- exactly throughput * env_power, without the two atan2, four texel fetches and three pow
+                radiance = radiance + throughout * sc.env_power;
             } else {                                                                     // PT_RGB.py:127-132
                 const float dis = tm_sqrt(direction.x * direction.x + direction.z * direction.z);
                 const float tx = (tm_atan2(direction.z, direction.x) + PI_SCENE) / PI_SCENE / 2.0f;
