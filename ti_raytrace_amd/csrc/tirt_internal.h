@@ -59,8 +59,11 @@ struct DevBuf {
 //   2,3, q6 = four codes (>= 0: qnode index, < 0: leaf as above, TR_EMPTY: unused slot), q7 unused.
 //   The ordered traversal and BDPT walk these; wnode serves the exhaustive (reference-order) mode.
 constexpr int TR_EMPTY = (int)0x80000001;
-constexpr int TR_TOP_LEVELS = 4;                         // levels of 4-wide nodes that get a breadth-first slot
-constexpr int TR_TOP_SLOTS = 85;                         // (4^TR_TOP_LEVELS - 1) / 3
+#ifndef TR_TOP_LEVELS_N
+#define TR_TOP_LEVELS_N 5
+#endif
+constexpr int TR_TOP_LEVELS = TR_TOP_LEVELS_N;           // levels of 4-wide nodes that get a breadth-first slot
+constexpr int TR_TOP_SLOTS = ((1 << (2 * TR_TOP_LEVELS)) - 1) / 3;   // 341 for five levels (38 KB of LDS per block)
 constexpr int TR_TOP_BIT = 1 << 29;                      // child code of a 4-wide node that lives in the LDS-resident top: TR_TOP_BIT | slot
 struct BvhView {
     const float4 *wnode;
@@ -168,7 +171,7 @@ struct tirt_ctx {
     struct { bool valid = false; uint32_t begin = 0; int count = 0; uint32_t seed = 0; int max_depth = 0, stack_size = 0, flags = 0; } pend;
     // traversal tunables (options "trace_lds_depth", "trace_refill_min", "trace_node_min", "trace_grid",
     // "trace_slices" = number of ray-fetch cursors, "shade_grid" = persistent blocks of k_shade)
-    int tr_lds_depth = 24, tr_refill_min = 20, tr_node_min = 28, tr_grid = 1536, tr_slice_log2 = 5, sh_grid = 512;
+    int tr_lds_depth = 16, tr_refill_min = 20, tr_node_min = 28, tr_grid = 512, tr_slice_log2 = 5, sh_grid = 512;
     tirt::DevBuf counters_mem, spill;            // used by the batch trace entry points (main stream)
 
     // BDPT_RGB: persistent per-pixel vertex arrays + per-frame radiance (splat target)

@@ -31,7 +31,10 @@
 
 namespace tirt {
 
-constexpr int TR_BLOCK = 256;
+#ifndef TR_BLOCK_SIZE
+#define TR_BLOCK_SIZE 512
+#endif
+constexpr int TR_BLOCK = TR_BLOCK_SIZE;
 constexpr int TR_GRID_MAX = 4096;      // upper bound on persistent blocks (sizes the spill buffer)
 
 enum { KIND_CLOSEST = 0, KIND_SHADOW_ACC = 1, KIND_MIXED = 2 };   // MIXED: closest rays of bounce b + shadow rays of bounce b-1 in one launch
