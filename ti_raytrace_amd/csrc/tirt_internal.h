@@ -63,7 +63,11 @@ constexpr int TR_EMPTY = (int)0x80000001;
 #define TR_TOP_LEVELS_N 5
 #endif
 constexpr int TR_TOP_LEVELS = TR_TOP_LEVELS_N;           // levels of 4-wide nodes that get a breadth-first slot
-constexpr int TR_TOP_SLOTS = ((1 << (2 * TR_TOP_LEVELS)) - 1) / 3;   // 341 for five levels (38 KB of LDS per block)
+#ifndef TR_TOP_CAP
+#define TR_TOP_CAP 1000000
+#endif
+constexpr int TR_TOP_FULL = ((1 << (2 * TR_TOP_LEVELS)) - 1) / 3;
+constexpr int TR_TOP_SLOTS = TR_TOP_FULL < TR_TOP_CAP ? TR_TOP_FULL : TR_TOP_CAP;   // 341 for five levels (38 KB of LDS per block)
 constexpr int TR_TOP_BIT = 1 << 29;                      // child code of a 4-wide node that lives in the LDS-resident top: TR_TOP_BIT | slot
 struct BvhView {
     const float4 *wnode;

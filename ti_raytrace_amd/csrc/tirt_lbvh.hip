@@ -340,7 +340,9 @@ __global__ void k_flatten(int n, const float *bvh_node, const int *parent, const
     // the first TR_TOP_LEVELS levels of 4-wide nodes also get a breadth-first slot (heap numbering by
     // path): the traversal kernel keeps those records in LDS
     const int qd = depth >> 1;
-    quad_top[off] = (is_quad && qd < TR_TOP_LEVELS) ? (int)(((1u << (2 * qd)) - 1u) / 3u + path) : -1;
+    int top_slot = (is_quad && qd < TR_TOP_LEVELS) ? (int)(((1u << (2 * qd)) - 1u) / 3u + path) : -1;
+    if (top_slot >= TR_TOP_SLOTS) top_slot = -1;
+    quad_top[off] = top_slot;
     if ((((int)nd[0]) & 1) == 1) {
         cn[1] = nd[4];
         leaf_compact[(int)nd[4]] = off;

@@ -35,7 +35,7 @@ namespace tirt {
 #define TR_BLOCK_SIZE 512
 #endif
 constexpr int TR_BLOCK = TR_BLOCK_SIZE;
-constexpr int TR_GRID_MAX = 4096;      // upper bound on persistent blocks (sizes the spill buffer)
+constexpr int TR_GRID_MAX = 2048;      // upper bound on persistent blocks (sizes the spill buffer)
 
 enum { KIND_CLOSEST = 0, KIND_SHADOW_ACC = 1, KIND_MIXED = 2 };   // MIXED: closest rays of bounce b + shadow rays of bounce b-1 in one launch
 
