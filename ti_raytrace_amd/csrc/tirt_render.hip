@@ -20,7 +20,7 @@
 //   EXHAUSTIVE  the reference's, on the 64-byte two-child nodes: every internal node whose box
 //               passes `slabs` has both children visited, leaves are intersected unconditionally.
 //               Used for the N_box / N_leaf "algorithmic bytes" counts and as a parity cross-check.
-//   ORDERED     on the 128-byte 4-wide nodes (tirt_internal.h; top four levels in LDS): children
+//   ORDERED     on the 128-byte 4-wide nodes (tirt_internal.h; top five levels in LDS): children
 //               near to far, children whose entry distance exceeds the current hit (with a 1e-4
 //               relative margin) are skipped, leaf children are pre-tested against their
 //               (slightly inflated) box.  Product default.
