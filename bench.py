@@ -79,13 +79,22 @@ def main():
         raise SystemExit("--gpus %d needs one process per GPU: launch with torch.distributed.run" % args.gpus)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    # self-test knobs (not used by the driver): TIRT_FORCE_DIST=1 exercises the RCCL path with one rank;
+    # TIRT_BENCH_ONE_DEVICE=1 + TIRT_BENCH_BACKEND=gloo lets N ranks share cuda:0 on a 1-GPU box, which runs the
+    # whole N-rank flow (tile split, merged submission, film reduce, max over ranks) on real hardware
+    if os.environ.get("TIRT_BENCH_ONE_DEVICE", "0") == "1":
+        local_rank = 0
+    backend = os.environ.get("TIRT_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
-    force_dist = os.environ.get("TIRT_FORCE_DIST", "0") == "1"      # exercise the RCCL path with one rank (self-test)
+    force_dist = os.environ.get("TIRT_FORCE_DIST", "0") == "1"
     if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     from ti_raytrace_amd import scenes, _native
     from ti_raytrace_amd import distributed as tdist

@@ -1,0 +1,34 @@
+"""bench.py's N-rank flow on real hardware: three processes share cuda:0 (gloo backend instead of RCCL, which
+refuses two ranks on one device) -- pixel tiles round-robin, deferred submission, one film reduce onto rank 0,
+MAX-over-ranks timing, JSON as the last stdout line -- and the reduced film equals the 1-process render
+byte for byte (as PNG)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run(cmd, env_extra, tmp_path, tag):
+    env = dict(os.environ)
+    env.update(env_extra)
+    out = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    last = out.stdout.decode().strip().splitlines()[-1]
+    return json.loads(last)
+
+
+def test_three_ranks_on_one_device_equal_one_process(gpu_ctx_ok, tmp_path):
+    common = ["--steps", "3", "--warmup", "1", "--frames-per-step", "4", "--size", "320", "--ntri", "20000",
+              "--tile-size", "1024", "--no-cpu-baseline", "--no-roofline"]
+    one = run([sys.executable, "bench.py"] + common + ["--save-png", str(tmp_path / "one.png")], {}, tmp_path, "one")
+    three = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1",
+                 "--master-port", "29517", "bench.py", "--gpus", "3"] + common + ["--save-png", str(tmp_path / "three.png")],
+                {"TIRT_BENCH_ONE_DEVICE": "1", "TIRT_BENCH_BACKEND": "gloo"}, tmp_path, "three")
+    assert three["n_gpus"] == 3 and one["n_gpus"] == 1 and three["scaling"] == "strong"
+    assert three["rays"] == one["rays"]                       # every pixel-sample traced exactly once across the ranks
+    assert (tmp_path / "one.png").read_bytes() == (tmp_path / "three.png").read_bytes()
