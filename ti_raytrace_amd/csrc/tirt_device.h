@@ -263,23 +263,33 @@ TD v3 offset_ray(v3 p, v3 n) { return V(offset_ray1(p.x, n.x), offset_ray1(p.y, 
 // ---- brdf/Disney.py:17-40 -----------------------------------------------------------------------------
 TD v3 disney_sample(const float *m, v3 dir, v3 N, float probability, float r1, float r2)
 {
+    // Both lobes of the reference (diffuse: cosine_sample_hemisphere + inverse_transform, specular: GTR2
+    // half vector + inverse_transform + reflect) take one sin/cos pair of a lobe-specific angle and one change
+    // of basis around N.  Written so that a wave with lanes in both lobes evaluates the expensive shared
+    // pieces (sincos, the three normalisations of the basis) once; every lane still performs exactly the
+    // reference's operations for its lobe.
     float metal = m[5], rough = m[6];
     float diffuseRatio = 0.5f * (1.0f - metal);
     float specularAlpha = maxf(0.001f, rough);
-    v3 next_dir;
-    if (probability < diffuseRatio) {
-        next_dir = cosine_sample_hemisphere(r1, r2);
-        next_dir = inverse_transform(next_dir, N);
+    const bool diffuse = probability < diffuseRatio;
+    const float two_pi = (float)(2.0 * 3.1415956);
+    const float phi = diffuse ? two_pi * r2 : r1 * 2.0f * PI_UF;       // UtilsFunc.py:352-361 / Disney.py:28
+    float sinPhi, cosPhi; tm_sincos(phi, &sinPhi, &cosPhi);
+    v3 local;
+    if (diffuse) {
+        float r = tm_sqrt(r1);
+        v3 p;
+        p.x = r * cosPhi;
+        p.y = r * sinPhi;
+        p.z = tm_sqrt(maxf(0.0f, 1.0f - p.x * p.x - p.y * p.y));
+        local = normalized(p);
     } else {
-        float phi = r1 * 2.0f * PI_UF;
         float cosTheta = tm_sqrt((1.0f - r2) / (1.0f + (specularAlpha * specularAlpha - 1.0f) * r2));
         float sinTheta = tm_sqrt(1.0f - (cosTheta * cosTheta));
-        float sinPhi, cosPhi; tm_sincos(phi, &sinPhi, &cosPhi);
-        v3 half = V(sinTheta * cosPhi, sinTheta * sinPhi, cosTheta);
-        half = inverse_transform(half, N);
-        next_dir = reflect_(dir, half);
+        local = V(sinTheta * cosPhi, sinTheta * sinPhi, cosTheta);
     }
-    return next_dir;
+    const v3 world = inverse_transform(local, N);
+    return diffuse ? world : reflect_(dir, world);
 }
 // ---- brdf/Disney.py:65-108 -----------------------------------------------------------------------------
 TD float disney_evaluate_pdf(const float *m, v3 N, v3 Vv, v3 L, float &pdf)
