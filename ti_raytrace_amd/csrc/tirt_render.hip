@@ -42,6 +42,7 @@ enum { KIND_CLOSEST = 0, KIND_SHADOW_ACC = 1, KIND_MIXED = 2 };   // MIXED: clos
 struct TraceArgs {
     BvhView bvh;
     const float *ox, *oy, *oz, *dx, *dy, *dz;    // rays, dense: ray q at index q
+    float eye[3];                                // KIND_CLOSEST with ox == nullptr (camera rays): the common origin
     const int *count_ptr; int count_fixed;       // number of rays: *count_ptr if non-null
     float *ht, *hu, *hv; int *hprim;             // KIND_CLOSEST outputs, index q
     // KIND_SHADOW_ACC: contribution of ray q goes to (rr,rg,rb)[sdst[q]] or (fr,fg,fb)[~sdst[q]]
@@ -184,7 +185,8 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
                 q = my;
                 if (KIND == KIND_MIXED) { is_sh = my >= count_c; if (is_sh) q = my - count_c; }
                 const bool mixed_sh = (KIND == KIND_MIXED) && is_sh;
-                const v3 o = mixed_sh ? V(a.sox[q], a.soy[q], a.soz[q]) : V(a.ox[q], a.oy[q], a.oz[q]);
+                const v3 o = mixed_sh ? V(a.sox[q], a.soy[q], a.soz[q])
+                                      : ((KIND == KIND_CLOSEST && a.ox == nullptr) ? V(a.eye[0], a.eye[1], a.eye[2]) : V(a.ox[q], a.oy[q], a.oz[q]));
                 const v3 d = mixed_sh ? V(a.sdx[q], a.sdy[q], a.sdz[q]) : V(a.dx[q], a.dy[q], a.dz[q]);
                 r = make_ray(o, d);
                 par = ray_has_parallel_axis(r);
@@ -499,6 +501,9 @@ int launch_trace_batch(tirt_ctx *c, const float *rays, int nr, int stack_size, i
 __global__ void k_generate(PathSoA ps, CameraView cam, TileMap tm, int P, int S, uint32_t frame_begin, uint32_t seed,
                            DevCounters *ctr)
 {
+    // Camera rays.  Only the direction is stored: the origin is the eye for every path and the rest of the
+    // bounce-0 state is constant (throughput 1, radiance 0, pdf 1, specular flag set, path id = index), which
+    // k_trace / k_shade of bounce 0 know without reading 48 bytes per path back from HBM.
     int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= S) return;
     int f = s / P, k = s - f * P;
@@ -511,11 +516,7 @@ __global__ void k_generate(PathSoA ps, CameraView cam, TileMap tm, int P, int S,
         jy = tm_rand(seed, (uint32_t)p, frame, TM_DIM_JY) - 0.5f;
     }
     v3 d = camera_ray_direction(cam, i, j, jx, jy);
-    ps.ox[s] = cam.eye[0]; ps.oy[s] = cam.eye[1]; ps.oz[s] = cam.eye[2];
     ps.dx[s] = d.x; ps.dy[s] = d.y; ps.dz[s] = d.z;
-    ps.tr[s] = 1.0f; ps.tg[s] = 1.0f; ps.tb[s] = 1.0f;
-    ps.rr[s] = 0.0f; ps.rg[s] = 0.0f; ps.rb[s] = 0.0f;
-    ps.brdf_pdf[s] = 1.0f; ps.flags[s] = 1u; ps.slot[s] = s;
     if (s == 0) atomicAdd(&ctr->paths, (unsigned long long)S);
 }
 
@@ -526,10 +527,13 @@ __global__ void k_generate(PathSoA ps, CameraView cam, TileMap tm, int P, int S,
 #ifndef SH_BLOCK
 #define SH_BLOCK 512
 #endif
-__global__ __launch_bounds__(SH_BLOCK) void k_shade(PathState ps, PathSoA in, PathSoA out, SceneView sc, TileMap tm, int P,
+#ifndef SH_MIN_WAVES
+#define SH_MIN_WAVES 4
+#endif
+__global__ __launch_bounds__(SH_BLOCK, SH_MIN_WAVES) void k_shade(PathState ps, PathSoA in, PathSoA out, SceneView sc, TileMap tm, int P,
                                                    uint32_t frame_begin, uint32_t seed, int bounce, int last_bounce,
                                                    const int *count_ptr, int count_fixed, unsigned long long *append_ctr,
-                                                   DevCounters *ctr)
+                                                   DevCounters *ctr, v3 eye)
 {
     __shared__ unsigned s_wcnt[2][SH_BLOCK / 64];
     __shared__ unsigned long long s_base[2];
@@ -547,18 +551,19 @@ __global__ __launch_bounds__(SH_BLOCK) void k_shade(PathState ps, PathSoA in, Pa
         v3 sh_o = radiance, sh_d = radiance, sh_c = radiance;
         float next_pdf = 0.0f, sh_dist = 0.0f; int next_spec = 0, sh_expect = -2;
         if (live) {
-            slot = in.slot[q];
+            const bool first = bounce == 0;          // camera rays: constant state, see k_generate
+            slot = first ? q : in.slot[q];
             const int f = slot / P, k = slot - f * P;
             const uint32_t pixel = (uint32_t)local_to_pixel(tm, k);
             const uint32_t frame = frame_begin + (uint32_t)f;
             const uint32_t dim0 = TM_DIM_BOUNCE0 + TM_DIMS_PER_BOUNCE * (uint32_t)bounce;
-            const v3 origin = V(in.ox[q], in.oy[q], in.oz[q]);
+            const v3 origin = first ? eye : V(in.ox[q], in.oy[q], in.oz[q]);
             const v3 direction = V(in.dx[q], in.dy[q], in.dz[q]);
             const float t = ps.ht[q];
-            v3 throughout = V(in.tr[q], in.tg[q], in.tb[q]);
-            radiance = V(in.rr[q], in.rg[q], in.rb[q]);
-            float brdf_pdf = in.brdf_pdf[q];
-            int perfect_spec = (int)(in.flags[q] & 1u);
+            v3 throughout = first ? V(1.0f, 1.0f, 1.0f) : V(in.tr[q], in.tg[q], in.tb[q]);
+            radiance = first ? V(0.0f, 0.0f, 0.0f) : V(in.rr[q], in.rg[q], in.rb[q]);
+            float brdf_pdf = first ? 1.0f : in.brdf_pdf[q];
+            int perfect_spec = first ? 1 : (int)(in.flags[q] & 1u);
             if (t < INF_VALUE) {
                 const int prim_id = ps.hprim[q];
                 const HitAttr h = hit_attributes(sc, origin, direction, prim_id, t, ps.hu[q], ps.hv[q]);
@@ -823,6 +828,7 @@ int pt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed,
         hipLaunchKernelGGL(k_generate, dim3((S + B - 1) / B), dim3(B), 0, st, L.ps.st[0], c->cam, tm, P, S, f0, seed, ctr);
         int grid_full = (S + TR_BLOCK - 1) / TR_BLOCK; if (grid_full > c->tr_grid) grid_full = c->tr_grid;
         int grid_shade = (S + SH_BLOCK - 1) / SH_BLOCK; if (grid_shade > c->sh_grid) grid_shade = c->sh_grid;
+        v3 eye_v; eye_v.x = c->cam.eye[0]; eye_v.y = c->cam.eye[1]; eye_v.z = c->cam.eye[2];
         for (int b = 0; b < max_depth; b++) {
             const PathSoA &in = L.ps.st[b & 1], &out = L.ps.st[(b + 1) & 1];
             // closest hits of bounce b, together with the NEE shadow rays of bounce b-1 (they add into
@@ -830,6 +836,7 @@ int pt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed,
             TraceArgs a = {};
             a.bvh = bv;
             a.ox = in.ox; a.oy = in.oy; a.oz = in.oz; a.dx = in.dx; a.dy = in.dy; a.dz = in.dz;
+            if (b == 0) { a.ox = a.oy = a.oz = nullptr; for (int k = 0; k < 3; k++) a.eye[k] = c->cam.eye[k]; }   // camera rays share their origin
             a.count_ptr = (b == 0) ? nullptr : cnt_path(b); a.count_fixed = S;
             a.ht = L.ps.ht; a.hu = L.ps.hu; a.hv = L.ps.hv; a.hprim = L.ps.hprim;
             a.spill = L.spill.as<int>(); a.spill_depth = spill_depth; a.ctr = ctr; a.per_ray_counts = nullptr;
@@ -848,7 +855,7 @@ int pt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed,
             stamp(evh, true);
             hipLaunchKernelGGL(k_shade, dim3(grid_shade), dim3(SH_BLOCK), 0, st, L.ps, in, out, sv, tm, P, f0, seed, b,
                                (b == max_depth - 1) ? 1 : 0, (b == 0) ? (const int *)nullptr : cnt_path(b), S,
-                               append_ctr(b), ctr);
+                               append_ctr(b), ctr, eye_v);
             stamp(evh, false);
             c->launches_shade++;
 
