@@ -199,6 +199,23 @@ def test_ordered_equals_reference_order_on_mesh_scenes(gpu_ctx_ok):
         assert rays[0] == rays[1] and rays[0][0] > 0
 
 
+def test_odd_film_sizes_depths_and_frame_offsets(gpu_ctx_ok):
+    """Ragged inputs: 1x1, 5x3 and 37x61 films (not multiples of the wave, block or tile size), MAX_DEPTH 1 / 2 / 15,
+    renders that start at frame 7 on a film that holds frames 0..6 (bounce-0 state is implicit on the device,
+    later bounces are not), tile size 16: all bit-identical to the oracle."""
+    for (W, H, depth, tile) in ((1, 1, 15, 4096), (5, 3, 2, 4096), (37, 61, 1, 4096), (37, 61, 15, 16)):
+        ex = scenes.cornell_box(W, H, 16, device_id=0, tile_size=tile) if tile != 4096 else scenes.cornell_box(W, H, 16, device_id=0)
+        ex.build_scene()
+        o = oa.OracleScene(ex.scene, ex.cam); o.lbvh_build()
+        ctx = ex.scene.ctx
+        seed = ex.integrator.seed
+        ctx.pt_rgb_render(0, 7, seed, depth, 64, 0)
+        ctx.pt_rgb_render(7, 3, seed, depth, 64, 0)
+        got = ctx.film_download(W, H)[0]
+        want, _ = o.render(W, H, 0, 10, seed=seed, max_depth=depth, tile_size=tile)
+        assert np.array_equal(got, want), (W, H, depth, tile, rel_l2(got, want))
+
+
 def test_abi_error_behaviour(gpu_ctx_ok):
     """Call-order and argument errors come back as negative codes with a message, never a crash."""
     ctx = _native.Context(0)
