@@ -523,9 +523,11 @@ __global__ void k_generate(PathSoA ps, CameraView cam, TileMap tm, int P, int S,
 // Block size of k_shade.  The survivors / shadow rays of a block are appended with ONE 64-bit atomic per
 // block and round (low word: next-bounce paths, high word: shadow rays): same-address device atomics
 // retire at ~11 ns each on MI355X, so one atomic per wave and queue (2 x 524k per 33.5 M paths)
-// bounded the kernel at ~6 ms; per 512-thread block it is 65k.
+// bounded the kernel at ~6 ms; per 256-thread block it is 131k.  (512-thread blocks halve that again but
+// measured 4 % slower end to end: a 4-wave block needs 112 VGPRs per SIMD and fits next to the resident
+// k_trace waves of another lane's batch, an 8-wave block does not.)
 #ifndef SH_BLOCK
-#define SH_BLOCK 512
+#define SH_BLOCK 256
 #endif
 #ifndef SH_MIN_WAVES
 #define SH_MIN_WAVES 4
