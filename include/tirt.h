@@ -68,7 +68,7 @@ int tirt_sync(tirt_ctx *ctx);
  *            ctx stream so that tirt_stats reports per-kernel time (bench/roofline only)
  *            (also confines the batches to one lane so that kernel times are not overlapped)
  *          "overlap_lanes" (1..8, default 4) -- wavefront batches in flight on separate streams
- *          "trace_lds_depth" / "trace_refill_min" / "trace_node_min" / "trace_grid" / "trace_slices" /
+ *          "trace_lds_depth" / "trace_refill_min" / "trace_node_min" / "trace_grid" / "trace_grid_alone" / "trace_slices" /
  *          "shade_grid" -- kernel tuning
  *          "bdpt_bounded" (0/1, default 1) -- BDPT connection rays are cut off at their target distance (same
  *            visibility answers as the full closest-hit query; 0 = reference-style full query, for cross-checks)

@@ -828,7 +828,12 @@ int pt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed,
 
         TIRT_HIP(hipMemsetAsync(L.counters_mem.p, 0, lane_counter_bytes(max_depth), st));
         hipLaunchKernelGGL(k_generate, dim3((S + B - 1) / B), dim3(B), 0, st, L.ps.st[0], c->cam, tm, P, S, f0, seed, ctr);
-        int grid_full = (S + TR_BLOCK - 1) / TR_BLOCK; if (grid_full > c->tr_grid) grid_full = c->tr_grid;
+        // a batch that will run next to the previous one (still in flight on another lane) uses fewer persistent
+        // blocks, so that both traversal kernels find LDS on the CUs; a batch submitted to an idle GPU takes them all
+        bool busy = false;
+        if (c->last_film) { busy = hipEventQuery(c->last_film) == hipErrorNotReady; (void)hipGetLastError(); }
+        const int grid_cap = (busy && n_lanes > 1) ? c->tr_grid : c->tr_grid_alone;
+        int grid_full = (S + TR_BLOCK - 1) / TR_BLOCK; if (grid_full > grid_cap) grid_full = grid_cap;
         int grid_shade = (S + SH_BLOCK - 1) / SH_BLOCK; if (grid_shade > c->sh_grid) grid_shade = c->sh_grid;
         v3 eye_v; eye_v.x = c->cam.eye[0]; eye_v.y = c->cam.eye[1]; eye_v.z = c->cam.eye[2];
         for (int b = 0; b < max_depth; b++) {
