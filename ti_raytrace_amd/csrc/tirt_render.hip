@@ -530,7 +530,7 @@ __global__ void k_generate(PathSoA ps, CameraView cam, TileMap tm, int P, int S,
 #define SH_BLOCK 256
 #endif
 #ifndef SH_MIN_WAVES
-#define SH_MIN_WAVES 4
+#define SH_MIN_WAVES 5
 #endif
 __global__ __launch_bounds__(SH_BLOCK, SH_MIN_WAVES) void k_shade(PathState ps, PathSoA in, PathSoA out, SceneView sc, TileMap tm, int P,
                                                    uint32_t frame_begin, uint32_t seed, int bounce, int last_bounce,
