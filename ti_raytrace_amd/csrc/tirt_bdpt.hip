@@ -80,7 +80,7 @@ TD SimpleHit trace_simple(const BvhView &b, v3 o, v3 d, int *stack /* LDS, [entr
         } else {
             const int code = ~cur;
             const int prim = code & 0x3fffffff;
-            const float4 *tp = b.tri + (size_t)prim * 3;
+            const float4 *tp = b.tri + (size_t)prim * TRI_STRIDE;
             const float4 ta = tp[0], e1 = tp[1], e2 = tp[2];
             float t, u, v;
             if (((code >> 30) & 1) == 0) t = intersect_tri_packed(o, d, V(ta.x, ta.y, ta.z), V(e1.x, e1.y, e1.z), V(e2.x, e2.y, e2.z), u, v);

@@ -58,6 +58,10 @@ struct DevBuf {
 //   its up to four grandchildren: (q0 q1 q2) boxes of slots 0,1 laid out like wnode's, (q3 q4 q5) slots
 //   2,3, q6 = four codes (>= 0: qnode index, < 0: leaf as above, TR_EMPTY: unused slot), q7 unused.
 //   The ordered traversal and BDPT walk these; wnode serves the exhaustive (reference-order) mode.
+#ifndef TRI_STRIDE_N
+#define TRI_STRIDE_N 3
+#endif
+constexpr int TRI_STRIDE = TRI_STRIDE_N;                 // float4 per primitive record
 constexpr int TR_EMPTY = (int)0x80000001;
 #ifndef TR_TOP_LEVELS_N
 #define TR_TOP_LEVELS_N 5

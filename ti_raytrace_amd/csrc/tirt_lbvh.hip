@@ -388,7 +388,7 @@ __global__ void k_tris(SceneView s, const int *leaf_compact, float4 *tri)
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= s.n) return;
     const int *pr = s.primitive + (size_t)i * PRI_VEC;
-    float4 *t = tri + (size_t)i * 3;
+    float4 *t = tri + (size_t)i * TRI_STRIDE;
     float lc = __int_as_float(leaf_compact[i]);
     if (pr[0] == PRIMITIVE_TRI) {
         v3 v0 = vtx_pos(s, pr[1]), v1 = vtx_pos(s, pr[1] + 1), v2 = vtx_pos(s, pr[1] + 2);
@@ -533,7 +533,7 @@ int lbvh_build(tirt_ctx *c)
     if (c->parent.ensure(sizeof(int) * (size_t)N) || c->flag.ensure(sizeof(int) * (size_t)N) ||
         c->subtree.ensure(sizeof(int) * (size_t)N) || c->build_status.ensure(sizeof(int) * 4) ||
         c->leaf_compact.ensure(sizeof(int) * (size_t)n)) return TIRT_ERR_HIP;
-    if (c->wnode.ensure(sizeof(float4) * 4 * (size_t)N) || c->tri.ensure(sizeof(float4) * 3 * (size_t)n)) return TIRT_ERR_HIP;
+    if (c->wnode.ensure(sizeof(float4) * 4 * (size_t)N) || c->tri.ensure(sizeof(float4) * TRI_STRIDE * (size_t)n)) return TIRT_ERR_HIP;
     // 4-wide nodes: one per internal node at even depth (< n of them); indices are used as 32-bit byte offsets / 128
     TIRT_REQUIRE(n <= (1 << 24), "tirt_lbvh_build: more than 16 Mi primitives");
     const int n_tiles = (N + SC_TILE - 1) / SC_TILE;

@@ -330,7 +330,7 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
         if (have && cur < 0 && cur != TR_SENT) {
             const int code = ~cur;
             const int prim = code & 0x3fffffff;
-            const float4 *tp = b.tri + (size_t)prim * 3;
+            const float4 *tp = b.tri + (size_t)prim * TRI_STRIDE;
             const float4 ta = tp[0], e1 = tp[1], e2 = tp[2];
             if (COUNT) nleaf += 1;
             const v3 o = V(r.ox, r.oy, r.oz), d = V(r.dx, r.dy, r.dz);
