@@ -514,19 +514,13 @@ TD v3 bd_connect_path(const BdCtx &c, bpixel *P, int i, int j, int e, int l, uin
     return radiance * misweight;
 }
 
-// BDPT_RGB.py:597-614: per-frame clear of beta/type/fpdf/rpdf (everything else persists)
-__global__ void k_bdpt_clear(bpixel *px, float *radiance, long npix)
-{
-    long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= npix) return;
-    radiance[3 * p] = 0.0f; radiance[3 * p + 1] = 0.0f; radiance[3 * p + 2] = 0.0f;
-    bpixel *P = px + p;
-    for (int e = 0; e < BD_EYE_MAX; e++) { P->eye[e].beta = V(0.0f, 0.0f, 0.0f); P->eye[e].type = VERTEX_NONE; P->eye[e].fpdf = 0.0f; P->eye[e].rpdf = 0.0f; }
-    for (int l = 0; l < BD_LIGHT_MAX; l++) { P->light[l].beta = V(0.0f, 0.0f, 0.0f); P->light[l].type = VERTEX_NONE; P->light[l].fpdf = 0.0f; P->light[l].rpdf = 0.0f; }
-}
-
-// BDPT_RGB.py:617-637: one thread per owned pixel
-__global__ __launch_bounds__(BD_BLOCK) void k_bdpt_pixel(BdCtx c, bpixel *px, float *radiance, TileMap tm, int P_local, uint32_t frame)
+// BDPT_RGB.py:597-637: one thread per owned pixel.  The thread runs `nframes` consecutive frames of its pixel
+// (the per-pixel vertex arrays persist from frame to frame, so a pixel's frames are sequential anyway): the
+// per-frame clear of its own state happens at the top of each frame, frame f splats into its own radiance
+// buffer, and the path-length imbalance between pixels averages out over the frames instead of leaving the
+// GPU half empty at the end of every single-frame launch (lane utilisation of this megakernel is ~10 %).
+__global__ __launch_bounds__(BD_BLOCK) void k_bdpt_pixel(BdCtx c, bpixel *px, float *radiance, TileMap tm, int P_local, uint32_t frame_begin,
+                                                       int nframes, long frame_stride)
 {
     __shared__ int lds_stack[BD_STACK * BD_BLOCK];
     c.stack = lds_stack + threadIdx.x;
@@ -536,23 +530,30 @@ __global__ __launch_bounds__(BD_BLOCK) void k_bdpt_pixel(BdCtx c, bpixel *px, fl
     const int i = p / c.bv.H, j = p - i * c.bv.H;
     bpixel *P = px + p;                     // (working on a private copy of the 1.7 KB state measured 4 % slower)
     unsigned n_closest = 0, n_shadow = 0;
-    const int eye_depth = bd_eye_path(c, P, i, j, frame, n_closest);
-    const int light_depth = bd_light_path(c, P, i, j, frame, n_closest);
-    for (int e = 1; e <= eye_depth; e++) {
-        for (int l = 0; l <= light_depth; l++) {
-            const int depth = l + e - 2;
-            if (((l == 1) & (e == 1)) | (depth < 0) | (depth > BD_MAX_DEPTH)) continue;
-            int nu, nv;
-            const v3 r = bd_connect_path(c, P, i, j, e, l, frame, nu, nv, n_shadow);
-            const long q = (e == 1) ? ((nu >= 0) ? (long)nu * c.bv.H + nv : -1) : (long)p;
-            if (q >= 0 && (r.x != 0.0f || r.y != 0.0f || r.z != 0.0f)) {
-                atomicAdd(&radiance[3 * q], r.x); atomicAdd(&radiance[3 * q + 1], r.y); atomicAdd(&radiance[3 * q + 2], r.z);
+    for (int f = 0; f < nframes; f++) {
+        const uint32_t frame = frame_begin + (uint32_t)f;
+        float *rad = radiance + (size_t)f * (size_t)frame_stride;
+        // BDPT_RGB.py:597-614: per-frame clear of beta/type/fpdf/rpdf (everything else persists)
+        for (int e = 0; e < BD_EYE_MAX; e++) { P->eye[e].beta = V(0.0f, 0.0f, 0.0f); P->eye[e].type = VERTEX_NONE; P->eye[e].fpdf = 0.0f; P->eye[e].rpdf = 0.0f; }
+        for (int l = 0; l < BD_LIGHT_MAX; l++) { P->light[l].beta = V(0.0f, 0.0f, 0.0f); P->light[l].type = VERTEX_NONE; P->light[l].fpdf = 0.0f; P->light[l].rpdf = 0.0f; }
+        const int eye_depth = bd_eye_path(c, P, i, j, frame, n_closest);
+        const int light_depth = bd_light_path(c, P, i, j, frame, n_closest);
+        for (int e = 1; e <= eye_depth; e++) {
+            for (int l = 0; l <= light_depth; l++) {
+                const int depth = l + e - 2;
+                if (((l == 1) & (e == 1)) | (depth < 0) | (depth > BD_MAX_DEPTH)) continue;
+                int nu, nv;
+                const v3 r = bd_connect_path(c, P, i, j, e, l, frame, nu, nv, n_shadow);
+                const long q = (e == 1) ? ((nu >= 0) ? (long)nu * c.bv.H + nv : -1) : (long)p;
+                if (q >= 0 && (r.x != 0.0f || r.y != 0.0f || r.z != 0.0f)) {
+                    atomicAdd(&rad[3 * q], r.x); atomicAdd(&rad[3 * q + 1], r.y); atomicAdd(&rad[3 * q + 2], r.z);
+                }
             }
         }
     }
     atomicAdd(c.rays_closest, (unsigned long long)n_closest);
     atomicAdd(c.rays_shadow, (unsigned long long)n_shadow);
-    atomicAdd(c.paths, 1ull);
+    atomicAdd(c.paths, (unsigned long long)nframes);
 }
 
 // BDPT_RGB.py:639-642
@@ -575,7 +576,9 @@ int bdpt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t see
         if (c->bdpt_px.ensure(sizeof(bpixel) * (size_t)NP)) return TIRT_ERR_HIP;
         TIRT_HIP(hipMemsetAsync(c->bdpt_px.p, 0, sizeof(bpixel) * (size_t)NP, c->stream));
     }
-    if (c->bdpt_rad.ensure(sizeof(float) * 3 * (size_t)NP)) return TIRT_ERR_HIP;
+    constexpr int BD_FRAMES = 16;                  // frames per launch (one radiance buffer each)
+    const int FMAX = frame_count < BD_FRAMES ? frame_count : BD_FRAMES;
+    if (c->bdpt_rad.ensure(sizeof(float) * 3 * (size_t)NP * (size_t)FMAX)) return TIRT_ERR_HIP;
     BdCtx bc;
     bc.sc = scene_view(c); bc.bvh = bvh_view(c); bc.cam = c->cam; bc.seed = seed; bc.stack = nullptr; bc.bounded = c->bdpt_bounded;
     for (int k = 0; k < 12; k++) bc.bv.view[k] = c->view[k];
@@ -585,12 +588,17 @@ int bdpt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t see
     const TileMap tm = {c->tile_rank, c->tile_count, c->tile_size, c->H};
     const int P = (int)c->npix_local;
     hipStream_t st = c->stream;
-    for (int f = 0; f < frame_count; f++) {
-        const uint32_t frame = frame_begin + (uint32_t)f;
-        hipLaunchKernelGGL(k_bdpt_clear, dim3((unsigned)((NP + 255) / 256)), dim3(256), 0, st, c->bdpt_px.as<bpixel>(), c->bdpt_rad.as<float>(), NP);
-        if (P > 0) hipLaunchKernelGGL(k_bdpt_pixel, dim3((P + BD_BLOCK - 1) / BD_BLOCK), dim3(BD_BLOCK), 0, st, bc, c->bdpt_px.as<bpixel>(), c->bdpt_rad.as<float>(), tm, P, frame);
-        const float coff = 1.0f / ((float)(int)frame + 1.0f);
-        hipLaunchKernelGGL(k_bdpt_film, dim3((unsigned)((3 * NP + 255) / 256)), dim3(256), 0, st, c->bdpt_rad.as<float>(), c->hdr.as<float>(), 3 * NP, coff);
+    for (int f0 = 0; f0 < frame_count; f0 += FMAX) {
+        const int F = frame_count - f0 < FMAX ? frame_count - f0 : FMAX;
+        const uint32_t frame0 = frame_begin + (uint32_t)f0;
+        TIRT_HIP(hipMemsetAsync(c->bdpt_rad.p, 0, sizeof(float) * 3 * (size_t)NP * (size_t)F, st));
+        if (P > 0) hipLaunchKernelGGL(k_bdpt_pixel, dim3((P + BD_BLOCK - 1) / BD_BLOCK), dim3(BD_BLOCK), 0, st, bc, c->bdpt_px.as<bpixel>(),
+                                      c->bdpt_rad.as<float>(), tm, P, frame0, F, 3 * NP);
+        for (int f = 0; f < F; f++) {                     // the running mean applies the frames in order
+            const float coff = 1.0f / ((float)(int)(frame0 + (uint32_t)f) + 1.0f);
+            hipLaunchKernelGGL(k_bdpt_film, dim3((unsigned)((3 * NP + 255) / 256)), dim3(256), 0, st, c->bdpt_rad.as<float>() + (size_t)f * 3 * NP,
+                               c->hdr.as<float>(), 3 * NP, coff);
+        }
     }
     TIRT_HIP(hipGetLastError());
     return TIRT_OK;
