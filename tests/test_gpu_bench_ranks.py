@@ -22,12 +22,19 @@ def run(cmd, env_extra, tmp_path, tag):
     return json.loads(last)
 
 
+def free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def test_three_ranks_on_one_device_equal_one_process(gpu_ctx_ok, tmp_path):
     common = ["--steps", "3", "--warmup", "1", "--frames-per-step", "4", "--size", "320", "--ntri", "20000",
               "--tile-size", "1024", "--no-cpu-baseline", "--no-roofline"]
     one = run([sys.executable, "bench.py"] + common + ["--save-png", str(tmp_path / "one.png")], {}, tmp_path, "one")
     three = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1",
-                 "--master-port", "29517", "bench.py", "--gpus", "3"] + common + ["--save-png", str(tmp_path / "three.png")],
+                 "--master-port", str(free_port()), "bench.py", "--gpus", "3"] + common + ["--save-png", str(tmp_path / "three.png")],
                 {"TIRT_BENCH_ONE_DEVICE": "1", "TIRT_BENCH_BACKEND": "gloo"}, tmp_path, "three")
     assert three["n_gpus"] == 3 and one["n_gpus"] == 1 and three["scaling"] == "strong"
     assert three["rays"] == one["rays"]                       # every pixel-sample traced exactly once across the ranks
