@@ -397,16 +397,28 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
     }
 }
 
+template <int MODE, bool COUNT, int KIND>
+static void launch_trace_as(hipStream_t stream, const TraceArgs &a, dim3 g, dim3 b, size_t lds)
+{
+    // more than 64 KB of dynamic LDS per block (stacks + tree top): tell the runtime once per kernel and size
+    static size_t allowed = 0;
+    if (lds > allowed) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trace<MODE, COUNT, KIND>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipGetLastError();
+        allowed = lds;
+    }
+    hipLaunchKernelGGL((k_trace<MODE, COUNT, KIND>), g, b, lds, stream, a);
+}
 template <int KIND>
 static void launch_trace(hipStream_t stream, const TraceArgs &a, int flags, int grid)
 {
     const bool exh = (flags & TIRT_TRAVERSE_EXHAUSTIVE) != 0, cnt = (flags & TIRT_COUNT_NODES) != 0;
     dim3 g(grid), b(TR_BLOCK);
     const size_t lds = sizeof(int) * (size_t)a.lds_depth * TR_BLOCK + (size_t)TR_TOP_SLOTS * 112;
-    if (exh && cnt) hipLaunchKernelGGL((k_trace<TIRT_TRAVERSE_EXHAUSTIVE, true, KIND>), g, b, lds, stream, a);
-    else if (exh) hipLaunchKernelGGL((k_trace<TIRT_TRAVERSE_EXHAUSTIVE, false, KIND>), g, b, lds, stream, a);
-    else if (cnt) hipLaunchKernelGGL((k_trace<TIRT_TRAVERSE_ORDERED, true, KIND>), g, b, lds, stream, a);
-    else hipLaunchKernelGGL((k_trace<TIRT_TRAVERSE_ORDERED, false, KIND>), g, b, lds, stream, a);
+    if (exh && cnt) launch_trace_as<TIRT_TRAVERSE_EXHAUSTIVE, true, KIND>(stream, a, g, b, lds);
+    else if (exh) launch_trace_as<TIRT_TRAVERSE_EXHAUSTIVE, false, KIND>(stream, a, g, b, lds);
+    else if (cnt) launch_trace_as<TIRT_TRAVERSE_ORDERED, true, KIND>(stream, a, g, b, lds);
+    else launch_trace_as<TIRT_TRAVERSE_ORDERED, false, KIND>(stream, a, g, b, lds);
 }
 
 static int ensure_spill(tirt_ctx *c, DevBuf &spill, int stack_size, int &spill_depth)
