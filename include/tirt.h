@@ -75,6 +75,8 @@ int tirt_sync(tirt_ctx *ctx);
  *          "merge_paths" -- consecutive tirt_pt_rgb_render calls over contiguous frames are merged
  *            until this many pixel-samples are pending (default 32 Mi = one full batch; 0 submits every call at once);
  *            every other entry point submits what is pending first
+ *          "job_frames" -- hint: frames the whole job will render (0 = unknown, default); lane buffers are then not
+ *            sized for merging more than that (a 512^2 x 8 spp job does not allocate 32 Mi-path lanes)
  *          "batch_paths" -- pixel-samples kept in flight per wavefront batch (default 32 Mi,
  *            112 B of HBM each) */
 int tirt_set_option(tirt_ctx *ctx, const char *name, double value);

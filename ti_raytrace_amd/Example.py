@@ -35,6 +35,8 @@ class example:
         self.integrator.setup_data_cpu()
         self.integrator.setup_data_gpu()
         self.scene.setup_data_gpu()
+        # hint for the device library: this job renders sample_count frames (bounds its batch buffers)
+        self.scene.ctx.set_option("job_frames", max(int(self.sample_count), 1))
 
     def add_sphere_light(self, pos=(0.0, 20.0, 0.0), radius=5.0, emission=50.0):
         """example/Example.py:27-36 (position/size/emission overridable for scaled scenes)."""

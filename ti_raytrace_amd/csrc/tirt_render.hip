@@ -802,6 +802,8 @@ int pt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed,
     if (c->merge_paths > 0 && P >= 65536) {
         size_t want = c->merge_paths + (size_t)frame_count * P;
         if (want > c->batch_paths) want = c->batch_paths;
+        // "job_frames" hint (the example classes pass their sample count): a short job never merges more than itself
+        if (c->job_frames > 0 && want > (size_t)c->job_frames * P) want = (size_t)c->job_frames * P;
         want = (want / P) * P;
         if (want > cap) cap = want;
     }
