@@ -19,24 +19,32 @@ torch.cuda.synchronize() + tirt_sync on both sides; MAX over ranks; rank 0 print
 line.  Inputs (scene, BVH) are resident in HBM before the timed region.
 
 Extra objects:
-  roofline      dominant kernel = closest-hit traversal (k_trace).  achieved = ALGORITHMIC
-                bytes per launch / mean launch duration, both measured live: bytes from the
-                reference-semantics pop counts (32 B x N_box + 36 B x N_leaf + 48 B per ray,
-                SURVEY.md 8d) gathered by an untimed exhaustive counting pass over the same
-                frames, duration from HIP events on the library's stream around every
-                closest-hit launch of an untimed instrumented pass.
+  roofline      dominant kernel = the traversal kernel k_trace (closest hits of bounce b + NEE shadow
+                rays of bounce b-1 in one launch).  rocprofv3 PMC (profiles/) shows it bound by the
+                L1 gather path (texture-address unit), not by HBM, so:
+                  achieved = bytes of node / primitive / ray records the launch gathers from global memory
+                             (device counters of an untimed counting pass over the same frames)
+                             / mean launch duration (HIP events on the library's stream, untimed pass)
+                  peak     = the ceiling of exactly that access pattern (random 64-byte records,
+                             4 x 16-byte loads per lane) measured in THIS run on an array of the BVH's
+                             actual byte size (tirt_micro_gather_rate)
+                  frac     = achieved / peak
+                  traffic  = HBM-side bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE, MI355X_MICROARCH.md)
+                             from two rocprofv3 --pmc passes this script runs itself on a child process;
+                             hbm_frac = traffic / duration / 8 TB/s
+                  alg_reference_semantics = SURVEY.md 8d's figure (32 B x N_box + 36 B x N_leaf + 48 B per
+                             ray with the REFERENCE's exhaustive pop counts): what the reference's
+                             algorithm would move, not what this kernel moves -- reported, not a fraction.
   cpu_baseline  the CPU oracle (oracle/, a restatement of the reference algorithm: AoS rows,
-                exhaustive unordered traversal, per-pixel loop) on all host cores over a
-                bounded pixel sample of the same scene/frame ("kind": "port"; the reference's
-                own ti.cpu path cannot run: Taichi is not installable here).
+                exhaustive unordered traversal, per-pixel loop) built -O3 -march=native on this box,
+                on all host cores over a bounded sample of the same scene/frames ("kind": "port"; the
+                reference's own ti.cpu path cannot run: Taichi is not installable here).
 """
 import argparse
 import json
 import os
 import sys
 import time
-
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # one hardware queue per render lane; must be set before the HIP runtime starts
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -57,11 +65,123 @@ def parse():
     ap.add_argument("--tile-size", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--cpu-target-s", type=float, default=15.0, help="seconds of CPU-oracle work for cpu_baseline")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc child passes behind roofline.traffic")
+    ap.add_argument("--cpu-target-s", type=float, default=12.0, help="seconds of CPU-oracle work for cpu_baseline")
     ap.add_argument("--save-png", default="")
     ap.add_argument("--emulate-world", type=int, default=0, help="render only rank 0's tiles of an N-rank job (scaling study on one GPU)")
     ap.add_argument("--opt", action="append", default=[], help="name=value passed to tirt_set_option (tuning)")
     return ap.parse_args()
+
+
+def measure_hbm_traffic(args):
+    """HBM-side bytes per k_trace launch, measured now: two rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE do not
+    fit one pass: TCC has 4 counter slots) over a child run of this script (1 warm-up + 1 step, one render lane).
+    FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950.  Returns a dict, or {"error": ...}."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return {"error": "rocprofv3 not found"}
+    if any(k.startswith("ROCPROF") or k.startswith("ROCP_") for k in os.environ):
+        return {"error": "this process is itself being profiled: nested rocprofv3 pass skipped"}
+    env = dict(os.environ); env["TMPDIR"] = "/tmp"
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="tirt_pmc_", dir="/tmp")
+    child = [sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "1", "--frames-per-step", str(args.frames_per_step),
+             "--size", str(args.size), "--ntri", str(args.ntri), "--seed", str(args.seed), "--no-cpu-baseline", "--no-roofline",
+             "--opt", "overlap_lanes=1"] + sum((["--opt", o] for o in args.opt), [])
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            cmd = ["timeout", "-k", "5", "240", exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "--"] + child
+            p = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+            fs = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if not fs:
+                return {"error": "%s pass produced no counter file (rc %d)" % (counter, p.returncode)}
+            total, ids = 0.0, set()
+            for r in csv.DictReader(open(max(fs, key=os.path.getmtime))):
+                if "k_trace" in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                    total += float(r["Counter_Value"]); ids.add(r["Dispatch_Id"])
+            if not ids:
+                return {"error": "no k_trace dispatch in the %s pass" % counter}
+            out[counter + "_KB_per_launch"] = round(total / len(ids), 1)
+            out["launches_" + counter] = len(ids)
+    except Exception as exc:            # noqa: BLE001 -- a failed profiler pass must not fail the bench line
+        return {"error": "%s: %s" % (type(exc).__name__, exc)}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    out["bytes_per_launch"] = round((2.0 * out["FETCH_SIZE_KB_per_launch"] + out["WRITE_SIZE_KB_per_launch"]) * 1024.0)
+    out["source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) run by bench.py on a child process; FETCH_SIZE x 2 (gfx950)"
+    return out
+
+
+def host_cpu_info():
+    info = {"nproc": os.cpu_count(), "affinity": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None}
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                info["cpu_model"] = line.split(":", 1)[1].strip(); break
+    except OSError:
+        pass
+    quota = None
+    try:                                                   # cgroup v2, then v1
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        quota = None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            quota = None if q <= 0 else q / per
+        except (OSError, ValueError):
+            pass
+    info["cgroup_cpu_quota"] = quota
+    return info
+
+
+def cpu_baseline(args, ex, W, H, build_ms):
+    """The CPU oracle timed on this box's host cores: -O3 -march=native build made here, dynamic chunk queue, bounded
+    sample (~cpu_target_s seconds) of the same scene and frames; 1-thread and N-thread rates, host description."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_api
+    host = host_cpu_info()
+    native = oracle_api.build_native() is not None
+    orc = oracle_api.OracleScene(ex.scene, ex.cam, native=native)
+    tb = time.perf_counter()
+    orc.lbvh_build()
+    cpu_build_s = time.perf_counter() - tb
+    if native:      # the native build must compute what the portable one does (same IEEE operations)
+        ref = oracle_api.OracleScene(ex.scene, ex.cam); ref.lbvh_build()
+        a, _ = orc.render(W, H, 1, 1, seed=args.seed, p_begin=W * H // 2, p_end=W * H // 2 + 2048, nthreads=4)
+        b, _ = ref.render(W, H, 1, 1, seed=args.seed, p_begin=W * H // 2, p_end=W * H // 2 + 2048, nthreads=4)
+        if not np.array_equal(a, b):
+            raise SystemExit("native oracle build differs from the portable build")
+    cores = host["affinity"] or host["nproc"] or 1
+    if host.get("cgroup_cpu_quota"):
+        cores = max(1, min(cores, int(host["cgroup_cpu_quota"] + 0.5)))
+    # 1-thread rate on a strip in the middle of the film (~2 s)
+    t1 = time.perf_counter()
+    _, s1 = orc.render(W, H, 1, 1, seed=args.seed, p_begin=W * H // 2, p_end=W * H // 2 + 16384, nthreads=1)
+    one_s = max(time.perf_counter() - t1, 1e-6)
+    rate1 = (s1["rays_closest"] + s1["rays_shadow"]) / one_s
+    # N threads: whole frames, sized from the 1-thread rate assuming linear scaling
+    rays_per_frame = (s1["rays_closest"] + s1["rays_shadow"]) * (W * H / 16384.0)
+    nframes = int(min(max(round(args.cpu_target_s * rate1 * cores / rays_per_frame), 1.0), 64.0))
+    tc = time.perf_counter()
+    _, ost = orc.render(W, H, 1, nframes, seed=args.seed, nthreads=cores)
+    cpu_s = time.perf_counter() - tc
+    cpu_rays = ost["rays_closest"] + ost["rays_shadow"]
+    return {
+        "value": round(cpu_rays / cpu_s / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
+        "build": "gcc -O3 -march=native on this host" if native else "portable -O2 build shipped with the repo (native build failed)",
+        "one_thread_Mrays_s": round(rate1 / 1e6, 5), "per_thread_Mrays_s": round(cpu_rays / cpu_s / cores / 1e6, 5),
+        "parallel_efficiency": round(cpu_rays / cpu_s / cores / rate1, 3), "host": host,
+        "sample": "frames 1..%d of the same scene at the full %dx%d (%d paths, %d rays) in %.2f s on %d threads (dynamic 64-pixel "
+                  "chunks); 1-thread rate from 16384 pixels of frame 1 in %.2f s; CPU oracle LBVH build %.3f s (GPU %.3f ms)" %
+                  (nframes, W, H, ost["paths"], cpu_rays, cpu_s, cores, one_s, cpu_build_s, build_ms),
+    }
 
 
 def main():
@@ -181,7 +301,7 @@ def main():
         write_png(ctx.film_download(W, H, want_hdr=False, want_rgb=True)[1], args.save_png)
 
     # ---- roofline for the dominant kernel (rank 0's shard, untimed extra passes) -----------------
-    if not args.no_roofline:
+    if not args.no_roofline and rank == 0:
         probe_frames = fps
         f0 = ex.cam.frame
         ctx.stats_reset()
@@ -200,77 +320,65 @@ def main():
         ctx.sync()
         t = ctx.stats()
         ctx.set_option("time_kernels", 0)
-        traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tpath) and args.size == 1024 and args.ntri == 100000 and fps == 32 and world == 1:
-            tj = json.load(open(tpath)).get("k_trace", {})
-            traffic, traffic_src = tj.get("hbm_bytes_per_launch"), tj.get("source")
-        # dominant kernel = k_trace (closest hits of bounce b + NEE shadow rays of bounce b-1 share a launch)
         n_launch = max(t["launches_trace_closest"] + t["launches_trace_shadow"], 1)
-        alg_trace = alg_closest + alg_shadow
         avg_ms = (t["ms_trace_closest"] + t["ms_trace_shadow"]) / n_launch
-        achieved = (alg_trace / n_launch) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        gather_bytes = (112.0 / 4.0 * (co["box_closest"] + co["box_shadow"]) + 48.0 * (co["leaf_closest"] + co["leaf_shadow"]) +
-                        24.0 * (co["rays_closest"] + co["rays_shadow"]))
+        rays_o = co["rays_closest"] + co["rays_shadow"]
+        # what the launch gathers from global memory: 64 B per 4-wide node visit that is not served by the LDS copy of
+        # the tree top, 48 B per primitive test, 24 B ray fetch + 16 B hit record per ray
+        node_visits = (co["box_closest"] + co["box_shadow"]) / 4.0
+        lds_visits = float(co["diag_it_outer"])
+        gather_bytes = 64.0 * (node_visits - lds_visits) + 48.0 * (co["leaf_closest"] + co["leaf_shadow"]) + 40.0 * rays_o
+        achieved = gather_bytes / n_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        info = ctx.bvh_info()
+        working_set = info["node_bytes"] + info["prim_bytes"]
+        peak = ctx.micro_gather_rate(working_set, 2000)
+        peak_l2 = ctx.micro_gather_rate(2 << 20, 2000)
+        traffic = None if args.no_traffic else measure_hbm_traffic(args)
+        tr_bytes = traffic["bytes_per_launch"] if traffic and traffic.get("bytes_per_launch") else None
+        alg_trace = alg_closest + alg_shadow
         result["roofline"] = {
-            "bound": "hbm", "kernel": "k_trace<ordered> (closest-hit + NEE shadow rays)",
-            "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
-            "hbm_GBps_measured": (round(traffic / (avg_ms * 1e-3) / 1e9, 1) if (traffic and avg_ms > 0) else None),
-            "alg_bytes_per_launch": round(alg_trace / n_launch, 1),
+            "bound": "l1_gather", "kernel": "k_trace<ordered> (closest-hit + NEE shadow rays)",
+            "achieved": round(achieved, 1), "peak": round(peak, 1), "unit": "GB/s",
+            "frac": round(achieved / peak, 4) if peak > 0 else None,
+            "traffic": tr_bytes,
+            "hbm_GBps": (round(tr_bytes / (avg_ms * 1e-3) / 1e9, 1) if (tr_bytes and avg_ms > 0) else None),
+            "hbm_frac": (round(tr_bytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if (tr_bytes and avg_ms > 0) else None),
+            "traffic_detail": traffic,
+            "peak_def": "tirt_micro_gather_rate measured in this run: random 64-byte records (4 x dwordx4 per lane) from an array of "
+                        "working_set_bytes = the traversal data of this scene; peak_l2_resident = the same from 2 MB",
+            "peak_l2_resident": round(peak_l2, 1), "working_set_bytes": int(working_set), "bvh": info,
+            "achieved_def": "64 B x 4-wide node visits not served from LDS + 48 B x primitive tests + 40 B x rays, ordered-traversal device "
+                            "counters of the same frames, / mean k_trace launch duration (HIP events)",
+            "gather_bytes_per_launch": round(gather_bytes / n_launch, 1),
+            "gather_bytes_per_ray": round(gather_bytes / max(rays_o, 1), 1),
             "avg_launch_ms": round(avg_ms, 5), "launches": int(n_launch),
-            "alg_bytes_per_closest_ray": round(alg_closest / max(c["rays_closest"], 1), 1),
-            "alg_bytes_per_shadow_ray": round(alg_shadow / max(c["rays_shadow"], 1), 1),
-            "n_box_per_closest_ray": round(c["box_closest"] / max(c["rays_closest"], 1), 2),
-            "n_leaf_per_closest_ray": round(c["leaf_closest"] / max(c["rays_closest"], 1), 2),
-            "n_box_ordered_per_closest_ray": round(co["box_closest"] / max(co["rays_closest"], 1), 2),
-            "n_leaf_ordered_per_closest_ray": round(co["leaf_closest"] / max(co["rays_closest"], 1), 2),
+            "node_visits_per_ray": round(node_visits / max(rays_o, 1), 2),
+            "lds_node_visits_per_ray": round(lds_visits / max(rays_o, 1), 2),
+            "prim_tests_per_ray": round((co["leaf_closest"] + co["leaf_shadow"]) / max(rays_o, 1), 2),
             "kernel_ms": {"trace_closest": round(t["ms_trace_closest"], 3), "trace_shadow": round(t["ms_trace_shadow"], 3),
                           "shade": round(t["ms_shade"], 3), "render_total": round(t["ms_render"], 3)},
-            "wave_diag_ordered": {"node_iters_per_ray": round(co["diag_it_node"] * 64.0 / max(co["rays_closest"] + co["rays_shadow"], 1), 2),
+            "wave_diag_ordered": {"node_iters_per_ray": round(co["diag_it_node"] * 64.0 / max(rays_o, 1), 2),
                                   "node_lane_util": round(co["diag_lanes_node"] / max(co["diag_it_node"] * 64.0, 1), 4),
-                                  "leaf_iters_per_ray": round(co["diag_it_leaf"] * 64.0 / max(co["rays_closest"] + co["rays_shadow"], 1), 2),
+                                  "leaf_iters_per_ray": round(co["diag_it_leaf"] * 64.0 / max(rays_o, 1), 2),
                                   "leaf_lane_util": round(co["diag_lanes_leaf"] / max(co["diag_it_leaf"] * 64.0, 1), 4),
-                                  "top_node_visits_per_ray": round(co["diag_it_outer"] / max(co["rays_closest"] + co["rays_shadow"], 1), 2),
-                                  "refills_per_wave_ray": round(co["diag_refills"] * 64.0 / max(co["rays_closest"] + co["rays_shadow"], 1), 3)},
-            # what actually limits the kernel: 16-byte-per-lane gathers of node / triangle records through the L1
-            # (TA/TD) path -- measured ceiling for scattered 64-byte records on MI355X (tools/micro/gather_rate.hip):
-            # 14.0 TB/s from an L2-resident array, 7.7 TB/s from an 8 MB one; rocprofv3: TA busy 94 % (profiles/)
-            "l1_gather": {"GBps": round(gather_bytes / n_launch / (avg_ms * 1e-3) / 1e9, 1) if avg_ms > 0 else None,
-                          "bytes_per_launch": round(gather_bytes / n_launch, 1),
-                          "measured_ceiling_GBps": {"l2_resident_records": 14000.0, "8MB_working_set": 7700.0},
-                          "def": "112 B per 4-wide node visit + 48 B per primitive test + 24 B per ray, ordered traversal counts"},
-            "whole_job_alg_GBps": round((alg_closest + alg_shadow + 260.0 * c["shaded"] + 24.0 * c["paths"]) /
-                                        max(t["ms_render"], 1e-9) / 1e6, 2),
-            "note": "the ~11 MB traversal data is L2/Infinity-Cache resident: HBM traffic is far below the algorithmic bytes; the kernel is bound by the L1 gather path (see l1_gather)",
+                                  "refills_per_wave_ray": round(co["diag_refills"] * 64.0 / max(rays_o, 1), 3)},
+            # SURVEY.md 8d's algorithmic bytes on the REFERENCE's traversal semantics (exhaustive pop counts): what the
+            # reference's algorithm would move for these rays -- the ordered traversal moves far less, so this is NOT a
+            # fraction of any roofline of this kernel
+            "alg_reference_semantics": {
+                "bytes_per_launch": round(alg_trace / n_launch, 1),
+                "GBps_equivalent": round((alg_trace / n_launch) / (avg_ms * 1e-3) / 1e9, 1) if avg_ms > 0 else None,
+                "bytes_per_closest_ray": round(alg_closest / max(c["rays_closest"], 1), 1),
+                "bytes_per_shadow_ray": round(alg_shadow / max(c["rays_shadow"], 1), 1),
+                "n_box_per_closest_ray": round(c["box_closest"] / max(c["rays_closest"], 1), 2),
+                "n_leaf_per_closest_ray": round(c["leaf_closest"] / max(c["rays_closest"], 1), 2),
+                "whole_job_GBps_equivalent": round((alg_closest + alg_shadow + 260.0 * c["shaded"] + 24.0 * c["paths"]) /
+                                                   max(t["ms_render"], 1e-9) / 1e6, 2)},
         }
 
     # ---- CPU baseline: oracle on the host cores, bounded sample (rank 0, N = 1 only) ---------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        import oracle_api
-        orc = oracle_api.OracleScene(ex.scene, ex.cam)
-        tb = time.perf_counter()
-        orc.lbvh_build()
-        cpu_build_s = time.perf_counter() - tb
-        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-        # probe 1/64 of one frame, then size the sample for ~15 s of CPU work (whole frames)
-        tp = time.perf_counter()
-        _, pst = orc.render(W, H, 1, 1, seed=args.seed, tile_rank=0, tile_count=64, tile_size=args.tile_size, nthreads=cores)
-        probe_s = max(time.perf_counter() - tp, 1e-3)
-        frame_s = probe_s * 64.0
-        # (the probe over-estimates on many-core hosts: thread start-up dominates its 16k paths)
-        nframes = int(min(max(round(1.7 * args.cpu_target_s / frame_s), 1.0), 16.0))
-        tc = time.perf_counter()
-        _, ost = orc.render(W, H, 1, nframes, seed=args.seed, nthreads=cores)
-        cpu_s = time.perf_counter() - tc
-        cpu_rays = ost["rays_closest"] + ost["rays_shadow"]
-        result["cpu_baseline"] = {
-            "value": round(cpu_rays / cpu_s / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": "frames 1..%d of the same scene at the full 1024^2 (%d paths, %d rays) in %.2f s on %d threads; "
-                      "CPU oracle LBVH build %.3f s (GPU %.3f ms)" %
-                      (nframes, ost["paths"], cpu_rays, cpu_s, cores, cpu_build_s, build_ms),
-        }
+        result["cpu_baseline"] = cpu_baseline(args, ex, W, H, build_ms)
 
     # RCCL writes its version banner to C stdio (block-buffered when piped): every rank pushes its buffer out, then
     # rank 0 prints the JSON line as the LAST line on stdout (no os._exit here: rocprofv3 writes its output from

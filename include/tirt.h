@@ -148,6 +148,17 @@ int tirt_trace_closest(tirt_ctx *ctx, const float *rays, int nr, int stack_size,
 int tirt_trace_shadow(tirt_ctx *ctx, const float *rays, int nr, int stack_size, int flags,
                       float *out_t, int32_t *out_prim, int32_t *counts);
 
+/* Measurement helpers for bench.py's roofline object (no counterpart in the reference).
+ * tirt_bvh_info: bytes of the traversal data the ordered traversal walks (out[0] = quantised 4-wide nodes,
+ *   out[1] = primitive records, out[2] = node count, out[3] = of those kept in LDS by every block).
+ * tirt_micro_gather_rate: the ceiling of the access pattern k_trace is bound by, measured on this device now --
+ *   every lane of 1536 x 256 threads gathers `iters` random 64-byte records (4 x 16-byte loads) from an array of
+ *   `working_set_bytes`; returns the rate in GB/s (best of 3 launches). */
+int tirt_bvh_info(tirt_ctx *ctx, uint64_t out[4]);
+int tirt_micro_gather_rate(tirt_ctx *ctx, uint64_t working_set_bytes, int iters, double *gbps_out);
+
+/* Fills *out.  Returns TIRT_ERR_STACK (with *out filled in) when stack_overflow > 0: rays dropped subtrees, what was
+ * rendered since the last tirt_stats_reset is wrong -- the reference prints "overflow, need larger stack" (Scene.py:741). */
 int tirt_stats(tirt_ctx *ctx, tirt_stats_t *out);
 int tirt_stats_reset(tirt_ctx *ctx);
 

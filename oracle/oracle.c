@@ -1027,7 +1027,9 @@ static v3 pt_rgb_pixel(const orc_scene *s, int i, int j, int H, uint32_t frame, 
                     brdf = 1.0f; brdf_pdf = 1.0f;                                   /* brdf/Glass.py:72-74 */
                 } else {
                     perfect_spec = 0;
-                    /* Scene.py:477-518 sample_li */
+                    /* Scene.py:477-518 sample_li.  A scene without emitters (light_count == 0, env-lit): the reference
+                     * would index light[-1] (Scene.py:423-428, undefined); defined here as "no NEE sample". */
+                    if (s->light_count > 0) {
                     int lidx = (int)(tm_rand(seed, pixel, frame, dim0 + TM_SLOT_LIGHT) * (float)s->light_count);
                     if (lidx >= s->light_count) lidx = s->light_count - 1;
                     int light_prim = s->light[lidx];
@@ -1064,6 +1066,7 @@ static v3 pt_rgb_pixel(const orc_scene *s, int i, int j, int H, uint32_t frame, 
                             }
                         }
                     }
+                    }   /* light_count > 0 */
                     float rnd[3] = { tm_rand(seed, pixel, frame, dim0 + TM_SLOT_LOBE),
                                      tm_rand(seed, pixel, frame, dim0 + TM_SLOT_R1),
                                      tm_rand(seed, pixel, frame, dim0 + TM_SLOT_R2) };
@@ -1127,11 +1130,24 @@ static void *render_worker(void *arg)
     return NULL;
 }
 
-typedef struct { render_job *jobs; int first, step, count; } thread_ctx;
+/* Work distribution: the pixel range is cut into small chunks handed out through one atomic counter
+ * (dynamic queue: path lengths vary a lot between pixels), every thread accumulates its statistics in a
+ * thread-local struct (the per-chunk structs of the first version sat next to each other in memory and
+ * were incremented per ray: false sharing across 256 threads). */
+typedef struct { render_job proto; long p_begin, total; int chunks; int *next; orc_stats st; char pad[128]; } thread_ctx;
 static void *thread_main(void *arg)
 {
     thread_ctx *tc = (thread_ctx *)arg;
-    for (int c = tc->first; c < tc->count; c += tc->step) render_worker(&tc->jobs[c]);
+    render_job jb = tc->proto;
+    memset(&jb.st, 0, sizeof(jb.st));
+    for (;;) {
+        int c = __atomic_fetch_add(tc->next, 1, __ATOMIC_RELAXED);
+        if (c >= tc->chunks) break;
+        jb.p_begin = tc->p_begin + tc->total * c / tc->chunks;
+        jb.p_end = tc->p_begin + tc->total * (c + 1) / tc->chunks;
+        render_worker(&jb);
+    }
+    tc->st = jb.st;
     return NULL;
 }
 
@@ -1148,34 +1164,31 @@ int orc_pt_rgb_render(const orc_scene *s, int W, int H, uint32_t frame_begin, in
     if (nthreads < 1) nthreads = 1;
     long total = p_end - p_begin;
     if (total <= 0) return 0;
-    /* many small chunks handed out round-robin so threads finish together */
-    int chunks = nthreads * 16;
-    if (chunks > total) chunks = (int)total;
-    render_job *jobs = (render_job *)calloc((size_t)chunks, sizeof(render_job));
-    for (int c = 0; c < chunks; c++) {
-        render_job *jb = &jobs[c];
+    long chunks_l = (total + 63) / 64;                 /* ~64 pixels per chunk */
+    if (chunks_l > (1l << 30)) chunks_l = 1l << 30;
+    int chunks = (int)chunks_l;
+    if (nthreads > chunks) nthreads = chunks;
+    int next = 0;
+    thread_ctx *tc = (thread_ctx *)calloc((size_t)nthreads, sizeof(thread_ctx));
+    for (int t = 0; t < nthreads; t++) {
+        render_job *jb = &tc[t].proto;
         jb->s = s; jb->W = W; jb->H = H; jb->frame_begin = frame_begin; jb->frame_count = frame_count;
         jb->seed = seed; jb->max_depth = max_depth; jb->stack_size = stack_size; jb->hdr = hdr;
-        jb->p_begin = p_begin + total * c / chunks; jb->p_end = p_begin + total * (c + 1) / chunks;
         jb->tile_rank = tile_rank; jb->tile_count = tile_count; jb->tile_size = tile_size > 0 ? tile_size : 1;
+        tc[t].p_begin = p_begin; tc[t].total = total; tc[t].chunks = chunks; tc[t].next = &next;
     }
     if (nthreads == 1) {
-        for (int c = 0; c < chunks; c++) render_worker(&jobs[c]);
+        thread_main(&tc[0]);
     } else {
-        /* thread t runs chunks t, t+nthreads, ... */
         pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)nthreads);
-        thread_ctx *tc = (thread_ctx *)malloc(sizeof(thread_ctx) * (size_t)nthreads);
-        for (int t = 0; t < nthreads; t++) {
-            tc[t].jobs = jobs; tc[t].first = t; tc[t].step = nthreads; tc[t].count = chunks;
-            pthread_create(&th[t], NULL, thread_main, &tc[t]);
-        }
+        for (int t = 0; t < nthreads; t++) pthread_create(&th[t], NULL, thread_main, &tc[t]);
         for (int t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
-        free(th); free(tc);
+        free(th);
     }
     if (stats) {
         memset(stats, 0, sizeof(*stats));
-        for (int c = 0; c < chunks; c++) {
-            const orc_stats *a = &jobs[c].st;
+        for (int t = 0; t < nthreads; t++) {
+            const orc_stats *a = &tc[t].st;
             stats->rays_closest += a->rays_closest; stats->rays_shadow += a->rays_shadow;
             stats->box_closest += a->box_closest; stats->leaf_closest += a->leaf_closest;
             stats->box_shadow += a->box_shadow; stats->leaf_shadow += a->leaf_shadow;
@@ -1183,7 +1196,7 @@ int orc_pt_rgb_render(const orc_scene *s, int W, int H, uint32_t frame_begin, in
             if (a->max_stack > stats->max_stack) stats->max_stack = a->max_stack;
         }
     }
-    free(jobs);
+    free(tc);
     return 0;
 }
 /* UtilsFunc.py:583-586; in/out: [npix*3] */

@@ -35,10 +35,25 @@ def build():
     subprocess.run(["make", "-s", "-C", ORACLE_DIR], check=True)
 
 
-def load(libm=False):
+def build_native():
+    """-O3 -march=native build made ON THE MACHINE THAT RUNS IT (bench.py's cpu_baseline leg; never shipped:
+    oracle/_native/ is git- and gpurun-ignored).  Returns the path, or None when gcc is not there."""
+    try:
+        subprocess.run(["make", "-s", "-C", ORACLE_DIR, "native"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    except Exception:
+        return None
+    path = os.path.join(ORACLE_DIR, "_native", "liboracle_native.so")
+    return path if os.path.exists(path) else None
+
+
+def load(libm=False, native=False):
     name = "liboracle_libm.so" if libm else "liboracle.so"
+    if native:
+        name = "_native/liboracle_native.so"
     if name not in _libs:
         path = os.path.join(ORACLE_DIR, name)
+        if native and build_native() is None:
+            raise OSError("cannot build the native oracle")
         if not os.path.exists(path):
             build()
         L = C.CDLL(path)
@@ -89,8 +104,8 @@ def load(libm=False):
 class OracleScene:
     """One oracle scene built from a host ``ti_raytrace_amd.Scene`` after setup_data_cpu()."""
 
-    def __init__(self, scene, cam=None, libm=False):
-        self.L = load(libm)
+    def __init__(self, scene, cam=None, libm=False, native=False):
+        self.L = load(libm, native)
         self.n = scene.primitive_count
         self.nv = scene.vertex_count
         self.N = 2 * self.n - 1

@@ -238,3 +238,46 @@ def test_abi_error_behaviour(gpu_ctx_ok):
     with pytest.raises(_native.TirtError):
         _native.Context(9999)
     ctx.close()
+
+
+def test_env_lit_scene_without_emitters(gpu_ctx_ok):
+    """light_count == 0 with an environment map (the reference would index light[-1], Scene.py:423-428): defined as
+    "no NEE sample" in the oracle and on the device; films, ray counts identical, no shadow rays at all."""
+    from ti_raytrace_amd import Example, PT_RGB
+    from ti_raytrace_amd import SceneData as SCD
+    W = H = 48
+    ex = Example.example(W, H, 4, 0)
+    mat = SCD.Material(); mat.type = SCD.MAT_DISNEY; mat.setMetal(0.0); mat.setRough(0.5); mat.setColor([0.8, 0.6, 0.4, 1.0]); mat.alebdoTex = -1
+    r = np.random.RandomState(5)
+    tris = r.uniform(-1, 1, size=(300, 1, 3)) + r.uniform(-0.25, 0.25, size=(300, 3, 3))
+    ex.scene.add_mesh(tris, mat)
+    ex.scene.add_env(scenes.asset("image", "env.png"), 2.0)
+    ex.integrator = PT_RGB.PathTrace(W, H, ex.cam, ex.scene, 64)
+    ex.build_scene()
+    assert ex.scene.light_count == 0
+    o = oa.OracleScene(ex.scene, ex.cam); o.lbvh_build()
+    ctx = ex.scene.ctx
+    ctx.stats_reset()
+    ex.integrator.render_frames(3)
+    got = ex.integrator.hdr.to_numpy()
+    want, ost = o.render(W, H, 0, 3, seed=ex.integrator.seed)
+    st = ctx.stats()
+    assert np.array_equal(got, want), rel_l2(got, want)
+    assert st["rays_shadow"] == 0 == ost["rays_shadow"] and st["rays_closest"] == ost["rays_closest"]
+    assert np.isfinite(got).all() and got.mean() > 0
+    with pytest.raises(_native.TirtError, match="no emitter"):
+        ctx.bdpt_rgb_render(0, 1, 1)
+
+
+def test_spot_and_laser_emitters_are_refused(gpu_ctx_ok):
+    ctx = _native.Context(0)
+    v = np.zeros((3, 9), np.float32); v[1, 0] = 1; v[2, 1] = 1
+    m = np.zeros((2, 10), np.float32); m[1, 0] = 2
+    prim = np.array([[1, 0, 0], [2, 0, 1]], np.int32)
+    for shape_type in (3, 4):
+        s = np.zeros((1, 10), np.float32); s[0, 0] = shape_type; s[0, 4] = 1.0
+        with pytest.raises(_native.TirtError, match="spot / laser"):
+            ctx.scene_upload(v, prim, m, s, np.array([1], np.int32), 1, -np.ones(3), np.ones(3))
+    s = np.zeros((1, 10), np.float32); s[0, 0] = 1; s[0, 4] = 1.0
+    ctx.scene_upload(v, prim, m, s, np.array([1], np.int32), 1, -np.ones(3), np.ones(3))
+    ctx.close()

@@ -155,3 +155,59 @@ def test_four_wide_nodes_on_unbalanced_trees(gpu_ctx_ok):
     leaf children next to collapsed ones, a root whose child is a leaf."""
     for n in (2, 3, 5, 6, 7, 9, 17):
         check_scene(tiny_scene(n, seed=20 + n, W=24, H=24, spread=0.6, device_id=0), 24, 24, random_rays(800, -2, 3, n))
+
+
+def _grazing_rays(ex, n, seed):
+    """Rays that run along the boundaries the quantised traversal must not get wrong: aimed exactly at triangle
+    vertices and edge points (they graze the leaf boxes and every ancestor box the vertex is extreme in), rays inside
+    the plane of axis-aligned triangles, far-away origins (the grid margin grows with the distance), origins exactly on
+    triangle vertices, axis-parallel rays through vertices."""
+    r = np.random.RandomState(seed)
+    sc = ex.scene
+    tri = sc.primitive_np[sc.primitive_np[:, 0] == 1]
+    v = sc.vertex_np[:, :3].astype(np.float64)
+    lo, hi = v.min(axis=0), v.max(axis=0)
+    ext = float((hi - lo).max())
+    pick = tri[r.randint(0, tri.shape[0], n), 1]
+    corner = v[pick + r.randint(0, 3, n)]
+    a, b = v[pick], v[pick + 1]
+    w = r.uniform(0, 1, (n, 1))
+    edge = a * w + b * (1 - w)
+    rays = []
+    for target in (corner, edge):
+        for dist in (0.3 * ext, 3.0 * ext, 300.0 * ext, 30000.0 * ext):
+            d = r.normal(size=(n, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+            o = target - d * dist
+            rays.append(np.concatenate([o, d], axis=1))
+    # axis-parallel rays through vertices, from outside and from the vertex itself
+    for ax in range(3):
+        d = np.zeros((n, 3)); d[:, ax] = r.choice([-1.0, 1.0], n)
+        rays.append(np.concatenate([corner - d * 2.0 * ext, d], axis=1))
+        rays.append(np.concatenate([corner, d], axis=1))
+    # rays lying in the plane of a triangle (flat boxes for axis-aligned geometry)
+    c = v[pick + 2]
+    inplane = (b - a) * r.uniform(-1, 1, (n, 1)) + (c - a) * r.uniform(-1, 1, (n, 1))
+    nn = np.linalg.norm(inplane, axis=1, keepdims=True); nn[nn == 0] = 1.0
+    inplane /= nn
+    rays.append(np.concatenate([edge - inplane * 0.5 * ext, inplane], axis=1))
+    return np.concatenate(rays, axis=0).astype(np.float32)
+
+
+def test_quantised_nodes_on_grazing_rays(gpu_ctx_ok):
+    """The ordered traversal walks 16-bit quantised boxes that CONTAIN the reference's and re-checks the reference's
+    own visiting condition before it accepts a hit (tirt_internal.h, BvhView): closest hits must equal the oracle's on
+    rays chosen to sit on box boundaries -- Cornell (axis-aligned walls: zero-thickness boxes), random soup, Teapot."""
+    for make, W in ((lambda: scenes.cornell_box(48, 48, 4, device_id=0), 48),
+                    (lambda: tiny_scene(3000, seed=31, W=48, H=48, spread=0.08, device_id=0), 48),
+                    (lambda: duplicate_code_scene(W=48, H=48, device_id=0), 48)):
+        ex = make()
+        ex.scene.setup_data_cpu()
+        rays = _grazing_rays(ex, 900, 17)
+        check_scene(make(), W, W, rays, max_rays=60000)
+
+
+def test_quantised_nodes_headline_scene_far_and_near(gpu_ctx_ok):
+    ex = scenes.synthetic(64, 64, 4, device_id=0)
+    ex.scene.setup_data_cpu()
+    rays = _grazing_rays(ex, 1500, 23)
+    check_scene(scenes.synthetic(64, 64, 4, device_id=0), 64, 64, rays, max_rays=60000)

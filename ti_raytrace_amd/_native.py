@@ -20,6 +20,18 @@ class TirtError(RuntimeError):
     pass
 
 
+class TirtStackOverflow(TirtError):
+    """tirt_stats found rays whose traversal stack overflowed (TIRT_ERR_STACK): subtrees were dropped, the
+    rendered result is wrong -- raise `stack_size`.  `.stats` holds the statistics that were read."""
+
+    def __init__(self, msg, stats):
+        TirtError.__init__(self, msg)
+        self.stats = stats
+
+
+ERR_STACK = -4
+
+
 class Stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in (
         "rays_closest", "rays_shadow", "box_closest", "leaf_closest", "box_shadow",
@@ -69,6 +81,8 @@ SIGNATURES = {
     "tirt_film_import_device": (C.c_int, [_vp, _vp]),
     "tirt_trace_closest": (C.c_int, [_vp, _f32p, C.c_int, C.c_int, C.c_int, _f32p, _i32p, _vp]),
     "tirt_trace_shadow": (C.c_int, [_vp, _f32p, C.c_int, C.c_int, C.c_int, _f32p, _i32p, _vp]),
+    "tirt_bvh_info": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
+    "tirt_micro_gather_rate": (C.c_int, [_vp, C.c_uint64, C.c_int, C.POINTER(C.c_double)]),
     "tirt_stats": (C.c_int, [_vp, C.POINTER(Stats)]),
     "tirt_stats_reset": (C.c_int, [_vp]),
     "tirt_kat_math": (C.c_int, [_vp, C.c_int, _f32p, _f32p, _f32p, C.c_int]),
@@ -250,9 +264,23 @@ class Context:
                                       out, prim, _ptr(counts)))
         return out, prim, counts
 
+    def bvh_info(self):
+        out = (C.c_uint64 * 4)()
+        check(lib().tirt_bvh_info(self.handle, out))
+        return {"node_bytes": int(out[0]), "prim_bytes": int(out[1]), "nodes": int(out[2]), "nodes_in_lds": int(out[3])}
+
+    def micro_gather_rate(self, working_set_bytes, iters=2000):
+        v = C.c_double(0.0)
+        check(lib().tirt_micro_gather_rate(self.handle, int(working_set_bytes), int(iters), C.byref(v)))
+        return float(v.value)
+
     def stats(self):
         st = Stats()
-        check(lib().tirt_stats(self.handle, C.byref(st)))
+        rc = lib().tirt_stats(self.handle, C.byref(st))
+        if rc == ERR_STACK:
+            msg = lib().tirt_last_error()
+            raise TirtStackOverflow("libtirt error %d: %s" % (rc, msg.decode() if msg else "?"), st.as_dict())
+        check(rc)
         return st.as_dict()
 
     def stats_reset(self):

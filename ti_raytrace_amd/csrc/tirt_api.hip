@@ -22,6 +22,8 @@ BvhView bvh_view(const tirt_ctx *c)
 {
     BvhView b;
     b.wnode = c->wnode.as<float4>(); b.qnode = c->qnode.as<float4>(); b.qtop = c->qtop.as<float4>(); b.tri = c->tri.as<float4>();
+    b.cnode = c->cnode.as<uint4>(); b.ctop = c->ctop.as<uint4>(); b.compact = c->compact.as<float>(); b.cparent = c->cparent.as<int>();
+    for (int k = 0; k < 3; k++) { b.grid_min[k] = c->grid_min[k]; b.cell[k] = c->grid_cell[k]; b.inv_extent[k] = c->grid_inv_extent[k]; }
     for (int k = 0; k < 3; k++) { b.root_min[k] = c->root_min[k]; b.root_max[k] = c->root_max[k]; }
     b.root_code = c->root_code;
     b.root_qcode = c->root_code >= 0 ? TR_TOP_BIT : c->root_code;
@@ -177,6 +179,22 @@ __global__ void k_kat_brdf(int which, const float *in, int in_stride, float *out
     }
 }
 
+// ---- bench helper: ceiling of scattered 64-byte record gathers (the node-fetch pattern of k_trace) ----
+TD uint32_t mg_mix(uint32_t x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
+__global__ __launch_bounds__(256) void k_micro_gather(const float4 *rec, uint32_t nrec, int iters, float *out)
+{
+    uint32_t s = mg_mix(blockIdx.x * 256 + threadIdx.x + 1);
+    float acc = 0.0f;
+    for (int it = 0; it < iters; it++) {
+        s = mg_mix(s + it);
+        const uint32_t idx = (uint32_t)(((unsigned long long)s * nrec) >> 32);
+        const float4 *p = rec + (size_t)idx * 4;
+        const float4 a = p[0], b = p[1], c = p[2], d = p[3];
+        acc += a.x + b.y + c.z + d.w;
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = acc;
+}
+
 static int upload(DevBuf &b, const void *src, size_t bytes, hipStream_t st)
 {
     if (b.ensure(bytes)) return TIRT_ERR_HIP;
@@ -228,6 +246,9 @@ int tirt_create(int device_id, tirt_ctx **out)
         TIRT_HIP(hipEventCreateWithFlags(&L.film_done, hipEventDisableTiming));
     }
     memset(&c->cam, 0, sizeof(c->cam));
+    int optin = 0;
+    if (hipDeviceGetAttribute(&optin, hipDeviceAttributeSharedMemPerBlockOptin, device_id) == hipSuccess && optin > 0) c->lds_optin = (size_t)optin;
+    else { (void)hipGetLastError(); if (hipDeviceGetAttribute(&optin, hipDeviceAttributeMaxSharedMemoryPerBlock, device_id) == hipSuccess && optin > 0) c->lds_optin = (size_t)optin; }
     *out = c;
     return TIRT_OK;
 }
@@ -240,7 +261,7 @@ void tirt_destroy(tirt_ctx *c)
     drain_render_events(c);
     DevBuf *bufs[] = {&c->vertex, &c->primitive, &c->material, &c->shape, &c->light, &c->env, &c->mat_lrgb, &c->morton_unsorted, &c->keys_a,
                       &c->keys_b, &c->vals_a, &c->vals_b, &c->hist, &c->morton_sorted, &c->bvh_node, &c->compact, &c->parent,
-                      &c->flag, &c->subtree, &c->build_status, &c->leaf_compact, &c->wnode, &c->tri, &c->qnode, &c->quad_flag, &c->quad_index, &c->quad_top, &c->qtop, &c->scan_tiles, &c->hdr, &c->rgb,
+                      &c->flag, &c->subtree, &c->build_status, &c->leaf_compact, &c->wnode, &c->tri, &c->qnode, &c->quad_flag, &c->quad_index, &c->quad_top, &c->qtop, &c->scan_tiles, &c->cnode, &c->ctop, &c->cparent, &c->hdr, &c->rgb,
                       &c->counters_mem, &c->spill, &c->tr_rays,
                       &c->tr_out, &c->tr_prim, &c->tr_counts, &c->dev_counters, &c->bdpt_px, &c->bdpt_rad};
     for (DevBuf *b : bufs) b->release();
@@ -288,7 +309,11 @@ int tirt_set_option(tirt_ctx *c, const char *name, double value)
         TIRT_REQUIRE(value >= 1.0 && value <= 1.0e9, "tirt_set_option: batch_paths out of range");
         c->batch_paths = (size_t)value; return TIRT_OK;
     }
-    if (!strcmp(name, "trace_lds_depth")) { TIRT_REQUIRE(value >= 12 && value <= 64, "trace_lds_depth: 12..64"); c->tr_lds_depth = (int)value; return TIRT_OK; }
+    if (!strcmp(name, "trace_lds_depth")) {
+        TIRT_REQUIRE(value >= 12 && value <= 64, "trace_lds_depth: 12..64");
+        TIRT_REQUIRE(trace_lds_bytes((int)value) <= c->lds_optin, "trace_lds_depth: stacks + tree top exceed the LDS a block can have on this device");
+        c->tr_lds_depth = (int)value; return TIRT_OK;
+    }
     if (!strcmp(name, "trace_refill_min")) { TIRT_REQUIRE(value >= 1 && value <= 64, "trace_refill_min: 1..64"); c->tr_refill_min = (int)value; return TIRT_OK; }
     if (!strcmp(name, "trace_node_min")) { TIRT_REQUIRE(value >= 1 && value <= 64, "trace_node_min: 1..64"); c->tr_node_min = (int)value; return TIRT_OK; }
     if (!strcmp(name, "bdpt_bounded")) { c->bdpt_bounded = value != 0.0 ? 1 : 0; return TIRT_OK; }
@@ -322,6 +347,15 @@ int tirt_scene_upload(tirt_ctx *c, const float *vertex, int nv, const int32_t *p
         TIRT_REQUIRE(pr[2] >= 0 && pr[2] < nm, "tirt_scene_upload: material index out of range");
     }
     for (int i = 0; i < nl; i++) TIRT_REQUIRE(light[i] >= 0 && light[i] < n, "tirt_scene_upload: light index out of range");
+    // sample_li's spot / laser branches (Scene.py:497-516, used by the spectral examples only) are not restated here:
+    // such emitters are refused instead of being lit as if they were spheres
+    for (int i = 0; i < light_count; i++) {
+        const int32_t *pr = primitive + (size_t)light[i] * 3;
+        if (pr[0] != PRIMITIVE_TRI) {
+            const int st = (int)shape[(size_t)pr[1] * 10];
+            TIRT_REQUIRE(st != SHAPE_SPOT && st != SHAPE_LASER, "tirt_scene_upload: spot / laser emitters (SceneData.SHPAE_SPOT / SHPAE_LASER) are not supported");
+        }
+    }
     hipStream_t st = c->stream;
     c->built = false;
     if (upload(c->vertex, vertex, sizeof(float) * 9 * (size_t)nv, st)) return TIRT_ERR_HIP;
@@ -565,6 +599,50 @@ int tirt_trace_shadow(tirt_ctx *c, const float *rays, int nr, int stack_size, in
     return launch_trace_batch(c, rays, nr, stack_size, flags, true, out_t, out_prim, counts);
 }
 
+int tirt_bvh_info(tirt_ctx *c, uint64_t out[4])
+{
+    CTX(c);
+    TIRT_REQUIRE(out && c->built, "tirt_bvh_info: LBVH not built");
+    int nq = 0;
+    if (c->n >= 2) {     // number of 4-wide nodes = exclusive scan of quad_flag at the last node + its flag
+        int last[2] = {0, 0};
+        const size_t N = 2 * (size_t)c->n - 1;
+        TIRT_HIP(hipMemcpyAsync(&last[0], c->quad_index.as<int>() + (N - 1), sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        TIRT_HIP(hipMemcpyAsync(&last[1], c->quad_flag.as<int>() + (N - 1), sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        TIRT_HIP(hipStreamSynchronize(c->stream));
+        nq = last[0] + last[1];
+    }
+    out[0] = (uint64_t)nq * 64u; out[1] = (uint64_t)c->n * sizeof(float4) * TRI_STRIDE; out[2] = (uint64_t)nq;
+    out[3] = (uint64_t)(nq < TR_TOP_SLOTS ? nq : TR_TOP_SLOTS);
+    return TIRT_OK;
+}
+
+int tirt_micro_gather_rate(tirt_ctx *c, uint64_t working_set_bytes, int iters, double *gbps_out)
+{
+    CTX(c);
+    if (sync_all(c)) return TIRT_ERR_HIP;
+    TIRT_REQUIRE(gbps_out && iters >= 1 && working_set_bytes >= 64 && working_set_bytes <= ((uint64_t)1 << 36), "tirt_micro_gather_rate: bad arguments");
+    const uint32_t nrec = (uint32_t)(working_set_bytes / 64);
+    const int blocks = 1536;
+    DevBuf rec, out;
+    if (rec.ensure((size_t)nrec * 64) || out.ensure(sizeof(float) * blocks * 256)) { rec.release(); out.release(); return TIRT_ERR_HIP; }
+    hipError_t e = hipMemsetAsync(rec.p, 0, (size_t)nrec * 64, c->stream);
+    float best = 1.0e30f;
+    for (int rep = 0; rep < 4 && e == hipSuccess; rep++) {          // first launch warms the caches
+        (void)hipEventRecord(c->ev0, c->stream);
+        hipLaunchKernelGGL(k_micro_gather, dim3(blocks), dim3(256), 0, c->stream, rec.as<float4>(), nrec, iters, out.as<float>());
+        (void)hipEventRecord(c->ev1, c->stream);
+        e = hipEventSynchronize(c->ev1);
+        float ms = 0.0f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, c->ev0, c->ev1);
+        if (rep > 0 && ms < best) best = ms;
+    }
+    rec.release(); out.release();
+    TIRT_HIP(e);
+    *gbps_out = (double)blocks * 256.0 * (double)iters * 64.0 / ((double)best * 1.0e-3) / 1.0e9;
+    return TIRT_OK;
+}
+
 int tirt_stats(tirt_ctx *c, tirt_stats_t *out)
 {
     CTX(c);
@@ -585,6 +663,10 @@ int tirt_stats(tirt_ctx *c, tirt_stats_t *out)
     out->ms_trace_closest = c->ms_trace_closest; out->ms_trace_shadow = c->ms_trace_shadow; out->ms_shade = c->ms_shade;
     out->launches_trace_closest = c->launches_trace_closest; out->launches_trace_shadow = c->launches_trace_shadow;
     out->launches_shade = c->launches_shade;
+    if (h.stack_overflow > 0) {      // results are wrong (subtrees were dropped): the statistics are filled in, the call reports it
+        set_error("traversal stack overflow on " + std::to_string((unsigned long long)h.stack_overflow) + " rays: raise stack_size");
+        return TIRT_ERR_STACK;
+    }
     return TIRT_OK;
 }
 

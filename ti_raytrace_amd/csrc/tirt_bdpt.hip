@@ -31,7 +31,7 @@ constexpr int BD_BLOCK = 64, BD_STACK = 64;
 // With expect >= -1 and t_bound > 0 the ray is a connection test ("is `expect` the closest hit, about t_bound
 // away?"): nodes beyond 1.01 x t_bound are skipped and a hit on another primitive before 0.99 x t_bound ends
 // the walk -- same yes/no (and the same t when yes) as the full closest-hit query, as in k_trace's shadow rays.
-TD SimpleHit trace_simple(const BvhView &b, v3 o, v3 d, int *stack /* LDS, [entry][lane] */, int expect = -3, float t_bound = -1.0f)
+TD SimpleHit trace_simple(const BvhView &b, v3 o, v3 d, int *stack /* LDS, [entry][lane] */, unsigned long long *ovf, int expect = -3, float t_bound = -1.0f)
 {
     const bool bounded = t_bound > 0.0f;
     const float cull_far = bounded ? t_bound * 1.01f : 3.0e38f, settle = bounded ? t_bound * 0.99f : -1.0f;
@@ -73,9 +73,9 @@ TD SimpleHit trace_simple(const BvhView &b, v3 o, v3 d, int *stack /* LDS, [entr
                 da = lo__; db = hi__; ca = clo__; cb = chi__;                                        \
             } while (0)
             BD_CE(d0, c0, d1, c1); BD_CE(d2, c2, d3, c3); BD_CE(d0, c0, d2, c2); BD_CE(d1, c1, d3, c3); BD_CE(d1, c1, d2, c2);
-            if (d3 < MISS && sp < BD_STACK) { stack[sp * BD_BLOCK] = c3; sp++; }
-            if (d2 < MISS && sp < BD_STACK) { stack[sp * BD_BLOCK] = c2; sp++; }
-            if (d1 < MISS && sp < BD_STACK) { stack[sp * BD_BLOCK] = c1; sp++; }
+            if (d3 < MISS) { if (sp < BD_STACK) { stack[sp * BD_BLOCK] = c3; sp++; } else atomicAdd(ovf, 1ull); }
+            if (d2 < MISS) { if (sp < BD_STACK) { stack[sp * BD_BLOCK] = c2; sp++; } else atomicAdd(ovf, 1ull); }
+            if (d1 < MISS) { if (sp < BD_STACK) { stack[sp * BD_BLOCK] = c1; sp++; } else atomicAdd(ovf, 1ull); }
             if (d0 < MISS) { cur = c0; continue; }
         } else {
             const int code = ~cur;
@@ -159,7 +159,7 @@ TD bsample bd_sample(const SceneView &s, v3 dir, v3 normal, v3 fnormal, int mat_
     return r;
 }
 
-struct BdCtx { SceneView sc; BvhView bvh; CameraView cam; BdView bv; uint32_t seed; unsigned long long *rays_closest, *rays_shadow, *paths; int *stack; int bounded; };
+struct BdCtx { SceneView sc; BvhView bvh; CameraView cam; BdView bv; uint32_t seed; unsigned long long *rays_closest, *rays_shadow, *paths, *stack_overflow; int *stack; int bounded; };
 
 // BDPT_RGB.py:103-198
 TD int bd_eye_path(const BdCtx &c, bpixel *P, int i, int j, uint32_t frame, unsigned &n_closest)
@@ -175,7 +175,7 @@ TD int bd_eye_path(const BdCtx &c, bpixel *P, int i, int j, uint32_t frame, unsi
     float pdfFwd = 1.0f, pdfRev = 0.0f;
     v3 beta = V(1.0f, 1.0f, 1.0f);
     while (depth < BD_EYE_MAX) {
-        const SimpleHit sh = trace_simple(c.bvh, origin, dir, c.stack);
+        const SimpleHit sh = trace_simple(c.bvh, origin, dir, c.stack, c.stack_overflow);
         n_closest++;
         if (sh.t < INF_VALUE) {
             const HitAttr h = hit_attributes(c.sc, origin, dir, sh.prim, sh.t, sh.u, sh.v);
@@ -254,7 +254,7 @@ TD int bd_light_path(const BdCtx &c, bpixel *P, int i, int j, uint32_t frame, un
     v3 beta = (emission / light_pdf) * absf(dot(lnor, ldir));
     v3 origin = lpos, dir = ldir;
     while (depth < BD_LIGHT_MAX) {
-        const SimpleHit sh = trace_simple(c.bvh, origin, dir, c.stack);
+        const SimpleHit sh = trace_simple(c.bvh, origin, dir, c.stack, c.stack_overflow);
         n_closest++;
         if (sh.t < INF_VALUE) {
             const HitAttr h = hit_attributes(s, origin, dir, sh.prim, sh.t, sh.u, sh.v);
@@ -436,7 +436,7 @@ TD v3 bd_connect_path(const BdCtx &c, bpixel *P, int i, int j, int e, int l, uin
         const v3 snormal = light[l - 1].snormal;
         const float NdotL = dot(wi, snormal);
         if ((nu >= 0) & (light[l - 1].delta != 1) & (NdotL < 0.0f) & (light[l - 1].type == VERTEX_SURFACE)) {
-            const SimpleHit sh = trace_simple(c.bvh, origin, wi, c.stack, c.bounded ? prim : -3, c.bounded ? norm(surface - origin) : -1.0f);
+            const SimpleHit sh = trace_simple(c.bvh, origin, wi, c.stack, c.stack_overflow, c.bounded ? prim : -3, c.bounded ? norm(surface - origin) : -1.0f);
             n_shadow++;
             if (sh.prim == prim) {
                 float pdf;
@@ -467,7 +467,7 @@ TD v3 bd_connect_path(const BdCtx &c, bpixel *P, int i, int j, int e, int l, uin
             wi = wi / light_dist;
             const float NdotLl = dot(wi, light_normal);
             const float NdotLe = dot(wi, eye[e - 1].snormal);
-            const SimpleHit sh = trace_simple(c.bvh, surface, -wi, c.stack, c.bounded ? light_prim : -3, c.bounded ? light_dist : -1.0f);
+            const SimpleHit sh = trace_simple(c.bvh, surface, -wi, c.stack, c.stack_overflow, c.bounded ? light_prim : -3, c.bounded ? light_dist : -1.0f);
             n_shadow++;
             if ((sh.prim == light_prim) & (sh.t > EPS_UF)) {
                 const float light_pdf = light_choice_pdf;
@@ -492,7 +492,7 @@ TD v3 bd_connect_path(const BdCtx &c, bpixel *P, int i, int j, int e, int l, uin
             const float dist = norm(dir);
             dir = dir / dist;
             const float NdotLl = dot(dir, light[l - 1].snormal), NdotLe = dot(dir, eye[e - 1].snormal);
-            const SimpleHit sh = trace_simple(c.bvh, surfaceL, dir, c.stack, c.bounded ? primE : -3, c.bounded ? dist : -1.0f);
+            const SimpleHit sh = trace_simple(c.bvh, surfaceL, dir, c.stack, c.stack_overflow, c.bounded ? primE : -3, c.bounded ? dist : -1.0f);
             n_shadow++;
             if ((sh.prim == primE) & (sh.t > EPS_UF)) {
                 float lpdf, epdf;
@@ -568,6 +568,8 @@ int bdpt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t see
 {
     TIRT_REQUIRE(c->built && c->cam_set && c->hdr.p, "tirt_bdpt_rgb_render: scene, camera and film must be set up");
     TIRT_REQUIRE(frame_count >= 0, "tirt_bdpt_rgb_render: bad frame_count");
+    // the light sub-path starts on an emitter (Scene.sample_light, Scene.py:430-474): a scene without one would index light[-1]
+    TIRT_REQUIRE(c->light_count >= 1, "tirt_bdpt_rgb_render: the scene has no emitter (BDPT_RGB samples its light sub-path from one)");
     if (frame_count == 0) return TIRT_OK;
     if (ensure_counters(c)) return TIRT_ERR_HIP;
     if (sync_all(c)) return TIRT_ERR_HIP;
@@ -584,7 +586,7 @@ int bdpt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t see
     for (int k = 0; k < 12; k++) bc.bv.view[k] = c->view[k];
     bc.bv.W = c->W; bc.bv.H = c->H;
     DevCounters *ctr = c->dev_counters.as<DevCounters>();
-    bc.rays_closest = &ctr->rays_closest; bc.rays_shadow = &ctr->rays_shadow; bc.paths = &ctr->paths;
+    bc.rays_closest = &ctr->rays_closest; bc.rays_shadow = &ctr->rays_shadow; bc.paths = &ctr->paths; bc.stack_overflow = &ctr->stack_overflow;
     const TileMap tm = {c->tile_rank, c->tile_count, c->tile_size, c->H};
     const int P = (int)c->npix_local;
     hipStream_t st = c->stream;

@@ -73,15 +73,39 @@ constexpr int TR_TOP_LEVELS = TR_TOP_LEVELS_N;           // levels of 4-wide nod
 constexpr int TR_TOP_FULL = ((1 << (2 * TR_TOP_LEVELS)) - 1) / 3;
 constexpr int TR_TOP_SLOTS = TR_TOP_FULL < TR_TOP_CAP ? TR_TOP_FULL : TR_TOP_CAP;   // 341 for five levels (38 KB of LDS per block)
 constexpr int TR_TOP_BIT = 1 << 29;                      // child code of a 4-wide node that lives in the LDS-resident top: TR_TOP_BIT | slot
+// cnode: the 4-wide nodes again, 64 bytes each, box planes quantised to 16 bits on ONE grid over the root box
+//   (k_cnodes): plane = grid_min + q * cell, min planes rounded down and max planes up by at least one cell, so a
+//   cnode box CONTAINS the reference box it stands for.  k_trace<ordered> walks these (4 dwordx4 loads per visit
+//   instead of 7, 3.2 MB instead of 6.4 MB at 100k triangles).  A conservative box can only add visits; it may,
+//   however, reach a leaf the reference does not (the reference tests its exact fp32 boxes with fp32 arithmetic
+//   and a grazing ray can fail an ancestor's box yet pass the triangle test), so a candidate hit is ACCEPTED only
+//   after the reference's own condition is re-established: `slabs` on the leaf's exact box -- which implies every
+//   ancestor's, `slabs` being monotone in the plane positions --, else `slabs` on every proper ancestor
+//   (compact rows, cparent chain; rare).  The closest accepted hit is therefore the reference's, bit for bit.
+//   dword 3c+a (c = child slot 0..3, a = axis): min plane | max plane << 16;  dwords 12..15: child codes as in qnode
+//   (TR_EMPTY slots hold the inverted box 65535 | 0, which no ray passes).
+#ifndef TR_BLOCK_SIZE
+#define TR_BLOCK_SIZE 512
+#endif
+constexpr int TR_BLOCK = TR_BLOCK_SIZE;                  // threads per persistent k_trace block
+constexpr int TIRT_MAX_DEVICES = 64;
+// dynamic LDS of a k_trace block: `depth` stack entries per lane + the LDS copy of the tree top (64-byte records)
+inline size_t trace_lds_bytes(int depth) { return sizeof(int) * (size_t)depth * TR_BLOCK + (size_t)TR_TOP_SLOTS * 64; }
 struct BvhView {
     const float4 *wnode;
     const float4 *qnode;
     const float4 *tri;
-    const float4 *qtop;           // the first TR_TOP_LEVELS levels of qnode in breadth-first slots (copied to LDS by k_trace)
+    const float4 *qtop;           // the first TR_TOP_LEVELS levels of qnode in breadth-first slots (BDPT's plain traversal)
+    const uint4 *cnode;           // quantised 4-wide nodes (ordered traversal)
+    const uint4 *ctop;            // their first TR_TOP_LEVELS levels in breadth-first slots (copied to LDS by k_trace)
+    const float *compact;         // reference compact_node rows [N*9] (exact boxes: hit verification)
+    const int *cparent;           // compact index of the parent of compact node i (-1 for the root)
+    float grid_min[3], cell[3], inv_extent[3];
     float root_min[3], root_max[3];
     int root_code;                // two-child layout: compact index 0, or the leaf code of a one-primitive scene
     int root_qcode;               // 4-wide layout: TR_TOP_BIT | 0, or the same leaf code
 };
+constexpr float TR_GRID_CELLS = 65531.0f;     // the root box spans cells 2 .. 65533 of the 16-bit grid: +-1 rounding guards never clamp
 
 // Wavefront state, struct-of-arrays in HBM.  Live paths are kept DENSE: every bounce the shade
 // kernel writes the surviving paths' state into the other PathSoA at consecutive indices
@@ -96,7 +120,7 @@ struct PathSoA {
 };
 struct PathState {
     PathSoA st[2];                               // ping-pong: bounce b reads st[b&1], writes st[(b+1)&1]
-    float *ht, *hu, *hv; int *hprim;            // closest hit of ray q (written by trace, read by shade)
+    float4 *hit;                                 // closest hit of ray q: (t, u, v, bits prim) -- one 16-byte store per ray
     float *sox, *soy, *soz, *sdx, *sdy, *sdz;    // shadow rays (dense, origin on the light)
     float *scr, *scg, *scb; int *sprim;         // contribution if sprim is the closest hit
     float *sdist;                               // distance light point -> shaded point
@@ -154,7 +178,10 @@ struct tirt_ctx {
     tirt::DevBuf bvh_node, compact;               // f32 [N*11], [N*9]
     tirt::DevBuf parent, flag, subtree, build_status, leaf_compact;
     tirt::DevBuf wnode, tri;                      // traversal layout
-    tirt::DevBuf qnode, quad_flag, quad_index, quad_top, qtop, scan_tiles;   // 4-wide traversal nodes (ordered traversal)
+    tirt::DevBuf qnode, quad_flag, quad_index, quad_top, qtop, scan_tiles;   // 4-wide traversal nodes (exact boxes)
+    tirt::DevBuf cnode, ctop, cparent;             // quantised 4-wide nodes + parent chain of the compact nodes (ordered traversal)
+    float grid_min[3] = {0, 0, 0}, grid_cell[3] = {1, 1, 1}, grid_inv_extent[3] = {1, 1, 1};
+    size_t lds_optin = 65536;                      // hipDeviceAttributeMaxSharedMemoryPerBlock (opt-in) of this device
     float root_min[3], root_max[3]; int root_code = 0;
 
     // camera

@@ -289,6 +289,9 @@ __global__ void k_refit(int n, float *bvh_node, const int *parent, int *flag, in
     while (cur >= 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this thread's sc1 stores of the node below have landed
         int old = __hip_atomic_fetch_add(&flag[cur], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // compiler barrier: the (relaxed) child loads below must not be hoisted above the arrival counter; in hardware
+        // they are issued after the atomic has returned (the branch depends on its value) and bypass L1 (sc1)
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
         if (old == 0) break;
         float *nd = bvh_node + (size_t)cur * NOD_VEC;
         int l = (int)nd[1], r = (int)nd[2];                     // written by k_karras (previous launch)
@@ -320,12 +323,12 @@ __global__ void k_refit(int n, float *bvh_node, const int *parent, int *flag, in
 // child of the left sibling's subtree size (accel/LBvh.py:138-161: left first, right's slot
 // stored in the parent's word 1, left implicit at slot+1).
 __global__ void k_flatten(int n, const float *bvh_node, const int *parent, const int *subtree, float *compact, int *leaf_compact,
-                          int *quad_flag, int *quad_top)
+                          int *quad_flag, int *quad_top, int *cparent)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     int N = 2 * n - 1;
     if (i >= N) return;
-    int off = 0, cur = i, depth = 0;
+    int off = 0, cur = i, depth = 0, first_step = 0;
     unsigned path = 0;                       // bit k: the step k levels above the node went to a right child
     while (true) {
         int p = parent[cur];
@@ -333,10 +336,12 @@ __global__ void k_flatten(int n, const float *bvh_node, const int *parent, const
         const float *pn = bvh_node + (size_t)p * NOD_VEC;
         int pl = (int)pn[1];
         if (cur != pl && depth < 32) path |= 1u << depth;
-        off += 1; depth += 1;
-        if (cur != pl) off += subtree[pl];
+        const int step = 1 + ((cur != pl) ? subtree[pl] : 0);
+        if (depth == 0) first_step = step;
+        off += step; depth += 1;
         cur = p;
     }
+    cparent[off] = (depth == 0) ? -1 : off - first_step;     // the parent's pre-order slot
     const float *nd = bvh_node + (size_t)i * NOD_VEC;
     float *cn = compact + (size_t)off * CPN_VEC;
     cn[0] = nd[0];
@@ -520,6 +525,45 @@ __global__ void k_qnodes(SceneView s, int N, const float *compact, const int *qu
     }
 }
 
+// Quantised 4-wide nodes (tirt_internal.h, BvhView::cnode): the same slots as k_qnodes, every plane mapped to the
+// 16-bit grid over the root box, min planes down and max planes up, one more cell outward against the rounding of
+// the mapping itself.  Leaf slots are padded like qnode's before the mapping.
+struct GridMap { float g0[3], inv_cell[3]; };
+TD unsigned grid_lo(float x, float g0, float inv_cell)
+{ float q = tm_floor((x - g0) * inv_cell) - 1.0f; q = q < 0.0f ? 0.0f : (q > 65535.0f ? 65535.0f : q); return (unsigned)q; }
+TD unsigned grid_hi(float x, float g0, float inv_cell)
+{ float v = (x - g0) * inv_cell, f = tm_floor(v); float q = (f < v ? f + 1.0f : f) + 1.0f; q = q < 0.0f ? 0.0f : (q > 65535.0f ? 65535.0f : q); return (unsigned)q; }
+__global__ void k_cnodes(SceneView s, int N, const float *compact, const int *quad_flag, const int *quad_index, const int *quad_top,
+                         uint4 *cnode, uint4 *ctop, float pad, GridMap gm)
+{
+    int o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= N || !quad_flag[o]) return;
+    const float *cn = compact + (size_t)o * CPN_VEC;
+    const int child[2] = {o + 1, (int)cn[1]};
+    QSlot sl[4];
+    for (int c = 0; c < 2; c++) {
+        const float *cc = compact + (size_t)child[c] * CPN_VEC;
+        if ((((int)cc[0]) & 1) == 1) { sl[2 * c] = quad_slot(s, compact, quad_index, quad_top, child[c], pad); sl[2 * c + 1] = quad_empty(); }
+        else {
+            sl[2 * c] = quad_slot(s, compact, quad_index, quad_top, child[c] + 1, pad);
+            sl[2 * c + 1] = quad_slot(s, compact, quad_index, quad_top, (int)cc[1], pad);
+        }
+    }
+    unsigned w[16];
+    for (int c = 0; c < 4; c++) {
+        for (int a = 0; a < 3; a++)
+            w[3 * c + a] = (sl[c].code == TR_EMPTY) ? 0x0000ffffu
+                                                    : (grid_lo(sl[c].mn[a], gm.g0[a], gm.inv_cell[a]) | (grid_hi(sl[c].mx[a], gm.g0[a], gm.inv_cell[a]) << 16));
+        w[12 + c] = (unsigned)sl[c].code;
+    }
+    uint4 *dst = cnode + (size_t)quad_index[o] * 4;
+    for (int k = 0; k < 4; k++) dst[k] = make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
+    if (quad_top[o] >= 0) {                  // copy for the LDS-resident top of the tree
+        uint4 *t = ctop + (size_t)quad_top[o] * 4;
+        for (int k = 0; k < 4; k++) t[k] = dst[k];
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Host driver
 // ---------------------------------------------------------------------------------------------
@@ -546,7 +590,10 @@ int lbvh_build(tirt_ctx *c)
     if (c->qnode.ensure(sizeof(float4) * 8 * (size_t)n) || c->quad_flag.ensure(sizeof(int) * (size_t)N) ||
         c->quad_index.ensure(sizeof(int) * (size_t)N) || c->scan_tiles.ensure(sizeof(int) * (size_t)n_tiles) ||
         c->quad_top.ensure(sizeof(int) * (size_t)N) || c->qtop.ensure(sizeof(float4) * 8 * TR_TOP_SLOTS)) return TIRT_ERR_HIP;
+    if (c->cnode.ensure(sizeof(uint4) * 4 * (size_t)n) || c->ctop.ensure(sizeof(uint4) * 4 * TR_TOP_SLOTS) ||
+        c->cparent.ensure(sizeof(int) * (size_t)N)) return TIRT_ERR_HIP;
     TIRT_HIP(hipMemsetAsync(c->qtop.p, 0, sizeof(float4) * 8 * TR_TOP_SLOTS, st0));
+    TIRT_HIP(hipMemsetAsync(c->ctop.p, 0, sizeof(uint4) * 4 * TR_TOP_SLOTS, st0));
 
     SceneView sv = scene_view(c);
     const int B = 256;
@@ -568,7 +615,8 @@ int lbvh_build(tirt_ctx *c)
     hipLaunchKernelGGL(k_refit, dim3((n + B - 1) / B), dim3(B), 0, st, n, c->bvh_node.as<float>(), c->parent.as<int>(),
                        c->flag.as<int>(), c->subtree.as<int>(), c->build_status.as<int>());
     hipLaunchKernelGGL(k_flatten, dim3((N + B - 1) / B), dim3(B), 0, st, n, c->bvh_node.as<float>(), c->parent.as<int>(),
-                       c->subtree.as<int>(), c->compact.as<float>(), c->leaf_compact.as<int>(), c->quad_flag.as<int>(), c->quad_top.as<int>());
+                       c->subtree.as<int>(), c->compact.as<float>(), c->leaf_compact.as<int>(), c->quad_flag.as<int>(), c->quad_top.as<int>(),
+                       c->cparent.as<int>());
     hipLaunchKernelGGL(k_scan_tiles, dim3(n_tiles), dim3(SC_BLOCK), 0, st, c->quad_flag.as<int>(), c->quad_index.as<int>(), c->scan_tiles.as<int>(), N);
     hipLaunchKernelGGL(k_scan_tops, dim3(1), dim3(1024), 0, st, c->scan_tiles.as<int>(), n_tiles);
     hipLaunchKernelGGL(k_scan_add, dim3((N + B - 1) / B), dim3(B), 0, st, c->quad_index.as<int>(), c->scan_tiles.as<int>(), N);
@@ -590,6 +638,17 @@ int lbvh_build(tirt_ctx *c)
     hipLaunchKernelGGL(k_tris, dim3((n + B - 1) / B), dim3(B), 0, st, sv, c->leaf_compact.as<int>(), c->tri.as<float4>());
     hipLaunchKernelGGL(k_qnodes, dim3((N + B - 1) / B), dim3(B), 0, st, sv, N, c->compact.as<float>(), c->quad_flag.as<int>(),
                        c->quad_index.as<int>(), c->quad_top.as<int>(), c->qnode.as<float4>(), c->qtop.as<float4>(), pad);
+    // 16-bit grid of the quantised nodes: the (padded) root box spans cells 2 .. TR_GRID_CELLS + 2
+    GridMap gm;
+    for (int k = 0; k < 3; k++) {
+        const float lo = c->root_min[k] - pad, hi = c->root_max[k] + pad;
+        float ext = hi - lo; if (!(ext > 0.0f)) ext = 1.0e-30f;
+        const float cell = ext / TR_GRID_CELLS;
+        c->grid_cell[k] = cell; c->grid_min[k] = lo - 2.0f * cell; c->grid_inv_extent[k] = 1.0f / ext;
+        gm.g0[k] = c->grid_min[k]; gm.inv_cell[k] = 1.0f / cell;
+    }
+    hipLaunchKernelGGL(k_cnodes, dim3((N + B - 1) / B), dim3(B), 0, st, sv, N, c->compact.as<float>(), c->quad_flag.as<int>(),
+                       c->quad_index.as<int>(), c->quad_top.as<int>(), c->cnode.as<uint4>(), c->ctop.as<uint4>(), pad, gm);
     if (n == 1) {
         int prim = 0, is_shape = 0;
         int pr0;

@@ -20,10 +20,12 @@
 //   EXHAUSTIVE  the reference's, on the 64-byte two-child nodes: every internal node whose box
 //               passes `slabs` has both children visited, leaves are intersected unconditionally.
 //               Used for the N_box / N_leaf "algorithmic bytes" counts and as a parity cross-check.
-//   ORDERED     on the 128-byte 4-wide nodes (tirt_internal.h; top five levels in LDS): children
-//               near to far, children whose entry distance exceeds the current hit (with a 1e-4
-//               relative margin) are skipped, leaf children are pre-tested against their
-//               (slightly inflated) box.  Product default.
+//   ORDERED     on the 64-byte quantised 4-wide nodes (tirt_internal.h `cnode`; top five levels in LDS):
+//               children near to far, children whose entry distance exceeds the current hit (with a
+//               1e-4 relative margin) are skipped, leaf children are pre-tested against their (slightly
+//               inflated) box.  The quantised boxes contain the reference's; a candidate hit is accepted
+//               only if the reference would have reached that leaf (`slabs` on the exact boxes, see
+//               BvhView), so the closest hit is the reference's.  Product default.
 // Exact-t ties are resolved as the reference's visit order does (it pops the right child
 // first and keeps the first-found candidate on `t < hit_t`): the candidate with the larger
 // compact-node index wins.
@@ -31,10 +33,6 @@
 
 namespace tirt {
 
-#ifndef TR_BLOCK_SIZE
-#define TR_BLOCK_SIZE 512
-#endif
-constexpr int TR_BLOCK = TR_BLOCK_SIZE;
 constexpr int TR_GRID_MAX = 2048;      // upper bound on persistent blocks (sizes the spill buffer)
 
 enum { KIND_CLOSEST = 0, KIND_SHADOW_ACC = 1, KIND_MIXED = 2 };   // MIXED: closest rays of bounce b + shadow rays of bounce b-1 in one launch
@@ -44,7 +42,7 @@ struct TraceArgs {
     const float *ox, *oy, *oz, *dx, *dy, *dz;    // rays, dense: ray q at index q
     float eye[3];                                // KIND_CLOSEST with ox == nullptr (camera rays): the common origin
     const int *count_ptr; int count_fixed;       // number of rays: *count_ptr if non-null
-    float *ht, *hu, *hv; int *hprim;             // KIND_CLOSEST outputs, index q
+    float4 *hit;                                 // KIND_CLOSEST output, index q: (t, u, v, bits prim)
     // KIND_SHADOW_ACC: contribution of ray q goes to (rr,rg,rb)[sdst[q]] or (fr,fg,fb)[~sdst[q]]
     const int *sprim, *sdst; const float *sdist, *scr, *scg, *scb; float *rr, *rg, *rb, *fr, *fg, *fb;
     int *spill; int spill_depth;                 // global stack tail: [entry][global thread]
@@ -110,11 +108,18 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
     float lim = INF_VALUE;                      // ordered mode: min(hit_t * 1.0001, cull_far, INF_VALUE), entry distances beyond it are skipped
     unsigned nbox = 0, nleaf = 0;
     RayCtx r = {};
+    // ordered mode: the ray in the 16-bit grid of the quantised nodes.  Plane q of axis a is crossed at
+    // t = q * gA + gB (gA = cell / d, gB = (grid_min - o) / d); gBn / gBf are gB moved outward by a margin that
+    // covers the rounding of this evaluation (0.25 cells + 0.25 cells per root-box extent of distance between the
+    // origin and the grid: 16 x the worst-case error); grot = 16 where gA < 0 rotates a (min | max << 16) plane
+    // pair so that the low half is always the near plane.  Axis-parallel components (|d| < 1e-6, where the
+    // reference tests the origin against the slab instead, UtilsFunc.py:500-503) are ignored: never a rejection.
+    float gAx = 0.0f, gAy = 0.0f, gAz = 0.0f, gBnx = 0.0f, gBny = 0.0f, gBnz = 0.0f, gBfx = 0.0f, gBfy = 0.0f, gBfz = 0.0f;
+    int grotx = 0, groty = 0, grotz = 0;
     bool exhausted = false;
     const int S_LOG = a.slice_log2, S_MASK = (1 << S_LOG) - 1;
     int home = (int)((blockIdx.x * (TR_BLOCK / 64) + (tid >> 6)) & S_MASK), tried = 0;      // wave-uniform
     const int full_chunks = count >> 6;
-    bool wave_par = false;                      // any lane of the wave holds an axis-parallel ray (rare)
     unsigned long long sum_box = 0, sum_leaf = 0, sum_box_s = 0, sum_leaf_s = 0, n_over = 0;
     unsigned long long d_it_node = 0, d_lanes_node = 0, d_it_leaf = 0, d_lanes_leaf = 0, d_refills = 0, d_outer = 0;
 
@@ -135,12 +140,12 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
     LDS_AT(sa_bottom) = TR_SENT;
     // the top TR_TOP_LEVELS levels of the 4-wide tree (7 x 16 bytes per record) sit behind the stacks: a
     // visit there costs LDS bandwidth instead of the texture-address path this kernel is bound by
-    typedef float f4v __attribute__((ext_vector_type(4)));
-    typedef __attribute__((address_space(3))) f4v lds_f4;
     const unsigned top_base = (unsigned)(size_t)(lds_int *)lds_stack + (unsigned)TR_LDS_DEPTH * ENTRY;
+    typedef unsigned u4v __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) u4v lds_u4;
     if (MODE != TIRT_TRAVERSE_EXHAUSTIVE) {
-        for (int k = tid; k < TR_TOP_SLOTS * 7; k += TR_BLOCK)
-        { const float4 g = b.qtop[(k / 7) * 8 + (k % 7)]; *(lds_f4 *)(size_t)(top_base + (unsigned)k * 16u) = f4v{g.x, g.y, g.z, g.w}; }
+        for (int k = tid; k < TR_TOP_SLOTS * 4; k += TR_BLOCK)
+        { const uint4 g = b.ctop[k]; *(lds_u4 *)(size_t)(top_base + (unsigned)k * 16u) = u4v{g.x, g.y, g.z, g.w}; }
         __syncthreads();
     }
 #define TR_PAGE_OUT()                                                                                \
@@ -198,6 +203,22 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
                     if (BOUNDED) { const float t_bound = a.sdist[q]; cull_far = t_bound * 1.01f; settle = t_bound * 0.99f; }
                 }
                 lim = minf(minf(hit_t * 1.0001f, cull_far), INF_VALUE);
+                if (MODE != TIRT_TRAVERSE_EXHAUSTIVE) {
+#define TR_GRID_AXIS(oo, dd, idd, k, gA, gBn, gBf, grot)                                             \
+                    do {                                                                             \
+                        if (absf(dd) < 0.000001f) { gA = 0.0f; gBn = -3.0e38f; gBf = 3.0e38f; grot = 0; } \
+                        else {                                                                       \
+                            const float rel__ = b.grid_min[k] - (oo);                                \
+                            gA = b.cell[k] * (idd);                                                  \
+                            const float gB__ = rel__ * (idd);                                        \
+                            const float m__ = (0.25f + 0.25f * absf(rel__) * b.inv_extent[k]) * absf(gA); \
+                            gBn = gB__ - m__; gBf = gB__ + m__; grot = gA < 0.0f ? 16 : 0;           \
+                        }                                                                            \
+                    } while (0)
+                    TR_GRID_AXIS(o.x, d.x, r.idx, 0, gAx, gBnx, gBfx, grotx);
+                    TR_GRID_AXIS(o.y, d.y, r.idy, 1, gAy, gBny, gBfy, groty);
+                    TR_GRID_AXIS(o.z, d.z, r.idz, 2, gAz, gBnz, gBfz, grotz);
+                }
                 cur = (MODE == TIRT_TRAVERSE_EXHAUSTIVE) ? b.root_code : b.root_qcode;
                 if (cur >= 0) {
                     float tn;
@@ -213,7 +234,6 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
             }
         }
         if (ballot64(have) == 0ull) { if (exhausted) break; continue; }
-        wave_par = ballot64(have && par) != 0ull;
 
         // ---- inner nodes.  Lanes that reached a leaf (or finished) wait here; the loop goes on
         // while at least node_min lanes still have inner-node work, or nobody is waiting at all.
@@ -252,51 +272,40 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
                     if (!(hl || hr)) TR_POP(next);
                     cur = next;
                 } else {
-                    // ordered mode on the 4-wide nodes: four box tests, children visited near to far
-                    float4 q0, q1, q2, q3, q4, q5, q6;
+                    // ordered mode on the quantised 4-wide nodes: four box tests, children visited near to far
+                    uint4 q0, q1, q2, q3;
                     if (cur & TR_TOP_BIT) {
-                        const lds_f4 *t = (const lds_f4 *)(size_t)(top_base + (unsigned)(cur & 0xffff) * 112u);
-#define TR_F4(v) make_float4((v).x, (v).y, (v).z, (v).w)
-                        const f4v t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3], t4 = t[4], t5 = t[5], t6 = t[6];
-                        q0 = TR_F4(t0); q1 = TR_F4(t1); q2 = TR_F4(t2); q3 = TR_F4(t3); q4 = TR_F4(t4); q5 = TR_F4(t5); q6 = TR_F4(t6);
+                        const lds_u4 *t = (const lds_u4 *)(size_t)(top_base + (unsigned)(cur & 0xffff) * 64u);
+                        const u4v t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3];
+#define TR_U4(v) make_uint4((v).x, (v).y, (v).z, (v).w)
+                        q0 = TR_U4(t0); q1 = TR_U4(t1); q2 = TR_U4(t2); q3 = TR_U4(t3);
                         if (COUNT) d_outer++;
                     } else {
-                        const float4 *w = (const float4 *)((const char *)b.qnode + ((unsigned)cur << 7));
-                        q0 = w[0]; q1 = w[1]; q2 = w[2]; q3 = w[3]; q4 = w[4]; q5 = w[5]; q6 = w[6];
+                        const uint4 *w = (const uint4 *)((const char *)b.cnode + ((unsigned)cur << 6));
+                        q0 = w[0]; q1 = w[1]; q2 = w[2]; q3 = w[3];
                     }
-                    int c0 = __float_as_int(q6.x), c1 = __float_as_int(q6.y), c2 = __float_as_int(q6.z), c3 = __float_as_int(q6.w);
+                    int c0 = (int)q3.x, c1 = (int)q3.y, c2 = (int)q3.z, c3 = (int)q3.w;
                     if (COUNT) nbox += 4;
                     constexpr float MISS = 3.0e38f;
                     float d0, d1, d2, d3;                // entry distance of a hit box, MISS otherwise
-                    // box hit (tmin <= min(tmax, INF)) and entry not beyond the cull distance: tmin <= min(tmax, lim)
-#define TR_QBOX(mnx, mny, mnz, mxx, mxy, mxz, dist)                                                  \
+                    // near/far crossing of each axis: one rotate, two u16 -> f32 conversions (SDWA), two FMAs; then
+                    // box hit and entry not beyond the cull distance: tn <= min(tf, lim)
+#define TR_CBOX(X, Y, Z, dist)                                                                       \
                     do {                                                                             \
-                        const float ax__ = ((mnx) - r.ox) * r.idx, bx__ = ((mxx) - r.ox) * r.idx;    \
-                        const float ay__ = ((mny) - r.oy) * r.idy, by__ = ((mxy) - r.oy) * r.idy;    \
-                        const float az__ = ((mnz) - r.oz) * r.idz, bz__ = ((mxz) - r.oz) * r.idz;    \
-                        const float tn__ = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax__, bx__), __builtin_fminf(ay__, by__)), \
-                                                           __builtin_fmaxf(__builtin_fminf(az__, bz__), 0.0f));                       \
-                        const float tf__ = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax__, bx__), __builtin_fmaxf(ay__, by__)), \
-                                                           __builtin_fminf(__builtin_fmaxf(az__, bz__), lim));                        \
+                        const unsigned ux__ = __builtin_amdgcn_alignbit((X), (X), grotx);            \
+                        const unsigned uy__ = __builtin_amdgcn_alignbit((Y), (Y), groty);            \
+                        const unsigned uz__ = __builtin_amdgcn_alignbit((Z), (Z), grotz);            \
+                        const float nx__ = __builtin_fmaf((float)(ux__ & 0xffffu), gAx, gBnx), fx__ = __builtin_fmaf((float)(ux__ >> 16), gAx, gBfx); \
+                        const float ny__ = __builtin_fmaf((float)(uy__ & 0xffffu), gAy, gBny), fy__ = __builtin_fmaf((float)(uy__ >> 16), gAy, gBfy); \
+                        const float nz__ = __builtin_fmaf((float)(uz__ & 0xffffu), gAz, gBnz), fz__ = __builtin_fmaf((float)(uz__ >> 16), gAz, gBfz); \
+                        const float tn__ = __builtin_fmaxf(__builtin_fmaxf(nx__, ny__), __builtin_fmaxf(nz__, 0.0f)); \
+                        const float tf__ = __builtin_fminf(__builtin_fminf(fx__, fy__), __builtin_fminf(fz__, lim));  \
                         dist = (tn__ <= tf__) ? tn__ : MISS;                                         \
                     } while (0)
-#define TR_QBOX_REF(mnx, mny, mnz, mxx, mxy, mxz, dist)                                              \
-                    do {                                                                             \
-                        float tn__;                                                                  \
-                        const int p__ = par ? slabs(r, mnx, mny, mnz, mxx, mxy, mxz, tn__) : slabs_fast(r, mnx, mny, mnz, mxx, mxy, mxz, tn__); \
-                        dist = ((p__ != 0) && (tn__ <= lim)) ? tn__ : MISS;                          \
-                    } while (0)
-                    if (!wave_par) {
-                        TR_QBOX(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, d0);
-                        TR_QBOX(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, d1);
-                        TR_QBOX(q3.x, q3.y, q3.z, q3.w, q4.x, q4.y, d2);
-                        TR_QBOX(q4.z, q4.w, q5.x, q5.y, q5.z, q5.w, d3);
-                    } else {                             // some lane of the wave holds an axis-parallel ray: reference form
-                        TR_QBOX_REF(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, d0);
-                        TR_QBOX_REF(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, d1);
-                        TR_QBOX_REF(q3.x, q3.y, q3.z, q3.w, q4.x, q4.y, d2);
-                        TR_QBOX_REF(q4.z, q4.w, q5.x, q5.y, q5.z, q5.w, d3);
-                    }
+                    TR_CBOX(q0.x, q0.y, q0.z, d0);
+                    TR_CBOX(q0.w, q1.x, q1.y, d1);
+                    TR_CBOX(q1.z, q1.w, q2.x, d2);
+                    TR_CBOX(q2.y, q2.z, q2.w, d3);
                     // sort the four (distance, child) pairs: misses end up last
 #define TR_CE(da, ca, db, cb)                                                                        \
                     do {                                                                             \
@@ -344,7 +353,22 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
             const int leaf = __float_as_int(ta.w);
             TR_POP(cur);
             // reference: accept iff 0 < t < hit_t (so never t >= INF_VALUE); equal-t candidates: see header
-            if ((t > 0.0f) & ((t < hit_t) | ((t == hit_t) & (hit_leaf >= 0) & (leaf > hit_leaf)))) {
+            bool cand = (t > 0.0f) & ((t < hit_t) | ((t == hit_t) & (hit_leaf >= 0) & (leaf > hit_leaf)));
+            if (MODE != TIRT_TRAVERSE_EXHAUSTIVE && cand) {
+                // The quantised boxes that led here contain the reference's: would the reference have visited this leaf
+                // (Scene.py:702-744: every proper ancestor's box passes `slabs`)?  The leaf's own exact box passing implies
+                // it (the outer of two nested boxes passes whenever the inner one does: `slabs` is monotone in the planes);
+                // otherwise -- a hit within rounding distance of the leaf box's boundary -- the ancestors are asked one by one.
+                const float *lb = b.compact + (size_t)leaf * CPN_VEC + 2;
+                float tn_;
+                if (!slabs(r, lb[0], lb[1], lb[2], lb[3], lb[4], lb[5], tn_)) {
+                    for (int an = b.cparent[leaf]; an >= 0; an = b.cparent[an]) {
+                        const float *ab = b.compact + (size_t)an * CPN_VEC + 2;
+                        if (!slabs(r, ab[0], ab[1], ab[2], ab[3], ab[4], ab[5], tn_)) { cand = false; break; }
+                    }
+                }
+            }
+            if (cand) {
                 hit_t = t; hit_u = u; hit_v = v; hit_prim = prim; hit_leaf = leaf;
                 lim = minf(minf(hit_t * 1.0001f, cull_far), INF_VALUE);
                 if (BOUNDED && prim != expect && t < settle) { cur = TR_SENT; paged = 0; }      // answer settled: "occluded"
@@ -359,7 +383,7 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
         // ---- finished rays write back and free their lane ---------------------------------------
         if (have && cur == TR_SENT) {
             if (!(MAY_SHADOW && is_sh)) {
-                a.ht[q] = hit_t; a.hu[q] = hit_u; a.hv[q] = hit_v; a.hprim[q] = hit_prim;
+                a.hit[q] = make_float4(hit_t, hit_u, hit_v, __int_as_float(hit_prim));
             } else if (hit_prim == expect) {                 // integrator/PT_RGB.py:105-109
                 const int dst = a.sdst[q];
                 float *pr = dst >= 0 ? a.rr + dst : a.fr + ~dst;
@@ -398,27 +422,29 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
 }
 
 template <int MODE, bool COUNT, int KIND>
-static void launch_trace_as(hipStream_t stream, const TraceArgs &a, dim3 g, dim3 b, size_t lds)
+static int launch_trace_as(tirt_ctx *c, hipStream_t stream, const TraceArgs &a, dim3 g, dim3 b, size_t lds)
 {
-    // more than 64 KB of dynamic LDS per block (stacks + tree top): tell the runtime once per kernel and size
-    static size_t allowed = 0;
-    if (lds > allowed) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trace<MODE, COUNT, KIND>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipGetLastError();
-        allowed = lds;
+    // more than 64 KB of dynamic LDS per block (stacks + tree top): the opt-in is per kernel AND per device
+    static size_t allowed[TIRT_MAX_DEVICES] = {};
+    TIRT_REQUIRE(lds <= c->lds_optin, "k_trace: trace_lds_depth needs more LDS than the device has per block");
+    const int dev = (c->device >= 0 && c->device < TIRT_MAX_DEVICES) ? c->device : 0;
+    if (lds > allowed[dev] || c->device >= TIRT_MAX_DEVICES) {
+        TIRT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trace<MODE, COUNT, KIND>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        allowed[dev] = lds;
     }
     hipLaunchKernelGGL((k_trace<MODE, COUNT, KIND>), g, b, lds, stream, a);
+    return TIRT_OK;
 }
 template <int KIND>
-static void launch_trace(hipStream_t stream, const TraceArgs &a, int flags, int grid)
+static int launch_trace(tirt_ctx *c, hipStream_t stream, const TraceArgs &a, int flags, int grid)
 {
     const bool exh = (flags & TIRT_TRAVERSE_EXHAUSTIVE) != 0, cnt = (flags & TIRT_COUNT_NODES) != 0;
     dim3 g(grid), b(TR_BLOCK);
-    const size_t lds = sizeof(int) * (size_t)a.lds_depth * TR_BLOCK + (size_t)TR_TOP_SLOTS * 112;
-    if (exh && cnt) launch_trace_as<TIRT_TRAVERSE_EXHAUSTIVE, true, KIND>(stream, a, g, b, lds);
-    else if (exh) launch_trace_as<TIRT_TRAVERSE_EXHAUSTIVE, false, KIND>(stream, a, g, b, lds);
-    else if (cnt) launch_trace_as<TIRT_TRAVERSE_ORDERED, true, KIND>(stream, a, g, b, lds);
-    else launch_trace_as<TIRT_TRAVERSE_ORDERED, false, KIND>(stream, a, g, b, lds);
+    const size_t lds = trace_lds_bytes(a.lds_depth);
+    if (exh && cnt) return launch_trace_as<TIRT_TRAVERSE_EXHAUSTIVE, true, KIND>(c, stream, a, g, b, lds);
+    if (exh) return launch_trace_as<TIRT_TRAVERSE_EXHAUSTIVE, false, KIND>(c, stream, a, g, b, lds);
+    if (cnt) return launch_trace_as<TIRT_TRAVERSE_ORDERED, true, KIND>(c, stream, a, g, b, lds);
+    return launch_trace_as<TIRT_TRAVERSE_ORDERED, false, KIND>(c, stream, a, g, b, lds);
 }
 
 static int ensure_spill(tirt_ctx *c, DevBuf &spill, int stack_size, int &spill_depth)
@@ -443,14 +469,15 @@ __global__ void k_split_rays(const float *rays, int nr, float *ox, float *oy, fl
     ox[i] = r[0]; oy[i] = r[1]; oz[i] = r[2]; dx[i] = r[3]; dy[i] = r[4]; dz[i] = r[5];
 }
 __global__ void k_hit_attr(SceneView s, int nr, const float *ox, const float *oy, const float *oz, const float *dx, const float *dy,
-                           const float *dz, const float *ht, const float *hu, const float *hv, const int *hprim, float *out)
+                           const float *dz, const float4 *hit, float *out, float *out_t, int *out_prim)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nr) return;
     float *o = out + (size_t)i * 13;
-    o[0] = ht[i];
+    const float4 hr = hit[i];
+    o[0] = hr.x; out_t[i] = hr.x; out_prim[i] = __float_as_int(hr.w);
     HitAttr h; h.pos = h.gnor = h.nor = h.tex = V(0.0f, 0.0f, 0.0f);
-    if (ht[i] < INF_VALUE) h = hit_attributes(s, V(ox[i], oy[i], oz[i]), V(dx[i], dy[i], dz[i]), hprim[i], ht[i], hu[i], hv[i]);
+    if (hr.x < INF_VALUE) h = hit_attributes(s, V(ox[i], oy[i], oz[i]), V(dx[i], dy[i], dz[i]), __float_as_int(hr.w), hr.x, hr.y, hr.z);
     else { h.gnor = normalized(h.gnor); h.nor = normalized(h.nor); }     // reference normalises (0,0,0) on a miss
     o[1] = h.pos.x; o[2] = h.pos.y; o[3] = h.pos.z;
     o[4] = h.gnor.x; o[5] = h.gnor.y; o[6] = h.gnor.z;
@@ -467,14 +494,15 @@ int launch_trace_batch(tirt_ctx *c, const float *rays, int nr, int stack_size, i
     if (ensure_counters(c)) return TIRT_ERR_HIP;
     hipStream_t st = c->stream;
     if (c->tr_rays.ensure(sizeof(float) * 6 * (size_t)nr)) return TIRT_ERR_HIP;
-    if (c->tr_out.ensure(sizeof(float) * (6 + 3 + 13) * (size_t)nr)) return TIRT_ERR_HIP;
+    if (c->tr_out.ensure(sizeof(float) * (6 + 4 + 1 + 13) * (size_t)nr + 64)) return TIRT_ERR_HIP;
     if (c->tr_prim.ensure(sizeof(int) * (size_t)nr)) return TIRT_ERR_HIP;
     if (c->tr_counts.ensure(sizeof(int2) * (size_t)nr)) return TIRT_ERR_HIP;
     int spill_depth;
     if (ensure_spill(c, c->spill, stack_size, spill_depth)) return TIRT_ERR_HIP;
     float *base = c->tr_out.as<float>();
     float *ox = base, *oy = ox + nr, *oz = oy + nr, *dx = oz + nr, *dy = dx + nr, *dz = dy + nr;
-    float *ht = dz + nr, *hu = ht + nr, *hv = hu + nr, *attr = hv + nr;
+    float4 *hit = (float4 *)(((uintptr_t)(dz + nr) + 15) & ~(uintptr_t)15);
+    float *ht = (float *)(hit + nr), *attr = ht + nr;
     TIRT_HIP(hipMemcpyAsync(c->tr_rays.p, rays, sizeof(float) * 6 * (size_t)nr, hipMemcpyHostToDevice, st));
     const int B = 256;
     hipLaunchKernelGGL(k_split_rays, dim3((nr + B - 1) / B), dim3(B), 0, st, c->tr_rays.as<float>(), nr, ox, oy, oz, dx, dy, dz);
@@ -482,7 +510,7 @@ int launch_trace_batch(tirt_ctx *c, const float *rays, int nr, int stack_size, i
     a.bvh = bvh_view(c);
     a.ox = ox; a.oy = oy; a.oz = oz; a.dx = dx; a.dy = dy; a.dz = dz;
     a.count_ptr = nullptr; a.count_fixed = nr;
-    a.ht = ht; a.hu = hu; a.hv = hv; a.hprim = c->tr_prim.as<int>();
+    a.hit = hit;
     a.spill = c->spill.as<int>(); a.spill_depth = spill_depth;
     a.ctr = c->dev_counters.as<DevCounters>();
     a.per_ray_counts = (flags & TIRT_COUNT_NODES) ? c->tr_counts.as<int2>() : nullptr;
@@ -491,14 +519,11 @@ int launch_trace_batch(tirt_ctx *c, const float *rays, int nr, int stack_size, i
     a.fetch = c->counters_mem.as<int>();
     fill_tunables(c, a);
     int grid = (nr + TR_BLOCK - 1) / TR_BLOCK; if (grid > c->tr_grid) grid = c->tr_grid;
-    launch_trace<KIND_CLOSEST>(st, a, flags, grid);
-    if (!shadow) {
-        hipLaunchKernelGGL(k_hit_attr, dim3((nr + B - 1) / B), dim3(B), 0, st, scene_view(c), nr, ox, oy, oz, dx, dy, dz, ht, hu, hv,
-                           c->tr_prim.as<int>(), attr);
-        TIRT_HIP(hipMemcpyAsync(out_f, attr, sizeof(float) * 13 * (size_t)nr, hipMemcpyDeviceToHost, st));
-    } else {
-        TIRT_HIP(hipMemcpyAsync(out_f, ht, sizeof(float) * (size_t)nr, hipMemcpyDeviceToHost, st));
-    }
+    if (int rc = launch_trace<KIND_CLOSEST>(c, st, a, flags, grid)) return rc;
+    hipLaunchKernelGGL(k_hit_attr, dim3((nr + B - 1) / B), dim3(B), 0, st, scene_view(c), nr, ox, oy, oz, dx, dy, dz, hit, attr, ht,
+                       c->tr_prim.as<int>());
+    if (!shadow) TIRT_HIP(hipMemcpyAsync(out_f, attr, sizeof(float) * 13 * (size_t)nr, hipMemcpyDeviceToHost, st));
+    else TIRT_HIP(hipMemcpyAsync(out_f, ht, sizeof(float) * (size_t)nr, hipMemcpyDeviceToHost, st));
     TIRT_HIP(hipMemcpyAsync(out_prim, c->tr_prim.p, sizeof(int) * (size_t)nr, hipMemcpyDeviceToHost, st));
     if (counts && (flags & TIRT_COUNT_NODES))
         TIRT_HIP(hipMemcpyAsync(counts, c->tr_counts.p, sizeof(int2) * (size_t)nr, hipMemcpyDeviceToHost, st));
@@ -573,14 +598,15 @@ __global__ __launch_bounds__(SH_BLOCK, SH_MIN_WAVES) void k_shade(PathState ps, 
             const uint32_t dim0 = TM_DIM_BOUNCE0 + TM_DIMS_PER_BOUNCE * (uint32_t)bounce;
             const v3 origin = first ? eye : V(in.ox[q], in.oy[q], in.oz[q]);
             const v3 direction = V(in.dx[q], in.dy[q], in.dz[q]);
-            const float t = ps.ht[q];
+            const float4 hrec = ps.hit[q];
+            const float t = hrec.x;
             v3 throughout = first ? V(1.0f, 1.0f, 1.0f) : V(in.tr[q], in.tg[q], in.tb[q]);
             radiance = first ? V(0.0f, 0.0f, 0.0f) : V(in.rr[q], in.rg[q], in.rb[q]);
             float brdf_pdf = first ? 1.0f : in.brdf_pdf[q];
             int perfect_spec = first ? 1 : (int)(in.flags[q] & 1u);
             if (t < INF_VALUE) {
-                const int prim_id = ps.hprim[q];
-                const HitAttr h = hit_attributes(sc, origin, direction, prim_id, t, ps.hu[q], ps.hv[q]);
+                const int prim_id = __float_as_int(hrec.w);
+                const HitAttr h = hit_attributes(sc, origin, direction, prim_id, t, hrec.y, hrec.z);
                 const v3 normal = h.nor;
                 const v3 fnormal = normal * signf(dot(-direction, h.gnor));            // UtilsFunc.py:465-467
                 const int mat_id = sc.primitive[(size_t)prim_id * PRI_VEC + 2];
@@ -607,7 +633,9 @@ __global__ __launch_bounds__(SH_BLOCK, SH_MIN_WAVES) void k_shade(PathState ps, 
                         brdf = 1.0f; brdf_pdf = 1.0f;
                     } else {
                         perfect_spec = 0;
-                        // Scene.py:477-518 sample_li
+                        // Scene.py:477-518 sample_li.  No emitters (env-lit scene): the reference would index light[-1]
+                        // (Scene.py:423-428, undefined) -- defined here, as in the oracle, as "no NEE sample"
+                        if (sc.light_count > 0) {
                         int lidx = (int)(tm_rand(seed, pixel, frame, dim0 + TM_SLOT_LIGHT) * (float)sc.light_count);
                         if (lidx >= sc.light_count) lidx = sc.light_count - 1;
                         const int light_prim = sc.light[lidx];
@@ -644,6 +672,7 @@ __global__ __launch_bounds__(SH_BLOCK, SH_MIN_WAVES) void k_shade(PathState ps, 
                             }
                             sh_o = light_pos; sh_d = light_dir; sh_c = c; sh_expect = expect; sh_dist = light_dist;
                         }
+                        }   // light_count > 0
                         next_dir = disney_sample(m, direction, fnormal, tm_rand(seed, pixel, frame, dim0 + TM_SLOT_LOBE),
                                                  tm_rand(seed, pixel, frame, dim0 + TM_SLOT_R1),
                                                  tm_rand(seed, pixel, frame, dim0 + TM_SLOT_R2));
@@ -755,11 +784,13 @@ static size_t lane_counter_bytes(int max_depth)
 { return LINE * (size_t)(max_depth + 1) + sizeof(int) * TR_FETCH_STRIDE * TR_SLICES_MAX * (size_t)(max_depth + 1); }
 
 constexpr int PATH_WORDS = 2 * 15 + 4 + 12 + 3;      // two PathSoA + hit record + shadow ray + final radiance
-static size_t path_state_bytes(size_t S) { return sizeof(float) * PATH_WORDS * S; }
+static size_t path_state_bytes(size_t S) { return sizeof(float) * PATH_WORDS * ((S + 3) & ~(size_t)3); }
 static int ensure_paths(Lane &L, size_t S, int max_depth)
 {
     if (S > L.path_capacity || !L.path_mem.p) {
         if (L.path_mem.ensure(path_state_bytes(S))) return TIRT_ERR_HIP;
+        const size_t S_user = S;
+        S = (S + 3) & ~(size_t)3;                     // array pitch: keeps every array (and the float4 hit records) 16-byte aligned
         float *w = L.path_mem.as<float>();
         PathState &p = L.ps;
         auto nxt = [&]() { float *r = w; w += S; return r; };
@@ -769,11 +800,11 @@ static int ensure_paths(Lane &L, size_t S, int max_depth)
             q.tr = nxt(); q.tg = nxt(); q.tb = nxt(); q.rr = nxt(); q.rg = nxt(); q.rb = nxt();
             q.brdf_pdf = nxt(); q.flags = (uint32_t *)nxt(); q.slot = (int *)nxt();
         }
-        p.ht = nxt(); p.hu = nxt(); p.hv = nxt(); p.hprim = (int *)nxt();
+        p.hit = (float4 *)w; w += 4 * S;             // S is a multiple of 4 words from a 256-byte aligned base: 16-byte aligned
         p.sox = nxt(); p.soy = nxt(); p.soz = nxt(); p.sdx = nxt(); p.sdy = nxt(); p.sdz = nxt();
         p.scr = nxt(); p.scg = nxt(); p.scb = nxt(); p.sprim = (int *)nxt(); p.sdist = nxt(); p.sdst = (int *)nxt();
         p.fr = nxt(); p.fg = nxt(); p.fb = nxt();
-        L.path_capacity = S;
+        L.path_capacity = S_user;
     }
     if (L.counters_mem.ensure(lane_counter_bytes(max_depth))) return TIRT_ERR_HIP;
     return 0;
@@ -865,7 +896,7 @@ int pt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed,
             a.ox = in.ox; a.oy = in.oy; a.oz = in.oz; a.dx = in.dx; a.dy = in.dy; a.dz = in.dz;
             if (b == 0) { a.ox = a.oy = a.oz = nullptr; for (int k = 0; k < 3; k++) a.eye[k] = c->cam.eye[k]; }   // camera rays share their origin
             a.count_ptr = (b == 0) ? nullptr : cnt_path(b); a.count_fixed = S;
-            a.ht = L.ps.ht; a.hu = L.ps.hu; a.hv = L.ps.hv; a.hprim = L.ps.hprim;
+            a.hit = L.ps.hit;
             a.spill = L.spill.as<int>(); a.spill_depth = spill_depth; a.ctr = ctr; a.per_ray_counts = nullptr;
             a.fetch = fetch(b);
             a.sox = L.ps.sox; a.soy = L.ps.soy; a.soz = L.ps.soz; a.sdx = L.ps.sdx; a.sdy = L.ps.sdy; a.sdz = L.ps.sdz;
@@ -874,8 +905,7 @@ int pt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed,
             a.scount_ptr = (b == 0) ? nullptr : cnt_shadow(b - 1);
             fill_tunables(c, a);
             stamp(evc, true);
-            if (b == 0) launch_trace<KIND_CLOSEST>(st, a, flags, grid_full);
-            else launch_trace<KIND_MIXED>(st, a, flags, grid_full);
+            if (int rc = (b == 0) ? launch_trace<KIND_CLOSEST>(c, st, a, flags, grid_full) : launch_trace<KIND_MIXED>(c, st, a, flags, grid_full)) return rc;
             stamp(evc, false);
             c->launches_trace_closest++;
 
@@ -897,7 +927,7 @@ int pt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed,
                 sa.fetch = fetch(max_depth);
                 fill_tunables(c, sa);
                 stamp(evs, true);
-                launch_trace<KIND_SHADOW_ACC>(st, sa, flags, grid_full);
+                if (int rc = launch_trace<KIND_SHADOW_ACC>(c, st, sa, flags, grid_full)) return rc;
                 stamp(evs, false);
                 c->launches_trace_shadow++;
             }
