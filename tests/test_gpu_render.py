@@ -254,6 +254,7 @@ def test_env_lit_scene_without_emitters(gpu_ctx_ok):
     ex.scene.add_env(scenes.asset("image", "env.png"), 2.0)
     ex.integrator = PT_RGB.PathTrace(W, H, ex.cam, ex.scene, 64)
     ex.build_scene()
+    ex.frame_camera(0.8)
     assert ex.scene.light_count == 0
     o = oa.OracleScene(ex.scene, ex.cam); o.lbvh_build()
     ctx = ex.scene.ctx

@@ -23,7 +23,7 @@ BvhView bvh_view(const tirt_ctx *c)
     BvhView b;
     b.wnode = c->wnode.as<float4>(); b.qnode = c->qnode.as<float4>(); b.qtop = c->qtop.as<float4>(); b.tri = c->tri.as<float4>();
     b.cnode = c->cnode.as<uint4>(); b.ctop = c->ctop.as<uint4>(); b.compact = c->compact.as<float>(); b.cparent = c->cparent.as<int>();
-    for (int k = 0; k < 3; k++) { b.grid_min[k] = c->grid_min[k]; b.cell[k] = c->grid_cell[k]; b.inv_extent[k] = c->grid_inv_extent[k]; }
+    for (int k = 0; k < 3; k++) { b.grid_min[k] = c->grid_min[k]; b.cell[k] = c->grid_cell[k]; b.inv_cell[k] = c->grid_inv_cell[k]; b.inv_extent[k] = c->grid_inv_extent[k]; }
     for (int k = 0; k < 3; k++) { b.root_min[k] = c->root_min[k]; b.root_max[k] = c->root_max[k]; }
     b.root_code = c->root_code;
     b.root_qcode = c->root_code >= 0 ? TR_TOP_BIT : c->root_code;

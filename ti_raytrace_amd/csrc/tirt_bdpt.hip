@@ -83,7 +83,7 @@ TD SimpleHit trace_simple(const BvhView &b, v3 o, v3 d, int *stack /* LDS, [entr
             const float4 *tp = b.tri + (size_t)prim * TRI_STRIDE;
             const float4 ta = tp[0], e1 = tp[1], e2 = tp[2];
             float t, u, v;
-            if (((code >> 30) & 1) == 0) t = intersect_tri_packed(o, d, V(ta.x, ta.y, ta.z), V(e1.x, e1.y, e1.z), V(e2.x, e2.y, e2.z), u, v);
+            if (((code >> 30) & 1) == 0) t = intersect_tri_packed(o, d, V(ta.x, ta.y, ta.z), V(e1.x, e1.y, e1.z) - V(ta.x, ta.y, ta.z), V(e2.x, e2.y, e2.z) - V(ta.x, ta.y, ta.z), u, v);
             else { float cc; u = 0.0f; v = 0.0f; t = ((int)e1.y == SHAPE_SPHERE) ? intersect_sphere(o, d, V(ta.x, ta.y, ta.z), e1.x, cc) : INF_VALUE; }
             const int leaf = __float_as_int(ta.w);
             if ((t > 0.0f) & ((t < h.t) | ((t == h.t) & (hit_leaf >= 0) & (leaf > hit_leaf)))) {

@@ -52,7 +52,9 @@ struct DevBuf {
 //   code <  0: leaf, prim = (~code) & 0x3fffffff, bit 30 of ~code set for shape primitives
 //              (box = leaf box inflated by `pad`, only used for culling in ordered mode).
 // tri: one 48-byte record per primitive, indexed by primitive id:
-//   triangles: (v0.xyz, bits leaf_compact_index) (E1.xyz, 0) (E2.xyz, 0)
+//   triangles: (v0.xyz, bits leaf_compact_index) (v1.xyz, 0) (v2.xyz, 0) -- the three positions themselves: the edges
+//              E1 = v1 - v0, E2 = v2 - v0 are formed per test as the reference does (Scene.py:608-609), and the exact
+//              leaf box (min / max of the three) is at hand for the hit verification of the ordered traversal
 //   spheres  : (centre.xyz, bits leaf_compact_index) (radius, 0, 0, 0) (0,0,0,0)
 // qnode: one 128-byte record per internal node at even depth (dense index in compact order), holding
 //   its up to four grandchildren: (q0 q1 q2) boxes of slots 0,1 laid out like wnode's, (q3 q4 q5) slots
@@ -100,7 +102,7 @@ struct BvhView {
     const uint4 *ctop;            // their first TR_TOP_LEVELS levels in breadth-first slots (copied to LDS by k_trace)
     const float *compact;         // reference compact_node rows [N*9] (exact boxes: hit verification)
     const int *cparent;           // compact index of the parent of compact node i (-1 for the root)
-    float grid_min[3], cell[3], inv_extent[3];
+    float grid_min[3], cell[3], inv_cell[3], inv_extent[3];
     float root_min[3], root_max[3];
     int root_code;                // two-child layout: compact index 0, or the leaf code of a one-primitive scene
     int root_qcode;               // 4-wide layout: TR_TOP_BIT | 0, or the same leaf code
@@ -180,7 +182,7 @@ struct tirt_ctx {
     tirt::DevBuf wnode, tri;                      // traversal layout
     tirt::DevBuf qnode, quad_flag, quad_index, quad_top, qtop, scan_tiles;   // 4-wide traversal nodes (exact boxes)
     tirt::DevBuf cnode, ctop, cparent;             // quantised 4-wide nodes + parent chain of the compact nodes (ordered traversal)
-    float grid_min[3] = {0, 0, 0}, grid_cell[3] = {1, 1, 1}, grid_inv_extent[3] = {1, 1, 1};
+    float grid_min[3] = {0, 0, 0}, grid_cell[3] = {1, 1, 1}, grid_inv_cell[3] = {1, 1, 1}, grid_inv_extent[3] = {1, 1, 1};
     size_t lds_optin = 65536;                      // hipDeviceAttributeMaxSharedMemoryPerBlock (opt-in) of this device
     float root_min[3], root_max[3]; int root_code = 0;
 

@@ -403,10 +403,9 @@ __global__ void k_tris(SceneView s, const int *leaf_compact, float4 *tri)
     float lc = __int_as_float(leaf_compact[i]);
     if (pr[0] == PRIMITIVE_TRI) {
         v3 v0 = vtx_pos(s, pr[1]), v1 = vtx_pos(s, pr[1] + 1), v2 = vtx_pos(s, pr[1] + 2);
-        v3 E1 = v1 - v0, E2 = v2 - v0;
         t[0] = make_float4(v0.x, v0.y, v0.z, lc);
-        t[1] = make_float4(E1.x, E1.y, E1.z, 0.0f);
-        t[2] = make_float4(E2.x, E2.y, E2.z, 0.0f);
+        t[1] = make_float4(v1.x, v1.y, v1.z, 0.0f);
+        t[2] = make_float4(v2.x, v2.y, v2.z, 0.0f);
     } else {
         const float *sh = s.shape + (size_t)pr[1] * SHA_VEC;
         t[0] = make_float4(sh[1], sh[2], sh[3], lc);
@@ -528,7 +527,12 @@ __global__ void k_qnodes(SceneView s, int N, const float *compact, const int *qu
 // Quantised 4-wide nodes (tirt_internal.h, BvhView::cnode): the same slots as k_qnodes, every plane mapped to the
 // 16-bit grid over the root box, min planes down and max planes up, one more cell outward against the rounding of
 // the mapping itself.  Leaf slots are padded like qnode's before the mapping.
+// Analytic shapes (the sphere light) keep the whole grid as their slot box: the reference never box-tests a leaf
+// (Scene.py:716-722), and its sphere test (Scene.py:565-596: a square root of a difference of squares of the distance
+// to the centre) answers "hit" for rays that pass the sphere at a distance that grows with the distance of the origin
+// -- no fixed padding of the sphere's box covers that.  Triangle leaves are safe behind `pad` plus the per-ray margin.
 struct GridMap { float g0[3], inv_cell[3]; };
+TD bool is_shape_leaf(int code) { return code < 0 && code != TR_EMPTY && (((~code) >> 30) & 1) != 0; }
 TD unsigned grid_lo(float x, float g0, float inv_cell)
 { float q = tm_floor((x - g0) * inv_cell) - 1.0f; q = q < 0.0f ? 0.0f : (q > 65535.0f ? 65535.0f : q); return (unsigned)q; }
 TD unsigned grid_hi(float x, float g0, float inv_cell)
@@ -553,7 +557,8 @@ __global__ void k_cnodes(SceneView s, int N, const float *compact, const int *qu
     for (int c = 0; c < 4; c++) {
         for (int a = 0; a < 3; a++)
             w[3 * c + a] = (sl[c].code == TR_EMPTY) ? 0x0000ffffu
-                                                    : (grid_lo(sl[c].mn[a], gm.g0[a], gm.inv_cell[a]) | (grid_hi(sl[c].mx[a], gm.g0[a], gm.inv_cell[a]) << 16));
+                           : is_shape_leaf(sl[c].code) ? 0xffff0000u
+                           : (grid_lo(sl[c].mn[a], gm.g0[a], gm.inv_cell[a]) | (grid_hi(sl[c].mx[a], gm.g0[a], gm.inv_cell[a]) << 16));
         w[12 + c] = (unsigned)sl[c].code;
     }
     uint4 *dst = cnode + (size_t)quad_index[o] * 4;
@@ -645,7 +650,7 @@ int lbvh_build(tirt_ctx *c)
         float ext = hi - lo; if (!(ext > 0.0f)) ext = 1.0e-30f;
         const float cell = ext / TR_GRID_CELLS;
         c->grid_cell[k] = cell; c->grid_min[k] = lo - 2.0f * cell; c->grid_inv_extent[k] = 1.0f / ext;
-        gm.g0[k] = c->grid_min[k]; gm.inv_cell[k] = 1.0f / cell;
+        gm.g0[k] = c->grid_min[k]; gm.inv_cell[k] = 1.0f / cell; c->grid_inv_cell[k] = gm.inv_cell[k];
     }
     hipLaunchKernelGGL(k_cnodes, dim3((N + B - 1) / B), dim3(B), 0, st, sv, N, c->compact.as<float>(), c->quad_flag.as<int>(),
                        c->quad_index.as<int>(), c->quad_top.as<int>(), c->cnode.as<uint4>(), c->ctop.as<uint4>(), pad, gm);

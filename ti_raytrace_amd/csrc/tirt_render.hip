@@ -83,7 +83,7 @@ TD unsigned long long wave_sum(unsigned long long v)
 }
 
 #ifndef TR_MIN_WAVES
-#define TR_MIN_WAVES 4
+#define TR_MIN_WAVES 6
 #endif
 template <int MODE, bool COUNT, int KIND>
 __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
@@ -109,11 +109,15 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
     unsigned nbox = 0, nleaf = 0;
     RayCtx r = {};
     // ordered mode: the ray in the 16-bit grid of the quantised nodes.  Plane q of axis a is crossed at
-    // t = q * gA + gB (gA = cell / d, gB = (grid_min - o) / d); gBn / gBf are gB moved outward by a margin that
-    // covers the rounding of this evaluation (0.25 cells + 0.25 cells per root-box extent of distance between the
-    // origin and the grid: 16 x the worst-case error); grot = 16 where gA < 0 rotates a (min | max << 16) plane
+    // t = q * gA + gB (gA = cell / d, gB = (grid_min - o) / d); gBn / gBf are gB moved outward by a margin of
+    // 0.25 cells + 0.25 cells per root-box extent of distance between the origin and the grid (see the set-up code
+    // for what it covers); grot = 16 where gA < 0 rotates a (min | max << 16) plane
     // pair so that the low half is always the near plane.  Axis-parallel components (|d| < 1e-6, where the
-    // reference tests the origin against the slab instead, UtilsFunc.py:500-503) are ignored: never a rejection.
+    // reference tests the origin against the slab instead, UtilsFunc.py:500-503) do the same in grid units through
+    // the same two FMAs: gA = 1e30, gBn / gBf = (-(origin cell) -+ margin) * 1e30, so that the "near distance" is hugely
+    // negative or positive and the "far distance" hugely positive or negative according to the side of the planes
+    // the origin lies on.  (Ignoring such an axis would be conservative too, but a ray that ignores an axis walks a
+    // whole slice of the scene: a few of them per million rays set the duration of every launch.)
     float gAx = 0.0f, gAy = 0.0f, gAz = 0.0f, gBnx = 0.0f, gBny = 0.0f, gBnz = 0.0f, gBfx = 0.0f, gBfy = 0.0f, gBfz = 0.0f;
     int grotx = 0, groty = 0, grotz = 0;
     bool exhausted = false;
@@ -204,20 +208,28 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
                 }
                 lim = minf(minf(hit_t * 1.0001f, cull_far), INF_VALUE);
                 if (MODE != TIRT_TRAVERSE_EXHAUSTIVE) {
-#define TR_GRID_AXIS(oo, dd, idd, k, gA, gBn, gBf, grot)                                             \
+                    // margin in cells, the same on all axes: 0.25 + 0.25 per root-box extent between the origin and the
+                    // grid (largest axis).  It has to cover (i) the rounding of q * gA + gB (<= 0.016 cells per extent of
+                    // distance) and (ii) what the reference's primitive tests accept outside a leaf box: Moller-Trumbore
+                    // works on o - v0 and is off by ~5e-7 of the origin's distance IN EVERY DIRECTION (0.03 cells per extent)
+                    const float relx__ = b.grid_min[0] - o.x, rely__ = b.grid_min[1] - o.y, relz__ = b.grid_min[2] - o.z;
+                    const float rho__ = maxf(maxf(absf(relx__) * b.inv_extent[0], absf(rely__) * b.inv_extent[1]), absf(relz__) * b.inv_extent[2]);
+                    const float mc__ = 0.25f + 0.25f * rho__;
+#define TR_GRID_AXIS(rel, dd, idd, k, gA, gBn, gBf, grot)                                            \
                     do {                                                                             \
-                        if (absf(dd) < 0.000001f) { gA = 0.0f; gBn = -3.0e38f; gBf = 3.0e38f; grot = 0; } \
-                        else {                                                                       \
-                            const float rel__ = b.grid_min[k] - (oo);                                \
+                        if (absf(dd) < 0.000001f) {      /* the reference's parallel case: origin inside the slab or no hit */ \
+                            const float og__ = -(rel) * b.inv_cell[k];                               \
+                            gA = 1.0e30f; gBn = (-og__ - (mc__ + 1.0f)) * 1.0e30f; gBf = (-og__ + (mc__ + 1.0f)) * 1.0e30f; grot = 0; \
+                        } else {                                                                     \
                             gA = b.cell[k] * (idd);                                                  \
-                            const float gB__ = rel__ * (idd);                                        \
-                            const float m__ = (0.25f + 0.25f * absf(rel__) * b.inv_extent[k]) * absf(gA); \
+                            const float gB__ = (rel) * (idd);                                        \
+                            const float m__ = mc__ * absf(gA);                                       \
                             gBn = gB__ - m__; gBf = gB__ + m__; grot = gA < 0.0f ? 16 : 0;           \
                         }                                                                            \
                     } while (0)
-                    TR_GRID_AXIS(o.x, d.x, r.idx, 0, gAx, gBnx, gBfx, grotx);
-                    TR_GRID_AXIS(o.y, d.y, r.idy, 1, gAy, gBny, gBfy, groty);
-                    TR_GRID_AXIS(o.z, d.z, r.idz, 2, gAz, gBnz, gBfz, grotz);
+                    TR_GRID_AXIS(relx__, d.x, r.idx, 0, gAx, gBnx, gBfx, grotx);
+                    TR_GRID_AXIS(rely__, d.y, r.idy, 1, gAy, gBny, gBfy, groty);
+                    TR_GRID_AXIS(relz__, d.z, r.idz, 2, gAz, gBnz, gBfz, grotz);
                 }
                 cur = (MODE == TIRT_TRAVERSE_EXHAUSTIVE) ? b.root_code : b.root_qcode;
                 if (cur >= 0) {
@@ -340,34 +352,47 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
             const int code = ~cur;
             const int prim = code & 0x3fffffff;
             const float4 *tp = b.tri + (size_t)prim * TRI_STRIDE;
-            const float4 ta = tp[0], e1 = tp[1], e2 = tp[2];
+            const float4 ta = tp[0], tb = tp[1], tc = tp[2];
             if (COUNT) nleaf += 1;
             const v3 o = V(r.ox, r.oy, r.oz), d = V(r.dx, r.dy, r.dz);
+            const bool is_tri = ((code >> 30) & 1) == 0;
+            const v3 pa = V(ta.x, ta.y, ta.z), pb = V(tb.x, tb.y, tb.z), pc = V(tc.x, tc.y, tc.z);
             float t, u, v;
-            if (((code >> 30) & 1) == 0) {
-                t = intersect_tri_packed(o, d, V(ta.x, ta.y, ta.z), V(e1.x, e1.y, e1.z), V(e2.x, e2.y, e2.z), u, v);
+            if (is_tri) {
+                t = intersect_tri_packed(o, d, pa, pb - pa, pc - pa, u, v);          // E1 = v2 - v1, E2 = v3 - v1 (Scene.py:608-609)
             } else {
                 float cc; u = 0.0f; v = 0.0f;
-                t = ((int)e1.y == SHAPE_SPHERE) ? intersect_sphere(o, d, V(ta.x, ta.y, ta.z), e1.x, cc) : INF_VALUE;
+                t = ((int)tb.y == SHAPE_SPHERE) ? intersect_sphere(o, d, pa, tb.x, cc) : INF_VALUE;
             }
             const int leaf = __float_as_int(ta.w);
             TR_POP(cur);
             // reference: accept iff 0 < t < hit_t (so never t >= INF_VALUE); equal-t candidates: see header
             bool cand = (t > 0.0f) & ((t < hit_t) | ((t == hit_t) & (hit_leaf >= 0) & (leaf > hit_leaf)));
+#ifndef TR_NO_VERIFY
             if (MODE != TIRT_TRAVERSE_EXHAUSTIVE && cand) {
                 // The quantised boxes that led here contain the reference's: would the reference have visited this leaf
                 // (Scene.py:702-744: every proper ancestor's box passes `slabs`)?  The leaf's own exact box passing implies
                 // it (the outer of two nested boxes passes whenever the inner one does: `slabs` is monotone in the planes);
-                // otherwise -- a hit within rounding distance of the leaf box's boundary -- the ancestors are asked one by one.
-                const float *lb = b.compact + (size_t)leaf * CPN_VEC + 2;
+                // that box is the min / max of the three positions just loaded (accel/LBvh.py:397-426; spheres: centre -+ r).
+                // Otherwise -- a hit within rounding distance of the leaf box's boundary -- the ancestors are asked one by one.
+                v3 bmn, bmx;
+                if (is_tri) {
+                    bmn = V(minf(minf(pa.x, pb.x), pc.x), minf(minf(pa.y, pb.y), pc.y), minf(minf(pa.z, pb.z), pc.z));
+                    bmx = V(maxf(maxf(pa.x, pb.x), pc.x), maxf(maxf(pa.y, pb.y), pc.y), maxf(maxf(pa.z, pb.z), pc.z));
+                } else {
+                    bmn = V(pa.x - tb.x, pa.y - tb.x, pa.z - tb.x); bmx = V(pa.x + tb.x, pa.y + tb.x, pa.z + tb.x);
+                }
                 float tn_;
-                if (!slabs(r, lb[0], lb[1], lb[2], lb[3], lb[4], lb[5], tn_)) {
+                const RayCtx rv = make_ray(o, d);           // 1/d again (same quotients) instead of three registers kept alive across the whole walk
+                const int inside = par ? slabs(rv, bmn.x, bmn.y, bmn.z, bmx.x, bmx.y, bmx.z, tn_) : slabs_fast(rv, bmn.x, bmn.y, bmn.z, bmx.x, bmx.y, bmx.z, tn_);
+                if (!inside) {
                     for (int an = b.cparent[leaf]; an >= 0; an = b.cparent[an]) {
                         const float *ab = b.compact + (size_t)an * CPN_VEC + 2;
-                        if (!slabs(r, ab[0], ab[1], ab[2], ab[3], ab[4], ab[5], tn_)) { cand = false; break; }
+                        if (!slabs(rv, ab[0], ab[1], ab[2], ab[3], ab[4], ab[5], tn_)) { cand = false; break; }
                     }
                 }
             }
+#endif
             if (cand) {
                 hit_t = t; hit_u = u; hit_v = v; hit_prim = prim; hit_leaf = leaf;
                 lim = minf(minf(hit_t * 1.0001f, cull_far), INF_VALUE);
