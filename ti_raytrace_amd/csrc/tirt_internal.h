@@ -75,17 +75,23 @@ constexpr int TR_TOP_LEVELS = TR_TOP_LEVELS_N;           // levels of 4-wide nod
 constexpr int TR_TOP_FULL = ((1 << (2 * TR_TOP_LEVELS)) - 1) / 3;
 constexpr int TR_TOP_SLOTS = TR_TOP_FULL < TR_TOP_CAP ? TR_TOP_FULL : TR_TOP_CAP;   // 341 for five levels (38 KB of LDS per block)
 constexpr int TR_TOP_BIT = 1 << 29;                      // child code of a 4-wide node that lives in the LDS-resident top: TR_TOP_BIT | slot
-// cnode: the 4-wide nodes again, 64 bytes each, box planes quantised to 16 bits on ONE grid over the root box
-//   (k_cnodes): plane = grid_min + q * cell, min planes rounded down and max planes up by at least one cell, so a
-//   cnode box CONTAINS the reference box it stands for.  k_trace<ordered> walks these (4 dwordx4 loads per visit
-//   instead of 7, 3.2 MB instead of 6.4 MB at 100k triangles).  A conservative box can only add visits; it may,
+// cnode: the 4-wide nodes again, 64 bytes each, box planes quantised on ONE grid over the root box (k_cnodes):
+//   plane = grid_min + h * cell with h an fp16 number of cells measured from the CENTRE of the root box (|h| <= 30000:
+//   the spacing of fp16 there is 16 cells = 2.7e-4 of the extent, finer towards the centre), min planes rounded down
+//   and max planes up by at least one cell, so a cnode box CONTAINS the reference box it stands for.  fp16 because
+//   v_fma_mix_f32 converts and multiplies-adds in one instruction: crossing distance of a plane = h * gA + gB, one
+//   VALU op (a 16-bit integer grid needs a conversion first: 24 more instructions per node visit of a kernel that is
+//   bound by VALU issue).  k_trace<ordered> walks these (4 dwordx4 loads per visit instead of 7, 3.2 MB instead of
+//   6.4 MB at 100k triangles).  A conservative box can only add visits; it may,
 //   however, reach a leaf the reference does not (the reference tests its exact fp32 boxes with fp32 arithmetic
 //   and a grazing ray can fail an ancestor's box yet pass the triangle test), so a candidate hit is ACCEPTED only
 //   after the reference's own condition is re-established: `slabs` on the leaf's exact box -- which implies every
 //   ancestor's, `slabs` being monotone in the plane positions --, else `slabs` on every proper ancestor
 //   (compact rows, cparent chain; rare).  The closest accepted hit is therefore the reference's, bit for bit.
-//   dword 3c+a (c = child slot 0..3, a = axis): min plane | max plane << 16;  dwords 12..15: child codes as in qnode
-//   (TR_EMPTY slots hold the inverted box 65535 | 0, which no ray passes).
+//   dword 3c+a (c = child slot 0..3, a = axis): half(min plane) | half(max plane) << 16;  dwords 12..15: child codes as
+//   in qnode (TR_EMPTY slots hold an inverted box, which no ray passes).
+constexpr float TR_GRID_HALF = 30000.0f;      // the padded root box spans cells -30000 .. +30000
+constexpr unsigned TR_H_POS = 0x7b53u, TR_H_NEG = 0xfb53u;      // fp16 +-60000
 #ifndef TR_BLOCK_SIZE
 #define TR_BLOCK_SIZE 512
 #endif
@@ -107,7 +113,6 @@ struct BvhView {
     int root_code;                // two-child layout: compact index 0, or the leaf code of a one-primitive scene
     int root_qcode;               // 4-wide layout: TR_TOP_BIT | 0, or the same leaf code
 };
-constexpr float TR_GRID_CELLS = 65531.0f;     // the root box spans cells 2 .. 65533 of the 16-bit grid: +-1 rounding guards never clamp
 
 // Wavefront state, struct-of-arrays in HBM.  Live paths are kept DENSE: every bounce the shade
 // kernel writes the surviving paths' state into the other PathSoA at consecutive indices

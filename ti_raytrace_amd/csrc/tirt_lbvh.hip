@@ -15,6 +15,7 @@
 // All integer work; the only fp32 arithmetic is the centroid/normalisation in k_morton and
 // the min/max of the boxes -- compiled with -ffp-contract=off, bit-identical to the oracle.
 #include "tirt_internal.h"
+#include <hip/hip_fp16.h>
 
 namespace tirt {
 
@@ -524,19 +525,20 @@ __global__ void k_qnodes(SceneView s, int N, const float *compact, const int *qu
     }
 }
 
-// Quantised 4-wide nodes (tirt_internal.h, BvhView::cnode): the same slots as k_qnodes, every plane mapped to the
-// 16-bit grid over the root box, min planes down and max planes up, one more cell outward against the rounding of
-// the mapping itself.  Leaf slots are padded like qnode's before the mapping.
+// Quantised 4-wide nodes (tirt_internal.h, BvhView::cnode): the same slots as k_qnodes, every plane mapped to grid
+// cells around the centre of the root box and stored as fp16, min planes rounded down and max planes up, one more cell
+// outward against the rounding of the mapping itself.  Leaf slots are padded like qnode's before the mapping.
 // Analytic shapes (the sphere light) keep the whole grid as their slot box: the reference never box-tests a leaf
 // (Scene.py:716-722), and its sphere test (Scene.py:565-596: a square root of a difference of squares of the distance
 // to the centre) answers "hit" for rays that pass the sphere at a distance that grows with the distance of the origin
 // -- no fixed padding of the sphere's box covers that.  Triangle leaves are safe behind `pad` plus the per-ray margin.
 struct GridMap { float g0[3], inv_cell[3]; };
 TD bool is_shape_leaf(int code) { return code < 0 && code != TR_EMPTY && (((~code) >> 30) & 1) != 0; }
+// fp16 bit pattern of the largest half <= x - 1 / the smallest half >= x + 1 (x in grid cells, |x| <= TR_GRID_HALF + a few)
 TD unsigned grid_lo(float x, float g0, float inv_cell)
-{ float q = tm_floor((x - g0) * inv_cell) - 1.0f; q = q < 0.0f ? 0.0f : (q > 65535.0f ? 65535.0f : q); return (unsigned)q; }
+{ const float v = (x - g0) * inv_cell - 1.0f; return (unsigned)__half_as_ushort(__float2half_rd(v < -60000.0f ? -60000.0f : (v > 60000.0f ? 60000.0f : v))); }
 TD unsigned grid_hi(float x, float g0, float inv_cell)
-{ float v = (x - g0) * inv_cell, f = tm_floor(v); float q = (f < v ? f + 1.0f : f) + 1.0f; q = q < 0.0f ? 0.0f : (q > 65535.0f ? 65535.0f : q); return (unsigned)q; }
+{ const float v = (x - g0) * inv_cell + 1.0f; return (unsigned)__half_as_ushort(__float2half_ru(v < -60000.0f ? -60000.0f : (v > 60000.0f ? 60000.0f : v))); }
 __global__ void k_cnodes(SceneView s, int N, const float *compact, const int *quad_flag, const int *quad_index, const int *quad_top,
                          uint4 *cnode, uint4 *ctop, float pad, GridMap gm)
 {
@@ -556,8 +558,8 @@ __global__ void k_cnodes(SceneView s, int N, const float *compact, const int *qu
     unsigned w[16];
     for (int c = 0; c < 4; c++) {
         for (int a = 0; a < 3; a++)
-            w[3 * c + a] = (sl[c].code == TR_EMPTY) ? 0x0000ffffu
-                           : is_shape_leaf(sl[c].code) ? 0xffff0000u
+            w[3 * c + a] = (sl[c].code == TR_EMPTY) ? (TR_H_POS | (TR_H_NEG << 16))       // inverted box: never hit
+                           : is_shape_leaf(sl[c].code) ? (TR_H_NEG | (TR_H_POS << 16))
                            : (grid_lo(sl[c].mn[a], gm.g0[a], gm.inv_cell[a]) | (grid_hi(sl[c].mx[a], gm.g0[a], gm.inv_cell[a]) << 16));
         w[12 + c] = (unsigned)sl[c].code;
     }
@@ -643,13 +645,13 @@ int lbvh_build(tirt_ctx *c)
     hipLaunchKernelGGL(k_tris, dim3((n + B - 1) / B), dim3(B), 0, st, sv, c->leaf_compact.as<int>(), c->tri.as<float4>());
     hipLaunchKernelGGL(k_qnodes, dim3((N + B - 1) / B), dim3(B), 0, st, sv, N, c->compact.as<float>(), c->quad_flag.as<int>(),
                        c->quad_index.as<int>(), c->quad_top.as<int>(), c->qnode.as<float4>(), c->qtop.as<float4>(), pad);
-    // 16-bit grid of the quantised nodes: the (padded) root box spans cells 2 .. TR_GRID_CELLS + 2
+    // grid of the quantised nodes: the (padded) root box spans cells -TR_GRID_HALF .. +TR_GRID_HALF around its centre
     GridMap gm;
     for (int k = 0; k < 3; k++) {
         const float lo = c->root_min[k] - pad, hi = c->root_max[k] + pad;
         float ext = hi - lo; if (!(ext > 0.0f)) ext = 1.0e-30f;
-        const float cell = ext / TR_GRID_CELLS;
-        c->grid_cell[k] = cell; c->grid_min[k] = lo - 2.0f * cell; c->grid_inv_extent[k] = 1.0f / ext;
+        const float cell = ext / (2.0f * TR_GRID_HALF);
+        c->grid_cell[k] = cell; c->grid_min[k] = lo + 0.5f * ext; c->grid_inv_extent[k] = 1.0f / ext;
         gm.g0[k] = c->grid_min[k]; gm.inv_cell[k] = 1.0f / cell; c->grid_inv_cell[k] = gm.inv_cell[k];
     }
     hipLaunchKernelGGL(k_cnodes, dim3((N + B - 1) / B), dim3(B), 0, st, sv, N, c->compact.as<float>(), c->quad_flag.as<int>(),

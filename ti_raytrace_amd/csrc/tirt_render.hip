@@ -68,6 +68,7 @@ struct TraceArgs {
 constexpr int TR_FETCH_STRIDE = 32;           // ints between two slice cursors (one 128-byte line each)
 constexpr int TR_SLICES_MAX = 64;
 typedef float f2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h2v __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) int lds_int;
 constexpr int TR_PAGE = 8;                    // stack entries moved per page-out / page-in
 constexpr int TR_SENT = (int)0x80000000;      // "stack empty": never a node index nor a leaf code
@@ -83,7 +84,7 @@ TD unsigned long long wave_sum(unsigned long long v)
 }
 
 #ifndef TR_MIN_WAVES
-#define TR_MIN_WAVES 6
+#define TR_MIN_WAVES 4
 #endif
 template <int MODE, bool COUNT, int KIND>
 __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
@@ -108,8 +109,8 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
     float lim = INF_VALUE;                      // ordered mode: min(hit_t * 1.0001, cull_far, INF_VALUE), entry distances beyond it are skipped
     unsigned nbox = 0, nleaf = 0;
     RayCtx r = {};
-    // ordered mode: the ray in the 16-bit grid of the quantised nodes.  Plane q of axis a is crossed at
-    // t = q * gA + gB (gA = cell / d, gB = (grid_min - o) / d); gBn / gBf are gB moved outward by a margin of
+    // ordered mode: the ray in the grid of the quantised nodes.  Plane h (fp16, in cells) of axis a is crossed at
+    // t = h * gA + gB (gA = cell / d, gB = (grid_min - o) / d); gBn / gBf are gB moved outward by a margin of
     // 0.25 cells + 0.25 cells per root-box extent of distance between the origin and the grid (see the set-up code
     // for what it covers); grot = 16 where gA < 0 rotates a (min | max << 16) plane
     // pair so that the low half is always the near plane.  Axis-parallel components (|d| < 1e-6, where the
@@ -300,16 +301,17 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
                     if (COUNT) nbox += 4;
                     constexpr float MISS = 3.0e38f;
                     float d0, d1, d2, d3;                // entry distance of a hit box, MISS otherwise
-                    // near/far crossing of each axis: one rotate, two u16 -> f32 conversions (SDWA), two FMAs; then
+                    // near/far crossing of each axis: one rotate, two v_fma_mix_f32 (fp16 plane x f32 + f32); then
                     // box hit and entry not beyond the cull distance: tn <= min(tf, lim)
 #define TR_CBOX(X, Y, Z, dist)                                                                       \
                     do {                                                                             \
                         const unsigned ux__ = __builtin_amdgcn_alignbit((X), (X), grotx);            \
                         const unsigned uy__ = __builtin_amdgcn_alignbit((Y), (Y), groty);            \
                         const unsigned uz__ = __builtin_amdgcn_alignbit((Z), (Z), grotz);            \
-                        const float nx__ = __builtin_fmaf((float)(ux__ & 0xffffu), gAx, gBnx), fx__ = __builtin_fmaf((float)(ux__ >> 16), gAx, gBfx); \
-                        const float ny__ = __builtin_fmaf((float)(uy__ & 0xffffu), gAy, gBny), fy__ = __builtin_fmaf((float)(uy__ >> 16), gAy, gBfy); \
-                        const float nz__ = __builtin_fmaf((float)(uz__ & 0xffffu), gAz, gBnz), fz__ = __builtin_fmaf((float)(uz__ >> 16), gAz, gBfz); \
+                        const h2v hx__ = __builtin_bit_cast(h2v, ux__), hy__ = __builtin_bit_cast(h2v, uy__), hz__ = __builtin_bit_cast(h2v, uz__); \
+                        const float nx__ = __builtin_fmaf((float)hx__.x, gAx, gBnx), fx__ = __builtin_fmaf((float)hx__.y, gAx, gBfx); \
+                        const float ny__ = __builtin_fmaf((float)hy__.x, gAy, gBny), fy__ = __builtin_fmaf((float)hy__.y, gAy, gBfy); \
+                        const float nz__ = __builtin_fmaf((float)hz__.x, gAz, gBnz), fz__ = __builtin_fmaf((float)hz__.y, gAz, gBfz); \
                         const float tn__ = __builtin_fmaxf(__builtin_fmaxf(nx__, ny__), __builtin_fmaxf(nz__, 0.0f)); \
                         const float tf__ = __builtin_fminf(__builtin_fminf(fx__, fy__), __builtin_fminf(fz__, lim));  \
                         dist = (tn__ <= tf__) ? tn__ : MISS;                                         \
@@ -383,7 +385,11 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
                     bmn = V(pa.x - tb.x, pa.y - tb.x, pa.z - tb.x); bmx = V(pa.x + tb.x, pa.y + tb.x, pa.z + tb.x);
                 }
                 float tn_;
+#ifdef TR_RECIP_AGAIN
                 const RayCtx rv = make_ray(o, d);           // 1/d again (same quotients) instead of three registers kept alive across the whole walk
+#else
+                const RayCtx &rv = r;
+#endif
                 const int inside = par ? slabs(rv, bmn.x, bmn.y, bmn.z, bmx.x, bmx.y, bmx.z, tn_) : slabs_fast(rv, bmn.x, bmn.y, bmn.z, bmx.x, bmx.y, bmx.z, tn_);
                 if (!inside) {
                     for (int an = b.cparent[leaf]; an >= 0; an = b.cparent[an]) {
