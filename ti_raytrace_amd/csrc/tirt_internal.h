@@ -214,7 +214,7 @@ struct tirt_ctx {
     struct { bool valid = false; uint32_t begin = 0; int count = 0; uint32_t seed = 0; int max_depth = 0, stack_size = 0, flags = 0; } pend;
     // traversal tunables (options "trace_lds_depth", "trace_refill_min", "trace_node_min", "trace_grid",
     // "trace_slices" = number of ray-fetch cursors, "shade_grid" = persistent blocks of k_shade)
-    int tr_lds_depth = 16, tr_refill_min = 20, tr_node_min = 28, tr_grid = 384, tr_slice_log2 = 5, sh_grid = 1024;
+    int tr_lds_depth = 16, tr_refill_min = 18, tr_node_min = 38, tr_grid = 384, tr_slice_log2 = 5, sh_grid = 1024;
     int tr_grid_alone = 512;                      // "trace_grid_alone": persistent blocks of a batch submitted to an idle GPU (two per CU);
                                                   // tr_grid (1.5 per CU) leaves LDS for the traversal kernel of the batch running next to it
     tirt::DevBuf counters_mem, spill;            // used by the batch trace entry points (main stream)
