@@ -263,7 +263,8 @@ void tirt_destroy(tirt_ctx *c)
                       &c->keys_b, &c->vals_a, &c->vals_b, &c->hist, &c->morton_sorted, &c->bvh_node, &c->compact, &c->parent,
                       &c->flag, &c->subtree, &c->build_status, &c->leaf_compact, &c->wnode, &c->tri, &c->qnode, &c->quad_flag, &c->quad_index, &c->quad_top, &c->qtop, &c->scan_tiles, &c->cnode, &c->ctop, &c->cparent, &c->hdr, &c->rgb,
                       &c->counters_mem, &c->spill, &c->tr_rays,
-                      &c->tr_out, &c->tr_prim, &c->tr_counts, &c->dev_counters, &c->bdpt_px, &c->bdpt_rad};
+                      &c->tr_out, &c->tr_prim, &c->tr_counts, &c->dev_counters, &c->bdpt_px, &c->bdpt_rad, &c->bdpt_items, &c->bdpt_state,
+                      &c->bdpt_rays, &c->bdpt_hits, &c->bdpt_qidx, &c->bdpt_ctr};
     for (DevBuf *b : bufs) b->release();
     for (Lane &L : c->lanes) {
         DevBuf *lb[] = {&L.path_mem, &L.counters_mem, &L.spill};
@@ -317,6 +318,7 @@ int tirt_set_option(tirt_ctx *c, const char *name, double value)
     if (!strcmp(name, "trace_refill_min")) { TIRT_REQUIRE(value >= 1 && value <= 64, "trace_refill_min: 1..64"); c->tr_refill_min = (int)value; return TIRT_OK; }
     if (!strcmp(name, "trace_node_min")) { TIRT_REQUIRE(value >= 1 && value <= 64, "trace_node_min: 1..64"); c->tr_node_min = (int)value; return TIRT_OK; }
     if (!strcmp(name, "bdpt_bounded")) { c->bdpt_bounded = value != 0.0 ? 1 : 0; return TIRT_OK; }
+    if (!strcmp(name, "bdpt_batch_items")) { TIRT_REQUIRE(value >= 1.0 && value <= 1.0e9, "bdpt_batch_items out of range"); c->bdpt_batch_items = (size_t)value; return TIRT_OK; }
     if (!strcmp(name, "trace_slices")) {
         const int iv = (int)value;
         TIRT_REQUIRE(iv >= 1 && iv <= 64 && (iv & (iv - 1)) == 0, "trace_slices: power of two, 1..64");

@@ -1,15 +1,30 @@
 // tirt_bdpt.hip -- BDPT_RGB (BASELINE config 5): bidirectional path tracing
-// with all (eye, light) sub-path connections, MIS and light-tracing splats.
+// with all (eye, light) sub-path connections, MIS and light-tracing splats, as a WAVEFRONT.
 //
-// Restates integrator/BDPT_RGB.py + BDPT_Vertex.py as ONE per-pixel kernel (like the reference's
-// render(): eye_path, light_path, then every connection) on top of this library's BVH layout,
-// with a plain per-thread traversal (stack in private memory).  The wavefront machinery of
-// PT_RGB is not used here yet: this row is about parity with the restated algorithm first.
-// Reference behaviours kept on purpose (see oracle/oracle.c for the same list): per-pixel vertex
-// arrays persist across frames with only beta/type/fpdf/rpdf cleared; material index compared
-// with MAT_DISNEY in mis_weight; restores to index -1 skipped.  Light-tracing contributions are
-// added to other pixels with float atomics, so a frame is reproducible only up to the order of
-// those additions (the parity test uses the north star's 1e-3 relative-L2 tolerance).
+// The reference (integrator/BDPT_RGB.py:595-642) is one per-pixel kernel: eye_path, light_path, then every (e, l)
+// connection, each with its traversal inlined.  Here every ray goes through the traversal kernel of PT_RGB
+// (tirt_render.hip, k_trace) in large batches, and the arithmetic around the rays runs in between:
+//
+//   k_bd_init          lens vertex + camera ray, light vertex + first light ray       BDPT_RGB.py:104-125, 201-228
+//   6 x { trace 2N rays ; k_bd_step(d) }   vertex d of the eye and of the light sub-path   BDPT_RGB.py:126-198, 229-294
+//   k_bd_delta         the one field that survives from frame to frame (see below)
+//   k_bd_connect<0>    geometry of every (e, l) connection, connection rays to a dense queue   BDPT_RGB.py:481-592
+//   trace queries      "is the expected primitive the closest hit?"  (k_trace<KIND_QUERY>, bounded)
+//   k_bd_connect<1>    contribution + MIS weight (BDPT_RGB.py:300-479), splats with float atomics
+//   k_bdpt_film        running mean, frames in order                                   BDPT_RGB.py:639-642
+//
+// An item is one (frame, pixel) pair with its own vertex arrays (`bpixel`, 1.5 KB); a batch holds up to
+// `bdpt_batch_items` of them (frames x owned pixels), so many frames are in flight at once.  The reference keeps ONE
+// set of vertex arrays per pixel and clears only beta/type/fpdf/rpdf between frames; walking through every read of a
+// field that the current frame has not written shows a single one that matters: the `delta` flag of an eye vertex
+// that ended on a light (eye_path breaks before it stores delta there, BDPT_RGB.py:152-158) is the delta some earlier
+// frame left in that slot, and connect_path's l == 1 branch reads it.  k_bd_delta replays exactly that: per pixel, in
+// frame order, over a small persistent per-pixel memory of the seven delta fields (`bdpt_px`).  Everything else
+// (sample/temp vertices of mis_weight, geometry of slots beyond the current depth) is written before it is read.
+// Other reference behaviours kept on purpose (see oracle/oracle.c for the same list): material INDEX compared with
+// MAT_DISNEY in mis_weight; restores to index -1 skipped.  Light-tracing contributions are added to other pixels with
+// float atomics, so a frame is reproducible only up to the order of those additions (the parity test uses the north
+// star's 1e-3 relative-L2 tolerance; measured 1e-7).
 #include "tirt_internal.h"
 
 namespace tirt {
@@ -24,77 +39,15 @@ struct bvert { v3 pos, normal, snormal, beta, wo; float fpdf, rpdf; int type, pr
 struct bpixel { bvert eye[BD_EYE_MAX], light[BD_LIGHT_MAX], sample, ltemp, etemp, lminustemp, eminustemp; };
 
 struct BdView { float view[12]; int W, H; };
-
-// ---- plain traversal (ordered, t-culled; same hit as the reference's exhaustive order) ------------
 struct SimpleHit { float t, u, v; int prim; };
-constexpr int BD_BLOCK = 64, BD_STACK = 64;
-// With expect >= -1 and t_bound > 0 the ray is a connection test ("is `expect` the closest hit, about t_bound
-// away?"): nodes beyond 1.01 x t_bound are skipped and a hit on another primitive before 0.99 x t_bound ends
-// the walk -- same yes/no (and the same t when yes) as the full closest-hit query, as in k_trace's shadow rays.
-TD SimpleHit trace_simple(const BvhView &b, v3 o, v3 d, int *stack /* LDS, [entry][lane] */, unsigned long long *ovf, int expect = -3, float t_bound = -1.0f)
+
+// A connection needs at most one ray.  Pass 0 of k_bd_connect records it (and sees a miss, so nothing downstream
+// runs and nothing is written); pass 1 is handed the traced result.
+struct Tracer { int phase; bool want; v3 o, d; int expect; float bound; SimpleHit res; };
+TD SimpleHit bd_trace(Tracer &T, v3 o, v3 d, int expect, float bound)
 {
-    const bool bounded = t_bound > 0.0f;
-    const float cull_far = bounded ? t_bound * 1.01f : 3.0e38f, settle = bounded ? t_bound * 0.99f : -1.0f;
-    SimpleHit h; h.t = INF_VALUE; h.u = 0.0f; h.v = 0.0f; h.prim = -1;
-    int hit_leaf = -1;
-    const RayCtx r = make_ray(o, d);
-    if (!((o.x == o.x) & (o.y == o.y) & (o.z == o.z) & (d.x == d.x) & (d.y == d.y) & (d.z == d.z))) return h;   // NaN ray: misses
-    int cur = b.root_qcode;
-    if (cur >= 0) {
-        float tn;
-        if (!slabs(r, b.root_min[0], b.root_min[1], b.root_min[2], b.root_max[0], b.root_max[1], b.root_max[2], tn)) return h;
-    }
-    int sp = 0;
-    const bool par = ray_has_parallel_axis(r);
-    constexpr float MISS = 3.0e38f;
-    for (;;) {
-        if (cur >= 0) {
-            // 4-wide node (tirt_internal.h): the first levels are addressed by breadth-first slot in qtop
-            const float4 *w = (cur & TR_TOP_BIT) ? b.qtop + (size_t)(cur & 0xffff) * 8 : b.qnode + (size_t)cur * 8;
-            const float4 q0 = w[0], q1 = w[1], q2 = w[2], q3 = w[3], q4 = w[4], q5 = w[5], q6 = w[6];
-            int c0 = __float_as_int(q6.x), c1 = __float_as_int(q6.y), c2 = __float_as_int(q6.z), c3 = __float_as_int(q6.w);
-            const float lim = minf(minf(h.t * 1.0001f, cull_far), INF_VALUE);
-            float d0, d1, d2, d3;
-#define BD_QBOX(mnx, mny, mnz, mxx, mxy, mxz, dist)                                                  \
-            do {                                                                                     \
-                float tn__;                                                                          \
-                const int p__ = par ? slabs(r, mnx, mny, mnz, mxx, mxy, mxz, tn__) : slabs_fast(r, mnx, mny, mnz, mxx, mxy, mxz, tn__); \
-                dist = ((p__ != 0) && (tn__ <= lim)) ? tn__ : MISS;                                  \
-            } while (0)
-            BD_QBOX(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, d0);
-            BD_QBOX(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, d1);
-            BD_QBOX(q3.x, q3.y, q3.z, q3.w, q4.x, q4.y, d2);
-            BD_QBOX(q4.z, q4.w, q5.x, q5.y, q5.z, q5.w, d3);
-#define BD_CE(da, ca, db, cb)                                                                        \
-            do {                                                                                     \
-                const bool s__ = (db) < (da);                                                        \
-                const float lo__ = s__ ? (db) : (da), hi__ = s__ ? (da) : (db);                      \
-                const int clo__ = s__ ? (cb) : (ca), chi__ = s__ ? (ca) : (cb);                      \
-                da = lo__; db = hi__; ca = clo__; cb = chi__;                                        \
-            } while (0)
-            BD_CE(d0, c0, d1, c1); BD_CE(d2, c2, d3, c3); BD_CE(d0, c0, d2, c2); BD_CE(d1, c1, d3, c3); BD_CE(d1, c1, d2, c2);
-            if (d3 < MISS) { if (sp < BD_STACK) { stack[sp * BD_BLOCK] = c3; sp++; } else atomicAdd(ovf, 1ull); }
-            if (d2 < MISS) { if (sp < BD_STACK) { stack[sp * BD_BLOCK] = c2; sp++; } else atomicAdd(ovf, 1ull); }
-            if (d1 < MISS) { if (sp < BD_STACK) { stack[sp * BD_BLOCK] = c1; sp++; } else atomicAdd(ovf, 1ull); }
-            if (d0 < MISS) { cur = c0; continue; }
-        } else {
-            const int code = ~cur;
-            const int prim = code & 0x3fffffff;
-            const float4 *tp = b.tri + (size_t)prim * TRI_STRIDE;
-            const float4 ta = tp[0], e1 = tp[1], e2 = tp[2];
-            float t, u, v;
-            if (((code >> 30) & 1) == 0) t = intersect_tri_packed(o, d, V(ta.x, ta.y, ta.z), V(e1.x, e1.y, e1.z) - V(ta.x, ta.y, ta.z), V(e2.x, e2.y, e2.z) - V(ta.x, ta.y, ta.z), u, v);
-            else { float cc; u = 0.0f; v = 0.0f; t = ((int)e1.y == SHAPE_SPHERE) ? intersect_sphere(o, d, V(ta.x, ta.y, ta.z), e1.x, cc) : INF_VALUE; }
-            const int leaf = __float_as_int(ta.w);
-            if ((t > 0.0f) & ((t < h.t) | ((t == h.t) & (hit_leaf >= 0) & (leaf > hit_leaf)))) {
-                h.t = t; h.u = u; h.v = v; h.prim = prim; hit_leaf = leaf;
-                if (bounded && prim != expect && t < settle) return h;          // occluded: the answer is settled
-            }
-        }
-        if (sp == 0) break;
-        sp--; cur = stack[sp * BD_BLOCK];
-    }
-    return h;
+    if (T.phase == 0) { T.want = true; T.o = o; T.d = d; T.expect = expect; T.bound = bound; SimpleHit m; m.t = INF_VALUE; m.u = 0.0f; m.v = 0.0f; m.prim = -1; return m; }
+    return T.res;
 }
 
 TD float cosine_hemisphere_pdf(float c) { return maxf(0.01f, c / PI_UF); }       // UtilsFunc.py:348-350
@@ -159,146 +112,8 @@ TD bsample bd_sample(const SceneView &s, v3 dir, v3 normal, v3 fnormal, int mat_
     return r;
 }
 
-struct BdCtx { SceneView sc; BvhView bvh; CameraView cam; BdView bv; uint32_t seed; unsigned long long *rays_closest, *rays_shadow, *paths, *stack_overflow; int *stack; int bounded; };
+struct BdCtx { SceneView sc; CameraView cam; BdView bv; uint32_t seed; int bounded; };
 
-// BDPT_RGB.py:103-198
-TD int bd_eye_path(const BdCtx &c, bpixel *P, int i, int j, uint32_t frame, unsigned &n_closest)
-{
-    const uint32_t pixel = (uint32_t)(i * c.bv.H + j);
-    bvert *eye = P->eye;
-    v3 origin = V(c.cam.eye[0], c.cam.eye[1], c.cam.eye[2]);
-    float jx = 0.0f, jy = 0.0f;
-    if (frame != 0) { jx = tm_rand(c.seed, pixel, frame, TM_DIM_JX) - 0.5f; jy = tm_rand(c.seed, pixel, frame, TM_DIM_JY) - 0.5f; }
-    v3 dir = camera_ray_direction(c.cam, i, j, jx, jy);
-    eye[0].pos = origin; eye[0].normal = dir; eye[0].beta = V(1.0f, 1.0f, 1.0f); eye[0].fpdf = 1.0f; eye[0].type = VERTEX_LENS;
-    int pre_depth = 0, depth = 1;
-    float pdfFwd = 1.0f, pdfRev = 0.0f;
-    v3 beta = V(1.0f, 1.0f, 1.0f);
-    while (depth < BD_EYE_MAX) {
-        const SimpleHit sh = trace_simple(c.bvh, origin, dir, c.stack, c.stack_overflow);
-        n_closest++;
-        if (sh.t < INF_VALUE) {
-            const HitAttr h = hit_attributes(c.sc, origin, dir, sh.prim, sh.t, sh.u, sh.v);
-            const v3 normal = h.nor, pos = h.pos;
-            const v3 fnormal = normal * signf(dot(-dir, h.gnor));
-            const int mat_id = c.sc.primitive[(size_t)sh.prim * PRI_VEC + 2];
-            const float *m = mat_row(c.sc, mat_id);
-            const v3 mat_color = V(m[2], m[3], m[4]);
-            const int mat_type = (int)m[0];
-            v3 to = pos - origin;
-            const float dist = maxf(norm(to), 0.01f);
-            const float inv_dist2 = 1.0f / (dist * dist);
-            to = to / dist;
-            bvert *e = &eye[depth];
-            e->pos = pos; e->normal = normal; e->snormal = fnormal; e->wo = dir; e->rpdf = 0.0f; e->prim = sh.prim; e->mat = mat_id;
-            e->fpdf = pdfFwd * absf(dot(to, eye[pre_depth].normal)) * inv_dist2;
-            if (mat_type == MAT_LIGHT) {
-                e->beta = (beta * mat_color) * absf(dot(normal, dir));
-                e->type = VERTEX_LIGHT;
-                depth += 1;
-                break;
-            } else {
-                e->beta = beta * absf(dot(dir, normal));
-                e->type = VERTEX_SURFACE;
-            }
-            const v3 reflect_color = srgb_to_lrgb(mat_color);
-            int delta = 0;
-            const bsample bs = bd_sample(c.sc, dir, normal, fnormal, mat_id, mat_type, c.seed, pixel, frame, BD_DIM_EYE + 8u * (uint32_t)depth, delta);
-            e->delta = delta;
-            pdfFwd = bs.pdfFwd;
-            if (pdfFwd > 0.0f) {
-                if (mat_type == MAT_GLASS) {
-                    pdfRev = 0.0f; pdfFwd = 0.0f;
-                    beta = beta * (reflect_color * bs.brdf);
-                } else {
-                    beta = beta * (((reflect_color * bs.brdf) * absf(dot(normal, bs.next_dir))) / pdfFwd);
-                    pdfRev = disney_pdf(m, fnormal, bs.next_dir, -dir);
-                }
-                eye[pre_depth].rpdf = pdfRev * absf(dot(to, e->normal)) * inv_dist2;
-                if (bs.f_or_b < 0.0f) {
-                    const float R = tm_exp(-sh.t / m[6]);
-                    if (tm_rand(c.seed, pixel, frame, BD_DIM_EYE + 8u * (uint32_t)depth + TM_SLOT_EXT) >= R) break;
-                }
-                depth += 1; pre_depth += 1;
-                origin = offset_ray(pos, fnormal * signf(bs.f_or_b));
-                dir = bs.next_dir;
-            } else break;
-        } else break;
-    }
-    return depth;
-}
-
-// BDPT_RGB.py:200-294 with Scene.sample_light (Scene.py:430-474)
-TD int bd_light_path(const BdCtx &c, bpixel *P, int i, int j, uint32_t frame, unsigned &n_closest)
-{
-    const uint32_t pixel = (uint32_t)(i * c.bv.H + j);
-    const SceneView &s = c.sc;
-    bvert *light = P->light;
-    int lidx = (int)(tm_rand(c.seed, pixel, frame, BD_DIM_LSTART + 0) * (float)s.light_count);
-    if (lidx >= s.light_count) lidx = s.light_count - 1;
-    const int lp = s.light[lidx];
-    v3 lpos, lnor;
-    get_prim_random_point_normal(s, lp, tm_rand(c.seed, pixel, frame, BD_DIM_LSTART + 1), tm_rand(c.seed, pixel, frame, BD_DIM_LSTART + 2), lpos, lnor);
-    const float *lm = mat_row(s, s.primitive[(size_t)lp * PRI_VEC + 2]);
-    const v3 emission = V(lm[2], lm[3], lm[4]);
-    const float choice_pdf = 1.0f / ((float)s.light_count * get_prim_area(s, lp));
-    lnor = normalized(lnor);
-    const v3 ld = cosine_sample_hemisphere(tm_rand(c.seed, pixel, frame, BD_DIM_LSTART + 3), tm_rand(c.seed, pixel, frame, BD_DIM_LSTART + 4));
-    const float dir_pdf = cosine_hemisphere_pdf(ld.z);
-    const v3 ldir = inverse_transform(ld, lnor);
-    const float light_pdf = choice_pdf;
-    light[0].pos = lpos; light[0].normal = lnor; light[0].beta = emission / light_pdf;
-    light[0].fpdf = light_pdf; light[0].rpdf = 0.0f; light[0].wo = ldir; light[0].type = VERTEX_LIGHT;
-    int pre_depth = 0, depth = 1;
-    float pdfFwd = dir_pdf, pdfRev = 0.0f;
-    v3 beta = (emission / light_pdf) * absf(dot(lnor, ldir));
-    v3 origin = lpos, dir = ldir;
-    while (depth < BD_LIGHT_MAX) {
-        const SimpleHit sh = trace_simple(c.bvh, origin, dir, c.stack, c.stack_overflow);
-        n_closest++;
-        if (sh.t < INF_VALUE) {
-            const HitAttr h = hit_attributes(s, origin, dir, sh.prim, sh.t, sh.u, sh.v);
-            const v3 normal = h.nor, pos = h.pos;
-            const v3 fnormal = normal * signf(dot(-dir, h.gnor));
-            const int mat_id = s.primitive[(size_t)sh.prim * PRI_VEC + 2];
-            const float *m = mat_row(s, mat_id);
-            const v3 mat_color = V(m[2], m[3], m[4]);
-            const int mat_type = (int)m[0];
-            if (mat_type == MAT_LIGHT) break;
-            bvert *L = &light[depth];
-            L->pos = pos; L->normal = normal; L->snormal = fnormal; L->beta = beta * absf(dot(dir, normal));
-            L->wo = dir; L->fpdf = pdfFwd; L->rpdf = 0.0f; L->type = VERTEX_SURFACE; L->prim = sh.prim; L->mat = mat_id;
-            v3 to = pos - light[pre_depth].pos;
-            const float dist = norm(to);
-            const float inv_dist2 = 1.0f / (dist * dist);
-            to = to / dist;
-            L->fpdf *= absf(dot(to, light[pre_depth].normal)) * inv_dist2;
-            const v3 reflect_color = srgb_to_lrgb(mat_color);
-            int delta = 0;
-            const bsample bs = bd_sample(s, dir, normal, fnormal, mat_id, mat_type, c.seed, pixel, frame, BD_DIM_LIGHT + 8u * (uint32_t)depth, delta);
-            L->delta = delta;
-            pdfFwd = bs.pdfFwd;
-            if (pdfFwd > 0.0f) {
-                if (mat_type == MAT_GLASS) {
-                    pdfRev = 0.0f; pdfFwd = 0.0f;
-                    beta = beta * (reflect_color * bs.brdf);
-                } else {
-                    beta = beta * (((reflect_color * bs.brdf) * absf(dot(normal, bs.next_dir))) / pdfFwd);
-                    pdfRev = disney_pdf(m, fnormal, bs.next_dir, -dir);
-                }
-                light[pre_depth].rpdf = pdfRev * absf(dot(to, L->normal)) * inv_dist2;
-                if (bs.f_or_b < 0.0f) {
-                    const float R = tm_exp(-sh.t / m[6]);
-                    if (tm_rand(c.seed, pixel, frame, BD_DIM_LIGHT + 8u * (uint32_t)depth + TM_SLOT_EXT) >= R) break;
-                }
-                origin = offset_ray(pos, fnormal * signf(bs.f_or_b));
-                dir = bs.next_dir;
-                depth += 1; pre_depth += 1;
-            } else break;
-        } else break;
-    }
-    return depth;
-}
 
 // BDPT_RGB.py:300-479
 TD float bd_mis_weight(const BdCtx &c, bpixel *P, int e, int l)
@@ -418,7 +233,7 @@ TD float bd_mis_weight(const BdCtx &c, bpixel *P, int e, int l)
 }
 
 // BDPT_RGB.py:481-592
-TD v3 bd_connect_path(const BdCtx &c, bpixel *P, int i, int j, int e, int l, uint32_t frame, int &nu, int &nv, unsigned &n_shadow)
+TD v3 bd_connect_path(const BdCtx &c, bpixel *P, int i, int j, int e, int l, uint32_t frame, int &nu, int &nv, Tracer &T)
 {
     const SceneView &s = c.sc;
     bvert *eye = P->eye, *light = P->light;
@@ -436,8 +251,7 @@ TD v3 bd_connect_path(const BdCtx &c, bpixel *P, int i, int j, int e, int l, uin
         const v3 snormal = light[l - 1].snormal;
         const float NdotL = dot(wi, snormal);
         if ((nu >= 0) & (light[l - 1].delta != 1) & (NdotL < 0.0f) & (light[l - 1].type == VERTEX_SURFACE)) {
-            const SimpleHit sh = trace_simple(c.bvh, origin, wi, c.stack, c.stack_overflow, c.bounded ? prim : -3, c.bounded ? norm(surface - origin) : -1.0f);
-            n_shadow++;
+            const SimpleHit sh = bd_trace(T, origin, wi, prim, c.bounded ? norm(surface - origin) : -1.0f);
             if (sh.prim == prim) {
                 float pdf;
                 const float brdf = disney_evaluate_pdf(mat_row(s, mat_id), snormal, -light[l - 1].wo, -wi, pdf);
@@ -467,8 +281,7 @@ TD v3 bd_connect_path(const BdCtx &c, bpixel *P, int i, int j, int e, int l, uin
             wi = wi / light_dist;
             const float NdotLl = dot(wi, light_normal);
             const float NdotLe = dot(wi, eye[e - 1].snormal);
-            const SimpleHit sh = trace_simple(c.bvh, surface, -wi, c.stack, c.stack_overflow, c.bounded ? light_prim : -3, c.bounded ? light_dist : -1.0f);
-            n_shadow++;
+            const SimpleHit sh = bd_trace(T, surface, -wi, light_prim, c.bounded ? light_dist : -1.0f);
             if ((sh.prim == light_prim) & (sh.t > EPS_UF)) {
                 const float light_pdf = light_choice_pdf;
                 float pdf;
@@ -492,8 +305,7 @@ TD v3 bd_connect_path(const BdCtx &c, bpixel *P, int i, int j, int e, int l, uin
             const float dist = norm(dir);
             dir = dir / dist;
             const float NdotLl = dot(dir, light[l - 1].snormal), NdotLe = dot(dir, eye[e - 1].snormal);
-            const SimpleHit sh = trace_simple(c.bvh, surfaceL, dir, c.stack, c.stack_overflow, c.bounded ? primE : -3, c.bounded ? dist : -1.0f);
-            n_shadow++;
+            const SimpleHit sh = bd_trace(T, surfaceL, dir, primE, c.bounded ? dist : -1.0f);
             if ((sh.prim == primE) & (sh.t > EPS_UF)) {
                 float lpdf, epdf;
                 const float brdfL = disney_evaluate_pdf(mat_row(s, mat_idL), light[l - 1].snormal, -light[l - 1].wo, dir, lpdf);
@@ -514,36 +326,276 @@ TD v3 bd_connect_path(const BdCtx &c, bpixel *P, int i, int j, int e, int l, uin
     return radiance * misweight;
 }
 
-// BDPT_RGB.py:597-637: one thread per owned pixel.  The thread runs `nframes` consecutive frames of its pixel
-// (the per-pixel vertex arrays persist from frame to frame, so a pixel's frames are sequential anyway): the
-// per-frame clear of its own state happens at the top of each frame, frame f splats into its own radiance
-// buffer, and the path-length imbalance between pixels averages out over the frames instead of leaving the
-// GPU half empty at the end of every single-frame launch (lane utilisation of this megakernel is ~10 %).
-__global__ __launch_bounds__(BD_BLOCK) void k_bdpt_pixel(BdCtx c, bpixel *px, float *radiance, TileMap tm, int P_local, uint32_t frame_begin,
-                                                       int nframes, long frame_stride)
+// ---- wavefront state ------------------------------------------------------------------------------------------
+struct BdStep { v3 e_beta; float e_pdfFwd; v3 l_beta; float l_pdfFwd; int e_alive, l_alive, eye_depth, light_depth; };
+struct BdRays { float *ox, *oy, *oz, *dx, *dy, *dz; };            // 2N entries: [0, N) eye rays, [N, 2N) light rays
+constexpr int BD_PAIRS = BD_EYE_MAX * (BD_LIGHT_MAX + 1);          // (e - 1) * 7 + l
+TD void put_ray(const BdRays &r, size_t k, v3 o, v3 d) { r.ox[k] = o.x; r.oy[k] = o.y; r.oz[k] = o.z; r.dx[k] = d.x; r.dy[k] = d.y; r.dz[k] = d.z; }
+TD void kill_ray(const BdRays &r, size_t k) { r.dx[k] = __int_as_float(0x7fc00000); }     // a NaN direction: k_trace answers "miss" without a walk
+TD void count_rays(unsigned long long *ctr, unsigned mine)
 {
-    __shared__ int lds_stack[BD_STACK * BD_BLOCK];
-    c.stack = lds_stack + threadIdx.x;
-    int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= P_local) return;
+    unsigned long long v = mine;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(ctr, v);
+}
+
+// BDPT_RGB.py:104-125 (lens vertex, camera ray) and :201-228 with Scene.sample_light (Scene.py:430-474)
+__global__ void k_bd_init(BdCtx c, bpixel *items, BdStep *steps, BdRays rays, TileMap tm, int P, int N, uint32_t frame_begin, unsigned long long *paths)
+{
+    const int it = blockIdx.x * blockDim.x + threadIdx.x;
+    if (it >= N) return;
+    const int f = it / P, k = it - f * P;
     const int p = local_to_pixel(tm, k);
     const int i = p / c.bv.H, j = p - i * c.bv.H;
-    bpixel *P = px + p;                     // (working on a private copy of the 1.7 KB state measured 4 % slower)
-    unsigned n_closest = 0, n_shadow = 0;
-    for (int f = 0; f < nframes; f++) {
-        const uint32_t frame = frame_begin + (uint32_t)f;
-        float *rad = radiance + (size_t)f * (size_t)frame_stride;
-        // BDPT_RGB.py:597-614: per-frame clear of beta/type/fpdf/rpdf (everything else persists)
-        for (int e = 0; e < BD_EYE_MAX; e++) { P->eye[e].beta = V(0.0f, 0.0f, 0.0f); P->eye[e].type = VERTEX_NONE; P->eye[e].fpdf = 0.0f; P->eye[e].rpdf = 0.0f; }
-        for (int l = 0; l < BD_LIGHT_MAX; l++) { P->light[l].beta = V(0.0f, 0.0f, 0.0f); P->light[l].type = VERTEX_NONE; P->light[l].fpdf = 0.0f; P->light[l].rpdf = 0.0f; }
-        const int eye_depth = bd_eye_path(c, P, i, j, frame, n_closest);
-        const int light_depth = bd_light_path(c, P, i, j, frame, n_closest);
-        for (int e = 1; e <= eye_depth; e++) {
-            for (int l = 0; l <= light_depth; l++) {
-                const int depth = l + e - 2;
-                if (((l == 1) & (e == 1)) | (depth < 0) | (depth > BD_MAX_DEPTH)) continue;
-                int nu, nv;
-                const v3 r = bd_connect_path(c, P, i, j, e, l, frame, nu, nv, n_shadow);
+    const uint32_t pixel = (uint32_t)p, frame = frame_begin + (uint32_t)f;
+    bpixel *B = items + it;
+    BdStep st;
+    // eye
+    {
+        bvert *eye = B->eye;
+        const v3 origin = V(c.cam.eye[0], c.cam.eye[1], c.cam.eye[2]);
+        float jx = 0.0f, jy = 0.0f;
+        if (frame != 0) { jx = tm_rand(c.seed, pixel, frame, TM_DIM_JX) - 0.5f; jy = tm_rand(c.seed, pixel, frame, TM_DIM_JY) - 0.5f; }
+        const v3 dir = camera_ray_direction(c.cam, i, j, jx, jy);
+        eye[0].pos = origin; eye[0].normal = dir; eye[0].beta = V(1.0f, 1.0f, 1.0f); eye[0].fpdf = 1.0f; eye[0].type = VERTEX_LENS;
+        st.e_beta = V(1.0f, 1.0f, 1.0f); st.e_pdfFwd = 1.0f; st.e_alive = 1; st.eye_depth = 1;
+        put_ray(rays, (size_t)it, origin, dir);
+    }
+    // light
+    {
+        const SceneView &s = c.sc;
+        bvert *light = B->light;
+        int lidx = (int)(tm_rand(c.seed, pixel, frame, BD_DIM_LSTART + 0) * (float)s.light_count);
+        if (lidx >= s.light_count) lidx = s.light_count - 1;
+        const int lp = s.light[lidx];
+        v3 lpos, lnor;
+        get_prim_random_point_normal(s, lp, tm_rand(c.seed, pixel, frame, BD_DIM_LSTART + 1), tm_rand(c.seed, pixel, frame, BD_DIM_LSTART + 2), lpos, lnor);
+        const float *lm = mat_row(s, s.primitive[(size_t)lp * PRI_VEC + 2]);
+        const v3 emission = V(lm[2], lm[3], lm[4]);
+        const float choice_pdf = 1.0f / ((float)s.light_count * get_prim_area(s, lp));
+        lnor = normalized(lnor);
+        const v3 ld = cosine_sample_hemisphere(tm_rand(c.seed, pixel, frame, BD_DIM_LSTART + 3), tm_rand(c.seed, pixel, frame, BD_DIM_LSTART + 4));
+        const float dir_pdf = cosine_hemisphere_pdf(ld.z);
+        const v3 ldir = inverse_transform(ld, lnor);
+        const float light_pdf = choice_pdf;
+        light[0].pos = lpos; light[0].normal = lnor; light[0].beta = emission / light_pdf;
+        light[0].fpdf = light_pdf; light[0].rpdf = 0.0f; light[0].wo = ldir; light[0].type = VERTEX_LIGHT;
+        st.l_beta = (emission / light_pdf) * absf(dot(lnor, ldir)); st.l_pdfFwd = dir_pdf; st.l_alive = 1; st.light_depth = 1;
+        put_ray(rays, (size_t)N + it, lpos, ldir);
+    }
+    steps[it] = st;
+    if (it == 0) atomicAdd(paths, (unsigned long long)N);
+}
+
+// One iteration of the while loops of eye_path (BDPT_RGB.py:126-198; threads [0, N)) and light_path (:229-294; threads
+// [N, 2N)): the hit of the ray traced for vertex `depth`, the vertex, the next ray.
+__global__ void k_bd_step(BdCtx c, bpixel *items, BdStep *steps, BdRays rays, const float4 *hits, TileMap tm, int P, int N, uint32_t frame_begin,
+                          int depth, unsigned long long *rays_closest)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned traced = 0;
+    if (t < 2 * N) {
+        const bool is_eye = t < N;
+        const int it = is_eye ? t : t - N;
+        BdStep *st = steps + it;
+        const bool alive = is_eye ? (st->e_alive != 0) : (st->l_alive != 0);
+        if (alive) {
+            traced = 1;
+            const int f = it / P, k = it - f * P;
+            const uint32_t pixel = (uint32_t)local_to_pixel(tm, k), frame = frame_begin + (uint32_t)f;
+            const SceneView &s = c.sc;
+            bpixel *B = items + it;
+            const v3 origin = V(rays.ox[t], rays.oy[t], rays.oz[t]), dir = V(rays.dx[t], rays.dy[t], rays.dz[t]);
+            const float4 hr = hits[t];
+            SimpleHit sh; sh.t = hr.x; sh.u = hr.y; sh.v = hr.z; sh.prim = __float_as_int(hr.w);
+            const int pre_depth = depth - 1;
+            int final_depth = depth;              // what the reference's function returns if the loop ends here
+            bool go_on = false;
+            v3 next_o = origin, next_d = dir;
+            if (is_eye) {
+                bvert *eye = B->eye;
+                float pdfFwd = st->e_pdfFwd, pdfRev = 0.0f;
+                v3 beta = st->e_beta;
+                if (sh.t < INF_VALUE) {
+                    const HitAttr h = hit_attributes(s, origin, dir, sh.prim, sh.t, sh.u, sh.v);
+                    const v3 normal = h.nor, pos = h.pos;
+                    const v3 fnormal = normal * signf(dot(-dir, h.gnor));
+                    const int mat_id = s.primitive[(size_t)sh.prim * PRI_VEC + 2];
+                    const float *m = mat_row(s, mat_id);
+                    const v3 mat_color = V(m[2], m[3], m[4]);
+                    const int mat_type = (int)m[0];
+                    v3 to = pos - origin;
+                    const float dist = maxf(norm(to), 0.01f);
+                    const float inv_dist2 = 1.0f / (dist * dist);
+                    to = to / dist;
+                    bvert *e = &eye[depth];
+                    e->pos = pos; e->normal = normal; e->snormal = fnormal; e->wo = dir; e->rpdf = 0.0f; e->prim = sh.prim; e->mat = mat_id;
+                    e->fpdf = pdfFwd * absf(dot(to, eye[pre_depth].normal)) * inv_dist2;
+                    if (mat_type == MAT_LIGHT) {
+                        e->beta = (beta * mat_color) * absf(dot(normal, dir));
+                        e->type = VERTEX_LIGHT;
+                        final_depth = depth + 1;
+                    } else {
+                        e->beta = beta * absf(dot(dir, normal));
+                        e->type = VERTEX_SURFACE;
+                        const v3 reflect_color = srgb_to_lrgb(mat_color);
+                        int delta = 0;
+                        const bsample bs = bd_sample(s, dir, normal, fnormal, mat_id, mat_type, c.seed, pixel, frame, BD_DIM_EYE + 8u * (uint32_t)depth, delta);
+                        e->delta = delta;
+                        pdfFwd = bs.pdfFwd;
+                        if (pdfFwd > 0.0f) {
+                            if (mat_type == MAT_GLASS) {
+                                pdfRev = 0.0f; pdfFwd = 0.0f;
+                                beta = beta * (reflect_color * bs.brdf);
+                            } else {
+                                beta = beta * (((reflect_color * bs.brdf) * absf(dot(normal, bs.next_dir))) / pdfFwd);
+                                pdfRev = disney_pdf(m, fnormal, bs.next_dir, -dir);
+                            }
+                            eye[pre_depth].rpdf = pdfRev * absf(dot(to, e->normal)) * inv_dist2;
+                            bool killed = false;
+                            if (bs.f_or_b < 0.0f) {
+                                const float R = tm_exp(-sh.t / m[6]);
+                                if (tm_rand(c.seed, pixel, frame, BD_DIM_EYE + 8u * (uint32_t)depth + TM_SLOT_EXT) >= R) killed = true;
+                            }
+                            if (!killed) {
+                                final_depth = depth + 1;
+                                go_on = (depth + 1 < BD_EYE_MAX);
+                                next_o = offset_ray(pos, fnormal * signf(bs.f_or_b));
+                                next_d = bs.next_dir;
+                            }
+                        }
+                    }
+                }
+                st->e_beta = beta; st->e_pdfFwd = pdfFwd; st->eye_depth = final_depth; st->e_alive = go_on ? 1 : 0;
+            } else {
+                bvert *light = B->light;
+                float pdfFwd = st->l_pdfFwd, pdfRev = 0.0f;
+                v3 beta = st->l_beta;
+                if (sh.t < INF_VALUE) {
+                    const HitAttr h = hit_attributes(s, origin, dir, sh.prim, sh.t, sh.u, sh.v);
+                    const v3 normal = h.nor, pos = h.pos;
+                    const v3 fnormal = normal * signf(dot(-dir, h.gnor));
+                    const int mat_id = s.primitive[(size_t)sh.prim * PRI_VEC + 2];
+                    const float *m = mat_row(s, mat_id);
+                    const v3 mat_color = V(m[2], m[3], m[4]);
+                    const int mat_type = (int)m[0];
+                    if (mat_type != MAT_LIGHT) {
+                        bvert *L = &light[depth];
+                        L->pos = pos; L->normal = normal; L->snormal = fnormal; L->beta = beta * absf(dot(dir, normal));
+                        L->wo = dir; L->fpdf = pdfFwd; L->rpdf = 0.0f; L->type = VERTEX_SURFACE; L->prim = sh.prim; L->mat = mat_id;
+                        v3 to = pos - light[pre_depth].pos;
+                        const float dist = norm(to);
+                        const float inv_dist2 = 1.0f / (dist * dist);
+                        to = to / dist;
+                        L->fpdf *= absf(dot(to, light[pre_depth].normal)) * inv_dist2;
+                        const v3 reflect_color = srgb_to_lrgb(mat_color);
+                        int delta = 0;
+                        const bsample bs = bd_sample(s, dir, normal, fnormal, mat_id, mat_type, c.seed, pixel, frame, BD_DIM_LIGHT + 8u * (uint32_t)depth, delta);
+                        L->delta = delta;
+                        pdfFwd = bs.pdfFwd;
+                        if (pdfFwd > 0.0f) {
+                            if (mat_type == MAT_GLASS) {
+                                pdfRev = 0.0f; pdfFwd = 0.0f;
+                                beta = beta * (reflect_color * bs.brdf);
+                            } else {
+                                beta = beta * (((reflect_color * bs.brdf) * absf(dot(normal, bs.next_dir))) / pdfFwd);
+                                pdfRev = disney_pdf(m, fnormal, bs.next_dir, -dir);
+                            }
+                            light[pre_depth].rpdf = pdfRev * absf(dot(to, L->normal)) * inv_dist2;
+                            bool killed = false;
+                            if (bs.f_or_b < 0.0f) {
+                                const float R = tm_exp(-sh.t / m[6]);
+                                if (tm_rand(c.seed, pixel, frame, BD_DIM_LIGHT + 8u * (uint32_t)depth + TM_SLOT_EXT) >= R) killed = true;
+                            }
+                            if (!killed) {
+                                final_depth = depth + 1;
+                                go_on = (depth + 1 < BD_LIGHT_MAX);
+                                next_o = offset_ray(pos, fnormal * signf(bs.f_or_b));
+                                next_d = bs.next_dir;
+                            }
+                        }
+                    }
+                }
+                st->l_beta = beta; st->l_pdfFwd = pdfFwd; st->light_depth = final_depth; st->l_alive = go_on ? 1 : 0;
+            }
+            if (go_on) put_ray(rays, (size_t)t, next_o, next_d); else kill_ray(rays, (size_t)t);
+        }
+    }
+    count_rays(rays_closest, traced);
+}
+
+// The `delta` field of an eye vertex that ended on a light is whatever an earlier frame of the same pixel left in that
+// slot (file header): replayed per pixel, in frame order, over the persistent per-pixel memory.
+__global__ void k_bd_delta(bpixel *items, const BdStep *steps, TileMap tm, int P, int F, int *delta_mem)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= P) return;
+    int *mem = delta_mem + (size_t)local_to_pixel(tm, k) * 8;
+    for (int f = 0; f < F; f++) {
+        const size_t it = (size_t)f * P + k;
+        bvert *eye = items[it].eye;
+        const int ed = steps[it].eye_depth;
+        for (int v = 1; v < ed && v < BD_EYE_MAX; v++) {
+            if (eye[v].type == VERTEX_SURFACE) mem[v] = eye[v].delta;
+            else if (eye[v].type == VERTEX_LIGHT) eye[v].delta = mem[v];
+        }
+    }
+}
+
+// BDPT_RGB.py:615-637, the double loop over (e, l), in two passes around the batched connection queries.
+template <int PHASE>
+__global__ void k_bd_connect(BdCtx c, bpixel *items, const BdStep *steps, TileMap tm, int P, int N, uint32_t frame_begin,
+                             BdRays srays, int *sexpect, float *sbound, int *qidx, int *scount, const float4 *shits,
+                             float *radiance, long frame_stride, unsigned long long *rays_shadow)
+{
+    const int it = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = it < N;
+    const int lane = threadIdx.x & 63;
+    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    int eye_depth = 0, light_depth = -1, i = 0, j = 0, p = 0, f = 0;
+    bpixel *B = items + (live ? it : 0);
+    if (live) {
+        f = it / P; const int k = it - f * P;
+        p = local_to_pixel(tm, k); i = p / c.bv.H; j = p - i * c.bv.H;
+        eye_depth = steps[it].eye_depth; light_depth = steps[it].light_depth;
+    }
+    const uint32_t frame = frame_begin + (uint32_t)f;
+    float *rad = radiance + (size_t)f * (size_t)frame_stride;
+    unsigned emitted = 0;
+    for (int e = 1; e <= BD_EYE_MAX; e++) {
+        for (int l = 0; l <= BD_LIGHT_MAX; l++) {
+            const int depth = l + e - 2;
+            if (((l == 1) & (e == 1)) | (depth < 0) | (depth > BD_MAX_DEPTH)) continue;       // wave-uniform
+            const bool valid = live && e <= eye_depth && l <= light_depth;
+            const int slot = (e - 1) * (BD_LIGHT_MAX + 1) + l;
+            Tracer T; T.phase = PHASE; T.want = false; T.res.t = INF_VALUE; T.res.u = 0.0f; T.res.v = 0.0f; T.res.prim = -1;
+            T.o = V(0.0f, 0.0f, 0.0f); T.d = T.o; T.expect = -3; T.bound = -1.0f;
+            if (PHASE == 1 && valid) {
+                const int qi = qidx[(size_t)it * BD_PAIRS + slot];
+                if (qi >= 0) { const float4 hr = shits[qi]; T.res.t = hr.x; T.res.u = hr.y; T.res.v = hr.z; T.res.prim = __float_as_int(hr.w); }
+            }
+            int nu = 0, nv = 0;
+            v3 r = V(0.0f, 0.0f, 0.0f);
+            if (valid && !(PHASE == 0 && l == 0)) r = bd_connect_path(c, B, i, j, e, l, frame, nu, nv, T);      // l == 0 needs no ray
+            if (PHASE == 0) {
+                // connection rays go to a dense queue: one atomic per wave and pair
+                const unsigned long long wm = __ballot(valid && T.want);
+                if (wm != 0ull) {
+                    const int leader = __ffsll((long long)wm) - 1;
+                    int base = 0;
+                    if (lane == leader) base = atomicAdd(scount, __popcll(wm));
+                    base = __shfl(base, leader, 64);
+                    if (valid && T.want) {
+                        const int qi = base + __popcll(wm & lt_mask);
+                        put_ray(srays, (size_t)qi, T.o, T.d);
+                        sexpect[qi] = T.expect; sbound[qi] = T.bound;
+                        qidx[(size_t)it * BD_PAIRS + slot] = qi;
+                        emitted++;
+                    }
+                }
+                if (valid && !T.want) qidx[(size_t)it * BD_PAIRS + slot] = -1;
+            } else if (valid) {
                 const long q = (e == 1) ? ((nu >= 0) ? (long)nu * c.bv.H + nv : -1) : (long)p;
                 if (q >= 0 && (r.x != 0.0f || r.y != 0.0f || r.z != 0.0f)) {
                     atomicAdd(&rad[3 * q], r.x); atomicAdd(&rad[3 * q + 1], r.y); atomicAdd(&rad[3 * q + 2], r.z);
@@ -551,9 +603,7 @@ __global__ __launch_bounds__(BD_BLOCK) void k_bdpt_pixel(BdCtx c, bpixel *px, fl
             }
         }
     }
-    atomicAdd(c.rays_closest, (unsigned long long)n_closest);
-    atomicAdd(c.rays_shadow, (unsigned long long)n_shadow);
-    atomicAdd(c.paths, (unsigned long long)nframes);
+    if (PHASE == 0) count_rays(rays_shadow, emitted);
 }
 
 // BDPT_RGB.py:639-642
@@ -574,28 +624,56 @@ int bdpt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t see
     if (ensure_counters(c)) return TIRT_ERR_HIP;
     if (sync_all(c)) return TIRT_ERR_HIP;
     const long NP = (long)c->W * c->H;
-    if (c->bdpt_px.bytes < sizeof(bpixel) * (size_t)NP) {
-        if (c->bdpt_px.ensure(sizeof(bpixel) * (size_t)NP)) return TIRT_ERR_HIP;
-        TIRT_HIP(hipMemsetAsync(c->bdpt_px.p, 0, sizeof(bpixel) * (size_t)NP, c->stream));
+    const int P = (int)c->npix_local;
+    hipStream_t st = c->stream;
+    if (c->bdpt_px.bytes < sizeof(int) * 8 * (size_t)NP) {         // the per-pixel delta memory (zero = what a fresh film starts from)
+        if (c->bdpt_px.ensure(sizeof(int) * 8 * (size_t)NP)) return TIRT_ERR_HIP;
+        TIRT_HIP(hipMemsetAsync(c->bdpt_px.p, 0, sizeof(int) * 8 * (size_t)NP, st));
     }
-    constexpr int BD_FRAMES = 16;                  // frames per launch (one radiance buffer each)
-    const int FMAX = frame_count < BD_FRAMES ? frame_count : BD_FRAMES;
-    if (c->bdpt_rad.ensure(sizeof(float) * 3 * (size_t)NP * (size_t)FMAX)) return TIRT_ERR_HIP;
+    if (P == 0) return TIRT_OK;
+    int FB = (int)(c->bdpt_batch_items / (size_t)P); if (FB < 1) FB = 1; if (FB > frame_count) FB = frame_count;
+    const size_t NMAX = (size_t)FB * P;
+    TIRT_REQUIRE(NMAX * BD_PAIRS < ((size_t)1 << 31), "tirt_bdpt_rgb_render: film too large for one frame per batch");
+    const size_t SCAP = NMAX * 27;                               // at most 27 (e, l) pairs per item carry a connection ray
+    if (c->bdpt_items.ensure(sizeof(bpixel) * NMAX) || c->bdpt_state.ensure(sizeof(BdStep) * NMAX) ||
+        c->bdpt_rays.ensure(sizeof(float) * (6 * 2 * NMAX + 8 * SCAP)) || c->bdpt_hits.ensure(sizeof(float4) * (2 * NMAX + SCAP)) ||
+        c->bdpt_qidx.ensure(sizeof(int) * NMAX * BD_PAIRS) || c->bdpt_ctr.ensure(256) ||
+        c->bdpt_rad.ensure(sizeof(float) * 3 * (size_t)NP * (size_t)FB)) return TIRT_ERR_HIP;
     BdCtx bc;
-    bc.sc = scene_view(c); bc.bvh = bvh_view(c); bc.cam = c->cam; bc.seed = seed; bc.stack = nullptr; bc.bounded = c->bdpt_bounded;
+    bc.sc = scene_view(c); bc.cam = c->cam; bc.seed = seed; bc.bounded = c->bdpt_bounded;
     for (int k = 0; k < 12; k++) bc.bv.view[k] = c->view[k];
     bc.bv.W = c->W; bc.bv.H = c->H;
     DevCounters *ctr = c->dev_counters.as<DevCounters>();
-    bc.rays_closest = &ctr->rays_closest; bc.rays_shadow = &ctr->rays_shadow; bc.paths = &ctr->paths; bc.stack_overflow = &ctr->stack_overflow;
     const TileMap tm = {c->tile_rank, c->tile_count, c->tile_size, c->H};
-    const int P = (int)c->npix_local;
-    hipStream_t st = c->stream;
-    for (int f0 = 0; f0 < frame_count; f0 += FMAX) {
-        const int F = frame_count - f0 < FMAX ? frame_count - f0 : FMAX;
+    float *rf = c->bdpt_rays.as<float>();
+    BdRays er = {rf, rf + 2 * NMAX, rf + 4 * NMAX, rf + 6 * NMAX, rf + 8 * NMAX, rf + 10 * NMAX};
+    float *sf = rf + 12 * NMAX;
+    BdRays sr = {sf, sf + SCAP, sf + 2 * SCAP, sf + 3 * SCAP, sf + 4 * SCAP, sf + 5 * SCAP};
+    int *sexpect = (int *)(sf + 6 * SCAP); float *sbound = sf + 7 * SCAP;
+    float4 *ehits = c->bdpt_hits.as<float4>(), *shits = ehits + 2 * NMAX;
+    int *scount = c->bdpt_ctr.as<int>();
+    const int B = 128;
+    for (int f0 = 0; f0 < frame_count; f0 += FB) {
+        const int F = frame_count - f0 < FB ? frame_count - f0 : FB;
+        const int N = F * P;
         const uint32_t frame0 = frame_begin + (uint32_t)f0;
         TIRT_HIP(hipMemsetAsync(c->bdpt_rad.p, 0, sizeof(float) * 3 * (size_t)NP * (size_t)F, st));
-        if (P > 0) hipLaunchKernelGGL(k_bdpt_pixel, dim3((P + BD_BLOCK - 1) / BD_BLOCK), dim3(BD_BLOCK), 0, st, bc, c->bdpt_px.as<bpixel>(),
-                                      c->bdpt_rad.as<float>(), tm, P, frame0, F, 3 * NP);
+        TIRT_HIP(hipMemsetAsync(c->bdpt_items.p, 0, sizeof(bpixel) * (size_t)N, st));
+        TIRT_HIP(hipMemsetAsync(scount, 0, sizeof(int), st));
+        hipLaunchKernelGGL(k_bd_init, dim3((N + B - 1) / B), dim3(B), 0, st, bc, c->bdpt_items.as<bpixel>(), c->bdpt_state.as<BdStep>(), er, tm, P, N, frame0, &ctr->paths);
+        // rays of the two sub-paths share the launches; entry [N + i] is item i's light ray (the array pitch is 2 NMAX, the live part 2 N)
+        BdRays er2 = er;            // light rays start at N of this batch, not NMAX: the step kernels index [0, 2N)
+        for (int d = 1; d < BD_EYE_MAX; d++) {
+            if (int rc = trace_arrays(c, er2.ox, er2.oy, er2.oz, er2.dx, er2.dy, er2.dz, 2 * N, nullptr, ehits, nullptr, nullptr, false)) return rc;
+            hipLaunchKernelGGL(k_bd_step, dim3((2 * N + B - 1) / B), dim3(B), 0, st, bc, c->bdpt_items.as<bpixel>(), c->bdpt_state.as<BdStep>(), er2, ehits, tm, P, N,
+                               frame0, d, &ctr->rays_closest);
+        }
+        hipLaunchKernelGGL(k_bd_delta, dim3((P + B - 1) / B), dim3(B), 0, st, c->bdpt_items.as<bpixel>(), c->bdpt_state.as<BdStep>(), tm, P, F, c->bdpt_px.as<int>());
+        hipLaunchKernelGGL(k_bd_connect<0>, dim3((N + B - 1) / B), dim3(B), 0, st, bc, c->bdpt_items.as<bpixel>(), c->bdpt_state.as<BdStep>(), tm, P, N, frame0,
+                           sr, sexpect, sbound, c->bdpt_qidx.as<int>(), scount, shits, c->bdpt_rad.as<float>(), 3 * NP, &ctr->rays_shadow);
+        if (int rc = trace_arrays(c, sr.ox, sr.oy, sr.oz, sr.dx, sr.dy, sr.dz, (int)(SCAP < (size_t)N * 27 ? SCAP : (size_t)N * 27), scount, shits, sexpect, sbound, false)) return rc;
+        hipLaunchKernelGGL(k_bd_connect<1>, dim3((N + B - 1) / B), dim3(B), 0, st, bc, c->bdpt_items.as<bpixel>(), c->bdpt_state.as<BdStep>(), tm, P, N, frame0,
+                           sr, sexpect, sbound, c->bdpt_qidx.as<int>(), scount, shits, c->bdpt_rad.as<float>(), 3 * NP, &ctr->rays_shadow);
         for (int f = 0; f < F; f++) {                     // the running mean applies the frames in order
             const float coff = 1.0f / ((float)(int)(frame0 + (uint32_t)f) + 1.0f);
             hipLaunchKernelGGL(k_bdpt_film, dim3((unsigned)((3 * NP + 255) / 256)), dim3(256), 0, st, c->bdpt_rad.as<float>() + (size_t)f * 3 * NP,

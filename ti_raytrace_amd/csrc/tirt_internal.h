@@ -220,7 +220,9 @@ struct tirt_ctx {
     tirt::DevBuf counters_mem, spill;            // used by the batch trace entry points (main stream)
 
     // BDPT_RGB: persistent per-pixel vertex arrays + per-frame radiance (splat target)
-    tirt::DevBuf bdpt_px, bdpt_rad;
+    tirt::DevBuf bdpt_px, bdpt_rad;               // bdpt_px: per-pixel memory of the eye vertices' `delta` fields (what persists from frame to frame)
+    tirt::DevBuf bdpt_items, bdpt_state, bdpt_rays, bdpt_hits, bdpt_qidx, bdpt_ctr;   // wavefront batch: vertex arrays per (frame, pixel), step state, rays, hits
+    size_t bdpt_batch_items = (size_t)4 << 20;   // option "bdpt_batch_items": (frame, pixel) items per wavefront batch
     int bdpt_bounded = 1;                          // option "bdpt_bounded": connection rays stop at their target distance
 
     // batch trace scratch
@@ -242,6 +244,8 @@ int launch_trace_batch(tirt_ctx *c, const float *rays, int nr, int stack_size, i
                        float *out_f, int32_t *out_prim, int32_t *counts);
 int pt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed, int max_depth, int stack_size, int flags);
 int bdpt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed);
+int trace_arrays(tirt_ctx *c, const float *ox, const float *oy, const float *oz, const float *dx, const float *dy, const float *dz,
+                 int count, const int *count_ptr, float4 *hit, const int *expect, const float *bound, bool count_rays);
 int ensure_counters(tirt_ctx *c);
 int sync_all(tirt_ctx *c);
 int flush_pending(tirt_ctx *c);

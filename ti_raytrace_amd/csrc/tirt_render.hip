@@ -35,7 +35,9 @@ namespace tirt {
 
 constexpr int TR_GRID_MAX = 2048;      // upper bound on persistent blocks (sizes the spill buffer)
 
-enum { KIND_CLOSEST = 0, KIND_SHADOW_ACC = 1, KIND_MIXED = 2 };   // MIXED: closest rays of bounce b + shadow rays of bounce b-1 in one launch
+enum { KIND_CLOSEST = 0, KIND_SHADOW_ACC = 1, KIND_MIXED = 2, KIND_QUERY = 3 };
+// MIXED: closest rays of bounce b + shadow rays of bounce b-1 in one launch.  QUERY: connection rays of BDPT -- "is sprim[q] the closest
+// hit, about sdist[q] away?" walked like a shadow ray (bounded), answered with the hit record (t, u, v, prim) instead of an accumulation.
 
 struct TraceArgs {
     BvhView bvh;
@@ -58,6 +60,7 @@ struct TraceArgs {
     int refill_min;                              // re-fetch rays when this many lanes of a wave are idle
     int node_min;                                // leave the inner-node loop below this many busy lanes
     DevCounters *ctr; int2 *per_ray_counts;
+    int no_ray_count;                            // the caller counts its rays itself (queues with dead entries)
 };
 
 // Persistent waves with ray re-fetch ("while-while" traversal): every wave keeps pulling rays
@@ -98,7 +101,7 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
     constexpr bool STASH = false;
 #endif
     constexpr bool BOUNDED = MAY_SHADOW && (MODE != TIRT_TRAVERSE_EXHAUSTIVE);
-    const int count_c = (KIND == KIND_SHADOW_ACC) ? 0 : (a.count_ptr ? *a.count_ptr : a.count_fixed);
+    const int count_c = (KIND == KIND_SHADOW_ACC || KIND == KIND_QUERY) ? 0 : (a.count_ptr ? *a.count_ptr : a.count_fixed);
     const int count_s = (KIND == KIND_CLOSEST) ? 0 : (KIND == KIND_MIXED ? *a.scount_ptr : (a.count_ptr ? *a.count_ptr : a.count_fixed));
     const int count = count_c + count_s;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -107,7 +110,7 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
     const BvhView &b = a.bvh;
 
     // per-lane ray state
-    bool have = false, par = false, is_sh = (KIND == KIND_SHADOW_ACC);
+    bool have = false, par = false, is_sh = (KIND == KIND_SHADOW_ACC || KIND == KIND_QUERY);
     int q = 0, cur = TR_SENT, hit_prim = -1, hit_leaf = -1, expect = -3;
     int pend = 0;                               // ordered mode: one stashed leaf code (0 = none; leaf codes are negative)
     unsigned n_overflow = 0;
@@ -211,7 +214,7 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
                 cull_far = 3.0e38f; settle = -1.0f; expect = -3;
                 if (MAY_SHADOW && is_sh) {
                     expect = a.sprim[q];
-                    if (BOUNDED) { const float t_bound = a.sdist[q]; cull_far = t_bound * 1.01f; settle = t_bound * 0.99f; }
+                    if (BOUNDED) { const float t_bound = a.sdist[q]; if (t_bound > 0.0f) { cull_far = t_bound * 1.01f; settle = t_bound * 0.99f; } }
                 }
                 lim = minf(minf(hit_t * 1.0001f, cull_far), INF_VALUE);
                 if (MODE != TIRT_TRAVERSE_EXHAUSTIVE) {
@@ -427,7 +430,7 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
 
         // ---- finished rays write back and free their lane ---------------------------------------
         if (have && cur == TR_SENT && pend == 0) {
-            if (!(MAY_SHADOW && is_sh)) {
+            if (!(MAY_SHADOW && is_sh) || KIND == KIND_QUERY) {
                 a.hit[q] = make_float4(hit_t, hit_u, hit_v, __int_as_float(hit_prim));
             } else if (hit_prim == expect) {                 // integrator/PT_RGB.py:105-109
                 const int dst = a.sdst[q];
@@ -459,7 +462,7 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
             atomicAdd(&a.ctr->refills, d_refills);
         }
         if (n_over) atomicAdd(&a.ctr->stack_overflow, n_over);
-        if (gtid == 0) {
+        if (gtid == 0 && !a.no_ray_count) {
             if (count_c) atomicAdd(&a.ctr->rays_closest, (unsigned long long)count_c);
             if (count_s) atomicAdd(&a.ctr->rays_shadow, (unsigned long long)count_s);
         }
@@ -575,6 +578,30 @@ int launch_trace_batch(tirt_ctx *c, const float *rays, int nr, int stack_size, i
     TIRT_HIP(hipStreamSynchronize(st));
     TIRT_HIP(hipGetLastError());
     return TIRT_OK;
+}
+
+// Closest hits (expect == nullptr) or bounded connection queries of `count` rays held in device arrays, hit records to
+// `hit` -- the traversal service of the BDPT wavefront (tirt_bdpt.hip).  Main stream, ordered traversal.
+int trace_arrays(tirt_ctx *c, const float *ox, const float *oy, const float *oz, const float *dx, const float *dy, const float *dz,
+                 int count, const int *count_ptr, float4 *hit, const int *expect, const float *bound, bool count_rays)
+{
+    if (count <= 0) return TIRT_OK;
+    hipStream_t st = c->stream;
+    int spill_depth;
+    if (ensure_spill(c, c->spill, 64, spill_depth)) return TIRT_ERR_HIP;
+    if (c->counters_mem.ensure(sizeof(int) * TR_FETCH_STRIDE * TR_SLICES_MAX)) return TIRT_ERR_HIP;
+    TIRT_HIP(hipMemsetAsync(c->counters_mem.p, 0, sizeof(int) * TR_FETCH_STRIDE * TR_SLICES_MAX, st));
+    TraceArgs a = {};
+    a.bvh = bvh_view(c);
+    a.ox = ox; a.oy = oy; a.oz = oz; a.dx = dx; a.dy = dy; a.dz = dz;
+    a.count_ptr = count_ptr; a.count_fixed = count; a.hit = hit;      // count: the capacity when count_ptr is given (sizes the grid)
+    a.sprim = expect; a.sdist = bound;
+    a.spill = c->spill.as<int>(); a.spill_depth = spill_depth;
+    a.ctr = c->dev_counters.as<DevCounters>(); a.per_ray_counts = nullptr; a.no_ray_count = count_rays ? 0 : 1;
+    a.fetch = c->counters_mem.as<int>();
+    fill_tunables(c, a);
+    int grid = (count + TR_BLOCK - 1) / TR_BLOCK; if (grid > c->tr_grid_alone) grid = c->tr_grid_alone;
+    return expect ? launch_trace<KIND_QUERY>(c, st, a, 0, grid) : launch_trace<KIND_CLOSEST>(c, st, a, 0, grid);
 }
 
 // ---------------------------------------------------------------------------------------------
