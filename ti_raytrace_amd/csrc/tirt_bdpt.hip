@@ -546,13 +546,12 @@ __global__ void k_bd_delta(bpixel *items, const BdStep *steps, TileMap tm, int P
 // BDPT_RGB.py:615-637, the double loop over (e, l), in two passes around the batched connection queries.
 template <int PHASE>
 __global__ void k_bd_connect(BdCtx c, bpixel *items, const BdStep *steps, TileMap tm, int P, int N, uint32_t frame_begin,
-                             BdRays srays, int *sexpect, float *sbound, int *qidx, int *scount, const float4 *shits,
+                             BdRays srays, int *sexpect, float *sbound, int *qidx, int *ibase, int *icount, int *scount, const float4 *shits,
                              float *radiance, long frame_stride, unsigned long long *rays_shadow)
 {
     const int it = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = it < N;
     const int lane = threadIdx.x & 63;
-    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     int eye_depth = 0, light_depth = -1, i = 0, j = 0, p = 0, f = 0;
     bpixel *B = items + (live ? it : 0);
     if (live) {
@@ -572,29 +571,25 @@ __global__ void k_bd_connect(BdCtx c, bpixel *items, const BdStep *steps, TileMa
             Tracer T; T.phase = PHASE; T.want = false; T.res.t = INF_VALUE; T.res.u = 0.0f; T.res.v = 0.0f; T.res.prim = -1;
             T.o = V(0.0f, 0.0f, 0.0f); T.d = T.o; T.expect = -3; T.bound = -1.0f;
             if (PHASE == 1 && valid) {
-                const int qi = qidx[(size_t)it * BD_PAIRS + slot];
-                if (qi >= 0) { const float4 hr = shits[qi]; T.res.t = hr.x; T.res.u = hr.y; T.res.v = hr.z; T.res.prim = __float_as_int(hr.w); }
+                const int ql = qidx[(size_t)slot * (size_t)N + it];
+                if (ql >= 0) { const float4 hr = shits[ibase[it] + ql]; T.res.t = hr.x; T.res.u = hr.y; T.res.v = hr.z; T.res.prim = __float_as_int(hr.w); }
             }
             int nu = 0, nv = 0;
             v3 r = V(0.0f, 0.0f, 0.0f);
             if (valid && !(PHASE == 0 && l == 0)) r = bd_connect_path(c, B, i, j, e, l, frame, nu, nv, T);      // l == 0 needs no ray
             if (PHASE == 0) {
-                // connection rays go to a dense queue: one atomic per wave and pair
-                const unsigned long long wm = __ballot(valid && T.want);
-                if (wm != 0ull) {
-                    const int leader = __ffsll((long long)wm) - 1;
-                    int base = 0;
-                    if (lane == leader) base = atomicAdd(scount, __popcll(wm));
-                    base = __shfl(base, leader, 64);
-                    if (valid && T.want) {
-                        const int qi = base + __popcll(wm & lt_mask);
-                        put_ray(srays, (size_t)qi, T.o, T.d);
-                        sexpect[qi] = T.expect; sbound[qi] = T.bound;
-                        qidx[(size_t)it * BD_PAIRS + slot] = qi;
-                        emitted++;
+                // the item's j-th connection ray goes to staging slot [j][item] (k_bd_compact makes the queue dense: one atomic
+                // per wave at the end of this kernel instead of one per wave and pair -- same-address atomics retire at ~11 ns)
+                if (valid) {
+                    int local = -1;
+                    if (T.want) {
+                        local = (int)emitted++;
+                        const size_t k = (size_t)local * (size_t)N + it;
+                        put_ray(srays, k, T.o, T.d);
+                        sexpect[k] = T.expect; sbound[k] = T.bound;
                     }
+                    qidx[(size_t)slot * (size_t)N + it] = local;
                 }
-                if (valid && !T.want) qidx[(size_t)it * BD_PAIRS + slot] = -1;
             } else if (valid) {
                 const long q = (e == 1) ? ((nu >= 0) ? (long)nu * c.bv.H + nv : -1) : (long)p;
                 if (q >= 0 && (r.x != 0.0f || r.y != 0.0f || r.z != 0.0f)) {
@@ -603,7 +598,32 @@ __global__ void k_bd_connect(BdCtx c, bpixel *items, const BdStep *steps, TileMa
             }
         }
     }
-    if (PHASE == 0) count_rays(rays_shadow, emitted);
+    if (PHASE == 0) {
+        // dense queue positions of this wave's rays: [base, base + total), lane by lane
+        int incl = (int)emitted;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
+        const int total = __shfl(incl, 63, 64);
+        int base = 0;
+        if (lane == 63 && total) { base = atomicAdd(scount, total); atomicAdd(rays_shadow, (unsigned long long)total); }
+        base = __shfl(base, 63, 64);
+        if (live) { ibase[it] = base + incl - (int)emitted; icount[it] = (int)emitted; }
+    }
+}
+
+// staging slots [j][item] -> dense connection-ray queue
+__global__ void k_bd_compact(int N, const int *ibase, const int *icount, BdRays stage, const int *sexpect_in, const float *sbound_in,
+                             BdRays dense, int *sexpect, float *sbound)
+{
+    const int it = blockIdx.x * blockDim.x + threadIdx.x;
+    if (it >= N) return;
+    const int n = icount[it], base = ibase[it];
+    for (int j = 0; j < n; j++) {
+        const size_t k = (size_t)j * (size_t)N + it, q = (size_t)(base + j);
+        dense.ox[q] = stage.ox[k]; dense.oy[q] = stage.oy[k]; dense.oz[q] = stage.oz[k];
+        dense.dx[q] = stage.dx[k]; dense.dy[q] = stage.dy[k]; dense.dz[q] = stage.dz[k];
+        sexpect[q] = sexpect_in[k]; sbound[q] = sbound_in[k];
+    }
 }
 
 // BDPT_RGB.py:639-642
@@ -634,10 +654,10 @@ int bdpt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t see
     int FB = (int)(c->bdpt_batch_items / (size_t)P); if (FB < 1) FB = 1; if (FB > frame_count) FB = frame_count;
     const size_t NMAX = (size_t)FB * P;
     TIRT_REQUIRE(NMAX * BD_PAIRS < ((size_t)1 << 31), "tirt_bdpt_rgb_render: film too large for one frame per batch");
-    const size_t SCAP = NMAX * 27;                               // at most 27 (e, l) pairs per item carry a connection ray
+    const size_t SCAP = NMAX * 27;                               // at most 27 (e, l) pairs per item carry a connection ray (staging: [27][N])
     if (c->bdpt_items.ensure(sizeof(bpixel) * NMAX) || c->bdpt_state.ensure(sizeof(BdStep) * NMAX) ||
-        c->bdpt_rays.ensure(sizeof(float) * (6 * 2 * NMAX + 8 * SCAP)) || c->bdpt_hits.ensure(sizeof(float4) * (2 * NMAX + SCAP)) ||
-        c->bdpt_qidx.ensure(sizeof(int) * NMAX * BD_PAIRS) || c->bdpt_ctr.ensure(256) ||
+        c->bdpt_rays.ensure(sizeof(float) * (6 * 2 * NMAX + 16 * SCAP)) || c->bdpt_hits.ensure(sizeof(float4) * (2 * NMAX + SCAP)) ||
+        c->bdpt_qidx.ensure(sizeof(int) * NMAX * (BD_PAIRS + 2)) || c->bdpt_ctr.ensure(256) ||
         c->bdpt_rad.ensure(sizeof(float) * 3 * (size_t)NP * (size_t)FB)) return TIRT_ERR_HIP;
     BdCtx bc;
     bc.sc = scene_view(c); bc.cam = c->cam; bc.seed = seed; bc.bounded = c->bdpt_bounded;
@@ -650,6 +670,10 @@ int bdpt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t see
     float *sf = rf + 12 * NMAX;
     BdRays sr = {sf, sf + SCAP, sf + 2 * SCAP, sf + 3 * SCAP, sf + 4 * SCAP, sf + 5 * SCAP};
     int *sexpect = (int *)(sf + 6 * SCAP); float *sbound = sf + 7 * SCAP;
+    float *gf = sf + 8 * SCAP;                                   // staging arrays, [slot j][item]
+    BdRays gr = {gf, gf + SCAP, gf + 2 * SCAP, gf + 3 * SCAP, gf + 4 * SCAP, gf + 5 * SCAP};
+    int *gexpect = (int *)(gf + 6 * SCAP); float *gbound = gf + 7 * SCAP;
+    int *ibase = c->bdpt_qidx.as<int>() + NMAX * BD_PAIRS, *icount = ibase + NMAX;
     float4 *ehits = c->bdpt_hits.as<float4>(), *shits = ehits + 2 * NMAX;
     int *scount = c->bdpt_ctr.as<int>();
     const int B = 128;
@@ -670,10 +694,11 @@ int bdpt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t see
         }
         hipLaunchKernelGGL(k_bd_delta, dim3((P + B - 1) / B), dim3(B), 0, st, c->bdpt_items.as<bpixel>(), c->bdpt_state.as<BdStep>(), tm, P, F, c->bdpt_px.as<int>());
         hipLaunchKernelGGL(k_bd_connect<0>, dim3((N + B - 1) / B), dim3(B), 0, st, bc, c->bdpt_items.as<bpixel>(), c->bdpt_state.as<BdStep>(), tm, P, N, frame0,
-                           sr, sexpect, sbound, c->bdpt_qidx.as<int>(), scount, shits, c->bdpt_rad.as<float>(), 3 * NP, &ctr->rays_shadow);
+                           gr, gexpect, gbound, c->bdpt_qidx.as<int>(), ibase, icount, scount, shits, c->bdpt_rad.as<float>(), 3 * NP, &ctr->rays_shadow);
+        hipLaunchKernelGGL(k_bd_compact, dim3((N + B - 1) / B), dim3(B), 0, st, N, ibase, icount, gr, gexpect, gbound, sr, sexpect, sbound);
         if (int rc = trace_arrays(c, sr.ox, sr.oy, sr.oz, sr.dx, sr.dy, sr.dz, (int)(SCAP < (size_t)N * 27 ? SCAP : (size_t)N * 27), scount, shits, sexpect, sbound, false)) return rc;
         hipLaunchKernelGGL(k_bd_connect<1>, dim3((N + B - 1) / B), dim3(B), 0, st, bc, c->bdpt_items.as<bpixel>(), c->bdpt_state.as<BdStep>(), tm, P, N, frame0,
-                           sr, sexpect, sbound, c->bdpt_qidx.as<int>(), scount, shits, c->bdpt_rad.as<float>(), 3 * NP, &ctr->rays_shadow);
+                           sr, sexpect, sbound, c->bdpt_qidx.as<int>(), ibase, icount, scount, shits, c->bdpt_rad.as<float>(), 3 * NP, &ctr->rays_shadow);
         for (int f = 0; f < F; f++) {                     // the running mean applies the frames in order
             const float coff = 1.0f / ((float)(int)(frame0 + (uint32_t)f) + 1.0f);
             hipLaunchKernelGGL(k_bdpt_film, dim3((unsigned)((3 * NP + 255) / 256)), dim3(256), 0, st, c->bdpt_rad.as<float>() + (size_t)f * 3 * NP,
