@@ -7,6 +7,10 @@ are what travels).
   out_png_blocks.npy      [32,32,3] f32 means of 16x16 pixel blocks of /root/reference/out.png
                           (Cornell, PT_RGB, 512^2, 512 spp, exposure 0.5; example/Example.py:49),
                           sRGB in [0,1], PNG row/col order
+  veach_bdpt512_blocks.npy, veach_pt512_blocks.npy
+                          the same block means of /root/reference/image/veach-bdpt512.png and veach-pt512.png, the
+                          gallery renders of example/veach_bdpt.py (BDPT_RGB) and of the same scene through PT_RGB
+                          (512^2; sample count and exposure not recorded by the reference: the tests fit one exposure)
 """
 import shutil
 import sys
@@ -20,3 +24,8 @@ img = np.asarray(Image.open(REF + "/out.png").convert("RGB")).astype(np.float32)
 blocks = img.reshape(32, 16, 32, 16, 3).mean(axis=(1, 3)).astype(np.float32)
 np.save("out_png_blocks.npy", blocks)
 print(blocks.shape, blocks.reshape(-1, 3).mean(0))
+for name in ("veach-bdpt512", "veach-pt512"):
+    img = np.asarray(Image.open(REF + "/image/" + name + ".png").convert("RGB")).astype(np.float32) / 255.0
+    blocks = img.reshape(32, 16, 32, 16, 3).mean(axis=(1, 3)).astype(np.float32)
+    np.save(name.replace("-", "_") + "_blocks.npy", blocks)
+    print(name, blocks.shape, blocks.reshape(-1, 3).mean(0))

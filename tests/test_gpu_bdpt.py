@@ -92,3 +92,46 @@ def test_bounded_connection_rays_give_the_same_film(gpu_ctx_ok):
     m = np.isfinite(films[0]).all(axis=2) & np.isfinite(films[1]).all(axis=2)
     assert (np.isfinite(films[0]).all(axis=2) == np.isfinite(films[1]).all(axis=2)).all() and m.mean() > 0.98
     assert rel_l2(films[0][m], films[1][m]) <= 1e-6
+
+
+def _blocks(rgb, n=32):
+    img = np.transpose(rgb, (1, 0, 2))[::-1]                  # film (i, j) -> PNG rows/cols (Example.write_png)
+    b = img.shape[0] // n
+    return img.reshape(n, b, n, b, 3).mean(axis=(1, 3))
+
+
+def test_config5_matches_the_reference_gallery_render(gpu_ctx_ok):
+    """BASELINE config 5 at its full size (veach_bdpt.py: bdpt.obj, BDPT_RGB, 512^2, exposure 0.5 of Example.py:43), 64 spp,
+    against the reference's own render of it, image/veach-bdpt512.png (block means in tests/golden; the reference recorded
+    neither seed nor sample count, so this is a statistical pin like the out.png one): mean colour within 2 %, 16x16-block
+    means within 5 % relative L2.  The same scene through PT_RGB is compared with image/veach-pt512.png more loosely (the
+    caustic paths PT finds rarely carry much of that image's energy: at 256 spp it still sits 10 % below the reference)."""
+    import os
+    from ti_raytrace_amd import UtilsFunc as UF
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    W = H = 512
+    ex = scenes.veach_bdpt(W, H, 64, device_id=0)
+    ex.build_scene()
+    ex.integrator.render_frames(64)
+    UF.tone_map(0.5, ex.integrator.hdr, ex.integrator.rgb_film)
+    ours = _blocks(ex.integrator.rgb_film.to_numpy())
+    ref = np.load(os.path.join(gold, "veach_bdpt512_blocks.npy"))
+    mean_err = np.abs(ours.reshape(-1, 3).mean(0) - ref.reshape(-1, 3).mean(0)) / ref.reshape(-1, 3).mean(0)
+    r = rel_l2(ours, ref)
+    print("veach BDPT 512^2 x64 vs veach-bdpt512.png: mean err %s, block rel-L2 %.4f" % (np.round(mean_err, 4), r))
+    assert (mean_err < 0.02).all() and r < 0.05
+    ex = scenes.veach_bdpt(W, H, 256, device_id=0, integrator="pt")
+    ex.build_scene()
+    ex.render_all(batch=64)
+    UF.tone_map(0.5, ex.integrator.hdr, ex.integrator.rgb_film)
+    ours = _blocks(ex.integrator.rgb_film.to_numpy())
+    ref = np.load(os.path.join(gold, "veach_pt512_blocks.npy"))
+    mean_err = np.abs(ours.reshape(-1, 3).mean(0) - ref.reshape(-1, 3).mean(0)) / ref.reshape(-1, 3).mean(0)
+    print("veach PT 512^2 x256 vs veach-pt512.png: mean err %s, block rel-L2 %.4f" % (np.round(mean_err, 4), rel_l2(ours, ref)))
+    assert (mean_err < 0.20).all() and rel_l2(ours, ref) < 0.25
+
+
+# (No Cornell-BDPT-vs-out.png test: with the reference's mis_weight comparing a material INDEX with MAT_DISNEY
+# (integrator/BDPT_RGB.py:364,379,432 -- kept, see oracle.c) BDPT_RGB is not a consistent estimator of PT_RGB's image on scenes
+# whose non-zero material indices are Disney materials: Cornell comes out ~2x brighter, in the oracle as on the device.  The
+# reference's own BDPT render exists only for config 5, which is what is pinned above.)
