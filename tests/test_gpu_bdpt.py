@@ -135,3 +135,16 @@ def test_config5_matches_the_reference_gallery_render(gpu_ctx_ok):
 # (integrator/BDPT_RGB.py:364,379,432 -- kept, see oracle.c) BDPT_RGB is not a consistent estimator of PT_RGB's image on scenes
 # whose non-zero material indices are Disney materials: Cornell comes out ~2x brighter, in the oracle as on the device.  The
 # reference's own BDPT render exists only for config 5, which is what is pinned above.)
+
+def test_config5_full_size_frame_against_the_oracle(gpu_ctx_ok):
+    """BASELINE config 5 at its full 512^2 (one frame = 262 144 eye + light sub-path pairs, 3.5 M rays): device film vs the
+    oracle's -- same NaN pixels, rel-L2 <= 1e-3 on the finite ones (float-atomic order of the splats), same ray counts."""
+    W = H = 512
+    ex = scenes.veach_bdpt(W, H, 4, device_id=0)
+    got, want, st, ost = run_both(ex, W, H, 1)
+    gn, wn = np.isnan(got).any(axis=2), np.isnan(want).any(axis=2)
+    print("config 5, 512^2 x 1 frame: %d NaN pixels (oracle %d), rays %d + %d" % (gn.sum(), wn.sum(), st["rays_closest"], st["rays_shadow"]))
+    assert (gn == wn).all()
+    m = np.isfinite(want).all(axis=2) & np.isfinite(got).all(axis=2)
+    assert rel_l2(got[m], want[m]) <= 1e-3
+    assert st["rays_closest"] == ost["rays_closest"] and st["rays_shadow"] == ost["rays_shadow"]

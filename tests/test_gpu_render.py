@@ -282,3 +282,29 @@ def test_spot_and_laser_emitters_are_refused(gpu_ctx_ok):
     s = np.zeros((1, 10), np.float32); s[0, 0] = 1; s[0, 4] = 1.0
     ctx.scene_upload(v, prim, m, s, np.array([1], np.int32), 1, -np.ones(3), np.ones(3))
     ctx.close()
+
+
+def test_config2_full_size_tile_sample_against_the_oracle(gpu_ctx_ok):
+    """BASELINE config 2 at its full 1024^2 x 64 spp (glass Teapot, sphere light, env map, smooth normals with the
+    reference's NaN normals, Scene.py:377): three 2048-pixel runs of the film, re-rendered by the oracle, must equal the
+    device film bit for bit -- NaN pixels included (a NaN sample makes a pixel NaN for good, PT_RGB.py:136) -- and the
+    whole film's NaN-pixel count is reported."""
+    W = H = 1024
+    ex = scenes.single_model(W, H, 64, device_id=0)
+    ex.build_scene()
+    o = oa.OracleScene(ex.scene, ex.cam)
+    o.lbvh_build(); o.process_normal(ex.scene.vertex_index_np)
+    ex.render_all(batch=32)
+    got = ex.integrator.hdr.to_numpy().reshape(-1, 3)
+    nan_px = int(np.isnan(got).any(axis=1).sum())
+    print("config 2, 1024^2 x 64 spp: %d NaN pixels of %d" % (nan_px, W * H))
+    checked = nan_checked = 0
+    for p0 in (300 * 1024 + 200, 512 * 1024 + 380, 700 * 1024 + 500):
+        want, _ = o.render(W, H, 0, 64, seed=ex.integrator.seed, p_begin=p0, p_end=p0 + 2048)
+        want = want.reshape(-1, 3)[p0:p0 + 2048]
+        mine = got[p0:p0 + 2048]
+        same = (mine.view(np.uint32) == want.view(np.uint32)) | (np.isnan(mine) & np.isnan(want))
+        assert same.all(), (p0, int((~same).sum()))
+        checked += 2048; nan_checked += int(np.isnan(want).any(axis=1).sum())
+    print("  %d pixels x 64 spp identical to the oracle (%d of them NaN)" % (checked, nan_checked))
+    assert (got[~np.isnan(got).any(axis=1)] >= 0).all()

@@ -30,6 +30,7 @@ def run(name, ex, spp, batch, warm=True):
                       "seconds": round(dt, 3), "rays_closest": st["rays_closest"], "rays_shadow": st["rays_shadow"],
                       "rays_per_path": round(rays / max(st["paths"], 1), 3), "lbvh_build_ms": round(st["ms_build"], 3),
                       "setup_wall_s": round(t_build, 3), "finite": bool(np.isfinite(hdr).all()),
+                      "nan_pixels": int(np.isnan(hdr).any(axis=2).sum()), "inf_pixels": int(np.isinf(hdr).any(axis=2).sum()),
                       "mean_srgb": [round(float(x), 4) for x in rgb.reshape(-1, 3).mean(0)], "stack_overflow": st["stack_overflow"]}))
 
 
