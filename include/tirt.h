@@ -148,6 +148,16 @@ int tirt_trace_closest(tirt_ctx *ctx, const float *rays, int nr, int stack_size,
 int tirt_trace_shadow(tirt_ctx *ctx, const float *rays, int nr, int stack_size, int flags,
                       float *out_t, int32_t *out_prim, int32_t *counts);
 
+/* Multi-GPU without a Python framework in the loop (the reference has nothing here): ONE host thread drives
+ * ndev contexts, one per device of the node, each created with tirt_film_create(..., tile_rank = i, tile_count = ndev, ...).
+ * tirt_comm_init builds one RCCL communicator over them (librccl is loaded on first use); tirt_film_reduce sums the films
+ * -- zero outside a context's own tiles -- onto ctxs[root] with one ncclReduce per device in a group (xGMI), and returns
+ * when every stream has finished.  bench.py's one-process-per-GPU runs use tirt_film_export_device / import_device around
+ * torch.distributed's RCCL reduce instead. */
+int tirt_comm_init(tirt_ctx **ctxs, int ndev);
+int tirt_film_reduce(tirt_ctx **ctxs, int ndev, int root);
+int tirt_comm_destroy(tirt_ctx **ctxs, int ndev);
+
 /* Measurement helpers for bench.py's roofline object (no counterpart in the reference).
  * tirt_bvh_info: bytes of the traversal data the ordered traversal walks (out[0] = quantised 4-wide nodes,
  *   out[1] = primitive records, out[2] = node count, out[3] = of those kept in LDS by every block).

@@ -308,3 +308,27 @@ def test_config2_full_size_tile_sample_against_the_oracle(gpu_ctx_ok):
         checked += 2048; nan_checked += int(np.isnan(want).any(axis=1).sum())
     print("  %d pixels x 64 spp identical to the oracle (%d of them NaN)" % (checked, nan_checked))
     assert (got[~np.isnan(got).any(axis=1)] >= 0).all()
+
+
+def test_rccl_film_reduce_through_the_c_abi(gpu_ctx_ok):
+    """tirt_comm_init / tirt_film_reduce (librccl loaded by the library itself, no torch): on this 1-GPU box a one-rank
+    communicator -- the reduce must leave the film as it was, twice in a row, and a second context on the SAME device
+    must be refused (one context per device in a communicator)."""
+    W = H = 64
+    ex = scenes.cornell_box(W, H, 4, device_id=0)
+    ex.build_scene()
+    ex.integrator.render_frames(2)
+    before = ex.integrator.hdr.to_numpy().copy()
+    comm = _native.Communicator([ex.scene.ctx])
+    comm.film_reduce(0); comm.film_reduce(0)
+    assert np.array_equal(ex.integrator.hdr.to_numpy(), before)
+    other = _native.Context(0)
+    with pytest.raises(_native.TirtError, match="already in a communicator|one context per device"):
+        _native.Communicator([ex.scene.ctx, other])
+    comm.close()
+    with pytest.raises(_native.TirtError, match="one context per device"):
+        _native.Communicator([ex.scene.ctx, other])
+    other.close()
+    # rendering goes on after the communicator is gone
+    ex.integrator.render_frames(1)
+    assert np.isfinite(ex.integrator.hdr.to_numpy()).all()

@@ -81,6 +81,9 @@ SIGNATURES = {
     "tirt_film_import_device": (C.c_int, [_vp, _vp]),
     "tirt_trace_closest": (C.c_int, [_vp, _f32p, C.c_int, C.c_int, C.c_int, _f32p, _i32p, _vp]),
     "tirt_trace_shadow": (C.c_int, [_vp, _f32p, C.c_int, C.c_int, C.c_int, _f32p, _i32p, _vp]),
+    "tirt_comm_init": (C.c_int, [C.POINTER(_vp), C.c_int]),
+    "tirt_film_reduce": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_int]),
+    "tirt_comm_destroy": (C.c_int, [C.POINTER(_vp), C.c_int]),
     "tirt_bvh_info": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
     "tirt_micro_gather_rate": (C.c_int, [_vp, C.c_uint64, C.c_int, C.POINTER(C.c_double)]),
     "tirt_stats": (C.c_int, [_vp, C.POINTER(Stats)]),
@@ -305,3 +308,20 @@ def device_count():
     v = C.c_int(0)
     check(lib().tirt_device_count(C.byref(v)))
     return v.value
+
+
+class Communicator:
+    """RCCL communicator over several contexts of ONE process (tirt_comm_init / tirt_film_reduce)."""
+
+    def __init__(self, contexts):
+        self.contexts = list(contexts)
+        self._arr = (C.c_void_p * len(self.contexts))(*[c.handle.value for c in self.contexts])
+        check(lib().tirt_comm_init(self._arr, len(self.contexts)))
+
+    def film_reduce(self, root=0):
+        check(lib().tirt_film_reduce(self._arr, len(self.contexts), int(root)))
+
+    def close(self):
+        if self._arr is not None:
+            lib().tirt_comm_destroy(self._arr, len(self.contexts))
+            self._arr = None

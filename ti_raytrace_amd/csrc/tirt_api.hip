@@ -256,6 +256,7 @@ int tirt_create(int device_id, tirt_ctx **out)
 void tirt_destroy(tirt_ctx *c)
 {
     if (!c) return;
+    if (c->comm) { tirt_ctx *one[1] = {c}; (void)tirt_comm_destroy(one, 1); }
     (void)hipSetDevice(c->device);
     (void)sync_all(c);
     drain_render_events(c);

@@ -228,6 +228,9 @@ struct tirt_ctx {
     // batch trace scratch
     tirt::DevBuf tr_rays, tr_out, tr_prim, tr_counts;
 
+    // RCCL communicator of tirt_comm_init (single-process multi-GPU film reduce; opaque ncclComm_t)
+    void *comm = nullptr; int comm_rank = 0, comm_size = 0;
+
     // stats
     tirt::DevBuf dev_counters;                    // DevCounters
     double ms_build = 0, ms_render = 0, ms_trace_closest = 0, ms_trace_shadow = 0, ms_shade = 0;
