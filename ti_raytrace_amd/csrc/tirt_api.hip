@@ -21,12 +21,12 @@ SceneView scene_view(const tirt_ctx *c)
 BvhView bvh_view(const tirt_ctx *c)
 {
     BvhView b;
-    b.wnode = c->wnode.as<float4>(); b.qnode = c->qnode.as<float4>(); b.qtop = c->qtop.as<float4>(); b.tri = c->tri.as<float4>();
-    b.cnode = c->cnode.as<uint4>(); b.ctop = c->ctop.as<uint4>(); b.compact = c->compact.as<float>(); b.cparent = c->cparent.as<int>();
+    b.wnode = c->wnode.as<float4>(); b.tri = c->tri.as<float4>();
+    b.cnode = c->cnode.as<uint4>(); b.top_count = c->wide_nodes < TR_TOP_SLOTS ? c->wide_nodes : TR_TOP_SLOTS; b.compact = c->compact.as<float>(); b.cparent = c->cparent.as<int>();
     for (int k = 0; k < 3; k++) { b.grid_min[k] = c->grid_min[k]; b.cell[k] = c->grid_cell[k]; b.inv_cell[k] = c->grid_inv_cell[k]; b.inv_extent[k] = c->grid_inv_extent[k]; }
     for (int k = 0; k < 3; k++) { b.root_min[k] = c->root_min[k]; b.root_max[k] = c->root_max[k]; }
     b.root_code = c->root_code;
-    b.root_qcode = c->root_code >= 0 ? TR_TOP_BIT : c->root_code;
+    b.root_qcode = c->root_code;        // >= 0: wide node 0
     return b;
 }
 int flush_pending(tirt_ctx *c)
@@ -262,7 +262,7 @@ void tirt_destroy(tirt_ctx *c)
     drain_render_events(c);
     DevBuf *bufs[] = {&c->vertex, &c->primitive, &c->material, &c->shape, &c->light, &c->env, &c->mat_lrgb, &c->morton_unsorted, &c->keys_a,
                       &c->keys_b, &c->vals_a, &c->vals_b, &c->hist, &c->morton_sorted, &c->bvh_node, &c->compact, &c->parent,
-                      &c->flag, &c->subtree, &c->build_status, &c->leaf_compact, &c->wnode, &c->tri, &c->qnode, &c->quad_flag, &c->quad_index, &c->quad_top, &c->qtop, &c->scan_tiles, &c->cnode, &c->ctop, &c->cparent, &c->hdr, &c->rgb,
+                      &c->flag, &c->subtree, &c->build_status, &c->leaf_compact, &c->wnode, &c->tri, &c->cnode, &c->cparent, &c->wide_queue, &c->wide_levels, &c->hdr, &c->rgb,
                       &c->counters_mem, &c->spill, &c->tr_rays,
                       &c->tr_out, &c->tr_prim, &c->tr_counts, &c->dev_counters, &c->bdpt_px, &c->bdpt_rad, &c->bdpt_items, &c->bdpt_state,
                       &c->bdpt_rays, &c->bdpt_hits, &c->bdpt_qidx, &c->bdpt_ctr};
@@ -606,15 +606,7 @@ int tirt_bvh_info(tirt_ctx *c, uint64_t out[4])
 {
     CTX(c);
     TIRT_REQUIRE(out && c->built, "tirt_bvh_info: LBVH not built");
-    int nq = 0;
-    if (c->n >= 2) {     // number of 4-wide nodes = exclusive scan of quad_flag at the last node + its flag
-        int last[2] = {0, 0};
-        const size_t N = 2 * (size_t)c->n - 1;
-        TIRT_HIP(hipMemcpyAsync(&last[0], c->quad_index.as<int>() + (N - 1), sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        TIRT_HIP(hipMemcpyAsync(&last[1], c->quad_flag.as<int>() + (N - 1), sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        TIRT_HIP(hipStreamSynchronize(c->stream));
-        nq = last[0] + last[1];
-    }
+    const int nq = c->wide_nodes;
     out[0] = (uint64_t)nq * 64u; out[1] = (uint64_t)c->n * sizeof(float4) * TRI_STRIDE; out[2] = (uint64_t)nq;
     out[3] = (uint64_t)(nq < TR_TOP_SLOTS ? nq : TR_TOP_SLOTS);
     return TIRT_OK;

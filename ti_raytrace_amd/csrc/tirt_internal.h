@@ -56,10 +56,6 @@ struct DevBuf {
 //              E1 = v1 - v0, E2 = v2 - v0 are formed per test as the reference does (Scene.py:608-609), and the exact
 //              leaf box (min / max of the three) is at hand for the hit verification of the ordered traversal
 //   spheres  : (centre.xyz, bits leaf_compact_index) (radius, 0, 0, 0) (0,0,0,0)
-// qnode: one 128-byte record per internal node at even depth (dense index in compact order), holding
-//   its up to four grandchildren: (q0 q1 q2) boxes of slots 0,1 laid out like wnode's, (q3 q4 q5) slots
-//   2,3, q6 = four codes (>= 0: qnode index, < 0: leaf as above, TR_EMPTY: unused slot), q7 unused.
-//   The ordered traversal and BDPT walk these; wnode serves the exhaustive (reference-order) mode.
 #ifndef TRI_STRIDE_N
 #define TRI_STRIDE_N 3
 #endif
@@ -74,7 +70,6 @@ constexpr int TR_TOP_LEVELS = TR_TOP_LEVELS_N;           // levels of 4-wide nod
 #endif
 constexpr int TR_TOP_FULL = ((1 << (2 * TR_TOP_LEVELS)) - 1) / 3;
 constexpr int TR_TOP_SLOTS = TR_TOP_FULL < TR_TOP_CAP ? TR_TOP_FULL : TR_TOP_CAP;   // 341 for five levels (38 KB of LDS per block)
-constexpr int TR_TOP_BIT = 1 << 29;                      // child code of a 4-wide node that lives in the LDS-resident top: TR_TOP_BIT | slot
 // cnode: the 4-wide nodes again, 64 bytes each, box planes quantised on ONE grid over the root box (k_cnodes):
 //   plane = grid_min + h * cell with h an fp16 number of cells measured from the CENTRE of the root box (|h| <= 30000:
 //   the spacing of fp16 there is 16 cells = 2.7e-4 of the extent, finer towards the centre), min planes rounded down
@@ -101,17 +96,15 @@ constexpr int TIRT_MAX_DEVICES = 64;
 inline size_t trace_lds_bytes(int depth) { return sizeof(int) * (size_t)depth * TR_BLOCK + (size_t)TR_TOP_SLOTS * 64; }
 struct BvhView {
     const float4 *wnode;
-    const float4 *qnode;
     const float4 *tri;
-    const float4 *qtop;           // the first TR_TOP_LEVELS levels of qnode in breadth-first slots (BDPT's plain traversal)
-    const uint4 *cnode;           // quantised 4-wide nodes (ordered traversal)
-    const uint4 *ctop;            // their first TR_TOP_LEVELS levels in breadth-first slots (copied to LDS by k_trace)
+    const uint4 *cnode;           // quantised 4-wide nodes in breadth-first order: the first TR_TOP_SLOTS are copied to LDS by k_trace
+    int top_count;                // min(number of nodes, TR_TOP_SLOTS)
     const float *compact;         // reference compact_node rows [N*9] (exact boxes: hit verification)
     const int *cparent;           // compact index of the parent of compact node i (-1 for the root)
     float grid_min[3], cell[3], inv_cell[3], inv_extent[3];
     float root_min[3], root_max[3];
     int root_code;                // two-child layout: compact index 0, or the leaf code of a one-primitive scene
-    int root_qcode;               // 4-wide layout: TR_TOP_BIT | 0, or the same leaf code
+    int root_qcode;               // 4-wide layout: node 0, or the same leaf code
 };
 
 // Wavefront state, struct-of-arrays in HBM.  Live paths are kept DENSE: every bounce the shade
@@ -185,8 +178,8 @@ struct tirt_ctx {
     tirt::DevBuf bvh_node, compact;               // f32 [N*11], [N*9]
     tirt::DevBuf parent, flag, subtree, build_status, leaf_compact;
     tirt::DevBuf wnode, tri;                      // traversal layout
-    tirt::DevBuf qnode, quad_flag, quad_index, quad_top, qtop, scan_tiles;   // 4-wide traversal nodes (exact boxes)
-    tirt::DevBuf cnode, ctop, cparent;             // quantised 4-wide nodes + parent chain of the compact nodes (ordered traversal)
+    tirt::DevBuf cnode, cparent, wide_queue, wide_levels;    // quantised 4-wide nodes (ordered traversal) + parent chain of the compact nodes + build scratch
+    int wide_nodes = 0;                            // number of 4-wide nodes
     float grid_min[3] = {0, 0, 0}, grid_cell[3] = {1, 1, 1}, grid_inv_cell[3] = {1, 1, 1}, grid_inv_extent[3] = {1, 1, 1};
     size_t lds_optin = 65536;                      // hipDeviceAttributeMaxSharedMemoryPerBlock (opt-in) of this device
     float root_min[3], root_max[3]; int root_code = 0;

@@ -324,19 +324,17 @@ __global__ void k_refit(int n, float *bvh_node, const int *parent, int *flag, in
 // child of the left sibling's subtree size (accel/LBvh.py:138-161: left first, right's slot
 // stored in the parent's word 1, left implicit at slot+1).
 __global__ void k_flatten(int n, const float *bvh_node, const int *parent, const int *subtree, float *compact, int *leaf_compact,
-                          int *quad_flag, int *quad_top, int *cparent)
+                          int *cparent)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     int N = 2 * n - 1;
     if (i >= N) return;
     int off = 0, cur = i, depth = 0, first_step = 0;
-    unsigned path = 0;                       // bit k: the step k levels above the node went to a right child
     while (true) {
         int p = parent[cur];
         if (p < 0) break;
         const float *pn = bvh_node + (size_t)p * NOD_VEC;
         int pl = (int)pn[1];
-        if (cur != pl && depth < 32) path |= 1u << depth;
         const int step = 1 + ((cur != pl) ? subtree[pl] : 0);
         if (depth == 0) first_step = step;
         off += step; depth += 1;
@@ -346,15 +344,6 @@ __global__ void k_flatten(int n, const float *bvh_node, const int *parent, const
     const float *nd = bvh_node + (size_t)i * NOD_VEC;
     float *cn = compact + (size_t)off * CPN_VEC;
     cn[0] = nd[0];
-    // internal nodes at even depth root the 4-wide traversal nodes (k_qnodes)
-    const bool is_quad = (((int)nd[0]) & 1) == 0 && (depth & 1) == 0;
-    quad_flag[off] = is_quad ? 1 : 0;
-    // the first TR_TOP_LEVELS levels of 4-wide nodes also get a breadth-first slot (heap numbering by
-    // path): the traversal kernel keeps those records in LDS
-    const int qd = depth >> 1;
-    int top_slot = (is_quad && qd < TR_TOP_LEVELS) ? (int)(((1u << (2 * qd)) - 1u) / 3u + path) : -1;
-    if (top_slot >= TR_TOP_SLOTS) top_slot = -1;
-    quad_top[off] = top_slot;
     if ((((int)nd[0]) & 1) == 1) {
         cn[1] = nd[4];
         leaf_compact[(int)nd[4]] = off;
@@ -416,159 +405,75 @@ __global__ void k_tris(SceneView s, const int *leaf_compact, float4 *tri)
 }
 
 // ---------------------------------------------------------------------------------------------
-// 4-wide traversal nodes for the ordered (product) traversal.  Every internal node at even depth
-// becomes one 128-byte record holding its (up to four) grandchildren: a child that is a leaf keeps its
-// slot, an internal child is replaced by its two children.  Boxes are the reference's own (leaf boxes
-// inflated by `pad`, as in k_wnodes); skipping the box test of the collapsed child changes no result:
-// a child box lies inside its parent's and `slabs` is monotone in the plane positions (fl(b - o) and
-// fl(x * (1/d)) are), so "grandchild passes" implies "child passes".
-//   q0 q1 q2 = boxes of slots 0,1 laid out like wnode's,  q3 q4 q5 = slots 2,3,  q6 = the four codes:
-//   >= 0 a 4-wide node (dense index, or TR_TOP_BIT | breadth-first slot for the first TR_TOP_LEVELS levels,
-//   which k_trace keeps in LDS), < 0 leaf (as in wnode), TR_EMPTY = unused slot (box never hit).
-// Records are numbered in compact (DFS) order by an exclusive scan of quad_flag.
+// 4-wide traversal nodes for the ordered (product) traversal (tirt_internal.h, BvhView::cnode).
+// The binary LBVH is collapsed top-down, one launch per level of the wide tree: a wide node starts with the two children
+// of its binary root and keeps replacing the internal candidate of LARGEST surface area by that node's two children
+// until it holds four (or only leaves are left) -- the usual surface-area collapse: 3.9 children per node instead of the
+// 3.0 of a fixed "every other level" collapse, i.e. a quarter fewer, fuller nodes and ~20 % fewer visits per ray.  Any
+// grouping of the reference's boxes is as good as another for the RESULT: a skipped binary node's box contains its
+// children's, `slabs` is monotone in the plane positions, and a hit is only accepted after the reference's own visiting
+// condition has been re-established (k_trace).  Nodes are numbered in breadth-first order (a level's nodes take the next
+// free indices), so the first TR_TOP_SLOTS records ARE the top of the tree that k_trace keeps in LDS.
+// Planes: fp16 cells around the centre of the root box, min planes rounded down and max planes up, one more cell outward
+// against the rounding of the mapping itself; leaf slots are padded by `pad` before the mapping (the reference never
+// box-tests a leaf: the padding keeps "box missed but Moller-Trumbore hit" impossible).
+// Analytic shapes (the sphere light) keep the whole grid as their slot box: the reference's sphere test (Scene.py:565-596:
+// a square root of a difference of squares of the distance to the centre) answers "hit" for rays that pass the sphere at
+// a distance that grows with the distance of the origin -- no fixed padding of the sphere's box covers that.
 // ---------------------------------------------------------------------------------------------
-constexpr int SC_BLOCK = 256, SC_ITEMS = 8, SC_TILE = SC_BLOCK * SC_ITEMS;
-__global__ __launch_bounds__(SC_BLOCK) void k_scan_tiles(const int *in, int *out, int *tile_sum, int N)
-{
-    __shared__ int sh[SC_BLOCK];
-    const int base = blockIdx.x * SC_TILE + threadIdx.x * SC_ITEMS;
-    int v[SC_ITEMS], t = 0;
-#pragma unroll
-    for (int k = 0; k < SC_ITEMS; k++) { v[k] = (base + k < N) ? in[base + k] : 0; t += v[k]; }
-    sh[threadIdx.x] = t;
-    __syncthreads();
-    for (int o = 1; o < SC_BLOCK; o <<= 1) {
-        int x = (threadIdx.x >= o) ? sh[threadIdx.x - o] : 0;
-        __syncthreads();
-        sh[threadIdx.x] += x;
-        __syncthreads();
-    }
-    int run = sh[threadIdx.x] - t;
-#pragma unroll
-    for (int k = 0; k < SC_ITEMS; k++) { if (base + k < N) out[base + k] = run; run += v[k]; }
-    if (threadIdx.x == SC_BLOCK - 1) tile_sum[blockIdx.x] = sh[threadIdx.x];
-}
-__global__ __launch_bounds__(1024) void k_scan_tops(int *tile_sum, int nt)
-{
-    __shared__ int sh[1024];
-    __shared__ int carry;
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    for (int b0 = 0; b0 < nt; b0 += 1024) {
-        const int i = b0 + threadIdx.x;
-        const int t = (i < nt) ? tile_sum[i] : 0;
-        sh[threadIdx.x] = t;
-        __syncthreads();
-        for (int o = 1; o < 1024; o <<= 1) {
-            int x = (threadIdx.x >= o) ? sh[threadIdx.x - o] : 0;
-            __syncthreads();
-            sh[threadIdx.x] += x;
-            __syncthreads();
-        }
-        if (i < nt) tile_sum[i] = carry + sh[threadIdx.x] - t;
-        __syncthreads();
-        if (threadIdx.x == 1023) carry += sh[1023];
-        __syncthreads();
-    }
-}
-__global__ void k_scan_add(int *out, const int *tile_sum, int N)
-{
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < N) out[i] += tile_sum[i / SC_TILE];
-}
-
-struct QSlot { float mn[3], mx[3]; int code; };
-TD QSlot quad_slot(SceneView s, const float *compact, const int *quad_index, const int *quad_top, int idx, float pad)
-{
-    const float *cn = compact + (size_t)idx * CPN_VEC;
-    QSlot q;
-    const bool leaf = (((int)cn[0]) & 1) == 1;
-    q.code = leaf ? child_code(s, cn, idx) : (quad_top[idx] >= 0 ? (TR_TOP_BIT | quad_top[idx]) : quad_index[idx]);
-    const float p = leaf ? pad : 0.0f;
-    for (int k = 0; k < 3; k++) { q.mn[k] = cn[2 + k] - p; q.mx[k] = cn[5 + k] + p; }
-    return q;
-}
-TD QSlot quad_empty()
-{
-    QSlot q; q.code = TR_EMPTY;
-    for (int k = 0; k < 3; k++) { q.mn[k] = 3.0e38f; q.mx[k] = 3.0e38f; }   // (3e38 - o) * (1/d) = +-inf on both planes: never hit
-    return q;
-}
-__global__ void k_qnodes(SceneView s, int N, const float *compact, const int *quad_flag, const int *quad_index, const int *quad_top,
-                         float4 *qnode, float4 *qtop, float pad)
-{
-    int o = blockIdx.x * blockDim.x + threadIdx.x;
-    if (o >= N || !quad_flag[o]) return;
-    const float *cn = compact + (size_t)o * CPN_VEC;
-    const int child[2] = {o + 1, (int)cn[1]};
-    QSlot sl[4];
-    for (int c = 0; c < 2; c++) {
-        const float *cc = compact + (size_t)child[c] * CPN_VEC;
-        if ((((int)cc[0]) & 1) == 1) { sl[2 * c] = quad_slot(s, compact, quad_index, quad_top, child[c], pad); sl[2 * c + 1] = quad_empty(); }
-        else {
-            sl[2 * c] = quad_slot(s, compact, quad_index, quad_top, child[c] + 1, pad);
-            sl[2 * c + 1] = quad_slot(s, compact, quad_index, quad_top, (int)cc[1], pad);
-        }
-    }
-    float4 *w = qnode + (size_t)quad_index[o] * 8;
-    for (int h = 0; h < 2; h++) {
-        const QSlot &a = sl[2 * h], &b = sl[2 * h + 1];
-        w[3 * h + 0] = make_float4(a.mn[0], a.mn[1], a.mn[2], a.mx[0]);
-        w[3 * h + 1] = make_float4(a.mx[1], a.mx[2], b.mn[0], b.mn[1]);
-        w[3 * h + 2] = make_float4(b.mn[2], b.mx[0], b.mx[1], b.mx[2]);
-    }
-    w[6] = make_float4(__int_as_float(sl[0].code), __int_as_float(sl[1].code), __int_as_float(sl[2].code), __int_as_float(sl[3].code));
-    w[7] = make_float4(__int_as_float(quad_top[o]), 0.0f, 0.0f, 0.0f);
-    if (quad_top[o] >= 0) {                  // copy for the LDS-resident top of the tree
-        float4 *t = qtop + (size_t)quad_top[o] * 8;
-        for (int k = 0; k < 8; k++) t[k] = w[k];
-    }
-}
-
-// Quantised 4-wide nodes (tirt_internal.h, BvhView::cnode): the same slots as k_qnodes, every plane mapped to grid
-// cells around the centre of the root box and stored as fp16, min planes rounded down and max planes up, one more cell
-// outward against the rounding of the mapping itself.  Leaf slots are padded like qnode's before the mapping.
-// Analytic shapes (the sphere light) keep the whole grid as their slot box: the reference never box-tests a leaf
-// (Scene.py:716-722), and its sphere test (Scene.py:565-596: a square root of a difference of squares of the distance
-// to the centre) answers "hit" for rays that pass the sphere at a distance that grows with the distance of the origin
-// -- no fixed padding of the sphere's box covers that.  Triangle leaves are safe behind `pad` plus the per-ray margin.
 struct GridMap { float g0[3], inv_cell[3]; };
-TD bool is_shape_leaf(int code) { return code < 0 && code != TR_EMPTY && (((~code) >> 30) & 1) != 0; }
 // fp16 bit pattern of the largest half <= x - 1 / the smallest half >= x + 1 (x in grid cells, |x| <= TR_GRID_HALF + a few)
 TD unsigned grid_lo(float x, float g0, float inv_cell)
 { const float v = (x - g0) * inv_cell - 1.0f; return (unsigned)__half_as_ushort(__float2half_rd(v < -60000.0f ? -60000.0f : (v > 60000.0f ? 60000.0f : v))); }
 TD unsigned grid_hi(float x, float g0, float inv_cell)
 { const float v = (x - g0) * inv_cell + 1.0f; return (unsigned)__half_as_ushort(__float2half_ru(v < -60000.0f ? -60000.0f : (v > 60000.0f ? 60000.0f : v))); }
-__global__ void k_cnodes(SceneView s, int N, const float *compact, const int *quad_flag, const int *quad_index, const int *quad_top,
-                         uint4 *cnode, uint4 *ctop, float pad, GridMap gm)
+TD bool cn_leaf(const float *compact, int i) { return (((int)compact[(size_t)i * CPN_VEC]) & 1) == 1; }
+TD float cn_area(const float *compact, int i)
 {
-    int o = blockIdx.x * blockDim.x + threadIdx.x;
-    if (o >= N || !quad_flag[o]) return;
-    const float *cn = compact + (size_t)o * CPN_VEC;
-    const int child[2] = {o + 1, (int)cn[1]};
-    QSlot sl[4];
-    for (int c = 0; c < 2; c++) {
-        const float *cc = compact + (size_t)child[c] * CPN_VEC;
-        if ((((int)cc[0]) & 1) == 1) { sl[2 * c] = quad_slot(s, compact, quad_index, quad_top, child[c], pad); sl[2 * c + 1] = quad_empty(); }
-        else {
-            sl[2 * c] = quad_slot(s, compact, quad_index, quad_top, child[c] + 1, pad);
-            sl[2 * c + 1] = quad_slot(s, compact, quad_index, quad_top, (int)cc[1], pad);
-        }
+    const float *c = compact + (size_t)i * CPN_VEC;
+    const float dx = c[5] - c[2], dy = c[6] - c[3], dz = c[7] - c[4];
+    return dx * dy + dy * dz + dz * dx;
+}
+// level_off[L] / level_cnt[L]: first wide index and number of wide nodes of level L; queue holds the binary roots (compact
+// indices) of all wide nodes in breadth-first order (queue[w] for wide node w)
+__global__ void k_wide_level(SceneView s, const float *compact, int level, int *level_off, int *level_cnt, int *queue, uint4 *cnode, float pad, GridMap gm)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n_in = level_cnt[level], off = level_off[level];
+    if (t == 0) level_off[level + 1] = off + n_in;           // this level's children are numbered from here on
+    if (t >= n_in) return;
+    const int w = off + t, root = queue[w];
+    const float *rc = compact + (size_t)root * CPN_VEC;
+    int cand[4] = {root + 1, (int)rc[1], -1, -1}, nc = 2;
+    for (;;) {
+        if (nc == 4) break;
+        int best = -1; float best_area = -1.0f;
+        for (int k = 0; k < nc; k++) if (!cn_leaf(compact, cand[k])) { const float a = cn_area(compact, cand[k]); if (a > best_area) { best_area = a; best = k; } }
+        if (best < 0) break;
+        const int b = cand[best];
+        cand[best] = b + 1; cand[nc++] = (int)compact[(size_t)b * CPN_VEC + 1];
     }
-    unsigned w[16];
+    unsigned wd[16];
+    const int next_off = off + n_in;
     for (int c = 0; c < 4; c++) {
-        for (int a = 0; a < 3; a++)
-            w[3 * c + a] = (sl[c].code == TR_EMPTY) ? (TR_H_POS | (TR_H_NEG << 16))       // inverted box: never hit
-                           : is_shape_leaf(sl[c].code) ? (TR_H_NEG | (TR_H_POS << 16))
-                           : (grid_lo(sl[c].mn[a], gm.g0[a], gm.inv_cell[a]) | (grid_hi(sl[c].mx[a], gm.g0[a], gm.inv_cell[a]) << 16));
-        w[12 + c] = (unsigned)sl[c].code;
+        int code = TR_EMPTY;
+        if (c < nc) {
+            const float *cn = compact + (size_t)cand[c] * CPN_VEC;
+            if ((((int)cn[0]) & 1) == 1) code = child_code(s, cn, cand[c]);
+            else { const int pos = atomicAdd(&level_cnt[level + 1], 1); queue[next_off + pos] = cand[c]; code = next_off + pos; }
+            const bool leaf = code < 0;
+            const bool shape = leaf && (((~code) >> 30) & 1) != 0;
+            const float p = leaf ? pad : 0.0f;
+            for (int a = 0; a < 3; a++)
+                wd[3 * c + a] = shape ? (TR_H_NEG | (TR_H_POS << 16))
+                                      : (grid_lo(cn[2 + a] - p, gm.g0[a], gm.inv_cell[a]) | (grid_hi(cn[5 + a] + p, gm.g0[a], gm.inv_cell[a]) << 16));
+        } else {
+            for (int a = 0; a < 3; a++) wd[3 * c + a] = TR_H_POS | (TR_H_NEG << 16);       // inverted box: never hit
+        }
+        wd[12 + c] = (unsigned)code;
     }
-    uint4 *dst = cnode + (size_t)quad_index[o] * 4;
-    for (int k = 0; k < 4; k++) dst[k] = make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
-    if (quad_top[o] >= 0) {                  // copy for the LDS-resident top of the tree
-        uint4 *t = ctop + (size_t)quad_top[o] * 4;
-        for (int k = 0; k < 4; k++) t[k] = dst[k];
-    }
+    uint4 *dst = cnode + (size_t)w * 4;
+    for (int k = 0; k < 4; k++) dst[k] = make_uint4(wd[4 * k], wd[4 * k + 1], wd[4 * k + 2], wd[4 * k + 3]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -591,16 +496,12 @@ int lbvh_build(tirt_ctx *c)
         c->subtree.ensure(sizeof(int) * (size_t)N) || c->build_status.ensure(sizeof(int) * 32 * REFIT_SLOTS) ||
         c->leaf_compact.ensure(sizeof(int) * (size_t)n)) return TIRT_ERR_HIP;
     if (c->wnode.ensure(sizeof(float4) * 4 * (size_t)N) || c->tri.ensure(sizeof(float4) * TRI_STRIDE * (size_t)n)) return TIRT_ERR_HIP;
-    // 4-wide nodes: one per internal node at even depth (< n of them); indices are used as 32-bit byte offsets / 128
+    // 4-wide nodes: fewer than n of them; indices are used as 32-bit byte offsets / 64
     TIRT_REQUIRE(n <= (1 << 24), "tirt_lbvh_build: more than 16 Mi primitives");
-    const int n_tiles = (N + SC_TILE - 1) / SC_TILE;
-    if (c->qnode.ensure(sizeof(float4) * 8 * (size_t)n) || c->quad_flag.ensure(sizeof(int) * (size_t)N) ||
-        c->quad_index.ensure(sizeof(int) * (size_t)N) || c->scan_tiles.ensure(sizeof(int) * (size_t)n_tiles) ||
-        c->quad_top.ensure(sizeof(int) * (size_t)N) || c->qtop.ensure(sizeof(float4) * 8 * TR_TOP_SLOTS)) return TIRT_ERR_HIP;
-    if (c->cnode.ensure(sizeof(uint4) * 4 * (size_t)n) || c->ctop.ensure(sizeof(uint4) * 4 * TR_TOP_SLOTS) ||
-        c->cparent.ensure(sizeof(int) * (size_t)N)) return TIRT_ERR_HIP;
-    TIRT_HIP(hipMemsetAsync(c->qtop.p, 0, sizeof(float4) * 8 * TR_TOP_SLOTS, st0));
-    TIRT_HIP(hipMemsetAsync(c->ctop.p, 0, sizeof(uint4) * 4 * TR_TOP_SLOTS, st0));
+    constexpr int WIDE_LEVELS_MAX = 96;
+    if (c->cnode.ensure(sizeof(uint4) * 4 * (size_t)n) || c->wide_queue.ensure(sizeof(int) * (size_t)n) ||
+        c->wide_levels.ensure(sizeof(int) * 2 * (WIDE_LEVELS_MAX + 2)) || c->cparent.ensure(sizeof(int) * (size_t)N)) return TIRT_ERR_HIP;
+    (void)st0;
 
     SceneView sv = scene_view(c);
     const int B = 256;
@@ -622,11 +523,7 @@ int lbvh_build(tirt_ctx *c)
     hipLaunchKernelGGL(k_refit, dim3((n + B - 1) / B), dim3(B), 0, st, n, c->bvh_node.as<float>(), c->parent.as<int>(),
                        c->flag.as<int>(), c->subtree.as<int>(), c->build_status.as<int>());
     hipLaunchKernelGGL(k_flatten, dim3((N + B - 1) / B), dim3(B), 0, st, n, c->bvh_node.as<float>(), c->parent.as<int>(),
-                       c->subtree.as<int>(), c->compact.as<float>(), c->leaf_compact.as<int>(), c->quad_flag.as<int>(), c->quad_top.as<int>(),
-                       c->cparent.as<int>());
-    hipLaunchKernelGGL(k_scan_tiles, dim3(n_tiles), dim3(SC_BLOCK), 0, st, c->quad_flag.as<int>(), c->quad_index.as<int>(), c->scan_tiles.as<int>(), N);
-    hipLaunchKernelGGL(k_scan_tops, dim3(1), dim3(1024), 0, st, c->scan_tiles.as<int>(), n_tiles);
-    hipLaunchKernelGGL(k_scan_add, dim3((N + B - 1) / B), dim3(B), 0, st, c->quad_index.as<int>(), c->scan_tiles.as<int>(), N);
+                       c->subtree.as<int>(), c->compact.as<float>(), c->leaf_compact.as<int>(), c->cparent.as<int>());
     // root box + refit status back to the host (one small read; the reference does ~depth of them)
     int done = 0, done_slots[32 * REFIT_SLOTS]; float root[11];
     TIRT_HIP(hipMemcpyAsync(done_slots, c->build_status.p, sizeof(done_slots), hipMemcpyDeviceToHost, st));
@@ -643,8 +540,6 @@ int lbvh_build(tirt_ctx *c)
     float pad = 1.0e-4f * diag;
     hipLaunchKernelGGL(k_wnodes, dim3((N + B - 1) / B), dim3(B), 0, st, sv, N, c->compact.as<float>(), c->wnode.as<float4>(), pad);
     hipLaunchKernelGGL(k_tris, dim3((n + B - 1) / B), dim3(B), 0, st, sv, c->leaf_compact.as<int>(), c->tri.as<float4>());
-    hipLaunchKernelGGL(k_qnodes, dim3((N + B - 1) / B), dim3(B), 0, st, sv, N, c->compact.as<float>(), c->quad_flag.as<int>(),
-                       c->quad_index.as<int>(), c->quad_top.as<int>(), c->qnode.as<float4>(), c->qtop.as<float4>(), pad);
     // grid of the quantised nodes: the (padded) root box spans cells -TR_GRID_HALF .. +TR_GRID_HALF around its centre
     GridMap gm;
     for (int k = 0; k < 3; k++) {
@@ -654,8 +549,29 @@ int lbvh_build(tirt_ctx *c)
         c->grid_cell[k] = cell; c->grid_min[k] = lo + 0.5f * ext; c->grid_inv_extent[k] = 1.0f / ext;
         gm.g0[k] = c->grid_min[k]; gm.inv_cell[k] = 1.0f / cell; c->grid_inv_cell[k] = gm.inv_cell[k];
     }
-    hipLaunchKernelGGL(k_cnodes, dim3((N + B - 1) / B), dim3(B), 0, st, sv, N, c->compact.as<float>(), c->quad_flag.as<int>(),
-                       c->quad_index.as<int>(), c->quad_top.as<int>(), c->cnode.as<uint4>(), c->ctop.as<uint4>(), pad, gm);
+    // surface-area collapse of the binary tree into 4-wide nodes, one launch per level of the wide tree (k_wide_level)
+    c->wide_nodes = 0;
+    if (n >= 2) {
+        int *lv_off = c->wide_levels.as<int>(), *lv_cnt = lv_off + (WIDE_LEVELS_MAX + 2);
+        TIRT_HIP(hipMemsetAsync(c->wide_levels.p, 0, sizeof(int) * 2 * (WIDE_LEVELS_MAX + 2), st));
+        const int one = 1;
+        TIRT_HIP(hipMemcpyAsync(lv_cnt, &one, sizeof(int), hipMemcpyHostToDevice, st));        // level 0: the root (compact index 0)
+        TIRT_HIP(hipMemsetAsync(c->wide_queue.p, 0, sizeof(int), st));
+        int level = 0, host_lv[2 * (WIDE_LEVELS_MAX + 2)];
+        for (;;) {
+            const int until = (level + 24 < WIDE_LEVELS_MAX) ? level + 24 : WIDE_LEVELS_MAX;
+            for (; level < until; level++) {
+                long cap = 1; for (int k = 0; k < level && cap < n; k++) cap *= 4;             // a level holds at most 4^level nodes
+                if (cap > n) cap = n;
+                hipLaunchKernelGGL(k_wide_level, dim3((unsigned)((cap + 127) / 128)), dim3(128), 0, st, sv, c->compact.as<float>(), level, lv_off, lv_cnt,
+                                   c->wide_queue.as<int>(), c->cnode.as<uint4>(), pad, gm);
+            }
+            TIRT_HIP(hipMemcpyAsync(host_lv, c->wide_levels.p, sizeof(host_lv), hipMemcpyDeviceToHost, st));
+            TIRT_HIP(hipStreamSynchronize(st));
+            if (host_lv[(WIDE_LEVELS_MAX + 2) + level] == 0) { c->wide_nodes = host_lv[level]; break; }       // the next level is empty: done
+            TIRT_REQUIRE(level < WIDE_LEVELS_MAX, "tirt_lbvh_build: the 4-wide tree is deeper than 96 levels");
+        }
+    }
     if (n == 1) {
         int prim = 0, is_shape = 0;
         int pr0;

@@ -158,8 +158,8 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
     typedef unsigned u4v __attribute__((ext_vector_type(4)));
     typedef __attribute__((address_space(3))) u4v lds_u4;
     if (MODE != TIRT_TRAVERSE_EXHAUSTIVE) {
-        for (int k = tid; k < TR_TOP_SLOTS * 4; k += TR_BLOCK)
-        { const uint4 g = b.ctop[k]; *(lds_u4 *)(size_t)(top_base + (unsigned)k * 16u) = u4v{g.x, g.y, g.z, g.w}; }
+        for (int k = tid; k < b.top_count * 4; k += TR_BLOCK)
+        { const uint4 g = b.cnode[k]; *(lds_u4 *)(size_t)(top_base + (unsigned)k * 16u) = u4v{g.x, g.y, g.z, g.w}; }
         __syncthreads();
     }
 #define TR_PAGE_OUT()                                                                                \
@@ -301,8 +301,8 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
                 } else {
                     // ordered mode on the quantised 4-wide nodes: four box tests, children visited near to far
                     uint4 q0, q1, q2, q3;
-                    if (cur & TR_TOP_BIT) {
-                        const lds_u4 *t = (const lds_u4 *)(size_t)(top_base + (unsigned)(cur & 0xffff) * 64u);
+                    if (cur < TR_TOP_SLOTS) {        // breadth-first numbering: the first nodes are the top of the tree, resident in LDS
+                        const lds_u4 *t = (const lds_u4 *)(size_t)(top_base + (unsigned)cur * 64u);
                         const u4v t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3];
 #define TR_U4(v) make_uint4((v).x, (v).y, (v).z, (v).w)
                         q0 = TR_U4(t0); q1 = TR_U4(t1); q2 = TR_U4(t2); q3 = TR_U4(t3);
