@@ -262,7 +262,7 @@ void tirt_destroy(tirt_ctx *c)
     drain_render_events(c);
     DevBuf *bufs[] = {&c->vertex, &c->primitive, &c->material, &c->shape, &c->light, &c->env, &c->mat_lrgb, &c->morton_unsorted, &c->keys_a,
                       &c->keys_b, &c->vals_a, &c->vals_b, &c->hist, &c->morton_sorted, &c->bvh_node, &c->compact, &c->parent,
-                      &c->flag, &c->subtree, &c->build_status, &c->leaf_compact, &c->wnode, &c->tri, &c->cnode, &c->cparent, &c->wide_queue, &c->wide_levels, &c->hdr, &c->rgb,
+                      &c->flag, &c->subtree, &c->build_status, &c->leaf_compact, &c->wnode, &c->tri, &c->cnode, &c->cparent, &c->csize, &c->wide_queue, &c->wide_levels, &c->hdr, &c->rgb,
                       &c->counters_mem, &c->spill, &c->tr_rays,
                       &c->tr_out, &c->tr_prim, &c->tr_counts, &c->dev_counters, &c->bdpt_px, &c->bdpt_rad, &c->bdpt_items, &c->bdpt_state,
                       &c->bdpt_rays, &c->bdpt_hits, &c->bdpt_qidx, &c->bdpt_ctr};

@@ -178,7 +178,7 @@ struct tirt_ctx {
     tirt::DevBuf bvh_node, compact;               // f32 [N*11], [N*9]
     tirt::DevBuf parent, flag, subtree, build_status, leaf_compact;
     tirt::DevBuf wnode, tri;                      // traversal layout
-    tirt::DevBuf cnode, cparent, wide_queue, wide_levels;    // quantised 4-wide nodes (ordered traversal) + parent chain of the compact nodes + build scratch
+    tirt::DevBuf cnode, cparent, csize, wide_queue, wide_levels;    // quantised 4-wide nodes (ordered traversal) + parent chain of the compact nodes + build scratch
     int wide_nodes = 0;                            // number of 4-wide nodes
     float grid_min[3] = {0, 0, 0}, grid_cell[3] = {1, 1, 1}, grid_inv_cell[3] = {1, 1, 1}, grid_inv_extent[3] = {1, 1, 1};
     size_t lds_optin = 65536;                      // hipDeviceAttributeMaxSharedMemoryPerBlock (opt-in) of this device

@@ -324,7 +324,7 @@ __global__ void k_refit(int n, float *bvh_node, const int *parent, int *flag, in
 // child of the left sibling's subtree size (accel/LBvh.py:138-161: left first, right's slot
 // stored in the parent's word 1, left implicit at slot+1).
 __global__ void k_flatten(int n, const float *bvh_node, const int *parent, const int *subtree, float *compact, int *leaf_compact,
-                          int *cparent)
+                          int *cparent, int *csize)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     int N = 2 * n - 1;
@@ -341,6 +341,7 @@ __global__ void k_flatten(int n, const float *bvh_node, const int *parent, const
         cur = p;
     }
     cparent[off] = (depth == 0) ? -1 : off - first_step;     // the parent's pre-order slot
+    csize[off] = subtree[i];                                   // nodes of the subtree (2 x leaves - 1)
     const float *nd = bvh_node + (size_t)i * NOD_VEC;
     float *cn = compact + (size_t)off * CPN_VEC;
     cn[0] = nd[0];
@@ -436,7 +437,7 @@ TD float cn_area(const float *compact, int i)
 }
 // level_off[L] / level_cnt[L]: first wide index and number of wide nodes of level L; queue holds the binary roots (compact
 // indices) of all wide nodes in breadth-first order (queue[w] for wide node w)
-__global__ void k_wide_level(SceneView s, const float *compact, int level, int *level_off, int *level_cnt, int *queue, uint4 *cnode, float pad, GridMap gm)
+__global__ void k_wide_level(SceneView s, const float *compact, const int *csize, int level, int *level_off, int *level_cnt, int *queue, uint4 *cnode, float pad, GridMap gm)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int n_in = level_cnt[level], off = level_off[level];
@@ -447,8 +448,16 @@ __global__ void k_wide_level(SceneView s, const float *compact, int level, int *
     int cand[4] = {root + 1, (int)rc[1], -1, -1}, nc = 2;
     for (;;) {
         if (nc == 4) break;
-        int best = -1; float best_area = -1.0f;
-        for (int k = 0; k < nc; k++) if (!cn_leaf(compact, cand[k])) { const float a = cn_area(compact, cand[k]); if (a > best_area) { best_area = a; best = k; } }
+        // first choice: an internal candidate small enough to be taken apart completely in the free slots (it then needs no
+        // node of its own -- otherwise the bottom of the tree is full of 2- and 3-leaf nodes); else the largest surface area
+        int best = -1, best_leaves = 1 << 30; float best_area = -1.0f;
+        const int free_slots = 4 - nc;
+        for (int k = 0; k < nc; k++) if (!cn_leaf(compact, cand[k])) {
+            const int leaves = (csize[cand[k]] + 1) >> 1;
+            if (leaves - 1 <= free_slots && leaves < best_leaves) { best_leaves = leaves; best = k; }
+        }
+        if (best < 0)
+            for (int k = 0; k < nc; k++) if (!cn_leaf(compact, cand[k])) { const float a = cn_area(compact, cand[k]); if (a > best_area) { best_area = a; best = k; } }
         if (best < 0) break;
         const int b = cand[best];
         cand[best] = b + 1; cand[nc++] = (int)compact[(size_t)b * CPN_VEC + 1];
@@ -500,7 +509,8 @@ int lbvh_build(tirt_ctx *c)
     TIRT_REQUIRE(n <= (1 << 24), "tirt_lbvh_build: more than 16 Mi primitives");
     constexpr int WIDE_LEVELS_MAX = 96;
     if (c->cnode.ensure(sizeof(uint4) * 4 * (size_t)n) || c->wide_queue.ensure(sizeof(int) * (size_t)n) ||
-        c->wide_levels.ensure(sizeof(int) * 2 * (WIDE_LEVELS_MAX + 2)) || c->cparent.ensure(sizeof(int) * (size_t)N)) return TIRT_ERR_HIP;
+        c->wide_levels.ensure(sizeof(int) * 2 * (WIDE_LEVELS_MAX + 2)) || c->cparent.ensure(sizeof(int) * (size_t)N) ||
+        c->csize.ensure(sizeof(int) * (size_t)N)) return TIRT_ERR_HIP;
     (void)st0;
 
     SceneView sv = scene_view(c);
@@ -523,7 +533,7 @@ int lbvh_build(tirt_ctx *c)
     hipLaunchKernelGGL(k_refit, dim3((n + B - 1) / B), dim3(B), 0, st, n, c->bvh_node.as<float>(), c->parent.as<int>(),
                        c->flag.as<int>(), c->subtree.as<int>(), c->build_status.as<int>());
     hipLaunchKernelGGL(k_flatten, dim3((N + B - 1) / B), dim3(B), 0, st, n, c->bvh_node.as<float>(), c->parent.as<int>(),
-                       c->subtree.as<int>(), c->compact.as<float>(), c->leaf_compact.as<int>(), c->cparent.as<int>());
+                       c->subtree.as<int>(), c->compact.as<float>(), c->leaf_compact.as<int>(), c->cparent.as<int>(), c->csize.as<int>());
     // root box + refit status back to the host (one small read; the reference does ~depth of them)
     int done = 0, done_slots[32 * REFIT_SLOTS]; float root[11];
     TIRT_HIP(hipMemcpyAsync(done_slots, c->build_status.p, sizeof(done_slots), hipMemcpyDeviceToHost, st));
@@ -563,7 +573,7 @@ int lbvh_build(tirt_ctx *c)
             for (; level < until; level++) {
                 long cap = 1; for (int k = 0; k < level && cap < n; k++) cap *= 4;             // a level holds at most 4^level nodes
                 if (cap > n) cap = n;
-                hipLaunchKernelGGL(k_wide_level, dim3((unsigned)((cap + 127) / 128)), dim3(128), 0, st, sv, c->compact.as<float>(), level, lv_off, lv_cnt,
+                hipLaunchKernelGGL(k_wide_level, dim3((unsigned)((cap + 127) / 128)), dim3(128), 0, st, sv, c->compact.as<float>(), c->csize.as<int>(), level, lv_off, lv_cnt,
                                    c->wide_queue.as<int>(), c->cnode.as<uint4>(), pad, gm);
             }
             TIRT_HIP(hipMemcpyAsync(host_lv, c->wide_levels.p, sizeof(host_lv), hipMemcpyDeviceToHost, st));
