@@ -81,46 +81,58 @@ __global__ __launch_bounds__(RS_BLOCK) void k_rs_hist(const int *keys, int n, in
         if (i < n) atomicAdd(&h[(keys[i] >> shift) & 255], 1);
     }
     __syncthreads();
-    hist[threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];      // digit-major
+    hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];      // digit-major
 }
 
-// exclusive scan of hist[0..total) in place, one block of 1024 threads
-__global__ __launch_bounds__(1024) void k_rs_scan(int *hist, int total)
+// exclusive scan of the digit-major histogram, in two levels: block d scans row d (the counts of digit d in all tiles) in
+// place and leaves the row total in row_total[d]; the 256 row totals are scanned by every scatter block itself.
+// (The first version scanned all 256 x tiles entries in ONE block: 2.1 ms of the build at 4 M primitives.)
+__global__ __launch_bounds__(256) void k_rs_scan_rows(int *hist, int nblocks, int *row_total)
 {
-    __shared__ int wsum[16];
+    __shared__ int wsum[4];
     __shared__ int carry_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int *row = hist + (size_t)blockIdx.x * nblocks;
     if (tid == 0) carry_s = 0;
     __syncthreads();
-    for (int base = 0; base < total; base += 1024) {
-        int i = base + tid;
-        int v = (i < total) ? hist[i] : 0;
+    for (int base = 0; base < nblocks; base += 256) {
+        const int i = base + tid;
+        const int v = (i < nblocks) ? row[i] : 0;
         int incl = v;
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            int t = __shfl_up(incl, d, 64);
-            if (lane >= d) incl += t;
-        }
+        for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
         if (lane == 63) wsum[wave] = incl;
         __syncthreads();
         int woff = 0;
         for (int w = 0; w < wave; w++) woff += wsum[w];
-        int carry = carry_s;
-        if (i < total) hist[i] = carry + woff + incl - v;
+        const int carry = carry_s;
+        if (i < nblocks) row[i] = carry + woff + incl - v;
         __syncthreads();
-        if (tid == 1023) carry_s = carry + woff + incl;
+        if (tid == 255) carry_s = carry + woff + incl;
         __syncthreads();
     }
+    if (tid == 0) row_total[blockIdx.x] = carry_s;
 }
 
 __global__ __launch_bounds__(RS_BLOCK) void k_rs_scatter(const int *keys_in, const int *vals_in, int *keys_out, int *vals_out,
-                                                       int n, int shift, const int *hist_scanned, int nblocks)
+                                                       int n, int shift, const int *hist_scanned, int nblocks, const int *row_total)
 {
     __shared__ int wcount[RS_WAVES][256];
     __shared__ int running[256];
+    __shared__ int rsum[RS_WAVES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    running[tid] = hist_scanned[tid * nblocks + blockIdx.x];
+    {   // exclusive scan of the 256 digit totals: where digit `tid` starts in the output
+        const int v = row_total[tid];
+        int incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
+        if (lane == 63) rsum[wave] = incl;
+        __syncthreads();
+        int woff = 0;
+        for (int w = 0; w < wave; w++) woff += rsum[w];
+        running[tid] = hist_scanned[(size_t)tid * nblocks + blockIdx.x] + woff + incl - v;
+    }
     const int base = blockIdx.x * RS_TILE;
     for (int c = 0; c < RS_ITEMS; c++) {
 #pragma unroll
@@ -499,7 +511,7 @@ int lbvh_build(tirt_ctx *c)
     if (c->keys_a.ensure(sizeof(int) * (size_t)n) || c->keys_b.ensure(sizeof(int) * (size_t)n) ||
         c->vals_a.ensure(sizeof(int) * (size_t)n) || c->vals_b.ensure(sizeof(int) * (size_t)n)) return TIRT_ERR_HIP;
     const int nblocks = (n + RS_TILE - 1) / RS_TILE;
-    if (c->hist.ensure(sizeof(int) * 256 * (size_t)nblocks)) return TIRT_ERR_HIP;
+    if (c->hist.ensure(sizeof(int) * 256 * ((size_t)nblocks + 1))) return TIRT_ERR_HIP;      // digit-major tile histograms + the 256 digit totals
     if (c->bvh_node.ensure(sizeof(float) * (size_t)N * NOD_VEC) || c->compact.ensure(sizeof(float) * (size_t)N * CPN_VEC)) return TIRT_ERR_HIP;
     if (c->parent.ensure(sizeof(int) * (size_t)N) || c->flag.ensure(sizeof(int) * (size_t)N) ||
         c->subtree.ensure(sizeof(int) * (size_t)N) || c->build_status.ensure(sizeof(int) * 32 * REFIT_SLOTS) ||
@@ -521,8 +533,9 @@ int lbvh_build(tirt_ctx *c)
     int *ka = c->keys_a.as<int>(), *kb = c->keys_b.as<int>(), *va = c->vals_a.as<int>(), *vb = c->vals_b.as<int>();
     for (int shift = 0; shift < 30; shift += 8) {
         hipLaunchKernelGGL(k_rs_hist, dim3(nblocks), dim3(RS_BLOCK), 0, st, ka, n, shift, c->hist.as<int>(), nblocks);
-        hipLaunchKernelGGL(k_rs_scan, dim3(1), dim3(1024), 0, st, c->hist.as<int>(), 256 * nblocks);
-        hipLaunchKernelGGL(k_rs_scatter, dim3(nblocks), dim3(RS_BLOCK), 0, st, ka, va, kb, vb, n, shift, c->hist.as<int>(), nblocks);
+        hipLaunchKernelGGL(k_rs_scan_rows, dim3(256), dim3(256), 0, st, c->hist.as<int>(), nblocks, c->hist.as<int>() + 256 * (size_t)nblocks);
+        hipLaunchKernelGGL(k_rs_scatter, dim3(nblocks), dim3(RS_BLOCK), 0, st, ka, va, kb, vb, n, shift, c->hist.as<int>(), nblocks,
+                           c->hist.as<int>() + 256 * (size_t)nblocks);
         int *t = ka; ka = kb; kb = t; t = va; va = vb; vb = t;
     }
     // 4 passes: the sorted data is back in keys_a / vals_a
@@ -569,19 +582,20 @@ int lbvh_build(tirt_ctx *c)
         TIRT_HIP(hipMemsetAsync(c->wide_queue.p, 0, sizeof(int), st));
         int level = 0, host_lv[2 * (WIDE_LEVELS_MAX + 2)];
         for (;;) {
-            const int until = (level + 24 < WIDE_LEVELS_MAX) ? level + 24 : WIDE_LEVELS_MAX;
+            const int until = (level + 16 < WIDE_LEVELS_MAX) ? level + 16 : WIDE_LEVELS_MAX;
             for (; level < until; level++) {
                 long cap = 1; for (int k = 0; k < level && cap < n; k++) cap *= 4;             // a level holds at most 4^level nodes
                 if (cap > n) cap = n;
                 hipLaunchKernelGGL(k_wide_level, dim3((unsigned)((cap + 127) / 128)), dim3(128), 0, st, sv, c->compact.as<float>(), c->csize.as<int>(), level, lv_off, lv_cnt,
                                    c->wide_queue.as<int>(), c->cnode.as<uint4>(), pad, gm);
             }
+            TIRT_HIP(hipEventRecord(c->ev1, st));
             TIRT_HIP(hipMemcpyAsync(host_lv, c->wide_levels.p, sizeof(host_lv), hipMemcpyDeviceToHost, st));
             TIRT_HIP(hipStreamSynchronize(st));
             if (host_lv[(WIDE_LEVELS_MAX + 2) + level] == 0) { c->wide_nodes = host_lv[level]; break; }       // the next level is empty: done
             TIRT_REQUIRE(level < WIDE_LEVELS_MAX, "tirt_lbvh_build: the 4-wide tree is deeper than 96 levels");
         }
-    }
+    } else TIRT_HIP(hipEventRecord(c->ev1, st));
     if (n == 1) {
         int prim = 0, is_shape = 0;
         int pr0;
@@ -590,7 +604,6 @@ int lbvh_build(tirt_ctx *c)
         is_shape = (pr0 == PRIMITIVE_TRI) ? 0 : 1;
         c->root_code = ~(prim | (is_shape << 30));
     } else c->root_code = 0;
-    TIRT_HIP(hipEventRecord(c->ev1, st));
     TIRT_HIP(hipStreamSynchronize(st));
     float ms = 0.0f;
     TIRT_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));
