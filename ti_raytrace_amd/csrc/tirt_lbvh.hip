@@ -451,29 +451,45 @@ TD float cn_area(const float *compact, int i)
 // indices) of all wide nodes in breadth-first order (queue[w] for wide node w)
 __global__ void k_wide_level(SceneView s, const float *compact, const int *csize, int level, int *level_off, int *level_cnt, int *queue, uint4 *cnode, float pad, GridMap gm)
 {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
     const int n_in = level_cnt[level], off = level_off[level];
     if (t == 0) level_off[level + 1] = off + n_in;           // this level's children are numbered from here on
-    if (t >= n_in) return;
-    const int w = off + t, root = queue[w];
-    const float *rc = compact + (size_t)root * CPN_VEC;
-    int cand[4] = {root + 1, (int)rc[1], -1, -1}, nc = 2;
-    for (;;) {
-        if (nc == 4) break;
-        // first choice: an internal candidate small enough to be taken apart completely in the free slots (it then needs no
-        // node of its own -- otherwise the bottom of the tree is full of 2- and 3-leaf nodes); else the largest surface area
-        int best = -1, best_leaves = 1 << 30; float best_area = -1.0f;
-        const int free_slots = 4 - nc;
-        for (int k = 0; k < nc; k++) if (!cn_leaf(compact, cand[k])) {
-            const int leaves = (csize[cand[k]] + 1) >> 1;
-            if (leaves - 1 <= free_slots && leaves < best_leaves) { best_leaves = leaves; best = k; }
+    const bool live = t < n_in;
+    const int w = off + t;
+    int cand[4] = {-1, -1, -1, -1}, nc = 0, n_int = 0;
+    if (live) {
+        const int root = queue[w];
+        const float *rc = compact + (size_t)root * CPN_VEC;
+        cand[0] = root + 1; cand[1] = (int)rc[1]; nc = 2;
+        for (;;) {
+            if (nc == 4) break;
+            // first choice: an internal candidate small enough to be taken apart completely in the free slots (it then needs no
+            // node of its own -- otherwise the bottom of the tree is full of 2- and 3-leaf nodes); else the largest surface area
+            int best = -1, best_leaves = 1 << 30; float best_area = -1.0f;
+            const int free_slots = 4 - nc;
+            for (int k = 0; k < nc; k++) if (!cn_leaf(compact, cand[k])) {
+                const int leaves = (csize[cand[k]] + 1) >> 1;
+                if (leaves - 1 <= free_slots && leaves < best_leaves) { best_leaves = leaves; best = k; }
+            }
+            if (best < 0)
+                for (int k = 0; k < nc; k++) if (!cn_leaf(compact, cand[k])) { const float a = cn_area(compact, cand[k]); if (a > best_area) { best_area = a; best = k; } }
+            if (best < 0) break;
+            const int b = cand[best];
+            cand[best] = b + 1; cand[nc++] = (int)compact[(size_t)b * CPN_VEC + 1];
         }
-        if (best < 0)
-            for (int k = 0; k < nc; k++) if (!cn_leaf(compact, cand[k])) { const float a = cn_area(compact, cand[k]); if (a > best_area) { best_area = a; best = k; } }
-        if (best < 0) break;
-        const int b = cand[best];
-        cand[best] = b + 1; cand[nc++] = (int)compact[(size_t)b * CPN_VEC + 1];
+        for (int c = 0; c < nc; c++) if (!cn_leaf(compact, cand[c])) n_int++;
     }
+    // queue positions of this wave's internal children: one atomic per wave (one per child serialised the level: same-address
+    // device atomics retire at ~11 ns each)
+    int incl = n_int;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
+    const int total = __shfl(incl, 63, 64);
+    int base = 0;
+    if (lane == 63 && total) base = atomicAdd(&level_cnt[level + 1], total);
+    base = __shfl(base, 63, 64);
+    if (!live) return;
+    int pos = base + incl - n_int;
     unsigned wd[16];
     const int next_off = off + n_in;
     for (int c = 0; c < 4; c++) {
@@ -481,7 +497,7 @@ __global__ void k_wide_level(SceneView s, const float *compact, const int *csize
         if (c < nc) {
             const float *cn = compact + (size_t)cand[c] * CPN_VEC;
             if ((((int)cn[0]) & 1) == 1) code = child_code(s, cn, cand[c]);
-            else { const int pos = atomicAdd(&level_cnt[level + 1], 1); queue[next_off + pos] = cand[c]; code = next_off + pos; }
+            else { queue[next_off + pos] = cand[c]; code = next_off + pos; pos++; }
             const bool leaf = code < 0;
             const bool shape = leaf && (((~code) >> 30) & 1) != 0;
             const float p = leaf ? pad : 0.0f;

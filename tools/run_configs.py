@@ -41,7 +41,7 @@ if __name__ == "__main__":
     if "2" in which:
         run("cfg2_teapot_1024_64spp", scenes.single_model(1024, 1024, 64, device_id=0), 64, 16)
     if "5" in which:
-        run("cfg5_veach_bdpt_512_64spp", scenes.veach_bdpt(512, 512, 64, device_id=0), 64, 16, warm=False)   # BDPT keeps per-pixel state across frames
+        run("cfg5_veach_bdpt_512_64spp", scenes.veach_bdpt(512, 512, 64, device_id=0), 64, 64)   # (film_clear also resets BDPT's per-pixel state)
         run("cfg5_veach_pt_512_64spp", scenes.veach_bdpt(512, 512, 64, device_id=0, integrator="pt"), 64, 32)
     if "3" in which:
         run("cfg3_synth100k_1024_256spp", scenes.synthetic(1024, 1024, 256, device_id=0), 256, 32)
