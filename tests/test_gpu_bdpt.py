@@ -148,3 +148,26 @@ def test_config5_full_size_frame_against_the_oracle(gpu_ctx_ok):
     m = np.isfinite(want).all(axis=2) & np.isfinite(got).all(axis=2)
     assert rel_l2(got[m], want[m]) <= 1e-3
     assert st["rays_closest"] == ost["rays_closest"] and st["rays_shadow"] == ost["rays_shadow"]
+
+
+def test_bdpt_on_a_deep_duplicate_chain(gpu_ctx_ok):
+    """Runs of identical Morton codes make right-deep chains under the reference's duplicate rule (accel/LBvh.py:240-251).
+    BDPT's rays go through the same paged traversal stack as PT_RGB's (round 1's BDPT had its own 64-entry stack that dropped
+    pushes silently): film and ray counts equal the oracle's, no overflow reported."""
+    from common import duplicate_code_scene
+    from ti_raytrace_amd import BDPT_RGB
+    W = H = 32
+    ex = duplicate_code_scene(W=W, H=H, device_id=0)
+    ex.integrator = BDPT_RGB.BDPT(W, H, ex.cam, ex.scene, 64)
+    ex.build_scene(); ex.frame_camera(0.8)
+    o = oa.OracleScene(ex.scene, ex.cam); o.lbvh_build()
+    ctx = ex.scene.ctx
+    ctx.set_option("trace_lds_depth", 12)            # page the stack as early as possible
+    ctx.stats_reset()
+    ex.integrator.render_frames(3)
+    got = ex.integrator.hdr.to_numpy()
+    want, ost, _ = o.bdpt_render(ex.cam, W, H, 0, 3, seed=ex.integrator.seed)
+    st = ctx.stats()                                 # raises TirtStackOverflow if a ray dropped a subtree
+    m = np.isfinite(want).all(axis=2) & np.isfinite(got).all(axis=2)
+    assert (np.isfinite(want).all(axis=2) == np.isfinite(got).all(axis=2)).all() and rel_l2(got[m], want[m]) <= 1e-3
+    assert st["rays_closest"] == ost["rays_closest"] and st["rays_shadow"] == ost["rays_shadow"] and st["stack_overflow"] == 0
