@@ -305,6 +305,7 @@ int tirt_set_option(tirt_ctx *c, const char *name, double value)
     TIRT_REQUIRE(name, "tirt_set_option: null name");
     if (!strcmp(name, "time_kernels")) { c->time_kernels = value != 0.0; return TIRT_OK; }
     if (!strcmp(name, "overlap_lanes")) { TIRT_REQUIRE(value >= 1.0 && value <= (double)TIRT_MAX_LANES, "overlap_lanes: 1..8"); if (sync_all(c)) return TIRT_ERR_HIP; c->n_lanes = (int)value; return TIRT_OK; }
+    if (!strcmp(name, "split_lone_batch")) { c->split_lone = value != 0.0 ? 1 : 0; return TIRT_OK; }
     if (!strcmp(name, "job_frames")) { TIRT_REQUIRE(value >= 0.0 && value <= 1.0e9, "job_frames out of range"); c->job_frames = (long)value; return TIRT_OK; }
     if (!strcmp(name, "merge_paths")) { TIRT_REQUIRE(value >= 0.0 && value <= 1.0e9, "merge_paths out of range"); c->merge_paths = (size_t)value; return TIRT_OK; }
     if (!strcmp(name, "batch_paths")) {
