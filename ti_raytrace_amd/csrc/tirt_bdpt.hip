@@ -119,115 +119,125 @@ struct BdCtx { SceneView sc; CameraView cam; BdView bv; uint32_t seed; int bound
 TD float bd_mis_weight(const BdCtx &c, bpixel *P, int e, int l)
 {
     const SceneView &s = c.sc;
-    bvert *light = P->light, *eye = P->eye;
+    const bvert *light = P->light, *eye = P->eye;
     float weight_sum = 0.0f;
     if (l + e != 2) {
-        if (l > 0) P->ltemp = light[l - 1];
-        if (e > 0) P->etemp = eye[e - 1];
-        if (l > 1) P->lminustemp = light[l - 2];
-        if (e > 1) P->eminustemp = eye[e - 2];
-        if (l == 1) light[0] = P->sample;
-        else if (e == 1) eye[0] = P->sample;
-        if (l > 0) light[l - 1].delta = 0;
-        if (e > 0) eye[e - 1].delta = 0;
+        // The reference saves the four vertices next to the connection (ltemp, etemp, lminustemp, eminustemp), overwrites
+        // them in place, reads the arrays, and restores them (BDPT_RGB.py:303-321, 472-477).  Same values here without
+        // the round trip through memory: private copies E1 = eye[e-1], E2 = eye[e-2], L1 = light[l-1], L2 = light[l-2]
+        // take the modifications, every other vertex is read where it lies.
+        bvert E1 = bvert(), E2 = bvert(), L1 = bvert(), L2 = bvert();
+        if (l > 0) L1 = light[l - 1];
+        if (e > 0) E1 = eye[e - 1];
+        if (l > 1) L2 = light[l - 2];
+        if (e > 1) E2 = eye[e - 2];
+        if (l == 1) L1 = P->sample;
+        else if (e == 1) E1 = P->sample;
+        if (l > 0) L1.delta = 0;
+        if (e > 0) E1.delta = 0;
 
         if (e > 0) {
             if (l == 0) {
-                const float pdfPos = 1.0f / get_prim_area(s, eye[e - 1].prim);
+                const float pdfPos = 1.0f / get_prim_area(s, E1.prim);
                 const float pdfChoice = 1.0f / (float)s.light_count;
-                eye[e - 1].rpdf = pdfPos * pdfChoice;
+                E1.rpdf = pdfPos * pdfChoice;
             } else if (l == 1) {
-                if (eye[e - 1].type == VERTEX_SURFACE) {
-                    v3 to = eye[e - 1].pos - light[0].pos;
+                if (E1.type == VERTEX_SURFACE) {
+                    v3 to = E1.pos - L1.pos;
                     const float dist = norm(to);
                     to = to / dist;
-                    const float pdfDir = cosine_hemisphere_pdf(absf(dot(to, light[0].normal)));
-                    const float LdotN = absf(dot(to, light[0].normal));
-                    eye[e - 1].rpdf = pdfDir * LdotN / (dist * dist);
-                } else eye[e - 1].rpdf = 1.0f;
+                    const float pdfDir = cosine_hemisphere_pdf(absf(dot(to, L1.normal)));
+                    const float LdotN = absf(dot(to, L1.normal));
+                    E1.rpdf = pdfDir * LdotN / (dist * dist);
+                } else E1.rpdf = 1.0f;
             } else {
-                v3 wi = light[l - 2].pos - light[l - 1].pos;
-                v3 wo = eye[e - 1].pos - light[l - 1].pos;
+                v3 wi = L2.pos - L1.pos;
+                v3 wo = E1.pos - L1.pos;
                 const float dist = norm(wo);
                 wi = normalized(wi); wo = normalized(wo);
                 float pdf = 1.0f;
-                const int mat_id = light[l - 1].mat;
-                if (mat_id == MAT_DISNEY) pdf = disney_pdf(mat_row(s, mat_id), light[l - 1].snormal, wi, wo);
-                eye[e - 1].rpdf = pdf * absf(dot(light[l - 1].normal, wo)) / (dist * dist);
+                const int mat_id = L1.mat;
+                if (mat_id == MAT_DISNEY) pdf = disney_pdf(mat_row(s, mat_id), L1.snormal, wi, wo);
+                E1.rpdf = pdf * absf(dot(L1.normal, wo)) / (dist * dist);
             }
         }
         if (l > 0) {
             if (e > 1) {
-                if (eye[e - 1].type == VERTEX_SURFACE) {
-                    v3 wi = eye[e - 2].pos - eye[e - 1].pos;
-                    v3 wo = light[l - 1].pos - eye[e - 1].pos;
+                if (E1.type == VERTEX_SURFACE) {
+                    v3 wi = E2.pos - E1.pos;
+                    v3 wo = L1.pos - E1.pos;
                     const float dist = norm(wo);
                     wi = normalized(wi); wo = normalized(wo);
                     float pdf = 1.0f;
-                    const int mat_id = eye[e - 1].mat;
-                    if (mat_id == MAT_DISNEY) pdf = disney_pdf(mat_row(s, mat_id), eye[e - 1].snormal, wi, wo);
-                    light[l - 1].rpdf = pdf * absf(dot(eye[e - 1].normal, wo)) / (dist * dist);
-                } else light[l - 1].rpdf = 1.0f;
+                    const int mat_id = E1.mat;
+                    if (mat_id == MAT_DISNEY) pdf = disney_pdf(mat_row(s, mat_id), E1.snormal, wi, wo);
+                    L1.rpdf = pdf * absf(dot(E1.normal, wo)) / (dist * dist);
+                } else L1.rpdf = 1.0f;
             } else {
-                v3 to = eye[0].pos - light[l - 1].pos;
+                v3 to = E1.pos - L1.pos;
                 const float dist = norm(to);
                 to = to / dist;
                 const v3 axis = V(c.bv.view[8], c.bv.view[9], c.bv.view[10]);      // Camera.py:126-127
                 const float LdotN = dot(to, axis);
-                light[l - 1].rpdf = LdotN / (dist * dist);
+                L1.rpdf = LdotN / (dist * dist);
             }
         }
         if (e > 1) {
             if (l == 0) {
-                v3 to = eye[e - 2].pos - eye[e - 1].pos;
+                v3 to = E2.pos - E1.pos;
                 const float dist = norm(to);
                 to = to / dist;
-                const float pdfDir = cosine_hemisphere_pdf(absf(dot(to, eye[e - 1].normal)));
-                const float LdotN = dot(to, eye[e - 1].normal);
-                eye[e - 2].rpdf = absf(pdfDir * LdotN) / (dist * dist);
+                const float pdfDir = cosine_hemisphere_pdf(absf(dot(to, E1.normal)));
+                const float LdotN = dot(to, E1.normal);
+                E2.rpdf = absf(pdfDir * LdotN) / (dist * dist);
             } else {
-                if (eye[e - 1].type == VERTEX_SURFACE) {
-                    v3 wi = light[l - 1].pos - eye[e - 1].pos;
-                    v3 wo = eye[e - 2].pos - eye[e - 1].pos;
+                if (E1.type == VERTEX_SURFACE) {
+                    v3 wi = L1.pos - E1.pos;
+                    v3 wo = E2.pos - E1.pos;
                     const float dist = norm(wo);
                     wi = normalized(wi); wo = normalized(wo);
-                    const int mat_id = eye[e - 1].mat;
-                    const float pdf = disney_pdf(mat_row(s, mat_id), eye[e - 1].snormal, wi, wo);
-                    eye[e - 2].rpdf = pdf / (dist * dist);
-                    if (eye[e - 2].type == VERTEX_SURFACE) eye[e - 2].rpdf *= absf(dot(eye[e - 1].normal, wo));
-                } else eye[e - 2].rpdf = 1.0f;
+                    const int mat_id = E1.mat;
+                    const float pdf = disney_pdf(mat_row(s, mat_id), E1.snormal, wi, wo);
+                    E2.rpdf = pdf / (dist * dist);
+                    if (E2.type == VERTEX_SURFACE) E2.rpdf *= absf(dot(E1.normal, wo));
+                } else E2.rpdf = 1.0f;
             }
         }
         if (l > 1) {
-            if (eye[e - 1].type != VERTEX_LIGHT) {
-                v3 wi = eye[e - 1].pos - light[l - 1].pos;
-                v3 wo = light[l - 2].pos - light[l - 1].pos;
+            if (E1.type != VERTEX_LIGHT) {
+                v3 wi = E1.pos - L1.pos;
+                v3 wo = L2.pos - L1.pos;
                 const float dist = norm(wo);
                 wi = normalized(wi); wo = normalized(wo);
                 float pdf = 1.0f;
-                const int mat_id = light[l - 1].mat;
-                if (mat_id == MAT_DISNEY) pdf = disney_pdf(mat_row(s, mat_id), light[l - 1].normal, wi, wo);
-                light[l - 2].rpdf = pdf / (dist * dist);
-                if (light[l - 2].type == VERTEX_SURFACE) light[l - 2].rpdf *= absf(dot(light[l - 1].normal, wo));
-            } else light[l - 2].rpdf = 1.0f;
+                const int mat_id = L1.mat;
+                if (mat_id == MAT_DISNEY) pdf = disney_pdf(mat_row(s, mat_id), L1.normal, wi, wo);
+                L2.rpdf = pdf / (dist * dist);
+                if (L2.type == VERTEX_SURFACE) L2.rpdf *= absf(dot(L1.normal, wo));
+            } else L2.rpdf = 1.0f;
         }
 
         float weight = 1.0f;
         for (int k = e - 1; k > 0; k--) {
-            weight *= remap0(eye[k].rpdf) / remap0(eye[k].fpdf);
-            if ((eye[k].delta == 0) & (eye[k - 1].delta == 0)) weight_sum += weight;
+            const float rp = (k == e - 1) ? E1.rpdf : ((k == e - 2) ? E2.rpdf : eye[k].rpdf);
+            const float fp = (k == e - 1) ? E1.fpdf : ((k == e - 2) ? E2.fpdf : eye[k].fpdf);
+            const int dk = (k == e - 1) ? E1.delta : ((k == e - 2) ? E2.delta : eye[k].delta);
+            const int dk1 = (k - 1 == e - 2) ? E2.delta : eye[k - 1].delta;
+            weight *= remap0(rp) / remap0(fp);
+            if ((dk == 0) & (dk1 == 0)) weight_sum += weight;
         }
         weight = 1.0f;
         for (int k = l - 1; k >= 0; k--) {
-            weight *= remap0(light[k].rpdf) / remap0(light[k].fpdf);
-            if (k == 0) { if (light[k].delta == 0) weight_sum += weight; }
-            else if ((light[k].delta == 0) & (light[k - 1].delta == 0)) weight_sum += weight;
+            const float rp = (k == l - 1) ? L1.rpdf : ((k == l - 2) ? L2.rpdf : light[k].rpdf);
+            const float fp = (k == l - 1) ? L1.fpdf : ((k == l - 2) ? L2.fpdf : light[k].fpdf);
+            const int dk = (k == l - 1) ? L1.delta : ((k == l - 2) ? L2.delta : light[k].delta);
+            weight *= remap0(rp) / remap0(fp);
+            if (k == 0) { if (dk == 0) weight_sum += weight; }
+            else {
+                const int dk1 = (k - 1 == l - 2) ? L2.delta : light[k - 1].delta;
+                if ((dk == 0) & (dk1 == 0)) weight_sum += weight;
+            }
         }
-        // give back the original data; copies to index -1 (Taichi: padding) are skipped
-        if (l - 1 >= 0) light[l - 1] = P->ltemp;
-        eye[e - 1] = P->etemp;
-        if (l > 0 && l - 2 >= 0) light[l - 2] = P->lminustemp;
-        if (e > 0 && e - 2 >= 0) eye[e - 2] = P->eminustemp;
     }
     return 1.0f / (1.0f + weight_sum);
 }
