@@ -36,7 +36,7 @@ constexpr uint32_t BD_DIM_EYE = 16, BD_DIM_LSTART = 80, BD_DIM_LIGHT = 96, BD_DI
 constexpr float EPS_UF = 0.00001f;                 // UtilsFunc.py:36
 
 struct bvert { v3 pos, normal, snormal, beta, wo; float fpdf, rpdf; int type, prim, mat, delta; };      // BDPT_Vertex.py:10-21
-struct bpixel { bvert eye[BD_EYE_MAX], light[BD_LIGHT_MAX], sample, ltemp, etemp, lminustemp, eminustemp; };
+struct bpixel { bvert eye[BD_EYE_MAX], light[BD_LIGHT_MAX]; };       // the reference's sample / temp vertices (BDPT_RGB.py:60-64) are locals of the connection code
 
 struct BdView { float view[12]; int W, H; };
 struct SimpleHit { float t, u, v; int prim; };
@@ -116,7 +116,7 @@ struct BdCtx { SceneView sc; CameraView cam; BdView bv; uint32_t seed; int bound
 
 
 // BDPT_RGB.py:300-479
-TD float bd_mis_weight(const BdCtx &c, bpixel *P, int e, int l)
+TD float bd_mis_weight(const BdCtx &c, const bpixel *P, const bvert &sample, int e, int l)
 {
     const SceneView &s = c.sc;
     const bvert *light = P->light, *eye = P->eye;
@@ -131,8 +131,8 @@ TD float bd_mis_weight(const BdCtx &c, bpixel *P, int e, int l)
         if (e > 0) E1 = eye[e - 1];
         if (l > 1) L2 = light[l - 2];
         if (e > 1) E2 = eye[e - 2];
-        if (l == 1) L1 = P->sample;
-        else if (e == 1) E1 = P->sample;
+        if (l == 1) L1 = sample;
+        else if (e == 1) E1 = sample;
         if (l > 0) L1.delta = 0;
         if (e > 0) E1.delta = 0;
 
@@ -243,10 +243,10 @@ TD float bd_mis_weight(const BdCtx &c, bpixel *P, int e, int l)
 }
 
 // BDPT_RGB.py:481-592
-TD v3 bd_connect_path(const BdCtx &c, bpixel *P, int i, int j, int e, int l, uint32_t frame, int &nu, int &nv, Tracer &T)
+TD v3 bd_connect_path(const BdCtx &c, const bpixel *P, bvert &sample, int i, int j, int e, int l, uint32_t frame, int &nu, int &nv, Tracer &T)
 {
     const SceneView &s = c.sc;
-    bvert *eye = P->eye, *light = P->light;
+    const bvert *eye = P->eye, *light = P->light;
     const uint32_t pixel = (uint32_t)(i * c.bv.H + j);
     v3 radiance = V(0.0f, 0.0f, 0.0f);
     nu = i; nv = j;
@@ -268,7 +268,7 @@ TD v3 bd_connect_path(const BdCtx &c, bpixel *P, int i, int j, int e, int l, uin
                 if (pdf > 0.0f) {
                     const float G = absf(NdotL) / (sh.t * sh.t);
                     radiance = ((((light[l - 1].beta * G) * mat_lrgb(s, mat_id)) * brdf) / pdf);
-                    P->sample.pos = origin; P->sample.wo = wi; P->sample.type = VERTEX_LENS; P->sample.fpdf = 1.0f;
+                    sample.pos = origin; sample.wo = wi; sample.type = VERTEX_LENS; sample.fpdf = 1.0f;
                 }
             }
         }
@@ -303,8 +303,8 @@ TD v3 bd_connect_path(const BdCtx &c, bpixel *P, int i, int j, int e, int l, uin
                     cc = cc * light_emission;
                     radiance = cc / light_pdf;
                 }
-                P->sample.pos = light_pos; P->sample.wo = wi; P->sample.type = VERTEX_LIGHT; P->sample.fpdf = light_pdf;
-                P->sample.prim = light_prim; P->sample.normal = light_normal; P->sample.snormal = light_normal;
+                sample.pos = light_pos; sample.wo = wi; sample.type = VERTEX_LIGHT; sample.fpdf = light_pdf;
+                sample.prim = light_prim; sample.normal = light_normal; sample.snormal = light_normal;
             }
         }
     } else {
@@ -332,7 +332,7 @@ TD v3 bd_connect_path(const BdCtx &c, bpixel *P, int i, int j, int e, int l, uin
         }
     }
     float misweight = 1.0f;
-    if ((radiance.x > 0.0f) & (radiance.y > 0.0f) & (radiance.z > 0.0f)) misweight = bd_mis_weight(c, P, e, l);
+    if ((radiance.x > 0.0f) & (radiance.y > 0.0f) & (radiance.z > 0.0f)) misweight = bd_mis_weight(c, P, sample, e, l);
     return radiance * misweight;
 }
 
@@ -572,6 +572,7 @@ __global__ void k_bd_connect(BdCtx c, bpixel *items, const BdStep *steps, TileMa
     const uint32_t frame = frame_begin + (uint32_t)f;
     float *rad = radiance + (size_t)f * (size_t)frame_stride;
     unsigned emitted = 0;
+    bvert sample = bvert();              // BDPT_RGB.py:60 `sample`: written by a connection, read by its MIS weight
     for (int e = 1; e <= BD_EYE_MAX; e++) {
         for (int l = 0; l <= BD_LIGHT_MAX; l++) {
             const int depth = l + e - 2;
@@ -586,7 +587,7 @@ __global__ void k_bd_connect(BdCtx c, bpixel *items, const BdStep *steps, TileMa
             }
             int nu = 0, nv = 0;
             v3 r = V(0.0f, 0.0f, 0.0f);
-            if (valid && !(PHASE == 0 && l == 0)) r = bd_connect_path(c, B, i, j, e, l, frame, nu, nv, T);      // l == 0 needs no ray
+            if (valid && !(PHASE == 0 && l == 0)) r = bd_connect_path(c, B, sample, i, j, e, l, frame, nu, nv, T);      // l == 0 needs no ray
             if (PHASE == 0) {
                 // the item's j-th connection ray goes to staging slot [j][item] (k_bd_compact makes the queue dense: one atomic
                 // per wave at the end of this kernel instead of one per wave and pair -- same-address atomics retire at ~11 ns)
