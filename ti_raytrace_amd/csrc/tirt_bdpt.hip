@@ -35,7 +35,8 @@ constexpr int VERTEX_NONE = 0, VERTEX_LIGHT = 1, VERTEX_LENS = 2, VERTEX_SURFACE
 constexpr uint32_t BD_DIM_EYE = 16, BD_DIM_LSTART = 80, BD_DIM_LIGHT = 96, BD_DIM_CONNECT = 176;
 constexpr float EPS_UF = 0.00001f;                 // UtilsFunc.py:36
 
-struct bvert { v3 pos, normal, snormal, beta, wo; float fpdf, rpdf; int type, prim, mat, delta; };      // BDPT_Vertex.py:10-21
+// BDPT_Vertex.py:10-21; padded to 96 bytes and 16-byte aligned: a vertex moves as six dwordx4 accesses instead of 21 scalar ones
+struct alignas(16) bvert { v3 pos, normal, snormal, beta, wo; float fpdf, rpdf; int type, prim, mat, delta; int pad_[3]; };
 struct bpixel { bvert eye[BD_EYE_MAX], light[BD_LIGHT_MAX]; };       // the reference's sample / temp vertices (BDPT_RGB.py:60-64) are locals of the connection code
 
 struct BdView { float view[12]; int W, H; };
@@ -246,36 +247,38 @@ TD float bd_mis_weight(const BdCtx &c, const bpixel *P, const bvert &sample, int
 TD v3 bd_connect_path(const BdCtx &c, const bpixel *P, bvert &sample, int i, int j, int e, int l, uint32_t frame, int &nu, int &nv, Tracer &T)
 {
     const SceneView &s = c.sc;
-    const bvert *eye = P->eye, *light = P->light;
+    // private copies of the two vertices being connected (one wide load each; nothing is written to the arrays)
+    const bvert EV = P->eye[e - 1];
+    const bvert LV = (l > 0) ? P->light[l - 1] : bvert();
     const uint32_t pixel = (uint32_t)(i * c.bv.H + j);
     v3 radiance = V(0.0f, 0.0f, 0.0f);
     nu = i; nv = j;
     if (l == 0) {
-        if (eye[e - 1].type == VERTEX_LIGHT) radiance = eye[e - 1].beta;
+        if (EV.type == VERTEX_LIGHT) radiance = EV.beta;
     } else if (e == 1) {
-        const int prim = light[l - 1].prim;
-        const v3 surface = light[l - 1].pos;
+        const int prim = LV.prim;
+        const v3 surface = LV.pos;
         const v3 wi = get_image_point(c.cam, c.bv, surface, nu, nv);
         const v3 origin = V(c.cam.eye[0], c.cam.eye[1], c.cam.eye[2]);
-        const int mat_id = light[l - 1].mat;
-        const v3 snormal = light[l - 1].snormal;
+        const int mat_id = LV.mat;
+        const v3 snormal = LV.snormal;
         const float NdotL = dot(wi, snormal);
-        if ((nu >= 0) & (light[l - 1].delta != 1) & (NdotL < 0.0f) & (light[l - 1].type == VERTEX_SURFACE)) {
+        if ((nu >= 0) & (LV.delta != 1) & (NdotL < 0.0f) & (LV.type == VERTEX_SURFACE)) {
             const SimpleHit sh = bd_trace(T, origin, wi, prim, c.bounded ? norm(surface - origin) : -1.0f);
             if (sh.prim == prim) {
                 float pdf;
-                const float brdf = disney_evaluate_pdf(mat_row(s, mat_id), snormal, -light[l - 1].wo, -wi, pdf);
+                const float brdf = disney_evaluate_pdf(mat_row(s, mat_id), snormal, -LV.wo, -wi, pdf);
                 if (pdf > 0.0f) {
                     const float G = absf(NdotL) / (sh.t * sh.t);
-                    radiance = ((((light[l - 1].beta * G) * mat_lrgb(s, mat_id)) * brdf) / pdf);
+                    radiance = ((((LV.beta * G) * mat_lrgb(s, mat_id)) * brdf) / pdf);
                     sample.pos = origin; sample.wo = wi; sample.type = VERTEX_LENS; sample.fpdf = 1.0f;
                 }
             }
         }
     } else if (l == 1) {
-        const v3 surface = offset_ray(eye[e - 1].pos, eye[e - 1].snormal);
-        const int mat_id = eye[e - 1].mat;
-        if (eye[e - 1].delta != 1) {
+        const v3 surface = offset_ray(EV.pos, EV.snormal);
+        const int mat_id = EV.mat;
+        if (EV.delta != 1) {
             const uint32_t d0 = BD_DIM_CONNECT + 4u * (uint32_t)e;              // Scene.py:477-518 sample_li(surface)
             int lidx = (int)(tm_rand(c.seed, pixel, frame, d0) * (float)s.light_count);
             if (lidx >= s.light_count) lidx = s.light_count - 1;
@@ -290,15 +293,15 @@ TD v3 bd_connect_path(const BdCtx &c, const bpixel *P, bvert &sample, int i, int
             const float light_dist = norm(wi);
             wi = wi / light_dist;
             const float NdotLl = dot(wi, light_normal);
-            const float NdotLe = dot(wi, eye[e - 1].snormal);
+            const float NdotLe = dot(wi, EV.snormal);
             const SimpleHit sh = bd_trace(T, surface, -wi, light_prim, c.bounded ? light_dist : -1.0f);
             if ((sh.prim == light_prim) & (sh.t > EPS_UF)) {
                 const float light_pdf = light_choice_pdf;
                 float pdf;
-                const float brdf = disney_evaluate_pdf(mat_row(s, mat_id), eye[e - 1].snormal, -eye[e - 1].wo, -wi, pdf);
+                const float brdf = disney_evaluate_pdf(mat_row(s, mat_id), EV.snormal, -EV.wo, -wi, pdf);
                 if (pdf > 0.0f) {
                     const float G = absf(NdotLe * NdotLl) / (sh.t * sh.t);
-                    v3 cc = ((eye[e - 1].beta * G) * brdf) / pdf;
+                    v3 cc = ((EV.beta * G) * brdf) / pdf;
                     cc = cc * mat_lrgb(s, mat_id);
                     cc = cc * light_emission;
                     radiance = cc / light_pdf;
@@ -308,21 +311,21 @@ TD v3 bd_connect_path(const BdCtx &c, const bpixel *P, bvert &sample, int i, int
             }
         }
     } else {
-        if ((light[l - 1].delta != 1) & (eye[e - 1].delta != 1) & (eye[e - 1].type == VERTEX_SURFACE) & (light[l - 1].type == VERTEX_SURFACE)) {
-            const int primE = eye[e - 1].prim, mat_idE = eye[e - 1].mat, mat_idL = light[l - 1].mat;
-            const v3 surfaceE = eye[e - 1].pos, surfaceL = light[l - 1].pos;
+        if ((LV.delta != 1) & (EV.delta != 1) & (EV.type == VERTEX_SURFACE) & (LV.type == VERTEX_SURFACE)) {
+            const int primE = EV.prim, mat_idE = EV.mat, mat_idL = LV.mat;
+            const v3 surfaceE = EV.pos, surfaceL = LV.pos;
             v3 dir = surfaceE - surfaceL;
             const float dist = norm(dir);
             dir = dir / dist;
-            const float NdotLl = dot(dir, light[l - 1].snormal), NdotLe = dot(dir, eye[e - 1].snormal);
+            const float NdotLl = dot(dir, LV.snormal), NdotLe = dot(dir, EV.snormal);
             const SimpleHit sh = bd_trace(T, surfaceL, dir, primE, c.bounded ? dist : -1.0f);
             if ((sh.prim == primE) & (sh.t > EPS_UF)) {
                 float lpdf, epdf;
-                const float brdfL = disney_evaluate_pdf(mat_row(s, mat_idL), light[l - 1].snormal, -light[l - 1].wo, dir, lpdf);
-                const float brdfE = disney_evaluate_pdf(mat_row(s, mat_idE), eye[e - 1].snormal, -eye[e - 1].wo, -dir, epdf);
+                const float brdfL = disney_evaluate_pdf(mat_row(s, mat_idL), LV.snormal, -LV.wo, dir, lpdf);
+                const float brdfE = disney_evaluate_pdf(mat_row(s, mat_idE), EV.snormal, -EV.wo, -dir, epdf);
                 if ((brdfL > 0.0f) & (brdfE > 0.0f)) {
                     const float G = absf(NdotLe * NdotLl) / (dist * dist);
-                    v3 cc = (eye[e - 1].beta * G) * light[l - 1].beta;
+                    v3 cc = (EV.beta * G) * LV.beta;
                     cc = (cc * brdfL) / lpdf;
                     cc = (cc * brdfE) / epdf;
                     cc = cc * mat_lrgb(s, mat_idE);
@@ -439,7 +442,7 @@ __global__ void k_bd_step(BdCtx c, bpixel *items, BdStep *steps, BdRays rays, co
                     const float dist = maxf(norm(to), 0.01f);
                     const float inv_dist2 = 1.0f / (dist * dist);
                     to = to / dist;
-                    bvert *e = &eye[depth];
+                    bvert ev = bvert(); bvert *e = &ev;
                     e->pos = pos; e->normal = normal; e->snormal = fnormal; e->wo = dir; e->rpdf = 0.0f; e->prim = sh.prim; e->mat = mat_id;
                     e->fpdf = pdfFwd * absf(dot(to, eye[pre_depth].normal)) * inv_dist2;
                     if (mat_type == MAT_LIGHT) {
@@ -476,6 +479,7 @@ __global__ void k_bd_step(BdCtx c, bpixel *items, BdStep *steps, BdRays rays, co
                             }
                         }
                     }
+                    eye[depth] = ev;                      // one 96-byte store
                 }
                 st->e_beta = beta; st->e_pdfFwd = pdfFwd; st->eye_depth = final_depth; st->e_alive = go_on ? 1 : 0;
             } else {
@@ -491,7 +495,7 @@ __global__ void k_bd_step(BdCtx c, bpixel *items, BdStep *steps, BdRays rays, co
                     const v3 mat_color = V(m[2], m[3], m[4]);
                     const int mat_type = (int)m[0];
                     if (mat_type != MAT_LIGHT) {
-                        bvert *L = &light[depth];
+                        bvert lv = bvert(); bvert *L = &lv;
                         L->pos = pos; L->normal = normal; L->snormal = fnormal; L->beta = beta * absf(dot(dir, normal));
                         L->wo = dir; L->fpdf = pdfFwd; L->rpdf = 0.0f; L->type = VERTEX_SURFACE; L->prim = sh.prim; L->mat = mat_id;
                         v3 to = pos - light[pre_depth].pos;
@@ -525,6 +529,7 @@ __global__ void k_bd_step(BdCtx c, bpixel *items, BdStep *steps, BdRays rays, co
                                 next_d = bs.next_dir;
                             }
                         }
+                        light[depth] = lv;
                     }
                 }
                 st->l_beta = beta; st->l_pdfFwd = pdfFwd; st->light_depth = final_depth; st->l_alive = go_on ? 1 : 0;
