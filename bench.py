@@ -87,7 +87,10 @@ def measure_hbm_traffic(args):
         return {"error": "rocprofv3 not found"}
     if any(k.startswith("ROCPROF") or k.startswith("ROCP_") for k in os.environ):
         return {"error": "this process is itself being profiled: nested rocprofv3 pass skipped"}
-    env = dict(os.environ); env["TMPDIR"] = "/tmp"
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT",
+                        "TORCHELASTIC_RUN_ID", "TIRT_FORCE_DIST")}            # the child is a plain one-process run
+    env["TMPDIR"] = "/tmp"
     out = {}
     tmp = tempfile.mkdtemp(prefix="tirt_pmc_", dir="/tmp")
     child = [sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "1", "--frames-per-step", str(args.frames_per_step),
@@ -333,7 +336,8 @@ def main():
         working_set = info["node_bytes"] + info["prim_bytes"]
         peak = ctx.micro_gather_rate(working_set, 2000)
         peak_l2 = ctx.micro_gather_rate(2 << 20, 2000)
-        traffic = None if args.no_traffic else measure_hbm_traffic(args)
+        # (the profiler passes run the one-GPU workload on this rank's device: only at N = 1, where that is the workload timed)
+        traffic = None if (args.no_traffic or world > 1) else measure_hbm_traffic(args)
         tr_bytes = traffic["bytes_per_launch"] if traffic and traffic.get("bytes_per_launch") else None
         alg_trace = alg_closest + alg_shadow
         result["roofline"] = {

@@ -332,3 +332,22 @@ def test_rccl_film_reduce_through_the_c_abi(gpu_ctx_ok):
     # rendering goes on after the communicator is gone
     ex.integrator.render_frames(1)
     assert np.isfinite(ex.integrator.hdr.to_numpy()).all()
+
+
+def test_example_loop_with_progressive_preview(gpu_ctx_ok, tmp_path):
+    """The reference's host loop (example/Example.py:38-59): render() returns 1 until sample_count frames are in, tone-maps a
+    preview on the way (headless: a PNG every `preview_every` frames instead of the ti.GUI blit), writes out.png at the end;
+    previews must not disturb the film (the frame-at-a-time film equals the batch film)."""
+    from PIL import Image
+    W = H = 48
+    ex = scenes.cornell_box(W, H, 6, device_id=0)
+    ex.build_scene()
+    ex.out_path = str(tmp_path / "out.png"); ex.preview_path = str(tmp_path / "preview.png"); ex.preview_every = 2
+    n = 0
+    while ex.render() == 1:
+        n += 1
+    assert n == 6 and ex.render() == 0
+    assert Image.open(ex.preview_path).size == (W, H) and Image.open(ex.out_path).size == (W, H)
+    a = ex.integrator.hdr.to_numpy()
+    ex2 = scenes.cornell_box(W, H, 6, device_id=0); ex2.build_scene(); ex2.integrator.render_frames(6)
+    assert np.array_equal(a, ex2.integrator.hdr.to_numpy())

@@ -29,6 +29,10 @@ class example:
         self.integrator = None
         self.out_path = "out.png"
         self.exposure = 0.5                  # example/Example.py:43
+        # progressive preview (example/Example.py:41-46 tone-maps and blits to a ti.GUI window every frame): headless here --
+        # every `preview_every` frames the film so far is tone-mapped and written to `preview_path` (0 = no preview)
+        self.preview_every = 0
+        self.preview_path = "preview.png"
 
     def build_scene(self):
         self.scene.setup_data_cpu()
@@ -62,6 +66,9 @@ class example:
         if self.cam.frame_cpu[0] < self.sample_count:
             self.integrator.render()
             self.cam.update_frame()
+            if self.preview_every > 0 and self.cam.frame_cpu[0] % self.preview_every == 0 and self.cam.frame_cpu[0] < self.sample_count:
+                UF.tone_map(self.exposure, self.integrator.hdr, self.integrator.rgb_film)
+                write_png(self.integrator.rgb_film.to_numpy(), self.preview_path)
             return 1
         if self.cam.frame_cpu[0] == self.sample_count:
             UF.tone_map(self.exposure, self.integrator.hdr, self.integrator.rgb_film)
