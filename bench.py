@@ -96,28 +96,41 @@ def measure_hbm_traffic(args):
     child = [sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "1", "--frames-per-step", str(args.frames_per_step),
              "--size", str(args.size), "--ntri", str(args.ntri), "--seed", str(args.seed), "--no-cpu-baseline", "--no-roofline",
              "--opt", "overlap_lanes=1"] + sum((["--opt", o] for o in args.opt), [])
+    def one_pass(counters):
+        d = os.path.join(tmp, counters[0])
+        cmd = ["timeout", "-k", "5", "240", exe, "--kernel-trace", "--pmc"] + list(counters) + ["--output-format", "csv", "-d", d, "--"] + child
+        p = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+        fs = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+        if not fs:
+            raise RuntimeError("%s pass produced no counter file (rc %d)" % (counters[0], p.returncode))
+        tot, ids = {c: 0.0 for c in counters}, set()
+        for r in csv.DictReader(open(max(fs, key=os.path.getmtime))):
+            if "k_trace" in r["Kernel_Name"] and r["Counter_Name"] in tot:
+                tot[r["Counter_Name"]] += float(r["Counter_Value"]); ids.add(r["Dispatch_Id"])
+        if not ids:
+            raise RuntimeError("no k_trace dispatch in the %s pass" % counters[0])
+        return tot, len(ids)
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-            d = os.path.join(tmp, counter)
-            cmd = ["timeout", "-k", "5", "240", exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "--"] + child
-            p = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
-            fs = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
-            if not fs:
-                return {"error": "%s pass produced no counter file (rc %d)" % (counter, p.returncode)}
-            total, ids = 0.0, set()
-            for r in csv.DictReader(open(max(fs, key=os.path.getmtime))):
-                if "k_trace" in r["Kernel_Name"] and r["Counter_Name"] == counter:
-                    total += float(r["Counter_Value"]); ids.add(r["Dispatch_Id"])
-            if not ids:
-                return {"error": "no k_trace dispatch in the %s pass" % counter}
-            out[counter + "_KB_per_launch"] = round(total / len(ids), 1)
-            out["launches_" + counter] = len(ids)
+            tot, n = one_pass((counter,))
+            out[counter + "_KB_per_launch"] = round(tot[counter] / n, 1)
+            out["launches_" + counter] = n
+        # what the kernel is busy with, same child run: VALU issue and texture-address cycles against the kernel's own clock count
+        # (SQ_ACTIVE_INST_VALU counts quad-cycles per SIMD, GRBM_GUI_ACTIVE is summed over the 8 XCDs; MI355X: 1024 SIMDs, 256 CUs)
+        try:
+            tot, n = one_pass(("SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE", "TA_TA_BUSY_sum"))
+            cyc = tot["GRBM_GUI_ACTIVE"] / 8.0
+            if cyc > 0:
+                out["valu_busy"] = round(tot["SQ_ACTIVE_INST_VALU"] * 4.0 / (cyc * 1024.0), 3)
+                out["ta_busy"] = round(tot["TA_TA_BUSY_sum"] / (cyc * 256.0), 3)
+        except Exception as exc:        # noqa: BLE001
+            out["busy_error"] = "%s: %s" % (type(exc).__name__, exc)
     except Exception as exc:            # noqa: BLE001 -- a failed profiler pass must not fail the bench line
         return {"error": "%s: %s" % (type(exc).__name__, exc)}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     out["bytes_per_launch"] = round((2.0 * out["FETCH_SIZE_KB_per_launch"] + out["WRITE_SIZE_KB_per_launch"]) * 1024.0)
-    out["source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) run by bench.py on a child process; FETCH_SIZE x 2 (gfx950)"
+    out["source"] = "rocprofv3 --pmc passes (FETCH_SIZE; WRITE_SIZE; SQ_ACTIVE_INST_VALU + GRBM_GUI_ACTIVE + TA_TA_BUSY_sum) run by bench.py on a child process; FETCH_SIZE x 2 (gfx950)"
     return out
 
 
@@ -341,7 +354,9 @@ def main():
         tr_bytes = traffic["bytes_per_launch"] if traffic and traffic.get("bytes_per_launch") else None
         alg_trace = alg_closest + alg_shadow
         result["roofline"] = {
-            "bound": "l1_gather", "kernel": "k_trace<ordered> (closest-hit + NEE shadow rays)",
+            # PMC (traffic_detail.valu_busy / ta_busy, measured by this run): the kernel is bound by VALU issue with the L1 gather path
+            # (texture-address unit) second; HBM is far from it.  The byte roofline below is stated on the gather path.
+            "bound": "valu_issue+l1_gather", "kernel": "k_trace<ordered> (closest-hit + NEE shadow rays)",
             "achieved": round(achieved, 1), "peak": round(peak, 1), "unit": "GB/s",
             "frac": round(achieved / peak, 4) if peak > 0 else None,
             "traffic": tr_bytes,
