@@ -208,3 +208,34 @@ def test_quantised_nodes_headline_scene_far_and_near(gpu_ctx_ok):
     ex.scene.setup_data_cpu()
     rays = _grazing_rays(ex, 1500, 23)
     check_scene(scenes.synthetic(64, 64, 4, device_id=0), 64, 64, rays, max_rays=60000)
+
+
+def test_very_long_duplicate_chain(gpu_ctx_ok):
+    """600 triangles with one Morton code: a 600-deep chain in the reference tree (its own 64-entry stack overflows there; the
+    oracle is given 2048 entries), ~200 levels of the collapsed 4-wide tree.  Build succeeds, hits equal the oracle's."""
+    from ti_raytrace_amd import Example, PT_RGB
+    from ti_raytrace_amd import SceneData as SCD
+    W = H = 32
+    ex = Example.example(W, H, 4, 0)
+    mat = SCD.Material(); mat.type = SCD.MAT_DISNEY; mat.setRough(0.5); mat.setColor([0.8, 0.8, 0.8, 1.0]); mat.alebdoTex = -1
+    r = np.random.RandomState(3)
+    tris = []
+    for k in range(600):
+        a = r.uniform(0.2, 1.0); th = r.uniform(0, 2 * np.pi)
+        p = np.array([[np.cos(th + 2 * np.pi * j / 3) * a, np.sin(th + 2 * np.pi * j / 3) * a, r.uniform(-0.3, 0.3)] for j in range(3)])
+        p -= p.mean(axis=0, keepdims=True)
+        tris.append(p)
+    for k in range(30):
+        c = r.uniform(-1.5, 1.5, size=3); tris.append(c[None, :] + r.uniform(-0.2, 0.2, size=(3, 3)))
+    ex.scene.add_mesh(np.asarray(tris), mat)
+    ex.add_sphere_light(pos=(0.0, 3.0, 0.0), radius=0.5, emission=30.0)
+    ex.integrator = PT_RGB.PathTrace(W, H, ex.cam, ex.scene, 2048)
+    ex.build_scene(); ex.frame_camera(0.8)
+    o = oa.OracleScene(ex.scene, ex.cam); o.lbvh_build()
+    rays = np.concatenate([oa.camera_rays(ex.cam, W, H), random_rays(3000, -1.5, 1.5, 9)], axis=0)
+    want, wprim, _ = o.closest_hit(rays, stack_size=2048)
+    for flags in (0, _native.TRAVERSE_EXHAUSTIVE):
+        got, gprim, _ = ex.scene.ctx.trace_closest(rays, 2048, flags)
+        assert np.array_equal(gprim, wprim) and bits_equal(got[:, 0], want[:, 0]).all()
+    print("600-chain: hit fraction %.3f" % (wprim >= 0).mean())
+    assert ex.scene.ctx.stats()["stack_overflow"] == 0 and (wprim >= 0).mean() > 0.05

@@ -535,7 +535,7 @@ int lbvh_build(tirt_ctx *c)
     if (c->wnode.ensure(sizeof(float4) * 4 * (size_t)N) || c->tri.ensure(sizeof(float4) * TRI_STRIDE * (size_t)n)) return TIRT_ERR_HIP;
     // 4-wide nodes: fewer than n of them; indices are used as 32-bit byte offsets / 64
     TIRT_REQUIRE(n <= (1 << 24), "tirt_lbvh_build: more than 16 Mi primitives");
-    constexpr int WIDE_LEVELS_MAX = 96;
+    constexpr int WIDE_LEVELS_MAX = 2048;     // runs of identical Morton codes make chains: a level per three leaves of a chain
     if (c->cnode.ensure(sizeof(uint4) * 4 * (size_t)n) || c->wide_queue.ensure(sizeof(int) * (size_t)n) ||
         c->wide_levels.ensure(sizeof(int) * 2 * (WIDE_LEVELS_MAX + 2)) || c->cparent.ensure(sizeof(int) * (size_t)N) ||
         c->csize.ensure(sizeof(int) * (size_t)N)) return TIRT_ERR_HIP;
@@ -609,7 +609,7 @@ int lbvh_build(tirt_ctx *c)
             TIRT_HIP(hipMemcpyAsync(host_lv, c->wide_levels.p, sizeof(host_lv), hipMemcpyDeviceToHost, st));
             TIRT_HIP(hipStreamSynchronize(st));
             if (host_lv[(WIDE_LEVELS_MAX + 2) + level] == 0) { c->wide_nodes = host_lv[level]; break; }       // the next level is empty: done
-            TIRT_REQUIRE(level < WIDE_LEVELS_MAX, "tirt_lbvh_build: the 4-wide tree is deeper than 96 levels");
+            TIRT_REQUIRE(level < WIDE_LEVELS_MAX, "tirt_lbvh_build: the 4-wide tree is deeper than 2048 levels");
         }
     } else TIRT_HIP(hipEventRecord(c->ev1, st));
     if (n == 1) {
