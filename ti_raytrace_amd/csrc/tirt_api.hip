@@ -14,7 +14,7 @@ SceneView scene_view(const tirt_ctx *c)
     SceneView s;
     s.vertex = c->vertex.as<float>(); s.primitive = c->primitive.as<int>(); s.material = c->material.as<float>();
     s.shape = c->shape.as<float>(); s.light = c->light.as<int>(); s.env = c->env.as<int>();
-    s.mat_lrgb = c->mat_lrgb.as<float>();
+    s.mat_lrgb = c->mat_lrgb.as<float>(); s.shade_rec = c->shade_rec.as<float4>();
     s.n = c->n; s.light_count = c->light_count; s.env_w = c->env_w; s.env_h = c->env_h; s.env_power = c->env_power;
     return s;
 }
@@ -64,6 +64,36 @@ static int refresh_material_table(tirt_ctx *c)
 {
     if (c->mat_lrgb.ensure(sizeof(float) * 3 * (size_t)c->nm)) return TIRT_ERR_HIP;
     hipLaunchKernelGGL(k_material_lrgb, dim3((c->nm + 63) / 64), dim3(64), 0, c->stream, c->material.as<float>(), c->nm, c->mat_lrgb.as<float>());
+    return 0;
+}
+
+// ---- 128-byte shading record per primitive (tirt_device.h, hit_attributes_rec) -----------------------
+__global__ void k_shade_records(SceneView s, float4 *rec)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= s.n) return;
+    const int *pr = s.primitive + (size_t)i * PRI_VEC;
+    float4 *r = rec + (size_t)i * 8;
+    const float mat = __int_as_float(pr[2]);
+    if (pr[0] == PRIMITIVE_TRI) {
+        const v3 v1 = vtx_pos(s, pr[1]), v2 = vtx_pos(s, pr[1] + 1), v3_ = vtx_pos(s, pr[1] + 2);
+        const v3 n1 = vtx_nor(s, pr[1]), n2 = vtx_nor(s, pr[1] + 1), n3 = vtx_nor(s, pr[1] + 2);
+        r[0] = make_float4(v1.x, v1.y, v1.z, mat); r[1] = make_float4(v2.x, v2.y, v2.z, __int_as_float(PRIMITIVE_TRI));
+        r[2] = make_float4(v3_.x, v3_.y, v3_.z, 0.0f);
+        r[3] = make_float4(n1.x, n1.y, n1.z, 0.0f); r[4] = make_float4(n2.x, n2.y, n2.z, 0.0f); r[5] = make_float4(n3.x, n3.y, n3.z, 0.0f);
+    } else {
+        const float *sh = s.shape + (size_t)pr[1] * SHA_VEC;
+        r[0] = make_float4(sh[1], sh[2], sh[3], mat); r[1] = make_float4(sh[4], sh[0], 0.0f, __int_as_float(2));
+        r[2] = r[3] = r[4] = r[5] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    r[6] = r[7] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+}
+int ensure_shade_records(tirt_ctx *c)
+{
+    if (c->shade_rec_valid && c->shade_rec.p) return 0;
+    if (c->shade_rec.ensure(sizeof(float4) * 8 * (size_t)c->n)) return TIRT_ERR_HIP;
+    hipLaunchKernelGGL(k_shade_records, dim3((c->n + 255) / 256), dim3(256), 0, c->stream, scene_view(c), c->shade_rec.as<float4>());
+    c->shade_rec_valid = true;
     return 0;
 }
 
@@ -260,7 +290,7 @@ void tirt_destroy(tirt_ctx *c)
     (void)hipSetDevice(c->device);
     (void)sync_all(c);
     drain_render_events(c);
-    DevBuf *bufs[] = {&c->vertex, &c->primitive, &c->material, &c->shape, &c->light, &c->env, &c->mat_lrgb, &c->morton_unsorted, &c->keys_a,
+    DevBuf *bufs[] = {&c->vertex, &c->primitive, &c->material, &c->shape, &c->light, &c->env, &c->mat_lrgb, &c->shade_rec, &c->morton_unsorted, &c->keys_a,
                       &c->keys_b, &c->vals_a, &c->vals_b, &c->hist, &c->morton_sorted, &c->bvh_node, &c->compact, &c->parent,
                       &c->flag, &c->subtree, &c->build_status, &c->leaf_compact, &c->wnode, &c->tri, &c->cnode, &c->cparent, &c->csize, &c->wide_queue, &c->wide_levels, &c->hdr, &c->rgb,
                       &c->counters_mem, &c->spill, &c->tr_rays,
@@ -367,7 +397,7 @@ int tirt_scene_upload(tirt_ctx *c, const float *vertex, int nv, const int32_t *p
     if (upload(c->material, material, sizeof(float) * 10 * (size_t)nm, st)) return TIRT_ERR_HIP;
     if (upload(c->shape, shape, sizeof(float) * 10 * (size_t)ns, st)) return TIRT_ERR_HIP;
     if (upload(c->light, light, sizeof(int) * (size_t)nl, st)) return TIRT_ERR_HIP;
-    c->nv = nv; c->n = n; c->nm = nm; c->ns = ns; c->nl = nl; c->light_count = light_count;
+    c->nv = nv; c->n = n; c->nm = nm; c->ns = ns; c->nl = nl; c->light_count = light_count; c->shade_rec_valid = false;
     for (int k = 0; k < 3; k++) { c->bmin[k] = bmin[k]; c->bmax[k] = bmax[k]; }
     if (refresh_material_table(c)) return TIRT_ERR_HIP;
     if (!c->env.p) {        // default: 1x1 black (Scene.py:295-296 loads image/black.png)
@@ -442,6 +472,7 @@ int tirt_process_normal(tirt_ctx *c, const int32_t *vertex_index)
     const int B = 128, G = (c->nv + B - 1) / B;
     hipLaunchKernelGGL(k_smooth_normal, dim3(G), dim3(B), 0, c->stream, scene_view(c), c->nv, c->compact.as<float>(), vi.as<int>(), smooth.as<float>());
     hipLaunchKernelGGL(k_write_normal, dim3(G), dim3(B), 0, c->stream, c->vertex.as<float>(), c->nv, smooth.as<float>());
+    c->shade_rec_valid = false;
     hipError_t e = hipStreamSynchronize(c->stream);
     vi.release(); smooth.release();
     TIRT_HIP(e);

@@ -52,6 +52,7 @@ struct SceneView {
     const int *light;        // [nl]
     const int *env;          // [w*h]
     const float *mat_lrgb;   // [nm*3] srgb_to_lrgb(material colour), filled on device at upload
+    const float4 *shade_rec; // [n*8] one 128-byte line per primitive: what k_shade needs to shade a hit on it (k_shade_records)
     int n, light_count, env_w, env_h;
     float env_power;
 };
@@ -182,6 +183,38 @@ TD HitAttr hit_attributes(const SceneView &s, v3 origin, v3 direction, int prim,
             nn = V(h.pos.x - c, h.pos.y - c, h.pos.z - c);          // quirk B3
             gn = nn;
         }
+    }
+    h.gnor = normalized(gn); h.nor = normalized(nn);
+    return h;
+}
+
+// The same from the 128-byte shading record of the primitive (one cache line instead of a 12-byte primitive row plus three
+// 36-byte vertex rows in three more lines; exact copies of the same floats, so the same results):
+//   triangles: (v1.xyz, bits mat) (v2.xyz, bits PRIMITIVE_TRI) (v3.xyz, -) (n1.xyz, -) (n2.xyz, -) (n3.xyz, -) - -
+//   shapes   : (centre.xyz, bits mat) (radius, shape type, -, bits 2)
+// uv is not carried: the path tracer does not use it (the reference's albedo textures are unused, PT_RGB.py:86).
+TD HitAttr hit_attributes_rec(const float4 *rec, v3 origin, v3 direction, int prim, float t, float u, float v, int &mat_id)
+{
+    HitAttr h; h.pos = h.gnor = h.nor = h.tex = V(0.0f, 0.0f, 0.0f);
+    const float4 *r = rec + (size_t)prim * 8;
+    const float4 r0 = r[0], r1 = r[1];
+    mat_id = __float_as_int(r0.w);
+    v3 gn = V(0.0f, 0.0f, 0.0f), nn = gn;
+    if (__float_as_int(r1.w) == PRIMITIVE_TRI) {
+        const float4 r2 = r[2], r3 = r[3], r4 = r[4], r5 = r[5];
+        float a = 1.0f - u - v, b = u, c = v;
+        v3 v1 = V(r0.x, r0.y, r0.z), v2 = V(r1.x, r1.y, r1.z), v3_ = V(r2.x, r2.y, r2.z);
+        v3 n1 = V(r3.x, r3.y, r3.z), n2 = V(r4.x, r4.y, r4.z), n3 = V(r5.x, r5.y, r5.z);
+        v3 v13 = v3_ - v1, v12 = v2 - v1;
+        gn = cross(v12, v13);
+        h.pos = (v1 * a + v2 * b) + v3_ * c;
+        nn = (n1 * a + n2 * b) + n3 * c;
+    } else if ((int)r1.y == SHAPE_SPHERE) {
+        float c;
+        (void)intersect_sphere(origin, direction, V(r0.x, r0.y, r0.z), r1.x, c);
+        h.pos = origin + direction * t;
+        nn = V(h.pos.x - c, h.pos.y - c, h.pos.z - c);          // quirk B3
+        gn = nn;
     }
     h.gnor = normalized(gn); h.nor = normalized(nn);
     return h;

@@ -166,7 +166,8 @@ struct tirt_ctx {
     // scene (Scene.py fields)
     int nv = 0, n = 0, nm = 0, ns = 0, nl = 0, light_count = 0;
     float bmin[3] = {0, 0, 0}, bmax[3] = {0, 0, 0};
-    tirt::DevBuf vertex, primitive, material, shape, light, env, mat_lrgb;
+    tirt::DevBuf vertex, primitive, material, shape, light, env, mat_lrgb, shade_rec;
+    bool shade_rec_valid = false;                  // shading records follow vertex / primitive / shape uploads and process_normal
     int env_w = 0, env_h = 0; float env_power = 0.0f;
 
     // LBVH (accel/LBvh.py fields)
@@ -244,6 +245,7 @@ int bdpt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t see
 int trace_arrays(tirt_ctx *c, const float *ox, const float *oy, const float *oz, const float *dx, const float *dy, const float *dz,
                  int count, const int *count_ptr, float4 *hit, const int *expect, const float *bound, bool count_rays);
 int ensure_counters(tirt_ctx *c);
+int ensure_shade_records(tirt_ctx *c);
 int sync_all(tirt_ctx *c);
 int flush_pending(tirt_ctx *c);
 }  // namespace tirt

@@ -678,10 +678,10 @@ __global__ __launch_bounds__(SH_BLOCK, SH_MIN_WAVES) void k_shade(PathState ps, 
             int perfect_spec = first ? 1 : (int)(in.flags[q] & 1u);
             if (t < INF_VALUE) {
                 const int prim_id = __float_as_int(hrec.w);
-                const HitAttr h = hit_attributes(sc, origin, direction, prim_id, t, hrec.y, hrec.z);
+                int mat_id;
+                const HitAttr h = hit_attributes_rec(sc.shade_rec, origin, direction, prim_id, t, hrec.y, hrec.z, mat_id);
                 const v3 normal = h.nor;
                 const v3 fnormal = normal * signf(dot(-direction, h.gnor));            // UtilsFunc.py:465-467
-                const int mat_id = sc.primitive[(size_t)prim_id * PRI_VEC + 2];
                 const float *m = sc.material + (size_t)mat_id * MAT_VEC;
                 const v3 mat_color = V(m[2], m[3], m[4]);
                 const int mat_type = (int)m[0];
@@ -890,6 +890,7 @@ int pt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed,
     TIRT_REQUIRE(frame_count >= 0 && max_depth >= 1 && max_depth <= 4096, "tirt_pt_rgb_render: bad frame_count/max_depth");
     if (frame_count == 0 || c->npix_local == 0) return TIRT_OK;
     if (ensure_counters(c)) return TIRT_ERR_HIP;
+    if (ensure_shade_records(c)) return TIRT_ERR_HIP;          // on the main stream: the lanes wait for ev_main below
     const int P = (int)c->npix_local;
     // frames per batch: up to batch_paths pixel-samples in flight (the per-bounce launches of a
     // batch end in a latency-bound tail of a few long rays, so bigger batches amortise it)
