@@ -431,10 +431,10 @@ __global__ void k_bd_step(BdCtx c, bpixel *items, BdStep *steps, BdRays rays, co
                 float pdfFwd = st->e_pdfFwd, pdfRev = 0.0f;
                 v3 beta = st->e_beta;
                 if (sh.t < INF_VALUE) {
-                    const HitAttr h = hit_attributes(s, origin, dir, sh.prim, sh.t, sh.u, sh.v);
+                    int mat_id;
+                    const HitAttr h = hit_attributes_rec(s.shade_rec, origin, dir, sh.prim, sh.t, sh.u, sh.v, mat_id);
                     const v3 normal = h.nor, pos = h.pos;
                     const v3 fnormal = normal * signf(dot(-dir, h.gnor));
-                    const int mat_id = s.primitive[(size_t)sh.prim * PRI_VEC + 2];
                     const float *m = mat_row(s, mat_id);
                     const v3 mat_color = V(m[2], m[3], m[4]);
                     const int mat_type = (int)m[0];
@@ -487,10 +487,10 @@ __global__ void k_bd_step(BdCtx c, bpixel *items, BdStep *steps, BdRays rays, co
                 float pdfFwd = st->l_pdfFwd, pdfRev = 0.0f;
                 v3 beta = st->l_beta;
                 if (sh.t < INF_VALUE) {
-                    const HitAttr h = hit_attributes(s, origin, dir, sh.prim, sh.t, sh.u, sh.v);
+                    int mat_id;
+                    const HitAttr h = hit_attributes_rec(s.shade_rec, origin, dir, sh.prim, sh.t, sh.u, sh.v, mat_id);
                     const v3 normal = h.nor, pos = h.pos;
                     const v3 fnormal = normal * signf(dot(-dir, h.gnor));
-                    const int mat_id = s.primitive[(size_t)sh.prim * PRI_VEC + 2];
                     const float *m = mat_row(s, mat_id);
                     const v3 mat_color = V(m[2], m[3], m[4]);
                     const int mat_type = (int)m[0];
@@ -659,6 +659,7 @@ int bdpt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t see
     if (frame_count == 0) return TIRT_OK;
     if (ensure_counters(c)) return TIRT_ERR_HIP;
     if (sync_all(c)) return TIRT_ERR_HIP;
+    if (ensure_shade_records(c)) return TIRT_ERR_HIP;
     const long NP = (long)c->W * c->H;
     const int P = (int)c->npix_local;
     hipStream_t st = c->stream;
