@@ -239,3 +239,13 @@ def test_very_long_duplicate_chain(gpu_ctx_ok):
         assert np.array_equal(gprim, wprim) and bits_equal(got[:, 0], want[:, 0]).all()
     print("600-chain: hit fraction %.3f" % (wprim >= 0).mean())
     assert ex.scene.ctx.stats()["stack_overflow"] == 0 and (wprim >= 0).mean() > 0.05
+
+
+def test_measurement_helpers(gpu_ctx_ok):
+    ex = scenes.synthetic(32, 32, 4, ntri=5000, device_id=0)
+    ex.build_scene()
+    info = ex.scene.ctx.bvh_info()
+    assert info["prim_bytes"] == 48 * 5001 and 1200 < info["nodes"] < 5001 and info["node_bytes"] == 64 * info["nodes"]
+    assert info["nodes_in_lds"] == min(info["nodes"], 341)
+    rate = ex.scene.ctx.micro_gather_rate(1 << 20, 200)
+    assert 500.0 < rate < 40000.0                      # GB/s: a sane number, not a benchmark
