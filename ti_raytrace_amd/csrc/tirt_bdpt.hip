@@ -344,7 +344,6 @@ struct BdStep { v3 e_beta; float e_pdfFwd; v3 l_beta; float l_pdfFwd; int e_aliv
 struct BdRays { float *ox, *oy, *oz, *dx, *dy, *dz; };            // 2N entries: [0, N) eye rays, [N, 2N) light rays
 constexpr int BD_PAIRS = BD_EYE_MAX * (BD_LIGHT_MAX + 1);          // (e - 1) * 7 + l
 TD void put_ray(const BdRays &r, size_t k, v3 o, v3 d) { r.ox[k] = o.x; r.oy[k] = o.y; r.oz[k] = o.z; r.dx[k] = d.x; r.dy[k] = d.y; r.dz[k] = d.z; }
-TD void kill_ray(const BdRays &r, size_t k) { r.dx[k] = __int_as_float(0x7fc00000); }     // a NaN direction: k_trace answers "miss" without a walk
 TD void count_rays(unsigned long long *ctr, unsigned mine)
 {
     unsigned long long v = mine;
@@ -354,7 +353,7 @@ TD void count_rays(unsigned long long *ctr, unsigned mine)
 }
 
 // BDPT_RGB.py:104-125 (lens vertex, camera ray) and :201-228 with Scene.sample_light (Scene.py:430-474)
-__global__ void k_bd_init(BdCtx c, bpixel *items, BdStep *steps, BdRays rays, TileMap tm, int P, int N, uint32_t frame_begin, unsigned long long *paths)
+__global__ void k_bd_init(BdCtx c, bpixel *items, BdStep *steps, BdRays rays, int *owner, int *alive_cnt, TileMap tm, int P, int N, uint32_t frame_begin, unsigned long long *paths)
 {
     const int it = blockIdx.x * blockDim.x + threadIdx.x;
     if (it >= N) return;
@@ -373,7 +372,7 @@ __global__ void k_bd_init(BdCtx c, bpixel *items, BdStep *steps, BdRays rays, Ti
         const v3 dir = camera_ray_direction(c.cam, i, j, jx, jy);
         eye[0].pos = origin; eye[0].normal = dir; eye[0].beta = V(1.0f, 1.0f, 1.0f); eye[0].fpdf = 1.0f; eye[0].type = VERTEX_LENS;
         st.e_beta = V(1.0f, 1.0f, 1.0f); st.e_pdfFwd = 1.0f; st.e_alive = 1; st.eye_depth = 1;
-        put_ray(rays, (size_t)it, origin, dir);
+        put_ray(rays, (size_t)it, origin, dir); owner[it] = it;
     }
     // light
     {
@@ -395,37 +394,43 @@ __global__ void k_bd_init(BdCtx c, bpixel *items, BdStep *steps, BdRays rays, Ti
         light[0].pos = lpos; light[0].normal = lnor; light[0].beta = emission / light_pdf;
         light[0].fpdf = light_pdf; light[0].rpdf = 0.0f; light[0].wo = ldir; light[0].type = VERTEX_LIGHT;
         st.l_beta = (emission / light_pdf) * absf(dot(lnor, ldir)); st.l_pdfFwd = dir_pdf; st.l_alive = 1; st.light_depth = 1;
-        put_ray(rays, (size_t)N + it, lpos, ldir);
+        put_ray(rays, (size_t)N + it, lpos, ldir); owner[N + it] = N + it;
     }
     steps[it] = st;
-    if (it == 0) atomicAdd(paths, (unsigned long long)N);
+    if (it == 0) { atomicAdd(paths, (unsigned long long)N); alive_cnt[1] = 2 * N; }        // depth 1: every sub-path has its first ray
 }
 
 // One iteration of the while loops of eye_path (BDPT_RGB.py:126-198; threads [0, N)) and light_path (:229-294; threads
 // [N, 2N)): the hit of the ray traced for vertex `depth`, the vertex, the next ray.
-__global__ void k_bd_step(BdCtx c, bpixel *items, BdStep *steps, BdRays rays, const float4 *hits, TileMap tm, int P, int N, uint32_t frame_begin,
-                          int depth, unsigned long long *rays_closest)
+// The rays of a depth are a dense list (`rays`, `owner`: which sub-path -- t < N eye of item t, else light of item t - N); the
+// sub-paths that go on append their next ray to the list of the next depth (one atomic per wave), so the later depths launch
+// work only for what is still alive.
+__global__ void k_bd_step(BdCtx c, bpixel *items, BdStep *steps, BdRays rays, const int *owner, BdRays rays_out, int *owner_out, int *alive_cnt,
+                          const float4 *hits, TileMap tm, int P, int N, uint32_t frame_begin, int depth, unsigned long long *rays_closest)
 {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int qi = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
     unsigned traced = 0;
-    if (t < 2 * N) {
+    bool go_on = false;
+    v3 next_o = V(0.0f, 0.0f, 0.0f), next_d = next_o;
+    int t = 0;
+    if (qi < alive_cnt[depth]) {
+        t = owner[qi];
         const bool is_eye = t < N;
         const int it = is_eye ? t : t - N;
         BdStep *st = steps + it;
-        const bool alive = is_eye ? (st->e_alive != 0) : (st->l_alive != 0);
-        if (alive) {
+        {
             traced = 1;
             const int f = it / P, k = it - f * P;
             const uint32_t pixel = (uint32_t)local_to_pixel(tm, k), frame = frame_begin + (uint32_t)f;
             const SceneView &s = c.sc;
             bpixel *B = items + it;
-            const v3 origin = V(rays.ox[t], rays.oy[t], rays.oz[t]), dir = V(rays.dx[t], rays.dy[t], rays.dz[t]);
-            const float4 hr = hits[t];
+            const v3 origin = V(rays.ox[qi], rays.oy[qi], rays.oz[qi]), dir = V(rays.dx[qi], rays.dy[qi], rays.dz[qi]);
+            const float4 hr = hits[qi];
             SimpleHit sh; sh.t = hr.x; sh.u = hr.y; sh.v = hr.z; sh.prim = __float_as_int(hr.w);
             const int pre_depth = depth - 1;
             int final_depth = depth;              // what the reference's function returns if the loop ends here
-            bool go_on = false;
-            v3 next_o = origin, next_d = dir;
+            next_o = origin; next_d = dir;
             if (is_eye) {
                 bvert *eye = B->eye;
                 float pdfFwd = st->e_pdfFwd, pdfRev = 0.0f;
@@ -534,7 +539,18 @@ __global__ void k_bd_step(BdCtx c, bpixel *items, BdStep *steps, BdRays rays, co
                 }
                 st->l_beta = beta; st->l_pdfFwd = pdfFwd; st->light_depth = final_depth; st->l_alive = go_on ? 1 : 0;
             }
-            if (go_on) put_ray(rays, (size_t)t, next_o, next_d); else kill_ray(rays, (size_t)t);
+        }
+    }
+    const unsigned long long gm = __ballot(go_on);
+    if (gm != 0ull) {
+        const int leader = __ffsll((long long)gm) - 1;
+        int base = 0;
+        if (lane == leader) base = atomicAdd(&alive_cnt[depth + 1], __popcll(gm));
+        base = __shfl(base, leader, 64);
+        if (go_on) {
+            const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+            const size_t qo = (size_t)(base + __popcll(gm & lt));
+            put_ray(rays_out, qo, next_o, next_d); owner_out[qo] = t;
         }
     }
     count_rays(rays_closest, traced);
@@ -700,14 +716,19 @@ int bdpt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t see
         const uint32_t frame0 = frame_begin + (uint32_t)f0;
         TIRT_HIP(hipMemsetAsync(c->bdpt_rad.p, 0, sizeof(float) * 3 * (size_t)NP * (size_t)F, st));
         TIRT_HIP(hipMemsetAsync(c->bdpt_items.p, 0, sizeof(bpixel) * (size_t)N, st));
-        TIRT_HIP(hipMemsetAsync(scount, 0, sizeof(int), st));
-        hipLaunchKernelGGL(k_bd_init, dim3((N + B - 1) / B), dim3(B), 0, st, bc, c->bdpt_items.as<bpixel>(), c->bdpt_state.as<BdStep>(), er, tm, P, N, frame0, &ctr->paths);
-        // rays of the two sub-paths share the launches; entry [N + i] is item i's light ray (the array pitch is 2 NMAX, the live part 2 N)
-        BdRays er2 = er;            // light rays start at N of this batch, not NMAX: the step kernels index [0, 2N)
+        TIRT_HIP(hipMemsetAsync(scount, 0, 64, st));                 // the connection-ray count and the alive counts of the depths
+        // during the sub-path phase the dense connection-ray arrays and the two `expect` arrays are free: they hold the second ray list and the owners
+        BdRays rset[2] = {sr, er};                                  // depth d reads rset[d & 1]
+        int *oset[2] = {sexpect, gexpect};
+        int *alive_cnt = scount + 4;
+        hipLaunchKernelGGL(k_bd_init, dim3((N + B - 1) / B), dim3(B), 0, st, bc, c->bdpt_items.as<bpixel>(), c->bdpt_state.as<BdStep>(), rset[1], oset[1], alive_cnt,
+                           tm, P, N, frame0, &ctr->paths);
+        // rays of the two sub-paths share the launches
         for (int d = 1; d < BD_EYE_MAX; d++) {
-            if (int rc = trace_arrays(c, er2.ox, er2.oy, er2.oz, er2.dx, er2.dy, er2.dz, 2 * N, nullptr, ehits, nullptr, nullptr, false)) return rc;
-            hipLaunchKernelGGL(k_bd_step, dim3((2 * N + B - 1) / B), dim3(B), 0, st, bc, c->bdpt_items.as<bpixel>(), c->bdpt_state.as<BdStep>(), er2, ehits, tm, P, N,
-                               frame0, d, &ctr->rays_closest);
+            const BdRays &ri = rset[d & 1], &ro = rset[(d + 1) & 1];
+            if (int rc = trace_arrays(c, ri.ox, ri.oy, ri.oz, ri.dx, ri.dy, ri.dz, 2 * N, alive_cnt + d, ehits, nullptr, nullptr, false)) return rc;
+            hipLaunchKernelGGL(k_bd_step, dim3((2 * N + B - 1) / B), dim3(B), 0, st, bc, c->bdpt_items.as<bpixel>(), c->bdpt_state.as<BdStep>(), ri, oset[d & 1], ro,
+                               oset[(d + 1) & 1], alive_cnt, ehits, tm, P, N, frame0, d, &ctr->rays_closest);
         }
         hipLaunchKernelGGL(k_bd_delta, dim3((P + B - 1) / B), dim3(B), 0, st, c->bdpt_items.as<bpixel>(), c->bdpt_state.as<BdStep>(), tm, P, F, c->bdpt_px.as<int>());
         hipLaunchKernelGGL(k_bd_connect<0>, dim3((N + B - 1) / B), dim3(B), 0, st, bc, c->bdpt_items.as<bpixel>(), c->bdpt_state.as<BdStep>(), tm, P, N, frame0,
