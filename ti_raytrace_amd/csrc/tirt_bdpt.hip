@@ -6,7 +6,8 @@
 // (tirt_render.hip, k_trace) in large batches, and the arithmetic around the rays runs in between:
 //
 //   k_bd_init          lens vertex + camera ray, light vertex + first light ray       BDPT_RGB.py:104-125, 201-228
-//   6 x { trace 2N rays ; k_bd_step(d) }   vertex d of the eye and of the light sub-path   BDPT_RGB.py:126-198, 229-294
+//   6 x { trace the live rays ; k_bd_step(d) }   vertex d of the eye and of the light sub-path; the rays of a depth are a
+//                      dense list, survivors append to the next depth's list               BDPT_RGB.py:126-198, 229-294
 //   k_bd_delta         the one field that survives from frame to frame (see below)
 //   k_bd_connect<0>    geometry of every (e, l) connection, connection rays to a dense queue   BDPT_RGB.py:481-592
 //   trace queries      "is the expected primitive the closest hit?"  (k_trace<KIND_QUERY>, bounded)
@@ -341,7 +342,7 @@ TD v3 bd_connect_path(const BdCtx &c, const bpixel *P, bvert &sample, int i, int
 
 // ---- wavefront state ------------------------------------------------------------------------------------------
 struct BdStep { v3 e_beta; float e_pdfFwd; v3 l_beta; float l_pdfFwd; int e_alive, l_alive, eye_depth, light_depth; };
-struct BdRays { float *ox, *oy, *oz, *dx, *dy, *dz; };            // 2N entries: [0, N) eye rays, [N, 2N) light rays
+struct BdRays { float *ox, *oy, *oz, *dx, *dy, *dz; };            // struct-of-arrays ray list
 constexpr int BD_PAIRS = BD_EYE_MAX * (BD_LIGHT_MAX + 1);          // (e - 1) * 7 + l
 TD void put_ray(const BdRays &r, size_t k, v3 o, v3 d) { r.ox[k] = o.x; r.oy[k] = o.y; r.oz[k] = o.z; r.dx[k] = d.x; r.dy[k] = d.y; r.dz[k] = d.z; }
 TD void count_rays(unsigned long long *ctr, unsigned mine)
