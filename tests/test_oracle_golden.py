@@ -134,3 +134,20 @@ def test_oracle_bdpt_against_the_reference_gallery_render(oracle_lib):
     r = rel_l2(ours, ref)
     print("oracle BDPT 128^2 x8 vs veach-bdpt512.png: mean err %s, block rel-L2 %.4f" % (np.round(mean_err, 4), r))
     assert (mean_err < 0.08).all() and r < 0.12
+
+
+def test_oracle_threading_does_not_change_the_film(oracle_lib):
+    """The oracle hands out 64-pixel chunks through an atomic counter (bench.py's cpu_baseline leg runs it on every host core):
+    pixels are independent, so 1 thread and 7 threads must produce the same film and the same counters."""
+    import oracle_api as oa
+    from ti_raytrace_amd import scenes
+    W = H = 40
+    ex = host_only(scenes.cornell_box(W, H, 4))
+    o = oa.OracleScene(ex.scene, ex.cam); o.lbvh_build()
+    a, sa = o.render(W, H, 0, 2, seed=3, nthreads=1)
+    b, sb = o.render(W, H, 0, 2, seed=3, nthreads=7)
+    assert np.array_equal(a, b) and sa == sb
+    # a ragged pixel range with tiles
+    c1, s1 = o.render(W, H, 0, 1, seed=3, p_begin=13, p_end=1207, tile_rank=1, tile_count=3, tile_size=50, nthreads=1)
+    c2, s2 = o.render(W, H, 0, 1, seed=3, p_begin=13, p_end=1207, tile_rank=1, tile_count=3, tile_size=50, nthreads=5)
+    assert np.array_equal(c1, c2) and s1 == s2 and s1["paths"] > 0
