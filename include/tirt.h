@@ -78,7 +78,11 @@ int tirt_sync(tirt_ctx *ctx);
  *          "job_frames" -- hint: frames the whole job will render (0 = unknown, default); lane buffers are then not
  *            sized for merging more than that (a 512^2 x 8 spp job does not allocate 32 Mi-path lanes)
  *          "batch_paths" -- pixel-samples kept in flight per wavefront batch (default 32 Mi,
- *            112 B of HBM each) */
+ *            196 B of HBM each)
+ *          "split_lone_batch" (0/1, default 1) -- a context that owns 1/6 or less of the film (tile_count >= 6) and whose
+ *            whole job is one batch runs it as two half batches on two lanes
+ *          "bdpt_batch_items" -- (frame, pixel) items per BDPT wavefront batch (default 2 Mi, ~3 KB of HBM each)
+ *          (trace_lds_depth is checked against the LDS a block can have on the device) */
 int tirt_set_option(tirt_ctx *ctx, const char *name, double value);
 
 /* Scene.setup_data_gpu field uploads (reference Scene.py:299-308).
