@@ -40,6 +40,7 @@ int sync_all(tirt_ctx *c)
     if (int rc = flush_pending(c)) return rc;
     for (Lane &L : c->lanes) if (L.stream) TIRT_HIP(hipStreamSynchronize(L.stream));
     TIRT_HIP(hipStreamSynchronize(c->stream));
+    c->batches_since_sync = 0;
     return 0;
 }
 int ensure_counters(tirt_ctx *c)

@@ -898,8 +898,9 @@ int pt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed,
     // A rank of a wide multi-GPU job renders its whole share as ONE batch, with nothing to overlap the per-bounce tails with:
     // as two half batches on two lanes it is 3.4 % faster at 8 ranks (measured on one GPU rendering rank 0's tiles; at 4 ranks
     // and below, and for a single GPU's stream of full batches, the halves lose 1-9 %: there 32 Mi-path batches win).
-    if (c->split_lone && c->tile_count >= 6 && FB == frame_count && frame_count >= 2 && c->n_lanes >= 2 && !c->time_kernels &&
-        (size_t)frame_count * P >= ((size_t)12 << 20))
+    // (Only for the first batch after a synchronisation: a rank with several batches in flight overlaps them anyway.)
+    if (c->split_lone && c->tile_count >= 6 && c->batches_since_sync == 0 && FB == frame_count && frame_count >= 2 && c->n_lanes >= 2 &&
+        !c->time_kernels && (size_t)frame_count * P >= ((size_t)12 << 20))
         FB = (frame_count + 1) / 2;
     const SceneView sv = scene_view(c);
     const BvhView bv = bvh_view(c);
@@ -935,6 +936,7 @@ int pt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed,
 
     for (int fb = 0; fb < frame_count; fb += FB) {
         Lane &L = c->lanes[n_lanes == 1 ? 0 : (c->lane_cursor++ % (unsigned)n_lanes)];
+        c->batches_since_sync++;
         hipStream_t st = L.stream;
         const int F = (frame_count - fb < FB) ? frame_count - fb : FB;
         const int S = F * P;
