@@ -293,7 +293,7 @@ void tirt_destroy(tirt_ctx *c)
     drain_render_events(c);
     DevBuf *bufs[] = {&c->vertex, &c->primitive, &c->material, &c->shape, &c->light, &c->env, &c->mat_lrgb, &c->shade_rec, &c->morton_unsorted, &c->keys_a,
                       &c->keys_b, &c->vals_a, &c->vals_b, &c->hist, &c->morton_sorted, &c->bvh_node, &c->compact, &c->parent,
-                      &c->flag, &c->subtree, &c->build_status, &c->leaf_compact, &c->wnode, &c->tri, &c->cnode, &c->cparent, &c->csize, &c->wide_queue, &c->wide_levels, &c->hdr, &c->rgb,
+                      &c->flag, &c->subtree, &c->build_status, &c->leaf_compact, &c->wnode, &c->tri, &c->cnode, &c->cparent, &c->csize, &c->wide_queue, &c->wide_levels, &c->sah_compact, &c->sah_csize, &c->sah_box, &c->sah_idx, &c->sah_tasks, &c->sah_counts, &c->hdr, &c->rgb,
                       &c->counters_mem, &c->spill, &c->tr_rays,
                       &c->tr_out, &c->tr_prim, &c->tr_counts, &c->dev_counters, &c->bdpt_px, &c->bdpt_rad, &c->bdpt_items, &c->bdpt_state,
                       &c->bdpt_rays, &c->bdpt_hits, &c->bdpt_qidx, &c->bdpt_ctr};
@@ -337,6 +337,10 @@ int tirt_set_option(tirt_ctx *c, const char *name, double value)
     if (!strcmp(name, "time_kernels")) { c->time_kernels = value != 0.0; return TIRT_OK; }
     if (!strcmp(name, "overlap_lanes")) { TIRT_REQUIRE(value >= 1.0 && value <= (double)TIRT_MAX_LANES, "overlap_lanes: 1..8"); if (sync_all(c)) return TIRT_ERR_HIP; c->n_lanes = (int)value; return TIRT_OK; }
     if (!strcmp(name, "split_lone_batch")) { c->split_lone = value != 0.0 ? 1 : 0; return TIRT_OK; }
+    if (!strcmp(name, "traversal_tree")) {       // takes effect at the next tirt_lbvh_build
+        TIRT_REQUIRE(value == 0.0 || value == 1.0, "traversal_tree: 0 (the reference's LBVH) or 1 (binned SAH)");
+        c->use_sah = (int)value; return TIRT_OK;
+    }
     if (!strcmp(name, "job_frames")) { TIRT_REQUIRE(value >= 0.0 && value <= 1.0e9, "job_frames out of range"); c->job_frames = (long)value; return TIRT_OK; }
     if (!strcmp(name, "merge_paths")) { TIRT_REQUIRE(value >= 0.0 && value <= 1.0e9, "merge_paths out of range"); c->merge_paths = (size_t)value; return TIRT_OK; }
     if (!strcmp(name, "batch_paths")) {
@@ -438,6 +442,16 @@ int tirt_lbvh_build(tirt_ctx *c)
     if (sync_all(c)) return TIRT_ERR_HIP;      // scene data must not change under batches still in flight
     return lbvh_build(c);
 }
+
+#ifdef TIRT_EXPERIMENTS
+int tirt_exp_wide_from_tree(tirt_ctx *c, const float *compact_host, const int32_t *csize_host)
+{
+    CTX(c);
+    TIRT_REQUIRE(c->built && c->n >= 2, "tirt_exp_wide_from_tree: LBVH not built");
+    if (sync_all(c)) return TIRT_ERR_HIP;
+    return exp_wide_from_tree(c, compact_host, csize_host);
+}
+#endif
 
 int tirt_lbvh_download(tirt_ctx *c, int32_t *morton_sorted, float *bvh_node, float *compact_node)
 {

@@ -181,6 +181,8 @@ struct tirt_ctx {
     tirt::DevBuf wnode, tri;                      // traversal layout
     tirt::DevBuf cnode, cparent, csize, wide_queue, wide_levels;    // quantised 4-wide nodes (ordered traversal) + parent chain of the compact nodes + build scratch
     int wide_nodes = 0;                            // number of 4-wide nodes
+    tirt::DevBuf sah_compact, sah_csize, sah_box, sah_idx, sah_tasks, sah_counts;   // traversal tree (tirt_sah.hip): `compact`-layout rows + subtree sizes, build scratch
+    int use_sah = 1, sah_levels = 0;               // option "traversal_tree": 1 = binned-SAH tree (default), 0 = the reference's LBVH
     float grid_min[3] = {0, 0, 0}, grid_cell[3] = {1, 1, 1}, grid_inv_cell[3] = {1, 1, 1}, grid_inv_extent[3] = {1, 1, 1};
     size_t lds_optin = 65536;                      // hipDeviceAttributeMaxSharedMemoryPerBlock (opt-in) of this device
     float root_min[3], root_max[3]; int root_code = 0;
@@ -239,6 +241,10 @@ namespace tirt {
 SceneView scene_view(const tirt_ctx *c);
 BvhView bvh_view(const tirt_ctx *c);
 int lbvh_build(tirt_ctx *c);
+int sah_build(tirt_ctx *c, const int *sorted_prims);      // tirt_sah.hip
+#ifdef TIRT_EXPERIMENTS
+int exp_wide_from_tree(tirt_ctx *c, const float *compact_host, const int *csize_host);     // tools/exp/sah_tree.py
+#endif
 int launch_trace_batch(tirt_ctx *c, const float *rays, int nr, int stack_size, int flags, bool shadow,
                        float *out_f, int32_t *out_prim, int32_t *counts);
 int pt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed, int max_depth, int stack_size, int flags);

@@ -513,6 +513,55 @@ __global__ void k_wide_level(SceneView s, const float *compact, const int *csize
     for (int k = 0; k < 4; k++) dst[k] = make_uint4(wd[4 * k], wd[4 * k + 1], wd[4 * k + 2], wd[4 * k + 3]);
 }
 
+// The level loop of the wide build over a binary tree in `compact` layout (pre-order, left child = self + 1) with subtree
+// sizes `csize`; ends with c->ev1 recorded after the last level.
+static int build_wide(tirt_ctx *c, const float *compact, const int *csize, float pad, const GridMap &gm)
+{
+    const int n = c->n;
+    hipStream_t st = c->stream;
+    SceneView sv = scene_view(c);
+    constexpr int WIDE_LEVELS_MAX = 2048;     // runs of identical Morton codes make chains: a level per three leaves of a chain
+    int *lv_off = c->wide_levels.as<int>(), *lv_cnt = lv_off + (WIDE_LEVELS_MAX + 2);
+    TIRT_HIP(hipMemsetAsync(c->wide_levels.p, 0, sizeof(int) * 2 * (WIDE_LEVELS_MAX + 2), st));
+    const int one = 1;
+    TIRT_HIP(hipMemcpyAsync(lv_cnt, &one, sizeof(int), hipMemcpyHostToDevice, st));        // level 0: the root (compact index 0)
+    TIRT_HIP(hipMemsetAsync(c->wide_queue.p, 0, sizeof(int), st));
+    int level = 0, host_lv[2 * (WIDE_LEVELS_MAX + 2)];
+    for (;;) {
+        const int until = (level + 16 < WIDE_LEVELS_MAX) ? level + 16 : WIDE_LEVELS_MAX;
+        for (; level < until; level++) {
+            long cap = 1; for (int k = 0; k < level && cap < n; k++) cap *= 4;             // a level holds at most 4^level nodes
+            if (cap > n) cap = n;
+            hipLaunchKernelGGL(k_wide_level, dim3((unsigned)((cap + 127) / 128)), dim3(128), 0, st, sv, compact, csize, level, lv_off, lv_cnt,
+                               c->wide_queue.as<int>(), c->cnode.as<uint4>(), pad, gm);
+        }
+        TIRT_HIP(hipEventRecord(c->ev1, st));
+        TIRT_HIP(hipMemcpyAsync(host_lv, c->wide_levels.p, sizeof(host_lv), hipMemcpyDeviceToHost, st));
+        TIRT_HIP(hipStreamSynchronize(st));
+        if (host_lv[(WIDE_LEVELS_MAX + 2) + level] == 0) { c->wide_nodes = host_lv[level]; break; }       // the next level is empty: done
+        TIRT_REQUIRE(level < WIDE_LEVELS_MAX, "tirt_lbvh_build: the 4-wide tree is deeper than 2048 levels");
+    }
+    return TIRT_OK;
+}
+
+#ifdef TIRT_EXPERIMENTS
+// tools/exp/sah_tree.py: traverse a 4-wide tree collapsed from ANOTHER binary tree over the same primitives (hits stay the
+// reference's: candidates are verified against the reference tree, k_trace)
+int exp_wide_from_tree(tirt_ctx *c, const float *compact_host, const int *csize_host)
+{
+    const int n = c->n, N = 2 * n - 1;
+    static DevBuf alt_compact, alt_csize;
+    if (alt_compact.ensure(sizeof(float) * (size_t)N * CPN_VEC) || alt_csize.ensure(sizeof(int) * (size_t)N)) return TIRT_ERR_HIP;
+    TIRT_HIP(hipMemcpy(alt_compact.p, compact_host, sizeof(float) * (size_t)N * CPN_VEC, hipMemcpyHostToDevice));
+    TIRT_HIP(hipMemcpy(alt_csize.p, csize_host, sizeof(int) * (size_t)N, hipMemcpyHostToDevice));
+    float ex = c->root_max[0] - c->root_min[0], ey = c->root_max[1] - c->root_min[1], ez = c->root_max[2] - c->root_min[2];
+    const float pad = 1.0e-4f * sqrtf(ex * ex + ey * ey + ez * ez);
+    GridMap gm;
+    for (int k = 0; k < 3; k++) { gm.g0[k] = c->grid_min[k]; gm.inv_cell[k] = c->grid_inv_cell[k]; }
+    return build_wide(c, alt_compact.as<float>(), alt_csize.as<int>(), pad, gm);
+}
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // Host driver
 // ---------------------------------------------------------------------------------------------
@@ -535,7 +584,7 @@ int lbvh_build(tirt_ctx *c)
     if (c->wnode.ensure(sizeof(float4) * 4 * (size_t)N) || c->tri.ensure(sizeof(float4) * TRI_STRIDE * (size_t)n)) return TIRT_ERR_HIP;
     // 4-wide nodes: fewer than n of them; indices are used as 32-bit byte offsets / 64
     TIRT_REQUIRE(n <= (1 << 24), "tirt_lbvh_build: more than 16 Mi primitives");
-    constexpr int WIDE_LEVELS_MAX = 2048;     // runs of identical Morton codes make chains: a level per three leaves of a chain
+    constexpr int WIDE_LEVELS_MAX = 2048;
     if (c->cnode.ensure(sizeof(uint4) * 4 * (size_t)n) || c->wide_queue.ensure(sizeof(int) * (size_t)n) ||
         c->wide_levels.ensure(sizeof(int) * 2 * (WIDE_LEVELS_MAX + 2)) || c->cparent.ensure(sizeof(int) * (size_t)N) ||
         c->csize.ensure(sizeof(int) * (size_t)N)) return TIRT_ERR_HIP;
@@ -591,26 +640,12 @@ int lbvh_build(tirt_ctx *c)
     // surface-area collapse of the binary tree into 4-wide nodes, one launch per level of the wide tree (k_wide_level)
     c->wide_nodes = 0;
     if (n >= 2) {
-        int *lv_off = c->wide_levels.as<int>(), *lv_cnt = lv_off + (WIDE_LEVELS_MAX + 2);
-        TIRT_HIP(hipMemsetAsync(c->wide_levels.p, 0, sizeof(int) * 2 * (WIDE_LEVELS_MAX + 2), st));
-        const int one = 1;
-        TIRT_HIP(hipMemcpyAsync(lv_cnt, &one, sizeof(int), hipMemcpyHostToDevice, st));        // level 0: the root (compact index 0)
-        TIRT_HIP(hipMemsetAsync(c->wide_queue.p, 0, sizeof(int), st));
-        int level = 0, host_lv[2 * (WIDE_LEVELS_MAX + 2)];
-        for (;;) {
-            const int until = (level + 16 < WIDE_LEVELS_MAX) ? level + 16 : WIDE_LEVELS_MAX;
-            for (; level < until; level++) {
-                long cap = 1; for (int k = 0; k < level && cap < n; k++) cap *= 4;             // a level holds at most 4^level nodes
-                if (cap > n) cap = n;
-                hipLaunchKernelGGL(k_wide_level, dim3((unsigned)((cap + 127) / 128)), dim3(128), 0, st, sv, c->compact.as<float>(), c->csize.as<int>(), level, lv_off, lv_cnt,
-                                   c->wide_queue.as<int>(), c->cnode.as<uint4>(), pad, gm);
-            }
-            TIRT_HIP(hipEventRecord(c->ev1, st));
-            TIRT_HIP(hipMemcpyAsync(host_lv, c->wide_levels.p, sizeof(host_lv), hipMemcpyDeviceToHost, st));
-            TIRT_HIP(hipStreamSynchronize(st));
-            if (host_lv[(WIDE_LEVELS_MAX + 2) + level] == 0) { c->wide_nodes = host_lv[level]; break; }       // the next level is empty: done
-            TIRT_REQUIRE(level < WIDE_LEVELS_MAX, "tirt_lbvh_build: the 4-wide tree is deeper than 2048 levels");
+        const float *tree = c->compact.as<float>(); const int *tree_size = c->csize.as<int>();
+        if (c->use_sah) {          // walk a better tree than the reference's (tirt_sah.hip); the hits stay the reference's (k_trace)
+            if (int rc = sah_build(c, va)) return rc;
+            tree = c->sah_compact.as<float>(); tree_size = c->sah_csize.as<int>();
         }
+        if (int rc = build_wide(c, tree, tree_size, pad, gm)) return rc;
     } else TIRT_HIP(hipEventRecord(c->ev1, st));
     if (n == 1) {
         int prim = 0, is_shape = 0;

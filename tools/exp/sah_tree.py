@@ -1,0 +1,112 @@
+"""Experiment: how much would a better traversal tree buy?  The 4-wide nodes k_trace walks are collapsed from the reference's
+LBVH; any tree over the same primitives gives the same hits (candidates are verified against the reference tree).  This builds
+a binned-SAH binary tree on the host (tools/exp/sah_build.c), collapses THAT into the wide nodes (needs libtirt built with
+EXTRA=-DTIRT_EXPERIMENTS) and compares rays/s, node visits and films on a scene.
+   python tools/exp/sah_tree.py [synthetic|teapot|veach] [size]"""
+import ctypes as C, os, subprocess, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import numpy as np
+from ti_raytrace_amd import scenes, _native
+
+which = sys.argv[1] if len(sys.argv) > 1 else "synthetic"
+W = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+so = "/tmp/sah_build.so"
+subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", "-o", so, os.path.join(ROOT, "tools/exp/sah_build.c"), "-lm"])
+sah = C.CDLL(so)
+
+ex = {"synthetic": scenes.synthetic, "teapot": scenes.single_model, "veach": scenes.veach_bdpt}[which](W, W, 4, device_id=0)
+ex.build_scene()
+sc = ex.scene; ctx = sc.ctx
+P = sc.primitive_np; V = sc.vertex_np[:, :3].astype(np.float32); S = np.asarray(sc.shape_np, np.float32).reshape(-1, 10) if sc.shape_np is not None and len(sc.shape_np) else np.zeros((0, 10), np.float32)
+n = P.shape[0]
+boxes = np.zeros((n, 6), np.float32)
+tri = P[:, 0] == 1
+vi = P[tri, 1]
+tv = np.stack([V[vi], V[vi + 1], V[vi + 2]], axis=1)
+boxes[tri, :3] = tv.min(axis=1); boxes[tri, 3:] = tv.max(axis=1)
+for i in np.flatnonzero(~tri):
+    sh = S[P[i, 1]]
+    boxes[i, :3] = sh[1:4] - sh[4]; boxes[i, 3:] = sh[1:4] + sh[4]
+N = 2 * n - 1
+compact = np.zeros((N, 9), np.float32); csize = np.zeros(N, np.int32)
+t0 = time.time()
+made = sah.sah_build(boxes.ctypes.data_as(C.c_void_p), n, compact.ctypes.data_as(C.c_void_p), csize.ctypes.data_as(C.c_void_p))
+print("SAH build %.2f s, %d nodes of %d" % (time.time() - t0, made, N))
+
+def run(label, steps=6, frames=32):
+    ctx.film_clear()
+    ctx.pt_rgb_render(0, frames, 1, 15, 64, 0); ctx.sync()
+    ctx.stats_reset()
+    t0 = time.time()
+    for s in range(steps):
+        ctx.pt_rgb_render(frames * (s + 1), frames, 1, 15, 64, 0)
+    ctx.sync()
+    dt = time.time() - t0
+    st = ctx.stats()
+    rays = st["rays_closest"] + st["rays_shadow"]
+    ctx.stats_reset()
+    ctx.pt_rgb_render(frames * 20, 4, 1, 15, 64, _native.COUNT_NODES); ctx.sync()
+    c = ctx.stats()
+    r2 = c["rays_closest"] + c["rays_shadow"]
+    film = ctx.film_download(W, W)[0]
+    print("%-10s %8.1f Mrays/s   %.2f node visits, %.2f prim tests per ray   wide nodes %d" %
+          (label, rays / dt / 1e6, (c["box_closest"] + c["box_shadow"]) / 4.0 / r2, (c["leaf_closest"] + c["leaf_shadow"]) / r2, ctx.bvh_info()["nodes"]))
+    return film
+
+a = run("LBVH")
+lib = _native.lib()
+lib.tirt_exp_wide_from_tree.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+
+def use(compact, csize, label):
+    rc = lib.tirt_exp_wide_from_tree(ctx.handle, compact.ctypes.data_as(C.c_void_p), csize.ctypes.data_as(C.c_void_p))
+    assert rc == 0, rc
+    b = run(label)
+    same = np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    print("   films bit-identical:", same, "" if same else "differing pixels: %d" % int((a.view(np.uint32) != b.view(np.uint32)).any(axis=-1).sum()))
+
+use(compact, csize, "SAH")
+if os.environ.get("SAH_BINS"):
+    for bins in [int(x) for x in os.environ["SAH_BINS"].split(",")]:
+        sob = "/tmp/sah_build_%d.so" % bins
+        subprocess.check_call(["gcc", "-O2", "-DBINS=%d" % bins, "-shared", "-fPIC", "-o", sob, os.path.join(ROOT, "tools/exp/sah_build.c"), "-lm"])
+        l2 = C.CDLL(sob)
+        c2 = np.zeros((N, 9), np.float32); s2 = np.zeros(N, np.int32)
+        l2.sah_build(boxes.ctypes.data_as(C.c_void_p), n, c2.ctypes.data_as(C.c_void_p), s2.ctypes.data_as(C.c_void_p))
+        use(c2, s2, "SAH %d bins" % bins)
+    sys.exit(0)
+
+if os.environ.get("SAH2_K"):
+    cen = 0.5 * (boxes[:, :3] + boxes[:, 3:])
+    lo, hi = boxes[:, :3].min(axis=0), boxes[:, 3:].max(axis=0)
+    g = np.clip((cen - lo) / np.maximum(hi - lo, 1e-30) * 1024.0, 0, 1023).astype(np.uint64)
+    def p1(x):
+        x = x & 0x3ff; x = (x | (x << 16)) & 0x30000ff; x = (x | (x << 8)) & 0x300f00f; x = (x | (x << 4)) & 0x30c30c3; x = (x | (x << 2)) & 0x9249249; return x
+    order = np.argsort(p1(g[:, 0]) | (p1(g[:, 1]) << 1) | (p1(g[:, 2]) << 2), kind="stable").astype(np.int32)
+    so3 = "/tmp/sah2_build.so"
+    subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", "-o", so3, os.path.join(ROOT, "tools/exp/sah2_build.c")])
+    l3 = C.CDLL(so3)
+    for K in [int(x) for x in os.environ["SAH2_K"].split(",")]:
+        c2 = np.zeros((N, 9), np.float32); s2 = np.zeros(N, np.int32)
+        made = l3.sah2_build(boxes.ctypes.data_as(C.c_void_p), order.ctypes.data_as(C.c_void_p), n, K, c2.ctypes.data_as(C.c_void_p), s2.ctypes.data_as(C.c_void_p))
+        assert made == N, (made, N)
+        use(c2, s2, "2-level K=%d" % K)
+    sys.exit(0)
+
+# PLOC over the Morton order of the primitive centroids (10 bits per axis, as the LBVH)
+so2 = "/tmp/ploc_build.so"
+subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", "-o", so2, os.path.join(ROOT, "tools/exp/ploc_build.c")])
+ploc = C.CDLL(so2)
+cen = 0.5 * (boxes[:, :3] + boxes[:, 3:])
+lo, hi = boxes[:, :3].min(axis=0), boxes[:, 3:].max(axis=0)
+g = np.clip((cen - lo) / np.maximum(hi - lo, 1e-30) * 1024.0, 0, 1023).astype(np.uint64)
+def p1(x):
+    x = x & 0x3ff; x = (x | (x << 16)) & 0x30000ff; x = (x | (x << 8)) & 0x300f00f; x = (x | (x << 4)) & 0x30c30c3; x = (x | (x << 2)) & 0x9249249; return x
+code = p1(g[:, 0]) | (p1(g[:, 1]) << 1) | (p1(g[:, 2]) << 2)
+order = np.argsort(code, kind="stable").astype(np.int32)
+for radius in [int(x) for x in (sys.argv[3].split(",") if len(sys.argv) > 3 else ["8", "16", "32"])]:
+    c2 = np.zeros((N, 9), np.float32); s2 = np.zeros(N, np.int32); it = C.c_int(0)
+    t0 = time.time()
+    made = ploc.ploc_build(boxes.ctypes.data_as(C.c_void_p), order.ctypes.data_as(C.c_void_p), n, radius, c2.ctypes.data_as(C.c_void_p), s2.ctypes.data_as(C.c_void_p), C.byref(it))
+    print("PLOC r=%d: %.2f s, %d iterations, %d nodes" % (radius, time.time() - t0, it.value, made))
+    use(c2, s2, "PLOC r=%d" % radius)
