@@ -105,6 +105,13 @@ int tirt_lbvh_build(tirt_ctx *ctx);
 /* any of the three may be NULL: morton_sorted[n*2] (code, prim), bvh_node[(2n-1)*11],
  * compact_node[(2n-1)*9] */
 int tirt_lbvh_download(tirt_ctx *ctx, int32_t *morton_sorted, float *bvh_node, float *compact_node);
+/* The tree the ordered traversal walks (option "traversal_tree" = 1, the default): a binned-SAH binary tree over the
+ * same primitives, built on the device after the LBVH, in the layout of compact_node -- rows [(2n-1)*9], pre-order, row =
+ * (1 | prim | box) for a leaf, (0 | index of the right child | box) otherwise, left child = row + 1.  No counterpart
+ * in the reference: its LBVH (tirt_lbvh_download) still decides every hit -- a candidate is accepted only if the
+ * reference's traversal would have visited that leaf (Scene.py:702-744) -- this tree only finds the candidates with fewer
+ * node visits.  With traversal_tree = 0 the rows are those of compact_node. */
+int tirt_traversal_tree_download(tirt_ctx *ctx, float *rows);
 /* unsorted Morton pairs [n*2] as produced by build_morton_3d (accel/LBvh.py:318-336) */
 int tirt_morton_download(tirt_ctx *ctx, int32_t *morton_unsorted);
 

@@ -1,0 +1,110 @@
+"""The traversal tree (ti_raytrace_amd/csrc/tirt_sah.hip): the binned-SAH binary tree the ordered traversal walks instead of
+the reference's LBVH (accel/LBvh.py:229-467).  It may be any hierarchy over the same primitives -- every candidate hit is
+verified against the reference tree (Scene.py:702-744) -- but it has to BE one: every primitive in exactly one leaf, every
+box the union of its children's, pre-order layout.  And the option must not change a single bit of any result."""
+import numpy as np
+import pytest
+
+import oracle_api as oa
+from ti_raytrace_amd import scenes, _native
+from common import duplicate_code_scene, tiny_scene
+from test_gpu_trace import random_rays
+
+pytestmark = pytest.mark.gpu
+
+
+def prim_boxes(sc):
+    P = sc.primitive_np
+    V = sc.vertex_np[:, :3].astype(np.float32)
+    n = P.shape[0]
+    box = np.zeros((n, 6), np.float32)
+    tri = P[:, 0] == 1
+    vi = P[tri, 1]
+    tv = np.stack([V[vi], V[vi + 1], V[vi + 2]], axis=1)
+    box[tri, :3] = tv.min(axis=1); box[tri, 3:] = tv.max(axis=1)
+    for i in np.flatnonzero(~tri):
+        sh = np.asarray(sc.shape_np, np.float32).reshape(-1, 10)[P[i, 1]]
+        box[i, :3] = sh[1:4] - sh[4]; box[i, 3:] = sh[1:4] + sh[4]
+    return box
+
+
+def check_tree(rows, box):
+    n = box.shape[0]
+    N = 2 * n - 1
+    assert rows.shape == (N, 9)
+    leaf = rows[:, 0] == 1.0
+    assert leaf.sum() == n and ((rows[:, 0] == 0.0) | leaf).all()
+    prims = rows[leaf, 1].astype(np.int64)
+    assert np.array_equal(np.sort(prims), np.arange(n)), "every primitive in exactly one leaf"
+    assert np.array_equal(rows[leaf, 2:8], box[prims]), "leaf boxes are the primitives' boxes"
+    # pre-order: subtree sizes bottom-up (children have larger indices than their parent)
+    size = np.ones(N, np.int64)
+    right = rows[:, 1].astype(np.int64)
+    for i in range(N - 1, -1, -1):
+        if not leaf[i]:
+            l, r = i + 1, right[i]
+            assert i + 1 < r < N, "right child after the left subtree"
+            assert l + size[l] == r, "left subtree ends where the right one begins"
+            size[i] = 1 + size[l] + size[r]
+            assert np.array_equal(rows[i, 2:5], np.minimum(rows[l, 2:5], rows[r, 2:5]))
+            assert np.array_equal(rows[i, 5:8], np.maximum(rows[l, 5:8], rows[r, 5:8]))
+    assert size[0] == N
+    return size
+
+
+@pytest.mark.parametrize("make", [
+    lambda: scenes.cornell_box(32, 32, 4, device_id=0),
+    lambda: scenes.single_model(32, 32, 4, device_id=0),
+    lambda: tiny_scene(3000, seed=5, W=32, H=32, spread=0.08, device_id=0),
+    lambda: tiny_scene(2, seed=3, W=16, H=16, spread=0.5, device_id=0),
+    lambda: tiny_scene(3, seed=4, W=16, H=16, spread=0.5, device_id=0),
+    lambda: tiny_scene(5000, seed=6, W=16, H=16, spread=0.0001, device_id=0),     # 5000 primitives on a handful of points: range halving
+    lambda: duplicate_code_scene(W=16, H=16, device_id=0),
+])
+def test_traversal_tree_is_a_tree(gpu_ctx_ok, make):
+    ex = make(); ex.build_scene()
+    sc = ex.scene
+    rows = sc.ctx.traversal_tree_download(sc.primitive_count)
+    check_tree(rows, prim_boxes(sc))
+    # with the option off the rows are the reference's compact_node
+    ex2 = make(); ex2.scene.ctx.set_option("traversal_tree", 0); ex2.build_scene()
+    lb = ex2.scene.ctx.traversal_tree_download(sc.primitive_count)
+    _, _, compact = ex2.scene.ctx.lbvh_download(sc.primitive_count)
+    assert np.array_equal(lb.view(np.uint32), compact.view(np.uint32))
+
+
+def test_traversal_tree_headline_scene(gpu_ctx_ok):
+    ex = scenes.synthetic(64, 64, 4, device_id=0); ex.build_scene()
+    sc = ex.scene
+    size = check_tree(sc.ctx.traversal_tree_download(sc.primitive_count), prim_boxes(sc))
+    # a top-down SAH tree of 100 001 primitives is shallow: depth well below the 64 levels after which ranges are halved
+    depth = np.zeros(size.shape[0], np.int32)
+    rows = sc.ctx.traversal_tree_download(sc.primitive_count)
+    for i in range(size.shape[0]):
+        if rows[i, 0] == 0.0:
+            depth[i + 1] = depth[i] + 1; depth[int(rows[i, 1])] = depth[i] + 1
+    assert depth.max() < 64
+
+
+@pytest.mark.parametrize("make,W", [
+    (lambda W: scenes.cornell_box(W, W, 4, device_id=0), 96),
+    (lambda W: scenes.single_model(W, W, 4, device_id=0), 96),
+    (lambda W: scenes.veach_bdpt(W, W, 4, device_id=0), 96),
+    (lambda W: scenes.synthetic(W, W, 4, ntri=20000, device_id=0), 128),
+])
+def test_traversal_tree_option_changes_no_bit(gpu_ctx_ok, make, W):
+    """films of 8 frames and the hit records of 60 000 rays, option on and off"""
+    out = []
+    for tree in (0, 1):
+        ex = make(W); ex.scene.ctx.set_option("traversal_tree", tree); ex.build_scene()
+        ctx = ex.scene.ctx
+        ctx.pt_rgb_render(0, 8, 1, 15, 64, 0)
+        film = ctx.film_download(W, W)[0]
+        lo, hi = ex.scene.minboundarynp.reshape(-1), ex.scene.maxboundarynp.reshape(-1)
+        ext = float((hi - lo).max())
+        rays = np.concatenate([oa.camera_rays(ex.cam, W, W), random_rays(40000, float(lo.min()) - 0.2 * ext, float(hi.max()) + 0.2 * ext, 11)], axis=0)
+        hit, prim, _ = ctx.trace_closest(rays, 64, 0)
+        st, sp, _ = ctx.trace_shadow(rays, 64, 0)
+        out.append((film, hit, prim, st, sp))
+    for a, b in zip(*out):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))

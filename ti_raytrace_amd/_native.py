@@ -66,6 +66,7 @@ SIGNATURES = {
     "tirt_env_upload": (C.c_int, [_vp, _i32p, C.c_int, C.c_int, C.c_float]),
     "tirt_lbvh_build": (C.c_int, [_vp]),
     "tirt_lbvh_download": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "tirt_traversal_tree_download": (C.c_int, [_vp, _vp]),
     "tirt_morton_download": (C.c_int, [_vp, _i32p]),
     "tirt_process_normal": (C.c_int, [_vp, _i32p]),
     "tirt_vertex_download": (C.c_int, [_vp, _f32p]),
@@ -194,6 +195,12 @@ class Context:
         compact = np.zeros((N, 9), np.float32) if want_compact else None
         check(lib().tirt_lbvh_download(self.handle, _ptr(morton), _ptr(bvh), _ptr(compact)))
         return morton, bvh, compact
+
+    def traversal_tree_download(self, n):
+        """rows [(2n-1), 9] of the tree the ordered traversal walks (tirt.h)"""
+        rows = np.zeros((2 * n - 1, 9), np.float32)
+        check(lib().tirt_traversal_tree_download(self.handle, _ptr(rows)))
+        return rows
 
     def morton_download(self, n):
         out = np.zeros((n, 2), np.int32)

@@ -465,6 +465,17 @@ int tirt_lbvh_download(tirt_ctx *c, int32_t *morton_sorted, float *bvh_node, flo
     return TIRT_OK;
 }
 
+int tirt_traversal_tree_download(tirt_ctx *c, float *rows)
+{
+    CTX(c);
+    TIRT_REQUIRE(c->built && rows, "tirt_traversal_tree_download: LBVH not built / null pointer");
+    const size_t N = 2 * (size_t)c->n - 1;
+    const bool sah = c->built_sah != 0;
+    TIRT_HIP(hipMemcpyAsync(rows, sah ? c->sah_compact.p : c->compact.p, sizeof(float) * N * CPN_VEC, hipMemcpyDeviceToHost, c->stream));
+    TIRT_HIP(hipStreamSynchronize(c->stream));
+    return TIRT_OK;
+}
+
 int tirt_morton_download(tirt_ctx *c, int32_t *out)
 {
     CTX(c);

@@ -570,7 +570,7 @@ int lbvh_build(tirt_ctx *c)
     TIRT_REQUIRE(c->n >= 1, "tirt_lbvh_build: no primitives uploaded");
     const int n = c->n, N = 2 * n - 1;
     hipStream_t st = c->stream, st0 = st;
-    c->built = false;
+    c->built = false; c->built_sah = 0;
     if (c->morton_unsorted.ensure(sizeof(int2) * (size_t)n)) return TIRT_ERR_HIP;
     if (c->morton_sorted.ensure(sizeof(int2) * (size_t)n)) return TIRT_ERR_HIP;
     if (c->keys_a.ensure(sizeof(int) * (size_t)n) || c->keys_b.ensure(sizeof(int) * (size_t)n) ||
@@ -644,6 +644,7 @@ int lbvh_build(tirt_ctx *c)
         if (c->use_sah) {          // walk a better tree than the reference's (tirt_sah.hip); the hits stay the reference's (k_trace)
             if (int rc = sah_build(c, va)) return rc;
             tree = c->sah_compact.as<float>(); tree_size = c->sah_csize.as<int>();
+            c->built_sah = 1;
         }
         if (int rc = build_wide(c, tree, tree_size, pad, gm)) return rc;
     } else TIRT_HIP(hipEventRecord(c->ev1, st));
