@@ -6,58 +6,184 @@
 // re-establishes exactly that condition for every candidate hit (leaf box / `cparent` chain of the reference tree, tie rule
 // on the reference's leaf index), so the structure that FINDS the candidates may be any hierarchy whose boxes contain their
 // leaves' boxes.  A Morton-split tree is a poor one to walk: measured on the same kernel, the SAH tree costs 26.8 node
-// visits per ray of the headline scene instead of 32.1 (+9 % rays/s), 9.6 instead of 14.5 on the Teapot (+13 %), 11.0
-// instead of 14.5 on the Veach scene (+15 %) -- with bit-identical films (tools/exp/sah_tree.py; PLOC, also tried there,
-// is worse than binned SAH on all three).
+// visits per ray of the headline scene instead of 32.1 (+10 % rays/s), 9.6 instead of 14.5 on the Teapot (+13 %), 11.0
+// instead of 14.5 on the Veach scene (+15 %) -- with bit-identical films (tools/exp/sah_tree.py; PLOC and a two-level
+// build over Morton clusters, also tried there, are worse than the plain top-down binned SAH on all three).
 //
-// Algorithm: top-down, level-synchronous, one primitive per leaf (as the reference).  A node is a contiguous range of a
-// primitive-index array; its pre-order index is known when it is created (left = self + 1, right = self + 2 * n_left: a
-// subtree of k leaves has 2k - 1 nodes), so nodes are written straight into the `compact` layout k_wide_level reads, with
-// no numbering pass and no atomics for node ids -- the tree is deterministic.  Per node: (A) box and centroid bounds,
-// (B) 32 bins per axis by centroid in LDS (integer-keyed min / max / count atomics), (C) the cheapest of the 3 x 31
-// candidate planes by area(L) * n_L + area(R) * n_R, (D) a stable partition of the range into the other index buffer.
-// All centroids in one bin on every axis (duplicates), or a tree deeper than 64 levels: the range is halved instead.
-// Small nodes (<= SAH_LARGE primitives) take one wave each, 16 to a block; large ones a 1024-thread block each.  The
-// next level's task lists are appended with one atomic per block and list (same-address atomics: ~11 ns each).
+// Algorithm: top-down, level-synchronous, one primitive per leaf (as the reference).  A node is a contiguous range of an
+// index array over the Morton-sorted primitives; its pre-order index is known when it is created (left = self + 1, right =
+// self + 2 * n_left: a subtree of k leaves has 2k - 1 nodes), so nodes are written straight into the `compact` layout
+// k_wide_level reads, with no numbering pass and no atomics for node ids -- the tree is deterministic.  Per node: (A) box
+// and centroid bounds, (B) 32 bins per axis by centroid (integer-keyed min / max / count atomics in LDS), (C) the cheapest
+// of the 3 x 31 candidate planes by area(L) * n_L + area(R) * n_R, (D) a stable partition of the range into the other
+// index buffer.  All centroids in one bin on every axis (duplicates), or a tree deeper than 64 levels: the range is halved.
+// Three sizes of node, so that the top of the tree is as parallel as its bottom:
+//   small  (<= SAH_LARGE primitives)  one wave per node, 16 nodes per block                     k_sah_level<1>
+//   large  (<= SAH_HUGE)              one 1024-thread block per node                            k_sah_level<16>
+//   huge                              a block per SAH_CHUNK primitives, three launches per level: bins of the chunks merged
+//                                     into the node's with global atomics (k_sah_huge_bin), plane + per-chunk output offsets
+//                                     from the chunks' bin counts (k_sah_huge_eval), partition + the bounds of huge children
+//                                     (k_sah_huge_part)
+// The next level's task lists are appended with one atomic per block and list (same-address atomics: ~11 ns each).
 #include "tirt_internal.h"
 #include "tirt_device.h"
 
 namespace tirt {
 
 constexpr int SAH_BINS = 32;
-constexpr int SAH_LARGE = 4096;          // more primitives than this: a whole block works on the node
+constexpr int SAH_BIN_WORDS = 3 * SAH_BINS * 7;      // per node: [axis][bin][min x y z, max x y z, count]
+constexpr int SAH_LARGE = 512;            // more primitives than this: a whole block works on the node
+constexpr int SAH_HUGE = 8192;            // more than this: a block per chunk
+constexpr int SAH_CHUNK = 1024;
 constexpr int SAH_BLOCK = 1024;
 constexpr int SAH_FORCE_HALVING_AFTER = 64;
+constexpr int SAH_MAX_LEVELS = 160;       // halving from level 64 on ends every range within 64 + log2(n) levels
 
 struct SahTask { int start, count, pre, pad; };
+struct SahHuge {
+    int start, count, pre, first_chunk;
+    unsigned bounds[12];                  // keyed: box min[3], max[3], centroid min[3], max[3]
+    int axis, plane, nl, pad;
+    int child[2], pad2[2];                // slots of huge children in the next level's list, or -1
+};
 
 TD unsigned sah_key(float f) { const unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }      // unsigned order = float order
 TD float sah_unkey(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
+TD bool sah_is_min(int k) { return (k < 3) || (k >= 6 && k < 9); }
+TD float sah_half_area(float dx, float dy, float dz) { return dx * dy + dy * dz + dz * dx; }
+TD int sah_bin(float c, float cmin, float scale) { const int b = (int)((c - cmin) * scale); return b < 0 ? 0 : (b >= SAH_BINS ? SAH_BINS - 1 : b); }
 
-__global__ void k_sah_prim_boxes(SceneView s, float4 *box)
+// 12 running bounds of one lane -> of the wave (all lanes get the result)
+TD void sah_wave_bounds(float r[12])
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= s.n) return;
-    const int *pr = s.primitive + (size_t)i * PRI_VEC;
-    v3 mn, mx;
-    if (pr[0] == PRIMITIVE_TRI) {                       // accel/LBvh.py:397-415
-        const v3 a = vtx_pos(s, pr[1]), b = vtx_pos(s, pr[1] + 1), c = vtx_pos(s, pr[1] + 2);
-        mn = V(fminf(fminf(a.x, b.x), c.x), fminf(fminf(a.y, b.y), c.y), fminf(fminf(a.z, b.z), c.z));
-        mx = V(fmaxf(fmaxf(a.x, b.x), c.x), fmaxf(fmaxf(a.y, b.y), c.y), fmaxf(fmaxf(a.z, b.z), c.z));
-    } else {                                            // accel/LBvh.py:416-426: centre -+ r
-        const float *sh = s.shape + (size_t)pr[1] * SHA_VEC;
-        mn = V(sh[1] - sh[4], sh[2] - sh[4], sh[3] - sh[4]); mx = V(sh[1] + sh[4], sh[2] + sh[4], sh[3] + sh[4]);
+#pragma unroll
+    for (int k = 0; k < 12; k++) {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) { const float v = __shfl_xor(r[k], o, 64); r[k] = sah_is_min(k) ? fminf(r[k], v) : fmaxf(r[k], v); }
     }
-    box[2 * (size_t)i] = make_float4(mn.x, mn.y, mn.z, 0.0f);
-    box[2 * (size_t)i + 1] = make_float4(mx.x, mx.y, mx.z, 0.0f);
+}
+TD void sah_bounds_init(float r[12])
+{
+#pragma unroll
+    for (int k = 0; k < 12; k++) r[k] = sah_is_min(k) ? 3.0e38f : -3.0e38f;
+}
+TD void sah_bounds_add(float r[12], float4 a, float4 b)
+{
+    r[0] = fminf(r[0], a.x); r[1] = fminf(r[1], a.y); r[2] = fminf(r[2], a.z);
+    r[3] = fmaxf(r[3], b.x); r[4] = fmaxf(r[4], b.y); r[5] = fmaxf(r[5], b.z);
+    const float cx = 0.5f * (a.x + b.x), cy = 0.5f * (a.y + b.y), cz = 0.5f * (a.z + b.z);
+    r[6] = fminf(r[6], cx); r[7] = fminf(r[7], cy); r[8] = fminf(r[8], cz);
+    r[9] = fmaxf(r[9], cx); r[10] = fmaxf(r[10], cy); r[11] = fmaxf(r[11], cz);
 }
 
-TD float sah_half_area(float dx, float dy, float dz) { return dx * dy + dy * dz + dz * dx; }
+// One primitive into the three axes' bins (LDS).
+TD void sah_bin_add(unsigned (*bin)[SAH_BINS][7], float4 a, float4 b, const float cmin[3], const float scale[3])
+{
+    const unsigned k0 = sah_key(a.x), k1 = sah_key(a.y), k2 = sah_key(a.z), k3 = sah_key(b.x), k4 = sah_key(b.y), k5 = sah_key(b.z);
+    const float c[3] = {0.5f * (a.x + b.x), 0.5f * (a.y + b.y), 0.5f * (a.z + b.z)};
+#pragma unroll
+    for (int ax = 0; ax < 3; ax++) {
+        unsigned *q = bin[ax][sah_bin(c[ax], cmin[ax], scale[ax])];
+        atomicMin(&q[0], k0); atomicMin(&q[1], k1); atomicMin(&q[2], k2);
+        atomicMax(&q[3], k3); atomicMax(&q[4], k4); atomicMax(&q[5], k5);
+        atomicAdd(&q[6], 1u);
+    }
+}
 
-// WPT waves per task: 1 (16 tasks per block) or 16 (one task per block).  Every thread of the block reaches every
-// barrier; a task slot without a task just has count == 0.
+// One wave: the cheapest of the 3 x 31 planes over the bins in LDS; axis = -1 (halve the range) when no plane separates
+// anything.  All lanes return the same values.  Ties: the lowest (axis, plane).
+TD void sah_pick(const unsigned (*bin)[SAH_BINS][7], int count, bool halve, int lane, int &axis, int &plane, int &n_left)
+{
+    float best = 3.0e38f; int best_id = 0x7fffffff, best_nl = 0;
+    if (!halve && count >= 2) {
+        for (int cand = lane; cand < 3 * SAH_BINS; cand += 64) {
+            const int ax = cand / SAH_BINS, sp = cand - ax * SAH_BINS;
+            if (sp == SAH_BINS - 1) continue;
+            float lmn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, lmx[3] = {-3.0e38f, -3.0e38f, -3.0e38f}, rmn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, rmx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+            unsigned nl = 0, nr = 0;
+            for (int b = 0; b < SAH_BINS; b++) {
+                const unsigned *q = bin[ax][b];
+                const unsigned cnt = q[6];
+                if (cnt == 0) continue;
+                const float m0 = sah_unkey(q[0]), m1 = sah_unkey(q[1]), m2 = sah_unkey(q[2]), x0 = sah_unkey(q[3]), x1 = sah_unkey(q[4]), x2 = sah_unkey(q[5]);
+                if (b <= sp) {
+                    lmn[0] = fminf(lmn[0], m0); lmn[1] = fminf(lmn[1], m1); lmn[2] = fminf(lmn[2], m2);
+                    lmx[0] = fmaxf(lmx[0], x0); lmx[1] = fmaxf(lmx[1], x1); lmx[2] = fmaxf(lmx[2], x2); nl += cnt;
+                } else {
+                    rmn[0] = fminf(rmn[0], m0); rmn[1] = fminf(rmn[1], m1); rmn[2] = fminf(rmn[2], m2);
+                    rmx[0] = fmaxf(rmx[0], x0); rmx[1] = fmaxf(rmx[1], x1); rmx[2] = fmaxf(rmx[2], x2); nr += cnt;
+                }
+            }
+            if (nl == 0 || nr == 0) continue;
+            const float cost = sah_half_area(lmx[0] - lmn[0], lmx[1] - lmn[1], lmx[2] - lmn[2]) * (float)nl +
+                               sah_half_area(rmx[0] - rmn[0], rmx[1] - rmn[1], rmx[2] - rmn[2]) * (float)nr;
+            if (cost < best || (cost == best && cand < best_id)) { best = cost; best_id = cand; best_nl = (int)nl; }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const float ob = __shfl_xor(best, o, 64); const int oi = __shfl_xor(best_id, o, 64), on = __shfl_xor(best_nl, o, 64);
+        if (ob < best || (ob == best && oi < best_id)) { best = ob; best_id = oi; best_nl = on; }
+    }
+    if (best_id != 0x7fffffff) { axis = best_id / SAH_BINS; plane = best_id % SAH_BINS; n_left = best_nl; }
+    else { axis = -1; plane = 0; n_left = count / 2; }
+}
+
+TD void sah_write_leaf(float *compact, int *csize, int row_index, int prim, float4 a, float4 b)
+{
+    float *row = compact + (size_t)row_index * CPN_VEC;
+    row[0] = 1.0f; row[1] = (float)prim; row[2] = a.x; row[3] = a.y; row[4] = a.z; row[5] = b.x; row[6] = b.y; row[7] = b.z; row[8] = 0.0f;
+    csize[row_index] = 1;
+}
+TD void sah_write_inner(float *compact, int *csize, int row_index, int right, int count, const float box[6])
+{
+    float *row = compact + (size_t)row_index * CPN_VEC;
+    row[0] = 0.0f; row[1] = (float)right;
+    row[2] = box[0]; row[3] = box[1]; row[4] = box[2]; row[5] = box[3]; row[6] = box[4]; row[7] = box[5]; row[8] = 0.0f;
+    csize[row_index] = 2 * count - 1;
+}
+
+// Boxes in Morton order (accel/LBvh.py:397-426: triangle min / max, sphere centre -+ r), the identity index array, the
+// bounds of everything (root of a huge scene) and the root's empty bins.
+__global__ __launch_bounds__(256) void k_sah_prim_boxes(SceneView s, const int *sorted_prims, float4 *sbox, int *idx0, SahHuge *root, unsigned *root_bins)
+{
+    __shared__ unsigned s_b[12];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (threadIdx.x < 12) s_b[threadIdx.x] = sah_is_min(threadIdx.x) ? 0xffffffffu : 0u;
+    if (blockIdx.x == 0) for (int k = threadIdx.x; k < SAH_BIN_WORDS; k += blockDim.x) root_bins[k] = (k % 7 < 3) ? 0xffffffffu : 0u;
+    __syncthreads();
+    float r[12]; sah_bounds_init(r);
+    if (i < s.n) {
+        const int p = sorted_prims[i];
+        const int *pr = s.primitive + (size_t)p * PRI_VEC;
+        v3 mn, mx;
+        if (pr[0] == PRIMITIVE_TRI) {
+            const v3 a = vtx_pos(s, pr[1]), b = vtx_pos(s, pr[1] + 1), c = vtx_pos(s, pr[1] + 2);
+            mn = V(fminf(fminf(a.x, b.x), c.x), fminf(fminf(a.y, b.y), c.y), fminf(fminf(a.z, b.z), c.z));
+            mx = V(fmaxf(fmaxf(a.x, b.x), c.x), fmaxf(fmaxf(a.y, b.y), c.y), fmaxf(fmaxf(a.z, b.z), c.z));
+        } else {
+            const float *sh = s.shape + (size_t)pr[1] * SHA_VEC;
+            mn = V(sh[1] - sh[4], sh[2] - sh[4], sh[3] - sh[4]); mx = V(sh[1] + sh[4], sh[2] + sh[4], sh[3] + sh[4]);
+        }
+        const float4 a = make_float4(mn.x, mn.y, mn.z, 0.0f), b = make_float4(mx.x, mx.y, mx.z, 0.0f);
+        sbox[2 * (size_t)i] = a; sbox[2 * (size_t)i + 1] = b;
+        idx0[i] = i;
+        sah_bounds_add(r, a, b);
+    }
+    sah_wave_bounds(r);
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < 12; k++) { if (sah_is_min(k)) atomicMin(&s_b[k], sah_key(r[k])); else atomicMax(&s_b[k], sah_key(r[k])); }
+    }
+    __syncthreads();
+    if (threadIdx.x < 12) { if (sah_is_min(threadIdx.x)) atomicMin(&root->bounds[threadIdx.x], s_b[threadIdx.x]); else atomicMax(&root->bounds[threadIdx.x], s_b[threadIdx.x]); }
+}
+
+// Small and large nodes.  WPT waves per task: 1 (16 tasks per block) or 16 (one task per block).  Every thread of a block
+// with work reaches every barrier; a task slot without a task has count == 0.
 template <int WPT>
-__global__ __launch_bounds__(SAH_BLOCK) void k_sah_level(const float4 *__restrict__ box, const int *__restrict__ idx_in, int *__restrict__ idx_out,
+__global__ __launch_bounds__(SAH_BLOCK) void k_sah_level(const float4 *__restrict__ sbox, const int *__restrict__ sorted_prims,
+                                                         const int *__restrict__ idx_in, int *__restrict__ idx_out,
                                                          const SahTask *__restrict__ tasks, const int *__restrict__ task_count,
                                                          SahTask *next_small, SahTask *next_large, int *next_count /* [0] small, [1] large */,
                                                          float *compact, int *csize, int halve)
@@ -70,49 +196,40 @@ __global__ __launch_bounds__(SAH_BLOCK) void k_sah_level(const float4 *__restric
     __shared__ int s_wcount[16][2];
     __shared__ SahTask s_child[TPB][2];
     __shared__ int s_base[2];
+    const int ntask = *task_count;
+    if ((int)blockIdx.x * TPB >= ntask) return;   // block-uniform
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int slot = wave / WPT;
     const int gt = threadIdx.x - slot * G;   // thread index within the task's group
     const int gwave = wave - slot * WPT;     // wave index within the group
     const int ti = blockIdx.x * TPB + slot;
-    const int ntask = *task_count;
     SahTask t = {0, 0, 0, 0};
     if (ti < ntask) t = tasks[ti];
     const int start = t.start, count = t.count, pre = t.pre;
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 
     // ---- A: node box and centroid bounds ---------------------------------------------------------
-    float r[12] = {3.0e38f, 3.0e38f, 3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f, 3.0e38f, 3.0e38f, 3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
+    float r[12]; sah_bounds_init(r);
     for (int i = gt; i < count; i += G) {
         const int p = idx_in[start + i];
-        const float4 a = box[2 * (size_t)p], b = box[2 * (size_t)p + 1];
-        r[0] = fminf(r[0], a.x); r[1] = fminf(r[1], a.y); r[2] = fminf(r[2], a.z);
-        r[3] = fmaxf(r[3], b.x); r[4] = fmaxf(r[4], b.y); r[5] = fmaxf(r[5], b.z);
-        const float cx = 0.5f * (a.x + b.x), cy = 0.5f * (a.y + b.y), cz = 0.5f * (a.z + b.z);
-        r[6] = fminf(r[6], cx); r[7] = fminf(r[7], cy); r[8] = fminf(r[8], cz);
-        r[9] = fmaxf(r[9], cx); r[10] = fmaxf(r[10], cy); r[11] = fmaxf(r[11], cz);
+        sah_bounds_add(r, sbox[2 * (size_t)p], sbox[2 * (size_t)p + 1]);
     }
-#pragma unroll
-    for (int k = 0; k < 12; k++) {
-        const bool is_min = (k < 3) || (k >= 6 && k < 9);
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) { const float v = __shfl_xor(r[k], o, 64); r[k] = is_min ? fminf(r[k], v) : fmaxf(r[k], v); }
-    }
+    sah_wave_bounds(r);
     if (WPT > 1) {                           // across the 16 waves: keyed LDS min / max
-        if (threadIdx.x < 12) s_redk[threadIdx.x] = ((threadIdx.x < 3) || (threadIdx.x >= 6 && threadIdx.x < 9)) ? 0xffffffffu : 0u;
+        if (threadIdx.x < 12) s_redk[threadIdx.x] = sah_is_min(threadIdx.x) ? 0xffffffffu : 0u;
         __syncthreads();
         if (lane == 0) {
 #pragma unroll
-            for (int k = 0; k < 12; k++) { if ((k < 3) || (k >= 6 && k < 9)) atomicMin(&s_redk[k], sah_key(r[k])); else atomicMax(&s_redk[k], sah_key(r[k])); }
+            for (int k = 0; k < 12; k++) { if (sah_is_min(k)) atomicMin(&s_redk[k], sah_key(r[k])); else atomicMax(&s_redk[k], sah_key(r[k])); }
         }
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < 12; k++) r[k] = sah_unkey(s_redk[k]);
     }
     float scale[3];
+    const float cmin[3] = {r[6], r[7], r[8]};
 #pragma unroll
     for (int a = 0; a < 3; a++) { const float ext = r[9 + a] - r[6 + a]; scale[a] = ext > 0.0f ? (float)SAH_BINS / ext : 0.0f; }
-#define SAH_BIN(c, a) ({ int b__ = (int)(((c) - r[6 + (a)]) * scale[a]); b__ < 0 ? 0 : (b__ >= SAH_BINS ? SAH_BINS - 1 : b__); })
 
     // ---- B: bins ---------------------------------------------------------------------------------
     for (int k = gt; k < 3 * SAH_BINS; k += G) {
@@ -123,57 +240,16 @@ __global__ __launch_bounds__(SAH_BLOCK) void k_sah_level(const float4 *__restric
     if (!halve) {
         for (int i = gt; i < count; i += G) {
             const int p = idx_in[start + i];
-            const float4 a = box[2 * (size_t)p], b = box[2 * (size_t)p + 1];
-            const unsigned k0 = sah_key(a.x), k1 = sah_key(a.y), k2 = sah_key(a.z), k3 = sah_key(b.x), k4 = sah_key(b.y), k5 = sah_key(b.z);
-            const float c[3] = {0.5f * (a.x + b.x), 0.5f * (a.y + b.y), 0.5f * (a.z + b.z)};
-#pragma unroll
-            for (int ax = 0; ax < 3; ax++) {
-                unsigned *q = s_bin[slot][ax][SAH_BIN(c[ax], ax)];
-                atomicMin(&q[0], k0); atomicMin(&q[1], k1); atomicMin(&q[2], k2);
-                atomicMax(&q[3], k3); atomicMax(&q[4], k4); atomicMax(&q[5], k5);
-                atomicAdd(&q[6], 1u);
-            }
+            sah_bin_add(s_bin[slot], sbox[2 * (size_t)p], sbox[2 * (size_t)p + 1], cmin, scale);
         }
     }
     __syncthreads();
 
-    // ---- C: the cheapest plane (wave 0 of the group: candidates gt and gt + 64 of 3 x 32) -----------
+    // ---- C: the cheapest plane (wave 0 of the group) -----------------------------------------------
     if (gwave == 0) {
-        float best = 3.0e38f; int best_id = 0x7fffffff, best_nl = 0;
-        if (!halve && count >= 2) {
-            for (int cand = lane; cand < 3 * SAH_BINS; cand += 64) {
-                const int ax = cand / SAH_BINS, sp = cand - ax * SAH_BINS;
-                if (sp == SAH_BINS - 1) continue;
-                float lmn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, lmx[3] = {-3.0e38f, -3.0e38f, -3.0e38f}, rmn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, rmx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
-                unsigned nl = 0, nr = 0;
-                for (int b = 0; b < SAH_BINS; b++) {
-                    const unsigned *q = s_bin[slot][ax][b];
-                    const unsigned cnt = q[6];
-                    if (cnt == 0) continue;
-                    const float m0 = sah_unkey(q[0]), m1 = sah_unkey(q[1]), m2 = sah_unkey(q[2]), x0 = sah_unkey(q[3]), x1 = sah_unkey(q[4]), x2 = sah_unkey(q[5]);
-                    if (b <= sp) {
-                        lmn[0] = fminf(lmn[0], m0); lmn[1] = fminf(lmn[1], m1); lmn[2] = fminf(lmn[2], m2);
-                        lmx[0] = fmaxf(lmx[0], x0); lmx[1] = fmaxf(lmx[1], x1); lmx[2] = fmaxf(lmx[2], x2); nl += cnt;
-                    } else {
-                        rmn[0] = fminf(rmn[0], m0); rmn[1] = fminf(rmn[1], m1); rmn[2] = fminf(rmn[2], m2);
-                        rmx[0] = fmaxf(rmx[0], x0); rmx[1] = fmaxf(rmx[1], x1); rmx[2] = fmaxf(rmx[2], x2); nr += cnt;
-                    }
-                }
-                if (nl == 0 || nr == 0) continue;
-                const float cost = sah_half_area(lmx[0] - lmn[0], lmx[1] - lmn[1], lmx[2] - lmn[2]) * (float)nl +
-                                   sah_half_area(rmx[0] - rmn[0], rmx[1] - rmn[1], rmx[2] - rmn[2]) * (float)nr;
-                if (cost < best || (cost == best && cand < best_id)) { best = cost; best_id = cand; best_nl = (int)nl; }
-            }
-        }
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) {
-            const float ob = __shfl_xor(best, o, 64); const int oi = __shfl_xor(best_id, o, 64), on = __shfl_xor(best_nl, o, 64);
-            if (ob < best || (ob == best && oi < best_id)) { best = ob; best_id = oi; best_nl = on; }
-        }
-        if (lane == 0) {
-            if (best_id != 0x7fffffff) { s_split[slot][0] = best_id / SAH_BINS; s_split[slot][1] = best_id % SAH_BINS; s_split[slot][2] = best_nl; }
-            else { s_split[slot][0] = -1; s_split[slot][1] = 0; s_split[slot][2] = count / 2; }
-        }
+        int ax, pl, nl_;
+        sah_pick(s_bin[slot], count, halve != 0, lane, ax, pl, nl_);
+        if (lane == 0) { s_split[slot][0] = ax; s_split[slot][1] = pl; s_split[slot][2] = nl_; }
     }
     __syncthreads();
     const int axis = s_split[slot][0], plane = s_split[slot][1], nl = s_split[slot][2], nr = count - nl;
@@ -188,9 +264,9 @@ __global__ __launch_bounds__(SAH_BLOCK) void k_sah_level(const float4 *__restric
         bool left = false;
         if (active) {
             p = idx_in[start + i];
-            a = box[2 * (size_t)p]; b = box[2 * (size_t)p + 1];
+            a = sbox[2 * (size_t)p]; b = sbox[2 * (size_t)p + 1];
             if (axis < 0) left = i < nl;
-            else { const float c = axis == 0 ? 0.5f * (a.x + b.x) : (axis == 1 ? 0.5f * (a.y + b.y) : 0.5f * (a.z + b.z)); int bb = (int)((c - sel_min) * sel_scale); bb = bb < 0 ? 0 : (bb >= SAH_BINS ? SAH_BINS - 1 : bb); left = bb <= plane; }
+            else { const float c = axis == 0 ? 0.5f * (a.x + b.x) : (axis == 1 ? 0.5f * (a.y + b.y) : 0.5f * (a.z + b.z)); left = sah_bin(c, sel_min, sel_scale) <= plane; }
         }
         const unsigned long long ml = __ballot(active && left), mr = __ballot(active && !left);
         int rank_l = __popcll(ml & lt_mask), rank_r = __popcll(mr & lt_mask), tot_l = __popcll(ml), tot_r = __popcll(mr);
@@ -203,24 +279,15 @@ __global__ __launch_bounds__(SAH_BLOCK) void k_sah_level(const float4 *__restric
             __syncthreads();
         }
         if (active) {
-            const int dst = left ? start + off_l + rank_l : start + nl + off_r + rank_r;
-            idx_out[dst] = p;
-            if ((left && nl == 1) || (!left && nr == 1)) {
-                const int leaf = left ? pre + 1 : pre + 2 * nl;
-                float *row = compact + (size_t)leaf * CPN_VEC;
-                row[0] = 1.0f; row[1] = (float)p; row[2] = a.x; row[3] = a.y; row[4] = a.z; row[5] = b.x; row[6] = b.y; row[7] = b.z; row[8] = 0.0f;
-                csize[leaf] = 1;
-            }
+            idx_out[left ? start + off_l + rank_l : start + nl + off_r + rank_r] = p;
+            if ((left && nl == 1) || (!left && nr == 1)) sah_write_leaf(compact, csize, left ? pre + 1 : pre + 2 * nl, sorted_prims[p], a, b);
         }
         off_l += tot_l; off_r += tot_r;
     }
     if (gt == 0) {
         s_child[slot][0].count = 0; s_child[slot][1].count = 0;
         if (count >= 2) {
-            float *row = compact + (size_t)pre * CPN_VEC;
-            row[0] = 0.0f; row[1] = (float)(pre + 2 * nl);
-            row[2] = r[0]; row[3] = r[1]; row[4] = r[2]; row[5] = r[3]; row[6] = r[4]; row[7] = r[5]; row[8] = 0.0f;
-            csize[pre] = 2 * count - 1;
+            sah_write_inner(compact, csize, pre, pre + 2 * nl, count, r);
             if (nl >= 2) s_child[slot][0] = SahTask{start, nl, pre + 1, 0};
             if (nr >= 2) s_child[slot][1] = SahTask{start + nl, nr, pre + 2 * nl, 0};
         }
@@ -238,50 +305,230 @@ __global__ __launch_bounds__(SAH_BLOCK) void k_sah_level(const float4 *__restric
             else if (c >= 2) next_small[s_base[0]++] = s_child[s][k];
         }
     }
-#undef SAH_BIN
+}
+
+// ---- huge nodes: level counters lc[] = (small, large, huge, chunks) ---------------------------------------------------
+// bins of one chunk, merged into the node's
+__global__ __launch_bounds__(SAH_CHUNK) void k_sah_huge_bin(const float4 *__restrict__ sbox, const int *__restrict__ idx_in, const SahHuge *__restrict__ huge,
+                                                             const int *__restrict__ lc, const int *__restrict__ chunk_task, unsigned *hbins, int *chunk_cnt, int halve)
+{
+    __shared__ unsigned s_bin[3][SAH_BINS][7];
+    const int c = blockIdx.x;
+    if (c >= lc[3] || halve) return;
+    const int slot = chunk_task[c];
+    const SahHuge *h = huge + slot;
+    const int i = (c - h->first_chunk) * SAH_CHUNK + (int)threadIdx.x;
+    float cmin[3], scale[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) { cmin[a] = sah_unkey(h->bounds[6 + a]); const float ext = sah_unkey(h->bounds[9 + a]) - cmin[a]; scale[a] = ext > 0.0f ? (float)SAH_BINS / ext : 0.0f; }
+    for (int k = threadIdx.x; k < 3 * SAH_BINS; k += SAH_CHUNK) {
+        unsigned *b = &s_bin[0][0][0] + k * 7;
+        b[0] = b[1] = b[2] = 0xffffffffu; b[3] = b[4] = b[5] = 0u; b[6] = 0u;
+    }
+    __syncthreads();
+    if (i < h->count) {
+        const int p = idx_in[h->start + i];
+        sah_bin_add(s_bin, sbox[2 * (size_t)p], sbox[2 * (size_t)p + 1], cmin, scale);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < 3 * SAH_BINS; k += SAH_CHUNK) {
+        const unsigned *b = &s_bin[0][0][0] + k * 7;
+        chunk_cnt[(size_t)c * 3 * SAH_BINS + k] = (int)b[6];
+        if (b[6]) {
+            unsigned *g = hbins + (size_t)slot * SAH_BIN_WORDS + k * 7;
+            atomicMin(&g[0], b[0]); atomicMin(&g[1], b[1]); atomicMin(&g[2], b[2]);
+            atomicMax(&g[3], b[3]); atomicMax(&g[4], b[4]); atomicMax(&g[5], b[5]);
+            atomicAdd(&g[6], b[6]);
+        }
+    }
+}
+
+// plane of a huge node, output offsets of its chunks, its row, its children
+__global__ __launch_bounds__(64) void k_sah_huge_eval(SahHuge *huge, const int *__restrict__ lc, const unsigned *__restrict__ hbins, const int *__restrict__ chunk_cnt,
+                                                       int *chunk_base, SahHuge *next_huge, unsigned *next_hbins, int *next_chunk_task,
+                                                       SahTask *next_small, SahTask *next_large, int *nc /* next level's counters */,
+                                                       float *compact, int *csize, int halve)
+{
+    __shared__ unsigned s_bin[3][SAH_BINS][7];
+    const int slot = blockIdx.x, lane = threadIdx.x;
+    if (slot >= lc[2]) return;
+    SahHuge *h = huge + slot;
+    const int start = h->start, count = h->count, pre = h->pre, first = h->first_chunk;
+    for (int k = lane; k < SAH_BIN_WORDS; k += 64) (&s_bin[0][0][0])[k] = hbins[(size_t)slot * SAH_BIN_WORDS + k];
+    __syncthreads();
+    int axis, plane, nl;
+    sah_pick(s_bin, count, halve != 0, lane, axis, plane, nl);
+    const int nr = count - nl, nchunks = (count + SAH_CHUNK - 1) / SAH_CHUNK;
+    int carry_l = 0, carry_r = 0;
+    for (int base = 0; base < nchunks; base += 64) {
+        const int k = base + lane;
+        int len = 0, left = 0;
+        if (k < nchunks) {
+            len = count - k * SAH_CHUNK; if (len > SAH_CHUNK) len = SAH_CHUNK;
+            if (axis < 0) { left = nl - k * SAH_CHUNK; left = left < 0 ? 0 : (left > len ? len : left); }
+            else { const int *cc = chunk_cnt + (size_t)(first + k) * 3 * SAH_BINS + axis * SAH_BINS; for (int b = 0; b <= plane; b++) left += cc[b]; }
+        }
+        int il = left, ir = len - left;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int vl = __shfl_up(il, o, 64), vr = __shfl_up(ir, o, 64); if (lane >= o) { il += vl; ir += vr; } }
+        if (k < nchunks) { chunk_base[2 * (size_t)(first + k)] = carry_l + il - left; chunk_base[2 * (size_t)(first + k) + 1] = carry_r + ir - (len - left); }
+        carry_l += __shfl(il, 63, 64); carry_r += __shfl(ir, 63, 64);
+    }
+    int child_slot[2] = {-1, -1}, child_first[2] = {0, 0};
+    if (lane == 0) {
+        const float box[6] = {sah_unkey(h->bounds[0]), sah_unkey(h->bounds[1]), sah_unkey(h->bounds[2]), sah_unkey(h->bounds[3]), sah_unkey(h->bounds[4]), sah_unkey(h->bounds[5])};
+        sah_write_inner(compact, csize, pre, pre + 2 * nl, count, box);
+        for (int side = 0; side < 2; side++) {
+            const SahTask t = side == 0 ? SahTask{start, nl, pre + 1, 0} : SahTask{start + nl, nr, pre + 2 * nl, 0};
+            if (t.count > SAH_HUGE) {
+                const int s = atomicAdd(&nc[2], 1), nch = (t.count + SAH_CHUNK - 1) / SAH_CHUNK, fc = atomicAdd(&nc[3], nch);
+                SahHuge n = {};
+                n.start = t.start; n.count = t.count; n.pre = t.pre; n.first_chunk = fc;
+                for (int k = 0; k < 12; k++) n.bounds[k] = sah_is_min(k) ? 0xffffffffu : 0u;
+                n.child[0] = n.child[1] = -1;
+                next_huge[s] = n;
+                child_slot[side] = s; child_first[side] = fc;
+            } else if (t.count > SAH_LARGE) next_large[atomicAdd(&nc[1], 1)] = t;
+            else if (t.count >= 2) next_small[atomicAdd(&nc[0], 1)] = t;
+        }
+        h->axis = axis; h->plane = plane; h->nl = nl; h->child[0] = child_slot[0]; h->child[1] = child_slot[1];
+    }
+    for (int side = 0; side < 2; side++) {
+        const int s = __shfl(child_slot[side], 0, 64), fc = __shfl(child_first[side], 0, 64);
+        if (s < 0) continue;
+        const int cnt = side == 0 ? nl : nr, nch = (cnt + SAH_CHUNK - 1) / SAH_CHUNK;
+        for (int k = lane; k < nch; k += 64) next_chunk_task[fc + k] = s;
+        for (int k = lane; k < SAH_BIN_WORDS; k += 64) next_hbins[(size_t)s * SAH_BIN_WORDS + k] = (k % 7 < 3) ? 0xffffffffu : 0u;
+    }
+}
+
+// partition of one chunk of a huge node (stable: the chunk's output offsets come from k_sah_huge_eval), the bounds of huge children
+__global__ __launch_bounds__(SAH_CHUNK) void k_sah_huge_part(const float4 *__restrict__ sbox, const int *__restrict__ sorted_prims, const int *__restrict__ idx_in, int *__restrict__ idx_out,
+                                                              const SahHuge *__restrict__ huge, const int *__restrict__ lc, const int *__restrict__ chunk_task,
+                                                              const int *__restrict__ chunk_base, SahHuge *next_huge, float *compact, int *csize)
+{
+    __shared__ int s_wcount[16][2];
+    __shared__ unsigned s_b[2][12];
+    const int c = blockIdx.x;
+    if (c >= lc[3]) return;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const SahHuge *h = huge + chunk_task[c];
+    const int start = h->start, count = h->count, pre = h->pre, axis = h->axis, plane = h->plane, nl = h->nl, nr = count - nl;
+    const int i = (c - h->first_chunk) * SAH_CHUNK + (int)threadIdx.x;
+    const bool active = i < count;
+    if (threadIdx.x < 24) s_b[threadIdx.x / 12][threadIdx.x % 12] = sah_is_min(threadIdx.x % 12) ? 0xffffffffu : 0u;
+    int p = 0; float4 a = make_float4(0, 0, 0, 0), b = a;
+    bool left = false;
+    if (active) {
+        p = idx_in[start + i];
+        a = sbox[2 * (size_t)p]; b = sbox[2 * (size_t)p + 1];
+        if (axis < 0) left = i < nl;
+        else {
+            const float cmin = sah_unkey(h->bounds[6 + axis]), ext = sah_unkey(h->bounds[9 + axis]) - cmin, scale = ext > 0.0f ? (float)SAH_BINS / ext : 0.0f;
+            const float cc = axis == 0 ? 0.5f * (a.x + b.x) : (axis == 1 ? 0.5f * (a.y + b.y) : 0.5f * (a.z + b.z));
+            left = sah_bin(cc, cmin, scale) <= plane;
+        }
+    }
+    const unsigned long long ml = __ballot(active && left), mr = __ballot(active && !left);
+    int rank_l = __popcll(ml & lt_mask), rank_r = __popcll(mr & lt_mask);
+    if (lane == 0) { s_wcount[wave][0] = __popcll(ml); s_wcount[wave][1] = __popcll(mr); }
+    __syncthreads();
+    for (int w = 0; w < wave; w++) { rank_l += s_wcount[w][0]; rank_r += s_wcount[w][1]; }
+    if (active) {
+        idx_out[left ? start + chunk_base[2 * (size_t)c] + rank_l : start + nl + chunk_base[2 * (size_t)c + 1] + rank_r] = p;
+        if ((left && nl == 1) || (!left && nr == 1)) sah_write_leaf(compact, csize, left ? pre + 1 : pre + 2 * nl, sorted_prims[p], a, b);
+    }
+    // bounds of the children that are huge again (the others measure themselves, k_sah_level)
+    for (int side = 0; side < 2; side++) {
+        const int cs = h->child[side];
+        if (cs < 0) continue;                            // block-uniform
+        float r[12]; sah_bounds_init(r);
+        if (active && (left == (side == 0))) sah_bounds_add(r, a, b);
+        sah_wave_bounds(r);
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 12; k++) { if (sah_is_min(k)) atomicMin(&s_b[side][k], sah_key(r[k])); else atomicMax(&s_b[side][k], sah_key(r[k])); }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 24) {
+        const int side = threadIdx.x / 12, k = threadIdx.x % 12, cs = h->child[side];
+        if (cs >= 0) { if (sah_is_min(k)) atomicMin(&next_huge[cs].bounds[k], s_b[side][k]); else atomicMax(&next_huge[cs].bounds[k], s_b[side][k]); }
+    }
 }
 
 // Builds the tree over the primitives in the order `sorted_prims` (Morton order: neighbours in the array are neighbours in
-// space, so the box gathers of the first levels are local) into c->sah_compact / c->sah_csize.  Work on c->stream.
+// space, so the box reads of the first levels are streams) into c->sah_compact / c->sah_csize.  Work on c->stream.
 int sah_build(tirt_ctx *c, const int *sorted_prims)
 {
     const int n = c->n, N = 2 * n - 1;
     hipStream_t st = c->stream;
-    constexpr int MAX_LEVELS = 160;
-    const size_t small_cap = (size_t)n / 2 + 2, large_cap = (size_t)n / SAH_LARGE + 2;
+    const size_t small_cap = (size_t)n / 2 + 2, large_cap = (size_t)n / SAH_LARGE + 2, huge_cap = (size_t)n / SAH_HUGE + 2;
+    const size_t chunk_cap = (size_t)n / SAH_CHUNK + huge_cap + 2;
+    // scratch: two task lists of each size, huge node records + their bins, chunk tables
+    const size_t task_bytes = sizeof(SahTask) * 2 * (small_cap + large_cap);
+    const size_t huge_bytes = sizeof(SahHuge) * 2 * huge_cap + sizeof(unsigned) * 2 * huge_cap * SAH_BIN_WORDS;
+    const size_t chunk_bytes = sizeof(int) * chunk_cap * (2 /* task, both levels */ + 3 * SAH_BINS + 2);
     if (c->sah_compact.ensure(sizeof(float) * (size_t)N * CPN_VEC) || c->sah_csize.ensure(sizeof(int) * (size_t)N) ||
         c->sah_box.ensure(sizeof(float4) * 2 * (size_t)n) || c->sah_idx.ensure(sizeof(int) * 2 * (size_t)n) ||
-        c->sah_tasks.ensure(sizeof(SahTask) * 2 * (small_cap + large_cap)) || c->sah_counts.ensure(sizeof(int) * 2 * (MAX_LEVELS + 2))) return TIRT_ERR_HIP;
+        c->sah_tasks.ensure(task_bytes + huge_bytes + chunk_bytes) || c->sah_counts.ensure(sizeof(int) * 4 * (SAH_MAX_LEVELS + 2))) return TIRT_ERR_HIP;
     SceneView sv = scene_view(c);
-    float4 *box = c->sah_box.as<float4>();
+    float4 *sbox = c->sah_box.as<float4>();
     int *idx[2] = {c->sah_idx.as<int>(), c->sah_idx.as<int>() + n};
     SahTask *small[2] = {c->sah_tasks.as<SahTask>(), c->sah_tasks.as<SahTask>() + small_cap};
     SahTask *large[2] = {small[1] + small_cap, small[1] + small_cap + large_cap};
-    int *counts = c->sah_counts.as<int>();                 // counts[2 * level + (0 small | 1 large)]
-    hipLaunchKernelGGL(k_sah_prim_boxes, dim3((n + 255) / 256), dim3(256), 0, st, sv, box);
-    TIRT_HIP(hipMemcpyAsync(idx[0], sorted_prims, sizeof(int) * (size_t)n, hipMemcpyDeviceToDevice, st));
-    TIRT_HIP(hipMemsetAsync(counts, 0, sizeof(int) * 2 * (MAX_LEVELS + 2), st));
+    SahHuge *huge[2] = {(SahHuge *)(large[1] + large_cap), (SahHuge *)(large[1] + large_cap) + huge_cap};
+    unsigned *hbins[2] = {(unsigned *)(huge[1] + huge_cap), (unsigned *)(huge[1] + huge_cap) + huge_cap * SAH_BIN_WORDS};
+    int *chunk_task[2] = {(int *)(hbins[1] + huge_cap * SAH_BIN_WORDS), (int *)(hbins[1] + huge_cap * SAH_BIN_WORDS) + chunk_cap};
+    int *chunk_cnt = chunk_task[1] + chunk_cap, *chunk_base = chunk_cnt + chunk_cap * 3 * SAH_BINS;
+    int *counts = c->sah_counts.as<int>();                 // counts[4 * level + (0 small | 1 large | 2 huge | 3 chunks)]
+    float *compact = c->sah_compact.as<float>(); int *csize = c->sah_csize.as<int>();
+
+    TIRT_HIP(hipMemsetAsync(counts, 0, sizeof(int) * 4 * (SAH_MAX_LEVELS + 2), st));
+    SahHuge root_huge = {};
+    root_huge.count = n; root_huge.child[0] = root_huge.child[1] = -1;
+    for (int k = 0; k < 12; k++) root_huge.bounds[k] = ((k < 3) || (k >= 6 && k < 9)) ? 0xffffffffu : 0u;
+    TIRT_HIP(hipMemcpyAsync(huge[0], &root_huge, sizeof(root_huge), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_sah_prim_boxes, dim3((n + 255) / 256), dim3(256), 0, st, sv, sorted_prims, sbox, idx[0], huge[0], hbins[0]);
     const SahTask root = {0, n, 0, 0};
-    const int one = 1;
-    const bool root_large = n > SAH_LARGE;
-    TIRT_HIP(hipMemcpyAsync(root_large ? large[0] : small[0], &root, sizeof(root), hipMemcpyHostToDevice, st));
-    TIRT_HIP(hipMemcpyAsync(counts + (root_large ? 1 : 0), &one, sizeof(int), hipMemcpyHostToDevice, st));
-    int level = 0, host_counts[2 * (MAX_LEVELS + 2)];
+    int first_counts[4] = {0, 0, 0, 0};
+    if (n > SAH_HUGE) {
+        first_counts[2] = 1; first_counts[3] = (n + SAH_CHUNK - 1) / SAH_CHUNK;
+        TIRT_HIP(hipMemsetAsync(chunk_task[0], 0, sizeof(int) * (size_t)first_counts[3], st));       // every chunk belongs to slot 0
+    } else if (n > SAH_LARGE) { first_counts[1] = 1; TIRT_HIP(hipMemcpyAsync(large[0], &root, sizeof(root), hipMemcpyHostToDevice, st)); }
+    else { first_counts[0] = 1; TIRT_HIP(hipMemcpyAsync(small[0], &root, sizeof(root), hipMemcpyHostToDevice, st)); }
+    TIRT_HIP(hipMemcpyAsync(counts, first_counts, sizeof(first_counts), hipMemcpyHostToDevice, st));
+
+    bool any_huge = n > SAH_HUGE, any_large = n > SAH_LARGE;
+    int level = 0, host_counts[4 * (SAH_MAX_LEVELS + 2)];
     for (;;) {
-        const int until = (level + 16 < MAX_LEVELS) ? level + 16 : MAX_LEVELS;
+        const int until = (level + 8 < SAH_MAX_LEVELS) ? level + 8 : SAH_MAX_LEVELS;
         for (; level < until; level++) {
             const int in = level & 1, out = in ^ 1, halve = level >= SAH_FORCE_HALVING_AFTER ? 1 : 0;
+            int *lc = counts + 4 * level, *nc = counts + 4 * (level + 1);
             long cap = 1; for (int k = 0; k < level && cap < n; k++) cap *= 2;              // a level holds at most 2^level nodes
-            long cap_small = cap < (long)small_cap ? cap : (long)small_cap, cap_large = cap < (long)large_cap ? cap : (long)large_cap;
-            hipLaunchKernelGGL(k_sah_level<16>, dim3((unsigned)cap_large), dim3(SAH_BLOCK), 0, st, box, idx[in], idx[out], large[in], counts + 2 * level + 1,
-                               small[out], large[out], counts + 2 * (level + 1), c->sah_compact.as<float>(), c->sah_csize.as<int>(), halve);
-            hipLaunchKernelGGL(k_sah_level<1>, dim3((unsigned)((cap_small + 15) / 16)), dim3(SAH_BLOCK), 0, st, box, idx[in], idx[out], small[in], counts + 2 * level,
-                               small[out], large[out], counts + 2 * (level + 1), c->sah_compact.as<float>(), c->sah_csize.as<int>(), halve);
+            const long cap_small = cap < (long)small_cap ? cap : (long)small_cap, cap_large = cap < (long)large_cap ? cap : (long)large_cap;
+            const long cap_huge = cap < (long)huge_cap ? cap : (long)huge_cap;
+            if (any_huge) {
+                hipLaunchKernelGGL(k_sah_huge_bin, dim3((unsigned)chunk_cap), dim3(SAH_CHUNK), 0, st, sbox, idx[in], huge[in], lc, chunk_task[in], hbins[in], chunk_cnt, halve);
+                hipLaunchKernelGGL(k_sah_huge_eval, dim3((unsigned)cap_huge), dim3(64), 0, st, huge[in], lc, hbins[in], chunk_cnt, chunk_base, huge[out], hbins[out], chunk_task[out],
+                                   small[out], large[out], nc, compact, csize, halve);
+                hipLaunchKernelGGL(k_sah_huge_part, dim3((unsigned)chunk_cap), dim3(SAH_CHUNK), 0, st, sbox, sorted_prims, idx[in], idx[out], huge[in], lc, chunk_task[in], chunk_base,
+                                   huge[out], compact, csize);
+            }
+            if (any_large)
+                hipLaunchKernelGGL(k_sah_level<16>, dim3((unsigned)cap_large), dim3(SAH_BLOCK), 0, st, sbox, sorted_prims, idx[in], idx[out], large[in], lc + 1,
+                                   small[out], large[out], nc, compact, csize, halve);
+            hipLaunchKernelGGL(k_sah_level<1>, dim3((unsigned)((cap_small + 15) / 16)), dim3(SAH_BLOCK), 0, st, sbox, sorted_prims, idx[in], idx[out], small[in], lc,
+                               small[out], large[out], nc, compact, csize, halve);
         }
         TIRT_HIP(hipMemcpyAsync(host_counts, counts, sizeof(host_counts), hipMemcpyDeviceToHost, st));
         TIRT_HIP(hipStreamSynchronize(st));
-        if (host_counts[2 * level] == 0 && host_counts[2 * level + 1] == 0) break;
-        TIRT_REQUIRE(level < MAX_LEVELS, "tirt_lbvh_build: traversal tree deeper than 160 levels");
+        const int *lc = host_counts + 4 * level;
+        if (lc[0] == 0 && lc[1] == 0 && lc[2] == 0) break;
+        any_huge = lc[2] > 0; any_large = any_huge || lc[1] > 0;
+        TIRT_REQUIRE(level < SAH_MAX_LEVELS, "tirt_lbvh_build: traversal tree deeper than 160 levels");
     }
     c->sah_levels = level;
     TIRT_HIP(hipGetLastError());
