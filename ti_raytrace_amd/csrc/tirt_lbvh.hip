@@ -467,10 +467,12 @@ __global__ void k_wide_level(SceneView s, const float *compact, const int *csize
             // node of its own -- otherwise the bottom of the tree is full of 2- and 3-leaf nodes); else the largest surface area
             int best = -1, best_leaves = 1 << 30; float best_area = -1.0f;
             const int free_slots = 4 - nc;
+#ifndef WIDE_PURE_AREA
             for (int k = 0; k < nc; k++) if (!cn_leaf(compact, cand[k])) {
                 const int leaves = (csize[cand[k]] + 1) >> 1;
                 if (leaves - 1 <= free_slots && leaves < best_leaves) { best_leaves = leaves; best = k; }
             }
+#endif
             if (best < 0)
                 for (int k = 0; k < nc; k++) if (!cn_leaf(compact, cand[k])) { const float a = cn_area(compact, cand[k]); if (a > best_area) { best_area = a; best = k; } }
             if (best < 0) break;

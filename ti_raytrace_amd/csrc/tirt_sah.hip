@@ -503,7 +503,11 @@ int sah_build(tirt_ctx *c, const int *sorted_prims)
     bool any_huge = n > SAH_HUGE, any_large = n > SAH_LARGE;
     int level = 0, host_counts[4 * (SAH_MAX_LEVELS + 2)];
     for (;;) {
-        const int until = (level + 8 < SAH_MAX_LEVELS) ? level + 8 : SAH_MAX_LEVELS;
+        // a blocking read of the counters ends a round of levels: the first round is as long as a balanced tree is deep plus a
+        // few levels (an idle level costs two empty launches, a read ~50 us), later ones 8 levels
+        int round = 8;
+        if (level == 0) { round = 10; for (long k = 1; k < n; k *= 2) round++; }
+        const int until = (level + round < SAH_MAX_LEVELS) ? level + round : SAH_MAX_LEVELS;
         for (; level < until; level++) {
             const int in = level & 1, out = in ^ 1, halve = level >= SAH_FORCE_HALVING_AFTER ? 1 : 0;
             int *lc = counts + 4 * level, *nc = counts + 4 * (level + 1);
