@@ -81,6 +81,9 @@ int tirt_sync(tirt_ctx *ctx);
  *            196 B of HBM each)
  *          "split_lone_batch" (0/1, default 1) -- a context that owns 1/6 or less of the film (tile_count >= 6) and whose
  *            whole job is one batch runs it as two half batches on two lanes
+ *          "traversal_tree" (0/1, default 1) -- the tree tirt_lbvh_build collapses into the 4-wide traversal nodes: 1 = a binned-SAH
+ *            tree over the same primitives built on the device after the LBVH, 0 = the reference's LBVH itself; results are
+ *            bit-identical either way (tirt_traversal_tree_download); takes effect at the next tirt_lbvh_build
  *          "bdpt_batch_items" -- (frame, pixel) items per BDPT wavefront batch (default 2 Mi, ~3 KB of HBM each)
  *          (trace_lds_depth is checked against the LDS a block can have on the device) */
 int tirt_set_option(tirt_ctx *ctx, const char *name, double value);
