@@ -79,8 +79,8 @@ int tirt_sync(tirt_ctx *ctx);
  *            sized for merging more than that (a 512^2 x 8 spp job does not allocate 32 Mi-path lanes)
  *          "batch_paths" -- pixel-samples kept in flight per wavefront batch (default 32 Mi,
  *            196 B of HBM each)
- *          "split_lone_batch" (0/1, default 1) -- a context that owns 1/6 or less of the film (tile_count >= 6) and whose
- *            whole job is one batch runs it as two half batches on two lanes
+ *          "split_lone_batch" (0 = off, or the number of parts 2..8; default 2) -- a context that owns 1/6 or less of the film
+ *            (tile_count >= 6) and whose whole job is one batch runs it as that many smaller batches on as many lanes
  *          "traversal_tree" (0/1, default 1) -- the tree tirt_lbvh_build collapses into the 4-wide traversal nodes: 1 = a binned-SAH
  *            tree over the same primitives built on the device after the LBVH, 0 = the reference's LBVH itself; results are
  *            bit-identical either way (tirt_traversal_tree_download); takes effect at the next tirt_lbvh_build

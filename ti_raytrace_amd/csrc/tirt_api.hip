@@ -336,7 +336,7 @@ int tirt_set_option(tirt_ctx *c, const char *name, double value)
     TIRT_REQUIRE(name, "tirt_set_option: null name");
     if (!strcmp(name, "time_kernels")) { c->time_kernels = value != 0.0; return TIRT_OK; }
     if (!strcmp(name, "overlap_lanes")) { TIRT_REQUIRE(value >= 1.0 && value <= (double)TIRT_MAX_LANES, "overlap_lanes: 1..8"); if (sync_all(c)) return TIRT_ERR_HIP; c->n_lanes = (int)value; return TIRT_OK; }
-    if (!strcmp(name, "split_lone_batch")) { c->split_lone = value != 0.0 ? 1 : 0; return TIRT_OK; }
+    if (!strcmp(name, "split_lone_batch")) { TIRT_REQUIRE(value >= 0.0 && value <= 8.0, "split_lone_batch: 0 (off) or the number of parts, 2..8"); c->split_lone = (int)value; return TIRT_OK; }
     if (!strcmp(name, "traversal_tree")) {       // takes effect at the next tirt_lbvh_build
         TIRT_REQUIRE(value == 0.0 || value == 1.0, "traversal_tree: 0 (the reference's LBVH) or 1 (binned SAH)");
         c->use_sah = (int)value; return TIRT_OK;

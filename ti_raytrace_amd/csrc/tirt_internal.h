@@ -207,7 +207,7 @@ struct tirt_ctx {
     // of a multi-GPU job -- then run as one efficient batch); any other API call flushes first
     size_t merge_paths = (size_t)32 << 20;         // option "merge_paths" (0 = submit every call at once)
     unsigned batches_since_sync = 0;               // wavefront batches submitted since the last sync_all
-    int split_lone = 1;                            // option "split_lone_batch": a job that is one batch runs as two halves on two lanes
+    int split_lone = 2;                            // option "split_lone_batch": a job that is one batch runs as two halves on two lanes
     long job_frames = 0;                           // option "job_frames": expected frames of the whole job (0 = unknown); bounds the head-room
     struct { bool valid = false; uint32_t begin = 0; int count = 0; uint32_t seed = 0; int max_depth = 0, stack_size = 0, flags = 0; } pend;
     // traversal tunables (options "trace_lds_depth", "trace_refill_min", "trace_node_min", "trace_grid",

@@ -903,9 +903,9 @@ int pt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed,
     // as two half batches on two lanes it is 3.4 % faster at 8 ranks (measured on one GPU rendering rank 0's tiles; at 4 ranks
     // and below, and for a single GPU's stream of full batches, the halves lose 1-9 %: there 32 Mi-path batches win).
     // (Only for the first batch after a synchronisation: a rank with several batches in flight overlaps them anyway.)
-    if (c->split_lone && c->tile_count >= 6 && c->batches_since_sync == 0 && FB == frame_count && frame_count >= 2 && c->n_lanes >= 2 &&
+    if (c->split_lone >= 2 && c->tile_count >= 6 && c->batches_since_sync == 0 && FB == frame_count && frame_count >= 2 && c->n_lanes >= 2 &&
         !c->time_kernels && (size_t)frame_count * P >= ((size_t)12 << 20))
-        FB = (frame_count + 1) / 2;
+        { int parts = c->split_lone < c->n_lanes ? c->split_lone : c->n_lanes; if (parts > frame_count) parts = frame_count; FB = (frame_count + parts - 1) / parts; }
     const SceneView sv = scene_view(c);
     const BvhView bv = bvh_view(c);
     const TileMap tm = {c->tile_rank, c->tile_count, c->tile_size, c->H};

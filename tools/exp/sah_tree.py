@@ -76,6 +76,19 @@ if os.environ.get("SAH_BINS"):
         use(c2, s2, "SAH %d bins" % bins)
     sys.exit(0)
 
+if os.environ.get("SWEEP_MAX"):
+    so4 = "/tmp/sweep_build.so"
+    subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", "-o", so4, os.path.join(ROOT, "tools/exp/sweep_build.c")])
+    l4 = C.CDLL(so4)
+    for m in [int(x) for x in os.environ["SWEEP_MAX"].split(",")]:
+        c2 = np.zeros((N, 9), np.float32); s2 = np.zeros(N, np.int32)
+        t0 = time.time()
+        made = l4.sweep_build(boxes.ctypes.data_as(C.c_void_p), n, m, c2.ctypes.data_as(C.c_void_p), s2.ctypes.data_as(C.c_void_p))
+        assert made == N
+        print("sweep for nodes <= %d: %.1f s" % (m, time.time() - t0))
+        use(c2, s2, "sweep<=%d" % m)
+    sys.exit(0)
+
 if os.environ.get("SAH2_K"):
     cen = 0.5 * (boxes[:, :3] + boxes[:, 3:])
     lo, hi = boxes[:, :3].min(axis=0), boxes[:, 3:].max(axis=0)
