@@ -4,7 +4,8 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from ti_raytrace_amd import scenes, _native
 from test_gpu_trace import _grazing_rays
-ex = scenes.single_model(32, 32, 4, device_id=0); ex.build_scene(); ctx = ex.scene.ctx
+which = sys.argv[1] if len(sys.argv) > 1 else 'teapot'
+ex = {'teapot': scenes.single_model, 'veach': scenes.veach_bdpt, 'cornell': scenes.cornell_box}[which](32, 32, 4, device_id=0); ex.build_scene(); ctx = ex.scene.ctx
 n = 400000 // 14
 rays = _grazing_rays(ex, n, 41)
 a, ap, _ = ctx.trace_closest(rays, 64, 0)
@@ -24,7 +25,7 @@ v = ex.scene.vertex_np[:, :3].astype(np.float32)
 P = ex.scene.primitive_np
 for k, i in enumerate(bad):
     p = int(bp[i])
-    if p >= nprim - 1: continue
+    if p < 0 or P[p, 0] != 1: continue
     vi = P[p, 1]; A, B, C = v[vi], v[vi + 1], v[vi + 2]
     ro = rays[i, :3].astype(np.float32); rd = rays[i, 3:].astype(np.float32)
     e1 = B - A; e2 = C - A; pv = np.cross(rd, e2); det = np.dot(e1, pv)
