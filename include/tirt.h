@@ -84,6 +84,8 @@ int tirt_sync(tirt_ctx *ctx);
  *          "traversal_tree" (0/1, default 1) -- the tree tirt_lbvh_build collapses into the 4-wide traversal nodes: 1 = a binned-SAH
  *            tree over the same primitives built on the device after the LBVH, 0 = the reference's LBVH itself; results are
  *            bit-identical either way (tirt_traversal_tree_download); takes effect at the next tirt_lbvh_build
+ *          "wide_collapse" (0/1, default 0) -- how the binary tree is grouped into 4-wide nodes: 0 = greedily by surface area, 1 = the
+ *            grouping of least total node area (dynamic programme); same results, 1-9 % fewer node visits, no measurable gain
  *          "bdpt_batch_items" -- (frame, pixel) items per BDPT wavefront batch (default 2 Mi, ~3 KB of HBM each)
  *          (trace_lds_depth is checked against the LDS a block can have on the device) */
 int tirt_set_option(tirt_ctx *ctx, const char *name, double value);

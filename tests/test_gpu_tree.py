@@ -108,3 +108,20 @@ def test_traversal_tree_option_changes_no_bit(gpu_ctx_ok, make, W):
         out.append((film, hit, prim, st, sp))
     for a, b in zip(*out):
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_cost_optimal_collapse_changes_no_bit(gpu_ctx_ok):
+    """option wide_collapse = 1 (k_wide_dp): another grouping of the same binary tree into 4-wide nodes"""
+    out = []
+    W = 96
+    for collapse in (0, 1):
+        ex = scenes.veach_bdpt(W, W, 4, device_id=0); ex.scene.ctx.set_option("wide_collapse", collapse); ex.build_scene()
+        ctx = ex.scene.ctx
+        ctx.pt_rgb_render(0, 8, 1, 15, 64, 0)
+        film = ctx.film_download(W, W)[0]
+        rays = np.concatenate([oa.camera_rays(ex.cam, W, W), random_rays(40000, -3.0, 3.0, 12)], axis=0)
+        hit, prim, _ = ctx.trace_closest(rays, 64, 0)
+        out.append((film, hit, prim, ctx.bvh_info()["nodes"]))
+    assert out[0][3] != out[1][3], "the two groupings differ"
+    for a, b in zip(out[0][:3], out[1][:3]):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))

@@ -293,7 +293,7 @@ void tirt_destroy(tirt_ctx *c)
     drain_render_events(c);
     DevBuf *bufs[] = {&c->vertex, &c->primitive, &c->material, &c->shape, &c->light, &c->env, &c->mat_lrgb, &c->shade_rec, &c->morton_unsorted, &c->keys_a,
                       &c->keys_b, &c->vals_a, &c->vals_b, &c->hist, &c->morton_sorted, &c->bvh_node, &c->compact, &c->parent,
-                      &c->flag, &c->subtree, &c->build_status, &c->leaf_compact, &c->wnode, &c->tri, &c->cnode, &c->cparent, &c->csize, &c->wide_queue, &c->wide_levels, &c->sah_compact, &c->sah_csize, &c->sah_box, &c->sah_idx, &c->sah_tasks, &c->sah_counts, &c->hdr, &c->rgb,
+                      &c->flag, &c->subtree, &c->build_status, &c->leaf_compact, &c->wnode, &c->tri, &c->cnode, &c->cparent, &c->csize, &c->wide_queue, &c->wide_levels, &c->sah_compact, &c->sah_csize, &c->sah_parent, &c->wide_dp, &c->sah_box, &c->sah_idx, &c->sah_tasks, &c->sah_counts, &c->hdr, &c->rgb,
                       &c->counters_mem, &c->spill, &c->tr_rays,
                       &c->tr_out, &c->tr_prim, &c->tr_counts, &c->dev_counters, &c->bdpt_px, &c->bdpt_rad, &c->bdpt_items, &c->bdpt_state,
                       &c->bdpt_rays, &c->bdpt_hits, &c->bdpt_qidx, &c->bdpt_ctr};
@@ -337,6 +337,7 @@ int tirt_set_option(tirt_ctx *c, const char *name, double value)
     if (!strcmp(name, "time_kernels")) { c->time_kernels = value != 0.0; return TIRT_OK; }
     if (!strcmp(name, "overlap_lanes")) { TIRT_REQUIRE(value >= 1.0 && value <= (double)TIRT_MAX_LANES, "overlap_lanes: 1..8"); if (sync_all(c)) return TIRT_ERR_HIP; c->n_lanes = (int)value; return TIRT_OK; }
     if (!strcmp(name, "split_lone_batch")) { TIRT_REQUIRE(value >= 0.0 && value <= 8.0, "split_lone_batch: 0 (off) or the number of parts, 2..8"); c->split_lone = (int)value; return TIRT_OK; }
+    if (!strcmp(name, "wide_collapse")) { TIRT_REQUIRE(value == 0.0 || value == 1.0, "wide_collapse: 0 (greedy) or 1 (cost-optimal)"); c->wide_dp_on = (int)value; return TIRT_OK; }
     if (!strcmp(name, "traversal_tree")) {       // takes effect at the next tirt_lbvh_build
         TIRT_REQUIRE(value == 0.0 || value == 1.0, "traversal_tree: 0 (the reference's LBVH) or 1 (binned SAH)");
         c->use_sah = (int)value; return TIRT_OK;

@@ -447,9 +447,50 @@ TD float cn_area(const float *compact, int i)
     const float dx = c[5] - c[2], dy = c[6] - c[3], dz = c[7] - c[4];
     return dx * dy + dy * dz + dz * dx;
 }
+// Cost-optimal grouping of the binary tree into wide nodes (the dynamic programme of Ylitie, Karras, Laine 2017 for a
+// visit-count cost): every binary inner node either becomes the root of a wide node (cost: its surface area, the chance of a
+// visit) or is dissolved into the wide node above it (cost 0), under the constraint of four children per wide node.
+//   T(n, k) = cheapest way to hang the subtree of n below a wide node using at most k of its child slots (k = 1..3)
+//   T(n, 1) = area(n) + min_i [T(l, i) + T(r, 4 - i)]                       n becomes a wide node: slots 4 = i + (4 - i)
+//   T(n, k) = min(T(n, 1), min_i [T(l, i) + T(r, k - i)])                   or n is dissolved: its children share the k slots
+// with T(leaf, k) = 0.  Bottom-up, one thread per leaf climbing, the second arrival owns the node -- the hand-off of k_refit.
+// dec[n]: bits 0-1 = i of the root split; bit 2 = choice for k = 2 (0 node, 1 dissolve 1+1); bits 3-4 = choice for k = 3
+// (0 node, 1: 1+1, 2: 1+2, 3: 2+1).
+__global__ void k_wide_dp(int N, const float *compact, const int *parent, int *flag, float *dp_t, int *dp_dec)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N || !cn_leaf(compact, i)) return;
+    int cur = parent[i];
+    while (cur >= 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int old = __hip_atomic_fetch_add(&flag[cur], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+        if (old == 0) break;
+        const int l = cur + 1, r = (int)compact[(size_t)cur * CPN_VEC + 1];
+        float tl[4] = {0, 0, 0, 0}, tr[4] = {0, 0, 0, 0};
+        if (!cn_leaf(compact, l)) for (int k = 1; k <= 3; k++) tl[k] = __hip_atomic_load(&dp_t[(size_t)l * 3 + k - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!cn_leaf(compact, r)) for (int k = 1; k <= 3; k++) tr[k] = __hip_atomic_load(&dp_t[(size_t)r * 3 + k - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int root_i = 2; float best = tl[2] + tr[2];
+        if (tl[1] + tr[3] < best) { best = tl[1] + tr[3]; root_i = 1; }
+        if (tl[3] + tr[1] < best) { best = tl[3] + tr[1]; root_i = 3; }
+        const float t1 = cn_area(compact, cur) + best;
+        float t2 = t1; int d2 = 0;
+        if (tl[1] + tr[1] < t2) { t2 = tl[1] + tr[1]; d2 = 1; }
+        float t3 = t1; int d3 = 0;
+        if (tl[1] + tr[1] < t3) { t3 = tl[1] + tr[1]; d3 = 1; }
+        if (tl[1] + tr[2] < t3) { t3 = tl[1] + tr[2]; d3 = 2; }
+        if (tl[2] + tr[1] < t3) { t3 = tl[2] + tr[1]; d3 = 3; }
+        __hip_atomic_store(&dp_t[(size_t)cur * 3 + 0], t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&dp_t[(size_t)cur * 3 + 1], t2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&dp_t[(size_t)cur * 3 + 2], t3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        dp_dec[cur] = root_i | (d2 << 2) | (d3 << 3);                    // read by the next kernel only
+        cur = parent[cur];
+    }
+}
+
 // level_off[L] / level_cnt[L]: first wide index and number of wide nodes of level L; queue holds the binary roots (compact
 // indices) of all wide nodes in breadth-first order (queue[w] for wide node w)
-__global__ void k_wide_level(SceneView s, const float *compact, const int *csize, int level, int *level_off, int *level_cnt, int *queue, uint4 *cnode, float pad, GridMap gm)
+__global__ void k_wide_level(SceneView s, const float *compact, const int *csize, const int *dp_dec, int level, int *level_off, int *level_cnt, int *queue, uint4 *cnode, float pad, GridMap gm)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
     const int n_in = level_cnt[level], off = level_off[level];
@@ -460,6 +501,21 @@ __global__ void k_wide_level(SceneView s, const float *compact, const int *csize
     if (live) {
         const int root = queue[w];
         const float *rc = compact + (size_t)root * CPN_VEC;
+        if (dp_dec) {                    // the dynamic programme's choices (k_wide_dp), unfolded from this node's root split
+            int st_n[6], st_k[6], sp = 0;
+            const int ri = dp_dec[root] & 3;
+            st_n[sp] = (int)rc[1]; st_k[sp++] = 4 - ri;
+            st_n[sp] = root + 1; st_k[sp++] = ri;
+            while (sp > 0) {
+                const int c = st_n[--sp], k = st_k[sp];
+                int choice = 0;                                    // 0: c itself takes one slot
+                if (!cn_leaf(compact, c) && k >= 2) { const int d = dp_dec[c]; choice = (k == 2) ? ((d >> 2) & 1) : ((d >> 3) & 3); }
+                if (choice == 0) { cand[nc++] = c; continue; }
+                const int li = (choice == 3) ? 2 : 1, rk = (choice == 1) ? 1 : (choice == 2 ? 2 : 1);
+                st_n[sp] = (int)compact[(size_t)c * CPN_VEC + 1]; st_k[sp++] = rk;
+                st_n[sp] = c + 1; st_k[sp++] = li;
+            }
+        } else {
         cand[0] = root + 1; cand[1] = (int)rc[1]; nc = 2;
         for (;;) {
             if (nc == 4) break;
@@ -478,6 +534,7 @@ __global__ void k_wide_level(SceneView s, const float *compact, const int *csize
             if (best < 0) break;
             const int b = cand[best];
             cand[best] = b + 1; cand[nc++] = (int)compact[(size_t)b * CPN_VEC + 1];
+        }
         }
         for (int c = 0; c < nc; c++) if (!cn_leaf(compact, cand[c])) n_int++;
     }
@@ -517,11 +574,20 @@ __global__ void k_wide_level(SceneView s, const float *compact, const int *csize
 
 // The level loop of the wide build over a binary tree in `compact` layout (pre-order, left child = self + 1) with subtree
 // sizes `csize`; ends with c->ev1 recorded after the last level.
-static int build_wide(tirt_ctx *c, const float *compact, const int *csize, float pad, const GridMap &gm)
+static int build_wide(tirt_ctx *c, const float *compact, const int *csize, const int *parent, float pad, const GridMap &gm)
 {
-    const int n = c->n;
+    const int n = c->n, N = 2 * n - 1;
     hipStream_t st = c->stream;
     SceneView sv = scene_view(c);
+    const int *dp_dec = nullptr;
+    if (c->wide_dp_on && parent) {
+        // scratch: arrival counters [N] | choices [N] | costs [3N]
+        if (c->wide_dp.ensure(sizeof(int) * 5 * (size_t)N)) return TIRT_ERR_HIP;
+        int *flag = c->wide_dp.as<int>(), *dec = flag + N; float *t = (float *)(dec + N);
+        TIRT_HIP(hipMemsetAsync(flag, 0, sizeof(int) * (size_t)N, st));
+        hipLaunchKernelGGL(k_wide_dp, dim3((N + 255) / 256), dim3(256), 0, st, N, compact, parent, flag, t, dec);
+        dp_dec = dec;
+    }
     constexpr int WIDE_LEVELS_MAX = 2048;     // runs of identical Morton codes make chains: a level per three leaves of a chain
     int *lv_off = c->wide_levels.as<int>(), *lv_cnt = lv_off + (WIDE_LEVELS_MAX + 2);
     TIRT_HIP(hipMemsetAsync(c->wide_levels.p, 0, sizeof(int) * 2 * (WIDE_LEVELS_MAX + 2), st));
@@ -534,7 +600,7 @@ static int build_wide(tirt_ctx *c, const float *compact, const int *csize, float
         for (; level < until; level++) {
             long cap = 1; for (int k = 0; k < level && cap < n; k++) cap *= 4;             // a level holds at most 4^level nodes
             if (cap > n) cap = n;
-            hipLaunchKernelGGL(k_wide_level, dim3((unsigned)((cap + 127) / 128)), dim3(128), 0, st, sv, compact, csize, level, lv_off, lv_cnt,
+            hipLaunchKernelGGL(k_wide_level, dim3((unsigned)((cap + 127) / 128)), dim3(128), 0, st, sv, compact, csize, dp_dec, level, lv_off, lv_cnt,
                                c->wide_queue.as<int>(), c->cnode.as<uint4>(), pad, gm);
         }
         TIRT_HIP(hipEventRecord(c->ev1, st));
@@ -560,7 +626,7 @@ int exp_wide_from_tree(tirt_ctx *c, const float *compact_host, const int *csize_
     const float pad = 1.0e-4f * sqrtf(ex * ex + ey * ey + ez * ez);
     GridMap gm;
     for (int k = 0; k < 3; k++) { gm.g0[k] = c->grid_min[k]; gm.inv_cell[k] = c->grid_inv_cell[k]; }
-    return build_wide(c, alt_compact.as<float>(), alt_csize.as<int>(), pad, gm);
+    return build_wide(c, alt_compact.as<float>(), alt_csize.as<int>(), nullptr, pad, gm);
 }
 #endif
 
@@ -642,13 +708,13 @@ int lbvh_build(tirt_ctx *c)
     // surface-area collapse of the binary tree into 4-wide nodes, one launch per level of the wide tree (k_wide_level)
     c->wide_nodes = 0;
     if (n >= 2) {
-        const float *tree = c->compact.as<float>(); const int *tree_size = c->csize.as<int>();
+        const float *tree = c->compact.as<float>(); const int *tree_size = c->csize.as<int>(), *tree_parent = c->cparent.as<int>();
         if (c->use_sah) {          // walk a better tree than the reference's (tirt_sah.hip); the hits stay the reference's (k_trace)
             if (int rc = sah_build(c, va)) return rc;
-            tree = c->sah_compact.as<float>(); tree_size = c->sah_csize.as<int>();
+            tree = c->sah_compact.as<float>(); tree_size = c->sah_csize.as<int>(); tree_parent = c->sah_parent.as<int>();
             c->built_sah = 1;
         }
-        if (int rc = build_wide(c, tree, tree_size, pad, gm)) return rc;
+        if (int rc = build_wide(c, tree, tree_size, tree_parent, pad, gm)) return rc;
     } else TIRT_HIP(hipEventRecord(c->ev1, st));
     if (n == 1) {
         int prim = 0, is_shape = 0;

@@ -135,8 +135,10 @@ TD void sah_write_leaf(float *compact, int *csize, int row_index, int prim, floa
     row[0] = 1.0f; row[1] = (float)prim; row[2] = a.x; row[3] = a.y; row[4] = a.z; row[5] = b.x; row[6] = b.y; row[7] = b.z; row[8] = 0.0f;
     csize[row_index] = 1;
 }
-TD void sah_write_inner(float *compact, int *csize, int row_index, int right, int count, const float box[6])
+TD void sah_write_inner(float *compact, int *csize, int *parent, int row_index, int right, int count, const float box[6])
 {
+    parent[row_index + 1] = row_index; parent[right] = row_index;
+    if (row_index == 0) parent[0] = -1;
     float *row = compact + (size_t)row_index * CPN_VEC;
     row[0] = 0.0f; row[1] = (float)right;
     row[2] = box[0]; row[3] = box[1]; row[4] = box[2]; row[5] = box[3]; row[6] = box[4]; row[7] = box[5]; row[8] = 0.0f;
@@ -186,7 +188,7 @@ __global__ __launch_bounds__(SAH_BLOCK) void k_sah_level(const float4 *__restric
                                                          const int *__restrict__ idx_in, int *__restrict__ idx_out,
                                                          const SahTask *__restrict__ tasks, const int *__restrict__ task_count,
                                                          SahTask *next_small, SahTask *next_large, int *next_count /* [0] small, [1] large */,
-                                                         float *compact, int *csize, int halve)
+                                                         float *compact, int *csize, int *parent, int halve)
 {
     constexpr int TPB = 16 / WPT;            // tasks per block
     constexpr int G = 64 * WPT;              // threads per task
@@ -287,7 +289,7 @@ __global__ __launch_bounds__(SAH_BLOCK) void k_sah_level(const float4 *__restric
     if (gt == 0) {
         s_child[slot][0].count = 0; s_child[slot][1].count = 0;
         if (count >= 2) {
-            sah_write_inner(compact, csize, pre, pre + 2 * nl, count, r);
+            sah_write_inner(compact, csize, parent, pre, pre + 2 * nl, count, r);
             if (nl >= 2) s_child[slot][0] = SahTask{start, nl, pre + 1, 0};
             if (nr >= 2) s_child[slot][1] = SahTask{start + nl, nr, pre + 2 * nl, 0};
         }
@@ -347,7 +349,7 @@ __global__ __launch_bounds__(SAH_CHUNK) void k_sah_huge_bin(const float4 *__rest
 __global__ __launch_bounds__(64) void k_sah_huge_eval(SahHuge *huge, const int *__restrict__ lc, const unsigned *__restrict__ hbins, const int *__restrict__ chunk_cnt,
                                                        int *chunk_base, SahHuge *next_huge, unsigned *next_hbins, int *next_chunk_task,
                                                        SahTask *next_small, SahTask *next_large, int *nc /* next level's counters */,
-                                                       float *compact, int *csize, int halve)
+                                                       float *compact, int *csize, int *parent, int halve)
 {
     __shared__ unsigned s_bin[3][SAH_BINS][7];
     const int slot = blockIdx.x, lane = threadIdx.x;
@@ -377,7 +379,7 @@ __global__ __launch_bounds__(64) void k_sah_huge_eval(SahHuge *huge, const int *
     int child_slot[2] = {-1, -1}, child_first[2] = {0, 0};
     if (lane == 0) {
         const float box[6] = {sah_unkey(h->bounds[0]), sah_unkey(h->bounds[1]), sah_unkey(h->bounds[2]), sah_unkey(h->bounds[3]), sah_unkey(h->bounds[4]), sah_unkey(h->bounds[5])};
-        sah_write_inner(compact, csize, pre, pre + 2 * nl, count, box);
+        sah_write_inner(compact, csize, parent, pre, pre + 2 * nl, count, box);
         for (int side = 0; side < 2; side++) {
             const SahTask t = side == 0 ? SahTask{start, nl, pre + 1, 0} : SahTask{start + nl, nr, pre + 2 * nl, 0};
             if (t.count > SAH_HUGE) {
@@ -470,7 +472,7 @@ int sah_build(tirt_ctx *c, const int *sorted_prims)
     const size_t task_bytes = sizeof(SahTask) * 2 * (small_cap + large_cap);
     const size_t huge_bytes = sizeof(SahHuge) * 2 * huge_cap + sizeof(unsigned) * 2 * huge_cap * SAH_BIN_WORDS;
     const size_t chunk_bytes = sizeof(int) * chunk_cap * (2 /* task, both levels */ + 3 * SAH_BINS + 2);
-    if (c->sah_compact.ensure(sizeof(float) * (size_t)N * CPN_VEC) || c->sah_csize.ensure(sizeof(int) * (size_t)N) ||
+    if (c->sah_compact.ensure(sizeof(float) * (size_t)N * CPN_VEC) || c->sah_csize.ensure(sizeof(int) * (size_t)N) || c->sah_parent.ensure(sizeof(int) * (size_t)N) ||
         c->sah_box.ensure(sizeof(float4) * 2 * (size_t)n) || c->sah_idx.ensure(sizeof(int) * 2 * (size_t)n) ||
         c->sah_tasks.ensure(task_bytes + huge_bytes + chunk_bytes) || c->sah_counts.ensure(sizeof(int) * 4 * (SAH_MAX_LEVELS + 2))) return TIRT_ERR_HIP;
     SceneView sv = scene_view(c);
@@ -483,7 +485,7 @@ int sah_build(tirt_ctx *c, const int *sorted_prims)
     int *chunk_task[2] = {(int *)(hbins[1] + huge_cap * SAH_BIN_WORDS), (int *)(hbins[1] + huge_cap * SAH_BIN_WORDS) + chunk_cap};
     int *chunk_cnt = chunk_task[1] + chunk_cap, *chunk_base = chunk_cnt + chunk_cap * 3 * SAH_BINS;
     int *counts = c->sah_counts.as<int>();                 // counts[4 * level + (0 small | 1 large | 2 huge | 3 chunks)]
-    float *compact = c->sah_compact.as<float>(); int *csize = c->sah_csize.as<int>();
+    float *compact = c->sah_compact.as<float>(); int *csize = c->sah_csize.as<int>(), *parent = c->sah_parent.as<int>();
 
     TIRT_HIP(hipMemsetAsync(counts, 0, sizeof(int) * 4 * (SAH_MAX_LEVELS + 2), st));
     SahHuge root_huge = {};
@@ -517,15 +519,15 @@ int sah_build(tirt_ctx *c, const int *sorted_prims)
             if (any_huge) {
                 hipLaunchKernelGGL(k_sah_huge_bin, dim3((unsigned)chunk_cap), dim3(SAH_CHUNK), 0, st, sbox, idx[in], huge[in], lc, chunk_task[in], hbins[in], chunk_cnt, halve);
                 hipLaunchKernelGGL(k_sah_huge_eval, dim3((unsigned)cap_huge), dim3(64), 0, st, huge[in], lc, hbins[in], chunk_cnt, chunk_base, huge[out], hbins[out], chunk_task[out],
-                                   small[out], large[out], nc, compact, csize, halve);
+                                   small[out], large[out], nc, compact, csize, parent, halve);
                 hipLaunchKernelGGL(k_sah_huge_part, dim3((unsigned)chunk_cap), dim3(SAH_CHUNK), 0, st, sbox, sorted_prims, idx[in], idx[out], huge[in], lc, chunk_task[in], chunk_base,
                                    huge[out], compact, csize);
             }
             if (any_large)
                 hipLaunchKernelGGL(k_sah_level<16>, dim3((unsigned)cap_large), dim3(SAH_BLOCK), 0, st, sbox, sorted_prims, idx[in], idx[out], large[in], lc + 1,
-                                   small[out], large[out], nc, compact, csize, halve);
+                                   small[out], large[out], nc, compact, csize, parent, halve);
             hipLaunchKernelGGL(k_sah_level<1>, dim3((unsigned)((cap_small + 15) / 16)), dim3(SAH_BLOCK), 0, st, sbox, sorted_prims, idx[in], idx[out], small[in], lc,
-                               small[out], large[out], nc, compact, csize, halve);
+                               small[out], large[out], nc, compact, csize, parent, halve);
         }
         TIRT_HIP(hipMemcpyAsync(host_counts, counts, sizeof(host_counts), hipMemcpyDeviceToHost, st));
         TIRT_HIP(hipStreamSynchronize(st));
