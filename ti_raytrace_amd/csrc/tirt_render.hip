@@ -216,7 +216,7 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
                     expect = a.sprim[q];
                     if (BOUNDED) { const float t_bound = a.sdist[q]; if (t_bound > 0.0f) { cull_far = t_bound * 1.01f; settle = t_bound * 0.99f; } }
                 }
-                lim = minf(minf(hit_t * 1.0001f, cull_far), INF_VALUE);
+                lim = __builtin_fminf(__builtin_fminf(hit_t * 1.0001f, cull_far), INF_VALUE);      // (v_min: a canonical value, so the node loop does not re-canonicalise it every step)
                 if (MODE != TIRT_TRAVERSE_EXHAUSTIVE) {
                     // margin in cells, the same on all axes: 0.25 + 0.25 per root-box extent between the origin and the
                     // grid (largest axis).  It has to cover (i) the rounding of q * gA + gB (<= 0.016 cells per extent of
@@ -268,6 +268,7 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
         // all stashed leaves of the wave together (lane utilisation of the node loop 0.61 -> 0.73, of the leaf phase 0.38 -> 0.45), at the
         // price of a few node visits the earlier hit would have culled (+2 %).
         if (STASH) { if (have && cur < 0 && cur != TR_SENT && pend == 0) { pend = cur; TR_POP(cur); } }
+        const int lim_i = __float_as_int(lim);                  // > 0 always
         for (;;) {
             const bool act = cur >= 0;
             const unsigned long long am = ballot64(act);
@@ -327,7 +328,10 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
                         const float ny__ = __builtin_fmaf((float)hy__.x, gAy, gBny), fy__ = __builtin_fmaf((float)hy__.y, gAy, gBfy); \
                         const float nz__ = __builtin_fmaf((float)hz__.x, gAz, gBnz), fz__ = __builtin_fmaf((float)hz__.y, gAz, gBfz); \
                         const float tn__ = __builtin_fmaxf(__builtin_fmaxf(nx__, ny__), __builtin_fmaxf(nz__, 0.0f)); \
-                        const float tf__ = __builtin_fminf(__builtin_fminf(fx__, fy__), __builtin_fminf(fz__, lim));  \
+                        /* the far distance in the INTEGER domain (v_min_i32 / v_min3_i32: no canonicalisation of `lim` per step):   \
+                           exact for non-negative floats, and a negative operand (box behind the ray) gives a negative result */      \
+                        const int tfi__ = min(min(__float_as_int(fx__), __float_as_int(fy__)), min(__float_as_int(fz__), lim_i));     \
+                        const float tf__ = __int_as_float(tfi__);                                    \
                         dist = (tn__ <= tf__) ? tn__ : MISS;                                         \
                     } while (0)
                     TR_CBOX(q0.x, q0.y, q0.z, d0);
@@ -422,7 +426,7 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
 #endif
             if (cand) {
                 hit_t = t; hit_u = u; hit_v = v; hit_prim = prim; hit_leaf = leaf;
-                lim = minf(minf(hit_t * 1.0001f, cull_far), INF_VALUE);
+                lim = __builtin_fminf(__builtin_fminf(hit_t * 1.0001f, cull_far), INF_VALUE);      // (v_min: a canonical value, so the node loop does not re-canonicalise it every step)
                 if (BOUNDED && prim != expect && t < settle) { cur = TR_SENT; paged = 0; pend = 0; }      // answer settled: "occluded"
             }
         }
