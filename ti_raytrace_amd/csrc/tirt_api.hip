@@ -293,7 +293,7 @@ void tirt_destroy(tirt_ctx *c)
     drain_render_events(c);
     DevBuf *bufs[] = {&c->vertex, &c->primitive, &c->material, &c->shape, &c->light, &c->env, &c->mat_lrgb, &c->shade_rec, &c->morton_unsorted, &c->keys_a,
                       &c->keys_b, &c->vals_a, &c->vals_b, &c->hist, &c->morton_sorted, &c->bvh_node, &c->compact, &c->parent,
-                      &c->flag, &c->subtree, &c->build_status, &c->leaf_compact, &c->wnode, &c->tri, &c->cnode, &c->cparent, &c->csize, &c->wide_queue, &c->wide_levels, &c->sah_compact, &c->sah_csize, &c->sah_parent, &c->wide_dp, &c->sah_box, &c->sah_idx, &c->sah_tasks, &c->sah_counts, &c->hdr, &c->rgb,
+                      &c->flag, &c->subtree, &c->build_status, &c->leaf_compact, &c->wnode, &c->tri, &c->prim_slot, &c->cnode, &c->cparent, &c->csize, &c->wide_queue, &c->wide_levels, &c->sah_compact, &c->sah_csize, &c->sah_parent, &c->wide_dp, &c->sah_box, &c->sah_idx, &c->sah_tasks, &c->sah_counts, &c->hdr, &c->rgb,
                       &c->counters_mem, &c->spill, &c->tr_rays,
                       &c->tr_out, &c->tr_prim, &c->tr_counts, &c->dev_counters, &c->bdpt_px, &c->bdpt_rad, &c->bdpt_items, &c->bdpt_state,
                       &c->bdpt_rays, &c->bdpt_hits, &c->bdpt_qidx, &c->bdpt_ctr};
@@ -445,6 +445,15 @@ int tirt_lbvh_build(tirt_ctx *c)
 }
 
 #ifdef TIRT_EXPERIMENTS
+int tirt_exp_download(tirt_ctx *c, int which, void *out, uint64_t bytes)
+{
+    CTX(c);
+    if (sync_all(c)) return TIRT_ERR_HIP;
+    DevBuf *b = which == 0 ? &c->tri : which == 1 ? &c->prim_slot : which == 2 ? &c->leaf_compact : which == 3 ? &c->cnode : &c->cparent;
+    TIRT_REQUIRE(bytes <= b->bytes, "tirt_exp_download: too many bytes");
+    TIRT_HIP(hipMemcpy(out, b->p, bytes, hipMemcpyDeviceToHost));
+    return TIRT_OK;
+}
 int tirt_exp_wide_from_tree(tirt_ctx *c, const float *compact_host, const int32_t *csize_host)
 {
     CTX(c);

@@ -178,7 +178,7 @@ struct tirt_ctx {
     tirt::DevBuf morton_sorted;                   // int2[n]
     tirt::DevBuf bvh_node, compact;               // f32 [N*11], [N*9]
     tirt::DevBuf parent, flag, subtree, build_status, leaf_compact;
-    tirt::DevBuf wnode, tri;                      // traversal layout
+    tirt::DevBuf wnode, tri, prim_slot;           // traversal layout; prim_slot[prim] = index of its record in `tri` (leaf order of the traversal tree)
     tirt::DevBuf cnode, cparent, csize, wide_queue, wide_levels;    // quantised 4-wide nodes (ordered traversal) + parent chain of the compact nodes + build scratch
     int wide_nodes = 0;                            // number of 4-wide nodes
     tirt::DevBuf sah_compact, sah_csize, sah_parent, wide_dp, sah_box, sah_idx, sah_tasks, sah_counts;   // traversal tree (tirt_sah.hip): `compact`-layout rows + subtree sizes, build scratch

@@ -372,16 +372,23 @@ __global__ void k_flatten(int n, const float *bvh_node, const int *parent, const
 // ---------------------------------------------------------------------------------------------
 // Traversal layout
 // ---------------------------------------------------------------------------------------------
-TD int child_code(SceneView s, const float *cn, int idx)
+// leaf code: ~(index of the primitive's record in `tri` | shape << 30)
+TD int child_code(SceneView s, const int *prim_slot, const float *cn, int idx)
 {
     if ((((int)cn[0]) & 1) == 1) {
         int prim = (int)cn[1];
         int is_shape = (s.primitive[(size_t)prim * PRI_VEC] == PRIMITIVE_TRI) ? 0 : 1;
-        return ~(prim | (is_shape << 30));
+        return ~(prim_slot[prim] | (is_shape << 30));
     }
     return idx;
 }
-__global__ void k_wnodes(SceneView s, int N, const float *compact, float4 *wnode, float pad)
+// LBVH as the traversal tree: records in Morton order
+__global__ void k_slot_sorted(int n, const int *sorted_prims, int *prim_slot)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) prim_slot[sorted_prims[i]] = i;
+}
+__global__ void k_wnodes(SceneView s, const int *prim_slot, int N, const float *compact, float4 *wnode, float pad)
 {
     int o = blockIdx.x * blockDim.x + threadIdx.x;
     if (o >= N) return;
@@ -389,7 +396,7 @@ __global__ void k_wnodes(SceneView s, int N, const float *compact, float4 *wnode
     if ((((int)cn[0]) & 1) == 1) return;
     int li = o + 1, ri = (int)cn[1];
     const float *lc = compact + (size_t)li * CPN_VEC, *rc = compact + (size_t)ri * CPN_VEC;
-    int cl = child_code(s, lc, li), cr = child_code(s, rc, ri);
+    int cl = child_code(s, prim_slot, lc, li), cr = child_code(s, prim_slot, rc, ri);
     float lp = cl < 0 ? pad : 0.0f, rp = cr < 0 ? pad : 0.0f;
     float4 *w = wnode + (size_t)o * 4;
     w[0] = make_float4(lc[2] - lp, lc[3] - lp, lc[4] - lp, lc[5] + lp);
@@ -397,23 +404,26 @@ __global__ void k_wnodes(SceneView s, int N, const float *compact, float4 *wnode
     w[2] = make_float4(rc[4] - rp, rc[5] + rp, rc[6] + rp, rc[7] + rp);
     w[3] = make_float4(__int_as_float(cl), __int_as_float(cr), 0.0f, 0.0f);
 }
-__global__ void k_tris(SceneView s, const int *leaf_compact, float4 *tri)
+// One 48-byte record per primitive, stored in the leaf order of the traversal tree (prim_slot): rays that walk one part of the
+// tree read neighbouring records.  The primitive id rides in the last word.
+__global__ void k_tris(SceneView s, const int *leaf_compact, const int *prim_slot, float4 *tri)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= s.n) return;
     const int *pr = s.primitive + (size_t)i * PRI_VEC;
-    float4 *t = tri + (size_t)i * TRI_STRIDE;
+    float4 *t = tri + (size_t)prim_slot[i] * TRI_STRIDE;
+    const float id = __int_as_float(i);
     float lc = __int_as_float(leaf_compact[i]);
     if (pr[0] == PRIMITIVE_TRI) {
         v3 v0 = vtx_pos(s, pr[1]), v1 = vtx_pos(s, pr[1] + 1), v2 = vtx_pos(s, pr[1] + 2);
         t[0] = make_float4(v0.x, v0.y, v0.z, lc);
         t[1] = make_float4(v1.x, v1.y, v1.z, 0.0f);
-        t[2] = make_float4(v2.x, v2.y, v2.z, 0.0f);
+        t[2] = make_float4(v2.x, v2.y, v2.z, id);
     } else {
         const float *sh = s.shape + (size_t)pr[1] * SHA_VEC;
         t[0] = make_float4(sh[1], sh[2], sh[3], lc);
         t[1] = make_float4(sh[4], sh[0], 0.0f, 0.0f);
-        t[2] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        t[2] = make_float4(0.0f, 0.0f, 0.0f, id);
     }
 }
 
@@ -490,7 +500,7 @@ __global__ void k_wide_dp(int N, const float *compact, const int *parent, int *f
 
 // level_off[L] / level_cnt[L]: first wide index and number of wide nodes of level L; queue holds the binary roots (compact
 // indices) of all wide nodes in breadth-first order (queue[w] for wide node w)
-__global__ void k_wide_level(SceneView s, const float *compact, const int *csize, const int *dp_dec, int level, int *level_off, int *level_cnt, int *queue, uint4 *cnode, float pad, GridMap gm)
+__global__ void k_wide_level(SceneView s, const int *prim_slot, const float *compact, const int *csize, const int *dp_dec, int level, int *level_off, int *level_cnt, int *queue, uint4 *cnode, float pad, GridMap gm)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
     const int n_in = level_cnt[level], off = level_off[level];
@@ -555,7 +565,7 @@ __global__ void k_wide_level(SceneView s, const float *compact, const int *csize
         int code = TR_EMPTY;
         if (c < nc) {
             const float *cn = compact + (size_t)cand[c] * CPN_VEC;
-            if ((((int)cn[0]) & 1) == 1) code = child_code(s, cn, cand[c]);
+            if ((((int)cn[0]) & 1) == 1) code = child_code(s, prim_slot, cn, cand[c]);
             else { queue[next_off + pos] = cand[c]; code = next_off + pos; pos++; }
             const bool leaf = code < 0;
             const bool shape = leaf && (((~code) >> 30) & 1) != 0;
@@ -600,7 +610,7 @@ static int build_wide(tirt_ctx *c, const float *compact, const int *csize, const
         for (; level < until; level++) {
             long cap = 1; for (int k = 0; k < level && cap < n; k++) cap *= 4;             // a level holds at most 4^level nodes
             if (cap > n) cap = n;
-            hipLaunchKernelGGL(k_wide_level, dim3((unsigned)((cap + 127) / 128)), dim3(128), 0, st, sv, compact, csize, dp_dec, level, lv_off, lv_cnt,
+            hipLaunchKernelGGL(k_wide_level, dim3((unsigned)((cap + 127) / 128)), dim3(128), 0, st, sv, c->prim_slot.as<int>(), compact, csize, dp_dec, level, lv_off, lv_cnt,
                                c->wide_queue.as<int>(), c->cnode.as<uint4>(), pad, gm);
         }
         TIRT_HIP(hipEventRecord(c->ev1, st));
@@ -649,7 +659,7 @@ int lbvh_build(tirt_ctx *c)
     if (c->parent.ensure(sizeof(int) * (size_t)N) || c->flag.ensure(sizeof(int) * (size_t)N) ||
         c->subtree.ensure(sizeof(int) * (size_t)N) || c->build_status.ensure(sizeof(int) * 32 * REFIT_SLOTS) ||
         c->leaf_compact.ensure(sizeof(int) * (size_t)n)) return TIRT_ERR_HIP;
-    if (c->wnode.ensure(sizeof(float4) * 4 * (size_t)N) || c->tri.ensure(sizeof(float4) * TRI_STRIDE * (size_t)n)) return TIRT_ERR_HIP;
+    if (c->wnode.ensure(sizeof(float4) * 4 * (size_t)N) || c->tri.ensure(sizeof(float4) * TRI_STRIDE * (size_t)n) || c->prim_slot.ensure(sizeof(int) * (size_t)n)) return TIRT_ERR_HIP;
     // 4-wide nodes: fewer than n of them; indices are used as 32-bit byte offsets / 64
     TIRT_REQUIRE(n <= (1 << 24), "tirt_lbvh_build: more than 16 Mi primitives");
     constexpr int WIDE_LEVELS_MAX = 2048;
@@ -694,8 +704,6 @@ int lbvh_build(tirt_ctx *c)
     float ex = root[8] - root[5], ey = root[9] - root[6], ez = root[10] - root[7];
     float diag = sqrtf(ex * ex + ey * ey + ez * ez);
     float pad = 1.0e-4f * diag;
-    hipLaunchKernelGGL(k_wnodes, dim3((N + B - 1) / B), dim3(B), 0, st, sv, N, c->compact.as<float>(), c->wnode.as<float4>(), pad);
-    hipLaunchKernelGGL(k_tris, dim3((n + B - 1) / B), dim3(B), 0, st, sv, c->leaf_compact.as<int>(), c->tri.as<float4>());
     // grid of the quantised nodes: the (padded) root box spans cells -TR_GRID_HALF .. +TR_GRID_HALF around its centre
     GridMap gm;
     for (int k = 0; k < 3; k++) {
@@ -707,13 +715,15 @@ int lbvh_build(tirt_ctx *c)
     }
     // surface-area collapse of the binary tree into 4-wide nodes, one launch per level of the wide tree (k_wide_level)
     c->wide_nodes = 0;
+    const float *tree = c->compact.as<float>(); const int *tree_size = c->csize.as<int>(), *tree_parent = c->cparent.as<int>();
+    if (n >= 2 && c->use_sah) {          // walk a better tree than the reference's (tirt_sah.hip); the hits stay the reference's (k_trace)
+        if (int rc = sah_build(c, va)) return rc;                                  // also fills prim_slot
+        tree = c->sah_compact.as<float>(); tree_size = c->sah_csize.as<int>(); tree_parent = c->sah_parent.as<int>();
+        c->built_sah = 1;
+    } else hipLaunchKernelGGL(k_slot_sorted, dim3((n + B - 1) / B), dim3(B), 0, st, n, va, c->prim_slot.as<int>());
+    hipLaunchKernelGGL(k_wnodes, dim3((N + B - 1) / B), dim3(B), 0, st, sv, c->prim_slot.as<int>(), N, c->compact.as<float>(), c->wnode.as<float4>(), pad);
+    hipLaunchKernelGGL(k_tris, dim3((n + B - 1) / B), dim3(B), 0, st, sv, c->leaf_compact.as<int>(), c->prim_slot.as<int>(), c->tri.as<float4>());
     if (n >= 2) {
-        const float *tree = c->compact.as<float>(); const int *tree_size = c->csize.as<int>(), *tree_parent = c->cparent.as<int>();
-        if (c->use_sah) {          // walk a better tree than the reference's (tirt_sah.hip); the hits stay the reference's (k_trace)
-            if (int rc = sah_build(c, va)) return rc;
-            tree = c->sah_compact.as<float>(); tree_size = c->sah_csize.as<int>(); tree_parent = c->sah_parent.as<int>();
-            c->built_sah = 1;
-        }
         if (int rc = build_wide(c, tree, tree_size, tree_parent, pad, gm)) return rc;
     } else TIRT_HIP(hipEventRecord(c->ev1, st));
     if (n == 1) {

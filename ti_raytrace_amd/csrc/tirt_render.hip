@@ -373,9 +373,9 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
         }
         if (leaf_now) {
             const int code = ~(from_pend ? pend : cur);
-            const int prim = code & 0x3fffffff;
-            const float4 *tp = b.tri + (size_t)prim * TRI_STRIDE;
+            const float4 *tp = b.tri + (size_t)(code & 0x3fffffff) * TRI_STRIDE;          // records in the traversal tree's leaf order
             const float4 ta = tp[0], tb = tp[1], tc = tp[2];
+            int prim = __float_as_int(tc.w);                                              // the primitive id rides in the last word
             if (COUNT) nleaf += 1;
             const v3 o = V(r.ox, r.oy, r.oz), d = V(r.dx, r.dy, r.dz);
             const bool is_tri = ((code >> 30) & 1) == 0;
@@ -424,6 +424,9 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
                 }
             }
 #endif
+            // (keeps `prim` in a register of its own across the ancestor walk: without this the compiler (ROCm 7.2 hipcc, -O3) lets the
+            // walk's 16-byte row loads overwrite it and an accepted hit that went through the walk keeps the PREVIOUS hit's primitive id)
+            asm volatile("" : "+v"(prim));
             if (cand) {
                 hit_t = t; hit_u = u; hit_v = v; hit_prim = prim; hit_leaf = leaf;
                 lim = __builtin_fminf(__builtin_fminf(hit_t * 1.0001f, cull_far), INF_VALUE);      // (v_min: a canonical value, so the node loop does not re-canonicalise it every step)

@@ -129,8 +129,10 @@ TD void sah_pick(const unsigned (*bin)[SAH_BINS][7], int count, bool halve, int 
     else { axis = -1; plane = 0; n_left = count / 2; }
 }
 
-TD void sah_write_leaf(float *compact, int *csize, int row_index, int prim, float4 a, float4 b)
+// (slot = the leaf's position in the index array = its rank among the leaves in depth-first order: where its primitive record goes)
+TD void sah_write_leaf(float *compact, int *csize, int *prim_slot, int row_index, int slot, int prim, float4 a, float4 b)
 {
+    prim_slot[prim] = slot;
     float *row = compact + (size_t)row_index * CPN_VEC;
     row[0] = 1.0f; row[1] = (float)prim; row[2] = a.x; row[3] = a.y; row[4] = a.z; row[5] = b.x; row[6] = b.y; row[7] = b.z; row[8] = 0.0f;
     csize[row_index] = 1;
@@ -188,7 +190,7 @@ __global__ __launch_bounds__(SAH_BLOCK) void k_sah_level(const float4 *__restric
                                                          const int *__restrict__ idx_in, int *__restrict__ idx_out,
                                                          const SahTask *__restrict__ tasks, const int *__restrict__ task_count,
                                                          SahTask *next_small, SahTask *next_large, int *next_count /* [0] small, [1] large */,
-                                                         float *compact, int *csize, int *parent, int halve)
+                                                         float *compact, int *csize, int *parent, int *prim_slot, int halve)
 {
     constexpr int TPB = 16 / WPT;            // tasks per block
     constexpr int G = 64 * WPT;              // threads per task
@@ -281,8 +283,9 @@ __global__ __launch_bounds__(SAH_BLOCK) void k_sah_level(const float4 *__restric
             __syncthreads();
         }
         if (active) {
-            idx_out[left ? start + off_l + rank_l : start + nl + off_r + rank_r] = p;
-            if ((left && nl == 1) || (!left && nr == 1)) sah_write_leaf(compact, csize, left ? pre + 1 : pre + 2 * nl, sorted_prims[p], a, b);
+            const int dst = left ? start + off_l + rank_l : start + nl + off_r + rank_r;
+            idx_out[dst] = p;
+            if ((left && nl == 1) || (!left && nr == 1)) sah_write_leaf(compact, csize, prim_slot, left ? pre + 1 : pre + 2 * nl, dst, sorted_prims[p], a, b);
         }
         off_l += tot_l; off_r += tot_r;
     }
@@ -407,7 +410,7 @@ __global__ __launch_bounds__(64) void k_sah_huge_eval(SahHuge *huge, const int *
 // partition of one chunk of a huge node (stable: the chunk's output offsets come from k_sah_huge_eval), the bounds of huge children
 __global__ __launch_bounds__(SAH_CHUNK) void k_sah_huge_part(const float4 *__restrict__ sbox, const int *__restrict__ sorted_prims, const int *__restrict__ idx_in, int *__restrict__ idx_out,
                                                               const SahHuge *__restrict__ huge, const int *__restrict__ lc, const int *__restrict__ chunk_task,
-                                                              const int *__restrict__ chunk_base, SahHuge *next_huge, float *compact, int *csize)
+                                                              const int *__restrict__ chunk_base, SahHuge *next_huge, float *compact, int *csize, int *prim_slot)
 {
     __shared__ int s_wcount[16][2];
     __shared__ unsigned s_b[2][12];
@@ -438,8 +441,9 @@ __global__ __launch_bounds__(SAH_CHUNK) void k_sah_huge_part(const float4 *__res
     __syncthreads();
     for (int w = 0; w < wave; w++) { rank_l += s_wcount[w][0]; rank_r += s_wcount[w][1]; }
     if (active) {
-        idx_out[left ? start + chunk_base[2 * (size_t)c] + rank_l : start + nl + chunk_base[2 * (size_t)c + 1] + rank_r] = p;
-        if ((left && nl == 1) || (!left && nr == 1)) sah_write_leaf(compact, csize, left ? pre + 1 : pre + 2 * nl, sorted_prims[p], a, b);
+        const int dst = left ? start + chunk_base[2 * (size_t)c] + rank_l : start + nl + chunk_base[2 * (size_t)c + 1] + rank_r;
+        idx_out[dst] = p;
+        if ((left && nl == 1) || (!left && nr == 1)) sah_write_leaf(compact, csize, prim_slot, left ? pre + 1 : pre + 2 * nl, dst, sorted_prims[p], a, b);
     }
     // bounds of the children that are huge again (the others measure themselves, k_sah_level)
     for (int side = 0; side < 2; side++) {
@@ -485,7 +489,7 @@ int sah_build(tirt_ctx *c, const int *sorted_prims)
     int *chunk_task[2] = {(int *)(hbins[1] + huge_cap * SAH_BIN_WORDS), (int *)(hbins[1] + huge_cap * SAH_BIN_WORDS) + chunk_cap};
     int *chunk_cnt = chunk_task[1] + chunk_cap, *chunk_base = chunk_cnt + chunk_cap * 3 * SAH_BINS;
     int *counts = c->sah_counts.as<int>();                 // counts[4 * level + (0 small | 1 large | 2 huge | 3 chunks)]
-    float *compact = c->sah_compact.as<float>(); int *csize = c->sah_csize.as<int>(), *parent = c->sah_parent.as<int>();
+    float *compact = c->sah_compact.as<float>(); int *csize = c->sah_csize.as<int>(), *parent = c->sah_parent.as<int>(), *prim_slot = c->prim_slot.as<int>();
 
     TIRT_HIP(hipMemsetAsync(counts, 0, sizeof(int) * 4 * (SAH_MAX_LEVELS + 2), st));
     SahHuge root_huge = {};
@@ -521,13 +525,13 @@ int sah_build(tirt_ctx *c, const int *sorted_prims)
                 hipLaunchKernelGGL(k_sah_huge_eval, dim3((unsigned)cap_huge), dim3(64), 0, st, huge[in], lc, hbins[in], chunk_cnt, chunk_base, huge[out], hbins[out], chunk_task[out],
                                    small[out], large[out], nc, compact, csize, parent, halve);
                 hipLaunchKernelGGL(k_sah_huge_part, dim3((unsigned)chunk_cap), dim3(SAH_CHUNK), 0, st, sbox, sorted_prims, idx[in], idx[out], huge[in], lc, chunk_task[in], chunk_base,
-                                   huge[out], compact, csize);
+                                   huge[out], compact, csize, prim_slot);
             }
             if (any_large)
                 hipLaunchKernelGGL(k_sah_level<16>, dim3((unsigned)cap_large), dim3(SAH_BLOCK), 0, st, sbox, sorted_prims, idx[in], idx[out], large[in], lc + 1,
-                                   small[out], large[out], nc, compact, csize, parent, halve);
+                                   small[out], large[out], nc, compact, csize, parent, prim_slot, halve);
             hipLaunchKernelGGL(k_sah_level<1>, dim3((unsigned)((cap_small + 15) / 16)), dim3(SAH_BLOCK), 0, st, sbox, sorted_prims, idx[in], idx[out], small[in], lc,
-                               small[out], large[out], nc, compact, csize, parent, halve);
+                               small[out], large[out], nc, compact, csize, parent, prim_slot, halve);
         }
         TIRT_HIP(hipMemcpyAsync(host_counts, counts, sizeof(host_counts), hipMemcpyDeviceToHost, st));
         TIRT_HIP(hipStreamSynchronize(st));

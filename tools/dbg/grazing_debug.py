@@ -5,7 +5,7 @@ import oracle_api as oa
 from common import tiny_scene, duplicate_code_scene
 from test_gpu_trace import _grazing_rays
 from ti_raytrace_amd import scenes, _native
-for name, make, n, seed in (("tiny", lambda: tiny_scene(3000, seed=31, W=48, H=48, spread=0.08, device_id=0), 900, 17), ("dup", lambda: duplicate_code_scene(W=48, H=48, device_id=0), 900, 17),
+for name, make, n, seed in (("cornell", lambda: scenes.cornell_box(48, 48, 4, device_id=0), 900, 17), ("tiny", lambda: tiny_scene(3000, seed=31, W=48, H=48, spread=0.08, device_id=0), 900, 17), ("dup", lambda: duplicate_code_scene(W=48, H=48, device_id=0), 900, 17),
                             ("100k", lambda: scenes.synthetic(64, 64, 4, device_id=0), 1500, 23)):
     ex = make(); ex.scene.setup_data_cpu()
     rays = _grazing_rays(ex, n, seed)
