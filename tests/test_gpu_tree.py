@@ -125,3 +125,51 @@ def test_cost_optimal_collapse_changes_no_bit(gpu_ctx_ok):
     assert out[0][3] != out[1][3], "the two groupings differ"
     for a, b in zip(out[0][:3], out[1][:3]):
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def _custom_scene(tris, W=24, H=24):
+    from ti_raytrace_amd import Example, PT_RGB
+    from ti_raytrace_amd import SceneData as SCD
+    ex = Example.example(W, H, 4, 0)
+    mat = SCD.Material()
+    mat.type = SCD.MAT_DISNEY
+    mat.setMetal(0.0); mat.setRough(0.5); mat.setColor([0.8, 0.8, 0.8, 1.0]); mat.alebdoTex = -1
+    ex.scene.add_mesh(np.asarray(tris, np.float64), mat)
+    ex.add_sphere_light(pos=(0.0, 3.0, 0.0), radius=0.75, emission=50.0)
+    ex.integrator = PT_RGB.PathTrace(W, H, ex.cam, ex.scene, 64)
+    return ex
+
+
+@pytest.mark.parametrize("kind", ["exponential", "identical", "two_clusters"])
+def test_traversal_tree_on_hostile_distributions(gpu_ctx_ok, kind):
+    """Inputs a binned SAH build handles badly: centroids spaced exponentially (every split peels off a few primitives: the tree
+    is as deep as the 64 levels after which ranges are halved), 3000 identical triangles (no plane separates anything: halving
+    from the root), two far-apart clusters of very different size.  The tree must still be a tree and the hits the oracle's."""
+    r = np.random.RandomState(7)
+    if kind == "exponential":
+        n = 300
+        c = np.zeros((n, 3)); c[:, 0] = 1.05 ** np.arange(n) * 1e-3; c[:, 1] = r.uniform(-1, 1, n) * c[:, 0]
+        tris = c[:, None, :] + r.uniform(-0.2, 0.2, (n, 3, 3)) * c[:, 0][:, None, None]
+    elif kind == "identical":
+        one = r.uniform(-1, 1, (3, 3))
+        tris = np.repeat(one[None], 3000, axis=0)
+    else:
+        a = r.uniform(-1, 1, (5000, 1, 3)) * 0.01 + r.uniform(-0.001, 0.001, (5000, 3, 3))
+        b = r.uniform(-1, 1, (40, 1, 3)) * 50.0 + 1000.0 + r.uniform(-5, 5, (40, 3, 3))
+        tris = np.concatenate([a, b], axis=0)
+    ex = _custom_scene(tris); ex.build_scene()
+    sc = ex.scene
+    check_tree(sc.ctx.traversal_tree_download(sc.primitive_count), prim_boxes(sc))
+    o = oa.OracleScene(sc, ex.cam); o.lbvh_build()
+    lo, hi = np.asarray(tris).reshape(-1, 3).min(axis=0), np.asarray(tris).reshape(-1, 3).max(axis=0)
+    org = r.uniform(lo - 0.1 * (hi - lo) - 1e-3, hi + 0.1 * (hi - lo) + 1e-3, (6000, 3))
+    T = np.asarray(tris)[r.randint(0, len(tris), 6000)]                     # aimed at a point inside a triangle
+    w = r.dirichlet((1.0, 1.0, 1.0), 6000)
+    tgt = (T * w[:, :, None]).sum(axis=1)
+    d = tgt - org; d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.concatenate([org, d], axis=1).astype(np.float32)
+    want, wprim, _ = o.closest_hit(rays, stack_size=16384)      # (5000 primitives in one Morton cell: a chain as deep in the reference tree)
+    got, gprim, _ = sc.ctx.trace_closest(rays, 64, 0)
+    assert (wprim >= 0).mean() > 0.02        # (aimed from far away in fp32: the small cluster is mostly missed, in the oracle as on the device)
+    assert np.array_equal(gprim, wprim) and np.array_equal(got[:, 0].view(np.uint32), want[:, 0].view(np.uint32))
+    assert sc.ctx.stats()["stack_overflow"] == 0
