@@ -221,7 +221,7 @@ struct tirt_ctx {
     // BDPT_RGB: persistent per-pixel vertex arrays + per-frame radiance (splat target)
     tirt::DevBuf bdpt_px, bdpt_rad;               // bdpt_px: per-pixel memory of the eye vertices' `delta` fields (what persists from frame to frame)
     tirt::DevBuf bdpt_items, bdpt_state, bdpt_rays, bdpt_hits, bdpt_qidx, bdpt_ctr;   // wavefront batch: vertex arrays per (frame, pixel), step state, rays, hits
-    size_t bdpt_batch_items = (size_t)2 << 20;   // option "bdpt_batch_items": (frame, pixel) items per wavefront batch
+    size_t bdpt_batch_items = (size_t)8 << 20;   // option "bdpt_batch_items": (frame, pixel) items per wavefront batch
     int bdpt_bounded = 1;                          // option "bdpt_bounded": connection rays stop at their target distance
 
     // batch trace scratch
