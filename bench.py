@@ -261,6 +261,11 @@ def main():
         build_detail["with_sah_traversal_tree_ms" if tree else "lbvh_only_ms"] = round(build_ms, 3)
     fps = args.frames_per_step
 
+    # what the example classes tell the library at set-up (Example.build_scene: their sample count): the frames of the job ahead -- it
+    # sizes its wavefront batches and lane buffers by that (tirt_internal.h, plan_batches).  Here: the timed job; the warm-up step
+    # before it is a job of its own.
+    ctx.set_option("job_frames", args.steps * fps)
+
     def barrier():
         ctx.sync()
         torch.cuda.synchronize()

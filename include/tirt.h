@@ -75,10 +75,12 @@ int tirt_sync(tirt_ctx *ctx);
  *          "merge_paths" -- consecutive tirt_pt_rgb_render calls over contiguous frames are merged
  *            until this many pixel-samples are pending (default 32 Mi = one full batch; 0 submits every call at once);
  *            every other entry point submits what is pending first
- *          "job_frames" -- hint: frames the whole job will render (0 = unknown, default); lane buffers are then not
- *            sized for merging more than that (a 512^2 x 8 spp job does not allocate 32 Mi-path lanes)
- *          "batch_paths" -- pixel-samples kept in flight per wavefront batch (default 32 Mi,
- *            196 B of HBM each)
+ *          "job_frames" -- hint: frames the whole job will render (0 = unknown, default).  With it (and no explicit batch_paths)
+ *            the job is cut into as few wavefront batches as fit 128 Mi pixel-samples each, at least two, a multiple of the
+ *            lane count beyond four; lane buffers are sized for that and only as many lanes get one (a 512^2 x 8 spp job does
+ *            not allocate 32 Mi-path lanes).  Set it before the first render call of the job
+ *          "batch_paths" -- pixel-samples kept in flight per wavefront batch (default 32 Mi, or planned from "job_frames";
+ *            196 B of HBM each, lanes hold 1.5 x that)
  *          "split_lone_batch" (0 = off, or the number of parts 2..8; default 2) -- a context that owns 1/6 or less of the film
  *            (tile_count >= 6) and whose whole job is one batch runs it as that many smaller batches on as many lanes
  *          "traversal_tree" (0/1, default 1) -- the tree tirt_lbvh_build collapses into the 4-wide traversal nodes: 1 = a binned-SAH

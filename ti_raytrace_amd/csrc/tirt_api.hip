@@ -343,10 +343,10 @@ int tirt_set_option(tirt_ctx *c, const char *name, double value)
         c->use_sah = (int)value; return TIRT_OK;
     }
     if (!strcmp(name, "job_frames")) { TIRT_REQUIRE(value >= 0.0 && value <= 1.0e9, "job_frames out of range"); c->job_frames = (long)value; return TIRT_OK; }
-    if (!strcmp(name, "merge_paths")) { TIRT_REQUIRE(value >= 0.0 && value <= 1.0e9, "merge_paths out of range"); c->merge_paths = (size_t)value; return TIRT_OK; }
+    if (!strcmp(name, "merge_paths")) { TIRT_REQUIRE(value >= 0.0 && value <= 1.0e9, "merge_paths out of range"); c->merge_paths = (size_t)value; c->merge_user = true; return TIRT_OK; }
     if (!strcmp(name, "batch_paths")) {
         TIRT_REQUIRE(value >= 1.0 && value <= 1.0e9, "tirt_set_option: batch_paths out of range");
-        c->batch_paths = (size_t)value; return TIRT_OK;
+        c->batch_paths = (size_t)value; c->batch_user = true; return TIRT_OK;
     }
     if (!strcmp(name, "trace_lds_depth")) {
         TIRT_REQUIRE(value >= 12 && value <= 64, "trace_lds_depth: 12..64");
@@ -602,7 +602,7 @@ int tirt_pt_rgb_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint3
         p.valid = true; p.begin = frame_begin; p.count = frame_count; p.seed = seed;
         p.max_depth = max_depth; p.stack_size = stack_size; p.flags = flags;
     }
-    if ((size_t)p.count * (size_t)(c->npix_local > 0 ? c->npix_local : 1) >= c->merge_paths) return flush_pending(c);
+    if ((size_t)p.count * (size_t)(c->npix_local > 0 ? c->npix_local : 1) >= effective_merge_paths(c)) return flush_pending(c);
     return TIRT_OK;
 }
 

@@ -209,6 +209,7 @@ struct tirt_ctx {
     size_t merge_paths = (size_t)32 << 20;         // option "merge_paths" (0 = submit every call at once)
     unsigned batches_since_sync = 0;               // wavefront batches submitted since the last sync_all
     int split_lone = 2;                            // option "split_lone_batch": a job that is one batch runs as two halves on two lanes
+    bool batch_user = false, merge_user = false;   // batch_paths / merge_paths were set through tirt_set_option: no automatic sizing
     long job_frames = 0;                           // option "job_frames": expected frames of the whole job (0 = unknown); bounds the head-room
     struct { bool valid = false; uint32_t begin = 0; int count = 0; uint32_t seed = 0; int max_depth = 0, stack_size = 0, flags = 0; } pend;
     // traversal tunables (options "trace_lds_depth", "trace_refill_min", "trace_node_min", "trace_grid",
@@ -242,6 +243,30 @@ namespace tirt {
 SceneView scene_view(const tirt_ctx *c);
 BvhView bvh_view(const tirt_ctx *c);
 int lbvh_build(tirt_ctx *c);
+// Pixel-samples per wavefront batch and the lanes they run on.  Without a hint: batch_paths (32 Mi) on all lanes.  With the
+// "job_frames" hint and no explicit batch_paths, the job is cut into as few batches as fit 128 Mi paths each, at least two (two
+// batches of the largest size overlap each other's per-bounce tails as well as four smaller ones, and every launch is
+// fuller), in multiples of the lane count beyond that so that no batch runs alone at the end.  Measured on one GPU with a
+// 256 Mi-path job: 8 x 32 Mi 3 965, 4 x 64 Mi 4 037, 2 x 128 Mi 4 071 Mrays/s; rank 0's share of a 2 / 4 / 8-GPU job is
+// best as two batches as well (2 x 64, 2 x 32, 2 x 16 Mi).
+struct BatchPlan { size_t batch; int lanes; };
+inline BatchPlan plan_batches(const tirt_ctx *c)
+{
+    BatchPlan p = {c->batch_paths, c->n_lanes};
+    if (!c->batch_user && c->job_frames > 0 && c->npix_local > 0) {
+        const size_t P = (size_t)c->npix_local, J = (size_t)c->job_frames * P, MAXB = (size_t)128 << 20;
+        if (J >= ((size_t)24 << 20)) {
+            const size_t nb_min = (J + MAXB - 1) / MAXB, L = (size_t)(c->n_lanes > 0 ? c->n_lanes : 1);
+            const size_t nb = nb_min <= 2 ? 2 : (nb_min <= L ? nb_min : L * ((nb_min + L - 1) / L));
+            size_t frames = ((size_t)c->job_frames + nb - 1) / nb;
+            p.batch = frames * P;
+            p.lanes = (int)(nb < L ? nb : L);
+        }
+    }
+    return p;
+}
+inline size_t effective_batch_paths(const tirt_ctx *c) { return plan_batches(c).batch; }
+inline size_t effective_merge_paths(const tirt_ctx *c) { return (c->merge_user || c->merge_paths == 0) ? c->merge_paths : effective_batch_paths(c); }
 int sah_build(tirt_ctx *c, const int *sorted_prims);      // tirt_sah.hip
 #ifdef TIRT_EXPERIMENTS
 int exp_wide_from_tree(tirt_ctx *c, const float *compact_host, const int *csize_host);     // tools/exp/sah_tree.py

@@ -905,7 +905,10 @@ int pt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed,
     const int P = (int)c->npix_local;
     // frames per batch: up to batch_paths pixel-samples in flight (the per-bounce launches of a
     // batch end in a latency-bound tail of a few long rays, so bigger batches amortise it)
-    int FB = (int)(c->batch_paths / (size_t)P); if (FB < 1) FB = 1; if (FB > frame_count) FB = frame_count;
+    const size_t batch_paths = effective_batch_paths(c), merge_paths = effective_merge_paths(c);
+    // batches of equal size, as many as come closest to the planned size (up to 1.5 x it: never a full batch and a sliver)
+    int FB;
+    { size_t nb = ((size_t)frame_count * P + batch_paths / 2) / batch_paths; if (nb < 1) nb = 1; FB = (int)((frame_count + nb - 1) / nb); }
     // A rank of a wide multi-GPU job renders its whole share as ONE batch, with nothing to overlap the per-bounce tails with:
     // as two half batches on two lanes it is 3.4 % faster at 8 ranks (measured on one GPU rendering rank 0's tiles; at 4 ranks
     // and below, and for a single GPU's stream of full batches, the halves lose 1-9 %: there 32 Mi-path batches win).
@@ -921,15 +924,15 @@ int pt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed,
     // everything queued on the main stream (uploads, film clear, tone map) precedes the lanes' work
     TIRT_HIP(hipEventRecord(c->ev_main, c->stream));
     int n_lanes = c->time_kernels ? 1 : c->n_lanes;
+    { const int need = plan_batches(c).lanes + 1; if (need < n_lanes) n_lanes = need; }      // a job of two big batches needs path state on two lanes (+ one for a call the hint did not cover), not on all
 
     // all lanes get their buffers up front (an allocation inside a later call would stall the pipeline)
     // sized for what deferred submission can merge later (merge_paths + one call), so that a bigger
     // merged batch does not re-allocate in the middle of a job; small films skip the head-room
     int spill_depth = 0;
     size_t cap = (size_t)FB * P;
-    if (c->merge_paths > 0 && P >= 65536) {
-        size_t want = c->merge_paths + (size_t)frame_count * P;
-        if (want > c->batch_paths) want = c->batch_paths;
+    if (merge_paths > 0 && P >= 65536) {
+        size_t want = batch_paths + batch_paths / 2;        // the largest batch a call can become (the same for every call: a lane never re-allocates mid-job)
         // "job_frames" hint (the example classes pass their sample count): a short job never merges more than itself
         if (c->job_frames > 0 && want > (size_t)c->job_frames * P) want = (size_t)c->job_frames * P;
         want = (want / P) * P;
