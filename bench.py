@@ -95,7 +95,10 @@ def measure_hbm_traffic(args):
     tmp = tempfile.mkdtemp(prefix="tirt_pmc_", dir="/tmp")
     child = [sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "1", "--frames-per-step", str(args.frames_per_step),
              "--size", str(args.size), "--ntri", str(args.ntri), "--seed", str(args.seed), "--no-cpu-baseline", "--no-roofline",
-             "--opt", "overlap_lanes=1"] + sum((["--opt", o] for o in args.opt), [])
+             "--opt", "overlap_lanes=1",
+             # one batch per step, as in the instrumented pass whose launch duration the bytes are divided by
+             "--opt", "batch_paths=%d" % (args.frames_per_step * args.size * args.size),
+             "--opt", "merge_paths=%d" % (args.frames_per_step * args.size * args.size)] + sum((["--opt", o] for o in args.opt), [])
     def one_pass(counters):
         d = os.path.join(tmp, counters[0])
         cmd = ["timeout", "-k", "5", "240", exe, "--kernel-trace", "--pmc"] + list(counters) + ["--output-format", "csv", "-d", d, "--"] + child

@@ -9,6 +9,6 @@ timeout 900 python tools/big_scene_check.py 1000000 > gpurun_out/${T}_big1m.log 
 timeout 900 python tools/big_scene_check.py 4000000 > gpurun_out/${T}_big4m.log 2>&1
 bash tools/pmc_passes.sh $T
 cd /tmp && export TMPDIR=/tmp
-timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${T}_stats1lane -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --opt overlap_lanes=1 > $R/gpurun_out/${T}_stats1lane.log 2>&1
+timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${T}_stats1lane -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --opt overlap_lanes=1 --opt batch_paths=33554432 --opt merge_paths=33554432 > $R/gpurun_out/${T}_stats1lane.log 2>&1
 cd $R; bash tools/pmc_mem.sh ${T}mem
 echo done

@@ -2,7 +2,7 @@
 # block, each pass under its own timeout): bash tools/pmc_mem.sh <tag>
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; T=${1:-mem}
-B="python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --opt overlap_lanes=1"
+B="python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --opt overlap_lanes=1 --opt batch_paths=33554432 --opt merge_paths=33554432"
 p() { n=$1; shift; timeout -k 5 150 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $R/gpurun_out/${T}_$n -- $B > $R/gpurun_out/${T}_$n.log 2>&1; echo "pass $n rc=$?"; }
 p a GRBM_GUI_ACTIVE TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum
 p b TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum
