@@ -363,9 +363,9 @@ int tirt_set_option(tirt_ctx *c, const char *name, double value)
         int l = 0; while ((1 << l) < iv) l++;
         c->tr_slice_log2 = l; return TIRT_OK;
     }
-    if (!strcmp(name, "shade_grid")) { TIRT_REQUIRE(value >= 1 && value <= 65536, "shade_grid: 1..65536"); c->sh_grid = (int)value; return TIRT_OK; }
+    if (!strcmp(name, "shade_grid")) { TIRT_REQUIRE(value >= 1 && value <= 65536, "shade_grid: 1..65536"); c->sh_grid = (int)value; c->grid_user = true; return TIRT_OK; }
     if (!strcmp(name, "trace_grid_alone")) { TIRT_REQUIRE(value >= 1 && value <= 2048, "trace_grid_alone: 1..2048"); c->tr_grid_alone = (int)value; return TIRT_OK; }
-    if (!strcmp(name, "trace_grid")) { TIRT_REQUIRE(value >= 1 && value <= 2048, "trace_grid: 1..2048"); c->tr_grid = (int)value; return TIRT_OK; }
+    if (!strcmp(name, "trace_grid")) { TIRT_REQUIRE(value >= 1 && value <= 2048, "trace_grid: 1..2048"); c->tr_grid = (int)value; c->grid_user = true; return TIRT_OK; }
     set_error(std::string("tirt_set_option: unknown option ") + name);
     return TIRT_ERR_ARG;
 }

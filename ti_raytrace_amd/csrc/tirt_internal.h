@@ -209,6 +209,7 @@ struct tirt_ctx {
     size_t merge_paths = (size_t)32 << 20;         // option "merge_paths" (0 = submit every call at once)
     unsigned batches_since_sync = 0;               // wavefront batches submitted since the last sync_all
     int split_lone = 2;                            // option "split_lone_batch": a job that is one batch runs as two halves on two lanes
+    bool grid_user = false;                        // trace_grid / shade_grid were set through tirt_set_option
     bool batch_user = false, merge_user = false;   // batch_paths / merge_paths were set through tirt_set_option: no automatic sizing
     long job_frames = 0;                           // option "job_frames": expected frames of the whole job (0 = unknown); bounds the head-room
     struct { bool valid = false; uint32_t begin = 0; int count = 0; uint32_t seed = 0; int max_depth = 0, stack_size = 0, flags = 0; } pend;

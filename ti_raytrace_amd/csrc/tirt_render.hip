@@ -978,9 +978,14 @@ int pt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed,
         // blocks, so that both traversal kernels find LDS on the CUs; a batch submitted to an idle GPU takes them all
         bool busy = false;
         if (c->last_film) { busy = hipEventQuery(c->last_film) == hipErrorNotReady; (void)hipGetLastError(); }
-        const int grid_cap = (busy && n_lanes > 1) ? c->tr_grid : c->tr_grid_alone;
+        // (two big batches side by side -- what plan_batches makes of a hinted job -- do best with all persistent blocks each and
+        // twice the shading blocks: +2 % for 2 x 128 / 64 / 32 Mi paths; four batches in flight, or two small ones, do not: -2 %)
+        const BatchPlan plan = plan_batches(c);
+        const bool two_big = plan.lanes <= 2 && plan.batch >= ((size_t)24 << 20) && !c->grid_user;
+        const int grid_cap = (busy && n_lanes > 1 && !two_big) ? c->tr_grid : c->tr_grid_alone;
         int grid_full = (S + TR_BLOCK - 1) / TR_BLOCK; if (grid_full > grid_cap) grid_full = grid_cap;
-        int grid_shade = (S + SH_BLOCK - 1) / SH_BLOCK; if (grid_shade > c->sh_grid) grid_shade = c->sh_grid;
+        const int sh_cap = two_big ? 2 * c->sh_grid : c->sh_grid;
+        int grid_shade = (S + SH_BLOCK - 1) / SH_BLOCK; if (grid_shade > sh_cap) grid_shade = sh_cap;
         v3 eye_v; eye_v.x = c->cam.eye[0]; eye_v.y = c->cam.eye[1]; eye_v.z = c->cam.eye[2];
         for (int b = 0; b < max_depth; b++) {
             const PathSoA &in = L.ps.st[b & 1], &out = L.ps.st[(b + 1) & 1];
