@@ -1790,15 +1790,30 @@ int orc_bdpt_render(const orc_scene *s, orc_bdpt *B, uint32_t frame_begin, int f
             st.paths++;
             int eye_depth = bd_eye_path(s, P, i, j, H, frame, seed, stack, stack_size, &st);
             int light_depth = bd_light_path(s, P, i, j, H, frame, seed, stack, stack_size, &st);
+            const uint64_t shadow_before = st.rays_shadow;
             for (int e = 1; e <= eye_depth; e++) {
                 for (int l = 0; l <= light_depth; l++) {
                     int depth = l + e - 2;
                     if (((l == 1) & (e == 1)) | (depth < 0) | (depth > BD_MAX_DEPTH)) continue;
                     int nu, nv;
+                    const uint64_t sh0__ = st.rays_shadow;
                     v3 r = bd_connect_path(s, B, P, i, j, e, l, frame, seed, stack, stack_size, &st, &nu, &nv);
+                    if (getenv("ORC_BDPT_PIXEL") && atol(getenv("ORC_BDPT_PIXEL")) == p && f == frame_count - 1) {
+                        fprintf(stderr, "pixel %ld frame %u e %d l %d: shadow rays %d, r = %g %g %g\n", p, frame, e, l, (int)(st.rays_shadow - sh0__), r.x, r.y, r.z);
+                        if (e == 1 && l == 0) {
+                            for (int k = 0; k < BD_EYE_MAX; k++) fprintf(stderr, "   eye[%d] type %d prim %d mat %d delta %d beta %g %g %g fpdf %g rpdf %g pos %g %g %g\n", k, P->eye[k].type, P->eye[k].prim, P->eye[k].mat, P->eye[k].delta, P->eye[k].beta.x, P->eye[k].beta.y, P->eye[k].beta.z, P->eye[k].fpdf, P->eye[k].rpdf, P->eye[k].pos.x, P->eye[k].pos.y, P->eye[k].pos.z);
+                            for (int k = 0; k < BD_LIGHT_MAX; k++) fprintf(stderr, "   light[%d] type %d prim %d mat %d delta %d beta %g %g %g fpdf %g rpdf %g\n", k, P->light[k].type, P->light[k].prim, P->light[k].mat, P->light[k].delta, P->light[k].beta.x, P->light[k].beta.y, P->light[k].beta.z, P->light[k].fpdf, P->light[k].rpdf);
+                        }
+                    }
                     long q = (e == 1) ? ((nu >= 0) ? (long)nu * H + nv : -1) : p;
                     if (q >= 0) { radiance[3 * q] += r.x; radiance[3 * q + 1] += r.y; radiance[3 * q + 2] += r.z; }
                 }
+            }
+            /* debugging aid (tools/dbg/bdpt_counts.py): connection rays per pixel of the last frame, eye / light depths */
+            if (getenv("ORC_BDPT_DUMP") && f == frame_count - 1) {
+                static FILE *fp = NULL;
+                if (p == 0) { if (fp) fclose(fp); fp = fopen(getenv("ORC_BDPT_DUMP"), "w"); }
+                if (fp) { fprintf(fp, "%ld %d %d %d\n", p, (int)(st.rays_shadow - shadow_before), eye_depth, light_depth); if (p == (long)W * H - 1) { fclose(fp); fp = NULL; } }
             }
         }
         float ff = (float)(int32_t)frame, coff = 1.0f / (ff + 1.0f);

@@ -171,3 +171,31 @@ def test_bdpt_on_a_deep_duplicate_chain(gpu_ctx_ok):
     m = np.isfinite(want).all(axis=2) & np.isfinite(got).all(axis=2)
     assert (np.isfinite(want).all(axis=2) == np.isfinite(got).all(axis=2)).all() and rel_l2(got[m], want[m]) <= 1e-3
     assert st["rays_closest"] == ost["rays_closest"] and st["rays_shadow"] == ost["rays_shadow"] and st["stack_overflow"] == 0
+
+
+def test_bdpt_batching_and_lanes_change_nothing(gpu_ctx_ok):
+    """6 frames as one batch on the main stream, as batches of one frame alternating between the two BDPT lanes (the `delta`
+    memory of k_bd_delta and the running mean of the film are chained from batch to batch), and as two batches of three: the same
+    ray counts and films within the float-atomic order of the splats; the oracle's frame-by-frame render agrees."""
+    W = H = 48
+    films, counts = [], []
+    for items, lanes in ((1 << 29, 1), (W * H * 2, 4), (W * H * 6, 4)):        # one batch | 1 frame per lane batch | 3 frames per lane batch
+        ex = scenes.veach_bdpt(W, H, 8, device_id=0)
+        ex.build_scene()
+        ctx = ex.scene.ctx
+        ctx.set_option("bdpt_batch_items", items); ctx.set_option("overlap_lanes", lanes)
+        ctx.stats_reset()
+        ctx.bdpt_rgb_render(0, 6, 1)
+        st = ctx.stats()
+        films.append(ctx.film_download(W, H)[0]); counts.append((st["rays_closest"], st["rays_shadow"]))
+    assert counts[0] == counts[1] == counts[2]
+    m = np.isfinite(films[0]).all(axis=2)
+    for f in films[1:]:
+        assert (np.isfinite(f).all(axis=2) == m).all()
+        assert rel_l2(f[m], films[0][m]) <= 1e-5
+    o = oa.OracleScene(ex.scene, ex.cam); o.lbvh_build()
+    o.process_normal(ex.scene.vertex_index_np)
+    want, ost, _ = o.bdpt_render(ex.cam, W, H, 0, 6, seed=1)
+    mm = m & np.isfinite(want).all(axis=2)
+    assert mm.mean() > 0.95 and rel_l2(films[1][mm], want[mm]) <= 1e-3
+    assert counts[1] == (ost["rays_closest"], ost["rays_shadow"])

@@ -295,9 +295,14 @@ void tirt_destroy(tirt_ctx *c)
                       &c->keys_b, &c->vals_a, &c->vals_b, &c->hist, &c->morton_sorted, &c->bvh_node, &c->compact, &c->parent,
                       &c->flag, &c->subtree, &c->build_status, &c->leaf_compact, &c->wnode, &c->tri, &c->prim_slot, &c->cnode, &c->cparent, &c->csize, &c->wide_queue, &c->wide_levels, &c->sah_compact, &c->sah_csize, &c->sah_parent, &c->wide_dp, &c->sah_box, &c->sah_idx, &c->sah_tasks, &c->sah_counts, &c->hdr, &c->rgb,
                       &c->counters_mem, &c->spill, &c->tr_rays,
-                      &c->tr_out, &c->tr_prim, &c->tr_counts, &c->dev_counters, &c->bdpt_px, &c->bdpt_rad, &c->bdpt_items, &c->bdpt_state,
-                      &c->bdpt_rays, &c->bdpt_hits, &c->bdpt_qidx, &c->bdpt_ctr};
+                      &c->tr_out, &c->tr_prim, &c->tr_counts, &c->dev_counters, &c->bdpt_px};
     for (DevBuf *b : bufs) b->release();
+    for (auto &bl : c->bd) {
+        DevBuf *bb[] = {&bl.items, &bl.state, &bl.rays, &bl.hits, &bl.qidx, &bl.ctr, &bl.rad};
+        for (DevBuf *b : bb) b->release();
+        if (bl.delta_done) (void)hipEventDestroy(bl.delta_done);
+        if (bl.film_done) (void)hipEventDestroy(bl.film_done);
+    }
     for (Lane &L : c->lanes) {
         DevBuf *lb[] = {&L.path_mem, &L.counters_mem, &L.spill};
         for (DevBuf *b : lb) b->release();
@@ -449,7 +454,7 @@ int tirt_exp_download(tirt_ctx *c, int which, void *out, uint64_t bytes)
 {
     CTX(c);
     if (sync_all(c)) return TIRT_ERR_HIP;
-    DevBuf *b = which == 0 ? &c->tri : which == 1 ? &c->prim_slot : which == 2 ? &c->leaf_compact : which == 3 ? &c->cnode : &c->cparent;
+    DevBuf *b = which == 0 ? &c->tri : which == 1 ? &c->prim_slot : which == 2 ? &c->leaf_compact : which == 3 ? &c->cnode : which == 5 ? &c->bd[0].qidx : &c->cparent;
     TIRT_REQUIRE(bytes <= b->bytes, "tirt_exp_download: too many bytes");
     TIRT_HIP(hipMemcpy(out, b->p, bytes, hipMemcpyDeviceToHost));
     return TIRT_OK;

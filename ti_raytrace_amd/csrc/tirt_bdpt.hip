@@ -20,7 +20,8 @@
 // field that the current frame has not written shows a single one that matters: the `delta` flag of an eye vertex
 // that ended on a light (eye_path breaks before it stores delta there, BDPT_RGB.py:152-158) is the delta some earlier
 // frame left in that slot, and connect_path's l == 1 branch reads it.  k_bd_delta replays exactly that: per pixel, in
-// frame order, over a small persistent per-pixel memory of the seven delta fields (`bdpt_px`).  Everything else
+// frame order, over a small persistent per-pixel memory of the seven delta fields (`bdpt_px`) -- every surface vertex's store
+// counts, including the one of a vertex whose sampling ended the path and which the returned depth therefore leaves out.  Everything else
 // (sample/temp vertices of mis_weight, geometry of slots beyond the current depth) is written before it is read.
 // Other reference behaviours kept on purpose (see oracle/oracle.c for the same list): material INDEX compared with
 // MAT_DISNEY in mis_weight; restores to index -1 skipped.  Light-tracing contributions are added to other pixels with
@@ -568,9 +569,12 @@ __global__ void k_bd_delta(bpixel *items, const BdStep *steps, TileMap tm, int P
         const size_t it = (size_t)f * P + k;
         bvert *eye = items[it].eye;
         const int ed = steps[it].eye_depth;
-        for (int v = 1; v < ed && v < BD_EYE_MAX; v++) {
+        // v == ed: a surface vertex whose sampling ended the path (pdf 0, or the extinction roulette of a refraction) is not counted
+        // in the depth, but its delta has been stored (BDPT_RGB.py:160-187) -- the batch's vertex arrays start as zeros, so a
+        // SURFACE type there was written by this frame
+        for (int v = 1; v <= ed && v < BD_EYE_MAX; v++) {
             if (eye[v].type == VERTEX_SURFACE) mem[v] = eye[v].delta;
-            else if (eye[v].type == VERTEX_LIGHT) eye[v].delta = mem[v];
+            else if (v < ed && eye[v].type == VERTEX_LIGHT) eye[v].delta = mem[v];
         }
     }
 }
@@ -685,64 +689,97 @@ int bdpt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t see
         TIRT_HIP(hipMemsetAsync(c->bdpt_px.p, 0, sizeof(int) * 8 * (size_t)NP, st));
     }
     if (P == 0) return TIRT_OK;
+    // Two batches in flight on the streams of render lanes 0 and 1 (when the job has more than one batch): the traversal launches
+    // of one (VALU-bound) run next to the vertex / connection kernels of the other (HBM-bound).  What is order dependent --
+    // k_bd_delta's per-pixel memory and the running mean of the film -- is chained through events, batch after batch.
     int FB = (int)(c->bdpt_batch_items / (size_t)P); if (FB < 1) FB = 1; if (FB > frame_count) FB = frame_count;
+    int NL = 1;
+    if (c->n_lanes >= 2 && !c->time_kernels && frame_count >= 2 && (size_t)frame_count * P >= ((size_t)1 << 20)) {
+        NL = 2;
+        int half = (int)(c->bdpt_batch_items / 2 / (size_t)P); if (half < 1) half = 1;
+        if (FB > half) FB = half;                                   // the two lanes share the batch budget
+        if (FB > (frame_count + 1) / 2) FB = (frame_count + 1) / 2;
+    }
+    { const int nb = (frame_count + FB - 1) / FB; FB = (frame_count + nb - 1) / nb; }       // batches of equal size
     const size_t NMAX = (size_t)FB * P;
     TIRT_REQUIRE(NMAX * BD_PAIRS < ((size_t)1 << 31), "tirt_bdpt_rgb_render: film too large for one frame per batch");
     const size_t SCAP = NMAX * 27;                               // at most 27 (e, l) pairs per item carry a connection ray (staging: [27][N])
-    if (c->bdpt_items.ensure(sizeof(bpixel) * NMAX) || c->bdpt_state.ensure(sizeof(BdStep) * NMAX) ||
-        c->bdpt_rays.ensure(sizeof(float) * (6 * 2 * NMAX + 16 * SCAP)) || c->bdpt_hits.ensure(sizeof(float4) * (2 * NMAX + SCAP)) ||
-        c->bdpt_qidx.ensure(sizeof(int) * NMAX * (BD_PAIRS + 2)) || c->bdpt_ctr.ensure(256) ||
-        c->bdpt_rad.ensure(sizeof(float) * 3 * (size_t)NP * (size_t)FB)) return TIRT_ERR_HIP;
+    for (int l = 0; l < NL; l++) {
+        auto &bl = c->bd[l];
+        if (bl.items.ensure(sizeof(bpixel) * NMAX) || bl.state.ensure(sizeof(BdStep) * NMAX) ||
+            bl.rays.ensure(sizeof(float) * (6 * 2 * NMAX + 16 * SCAP)) || bl.hits.ensure(sizeof(float4) * (2 * NMAX + SCAP)) ||
+            bl.qidx.ensure(sizeof(int) * NMAX * (BD_PAIRS + 2)) || bl.ctr.ensure(256) ||
+            bl.rad.ensure(sizeof(float) * 3 * (size_t)NP * (size_t)FB)) return TIRT_ERR_HIP;
+        if (!bl.delta_done) TIRT_HIP(hipEventCreateWithFlags(&bl.delta_done, hipEventDisableTiming));
+        if (!bl.film_done) TIRT_HIP(hipEventCreateWithFlags(&bl.film_done, hipEventDisableTiming));
+    }
     BdCtx bc;
     bc.sc = scene_view(c); bc.cam = c->cam; bc.seed = seed; bc.bounded = c->bdpt_bounded;
     for (int k = 0; k < 12; k++) bc.bv.view[k] = c->view[k];
     bc.bv.W = c->W; bc.bv.H = c->H;
     DevCounters *ctr = c->dev_counters.as<DevCounters>();
     const TileMap tm = {c->tile_rank, c->tile_count, c->tile_size, c->H};
-    float *rf = c->bdpt_rays.as<float>();
-    BdRays er = {rf, rf + 2 * NMAX, rf + 4 * NMAX, rf + 6 * NMAX, rf + 8 * NMAX, rf + 10 * NMAX};
-    float *sf = rf + 12 * NMAX;
-    BdRays sr = {sf, sf + SCAP, sf + 2 * SCAP, sf + 3 * SCAP, sf + 4 * SCAP, sf + 5 * SCAP};
-    int *sexpect = (int *)(sf + 6 * SCAP); float *sbound = sf + 7 * SCAP;
-    float *gf = sf + 8 * SCAP;                                   // staging arrays, [slot j][item]
-    BdRays gr = {gf, gf + SCAP, gf + 2 * SCAP, gf + 3 * SCAP, gf + 4 * SCAP, gf + 5 * SCAP};
-    int *gexpect = (int *)(gf + 6 * SCAP); float *gbound = gf + 7 * SCAP;
-    int *ibase = c->bdpt_qidx.as<int>() + NMAX * BD_PAIRS, *icount = ibase + NMAX;
-    float4 *ehits = c->bdpt_hits.as<float4>(), *shits = ehits + 2 * NMAX;
-    int *scount = c->bdpt_ctr.as<int>();
     const int B = 128;
-    for (int f0 = 0; f0 < frame_count; f0 += FB) {
+    // everything queued on the main stream so far precedes the lanes' work
+    if (NL > 1) { TIRT_HIP(hipEventRecord(c->ev_main, c->stream)); for (int l = 0; l < NL; l++) TIRT_HIP(hipStreamWaitEvent(c->lanes[l].stream, c->ev_main, 0)); }
+    hipEvent_t last_delta = nullptr, last_film = nullptr;
+    int batch = 0;
+    for (int f0 = 0; f0 < frame_count; f0 += FB, batch++) {
+        const int lane = NL > 1 ? (batch & 1) : -1;
+        auto &bl = c->bd[NL > 1 ? (batch & 1) : 0];
+        hipStream_t st = lane < 0 ? c->stream : c->lanes[lane].stream;
+        float *rf = bl.rays.as<float>();
+        BdRays er = {rf, rf + 2 * NMAX, rf + 4 * NMAX, rf + 6 * NMAX, rf + 8 * NMAX, rf + 10 * NMAX};
+        float *sf = rf + 12 * NMAX;
+        BdRays sr = {sf, sf + SCAP, sf + 2 * SCAP, sf + 3 * SCAP, sf + 4 * SCAP, sf + 5 * SCAP};
+        int *sexpect = (int *)(sf + 6 * SCAP); float *sbound = sf + 7 * SCAP;
+        float *gf = sf + 8 * SCAP;                                   // staging arrays, [slot j][item]
+        BdRays gr = {gf, gf + SCAP, gf + 2 * SCAP, gf + 3 * SCAP, gf + 4 * SCAP, gf + 5 * SCAP};
+        int *gexpect = (int *)(gf + 6 * SCAP); float *gbound = gf + 7 * SCAP;
+        int *ibase = bl.qidx.as<int>() + NMAX * BD_PAIRS, *icount = ibase + NMAX;
+        float4 *ehits = bl.hits.as<float4>(), *shits = ehits + 2 * NMAX;
+        int *scount = bl.ctr.as<int>();
+        bpixel *items = bl.items.as<bpixel>(); BdStep *state = bl.state.as<BdStep>();
         const int F = frame_count - f0 < FB ? frame_count - f0 : FB;
         const int N = F * P;
         const uint32_t frame0 = frame_begin + (uint32_t)f0;
-        TIRT_HIP(hipMemsetAsync(c->bdpt_rad.p, 0, sizeof(float) * 3 * (size_t)NP * (size_t)F, st));
-        TIRT_HIP(hipMemsetAsync(c->bdpt_items.p, 0, sizeof(bpixel) * (size_t)N, st));
+        TIRT_HIP(hipMemsetAsync(bl.rad.p, 0, sizeof(float) * 3 * (size_t)NP * (size_t)F, st));
+        TIRT_HIP(hipMemsetAsync(bl.items.p, 0, sizeof(bpixel) * (size_t)N, st));
         TIRT_HIP(hipMemsetAsync(scount, 0, 64, st));                 // the connection-ray count and the alive counts of the depths
         // during the sub-path phase the dense connection-ray arrays and the two `expect` arrays are free: they hold the second ray list and the owners
         BdRays rset[2] = {sr, er};                                  // depth d reads rset[d & 1]
         int *oset[2] = {sexpect, gexpect};
         int *alive_cnt = scount + 4;
-        hipLaunchKernelGGL(k_bd_init, dim3((N + B - 1) / B), dim3(B), 0, st, bc, c->bdpt_items.as<bpixel>(), c->bdpt_state.as<BdStep>(), rset[1], oset[1], alive_cnt,
+        hipLaunchKernelGGL(k_bd_init, dim3((N + B - 1) / B), dim3(B), 0, st, bc, items, state, rset[1], oset[1], alive_cnt,
                            tm, P, N, frame0, &ctr->paths);
         // rays of the two sub-paths share the launches
         for (int d = 1; d < BD_EYE_MAX; d++) {
             const BdRays &ri = rset[d & 1], &ro = rset[(d + 1) & 1];
-            if (int rc = trace_arrays(c, ri.ox, ri.oy, ri.oz, ri.dx, ri.dy, ri.dz, 2 * N, alive_cnt + d, ehits, nullptr, nullptr, false)) return rc;
-            hipLaunchKernelGGL(k_bd_step, dim3((2 * N + B - 1) / B), dim3(B), 0, st, bc, c->bdpt_items.as<bpixel>(), c->bdpt_state.as<BdStep>(), ri, oset[d & 1], ro,
+            if (int rc = trace_arrays(c, ri.ox, ri.oy, ri.oz, ri.dx, ri.dy, ri.dz, 2 * N, alive_cnt + d, ehits, nullptr, nullptr, false, lane)) return rc;
+            hipLaunchKernelGGL(k_bd_step, dim3((2 * N + B - 1) / B), dim3(B), 0, st, bc, items, state, ri, oset[d & 1], ro,
                                oset[(d + 1) & 1], alive_cnt, ehits, tm, P, N, frame0, d, &ctr->rays_closest);
         }
-        hipLaunchKernelGGL(k_bd_delta, dim3((P + B - 1) / B), dim3(B), 0, st, c->bdpt_items.as<bpixel>(), c->bdpt_state.as<BdStep>(), tm, P, F, c->bdpt_px.as<int>());
-        hipLaunchKernelGGL(k_bd_connect<0>, dim3((N + B - 1) / B), dim3(B), 0, st, bc, c->bdpt_items.as<bpixel>(), c->bdpt_state.as<BdStep>(), tm, P, N, frame0,
-                           gr, gexpect, gbound, c->bdpt_qidx.as<int>(), ibase, icount, scount, shits, c->bdpt_rad.as<float>(), 3 * NP, &ctr->rays_shadow);
+        if (last_delta) TIRT_HIP(hipStreamWaitEvent(st, last_delta, 0));      // the per-pixel memory is replayed in frame order
+        hipLaunchKernelGGL(k_bd_delta, dim3((P + B - 1) / B), dim3(B), 0, st, items, state, tm, P, F, c->bdpt_px.as<int>());
+        if (NL > 1) { TIRT_HIP(hipEventRecord(bl.delta_done, st)); last_delta = bl.delta_done; }
+        hipLaunchKernelGGL(k_bd_connect<0>, dim3((N + B - 1) / B), dim3(B), 0, st, bc, items, state, tm, P, N, frame0,
+                           gr, gexpect, gbound, bl.qidx.as<int>(), ibase, icount, scount, shits, bl.rad.as<float>(), 3 * NP, &ctr->rays_shadow);
         hipLaunchKernelGGL(k_bd_compact, dim3((N + B - 1) / B), dim3(B), 0, st, N, ibase, icount, gr, gexpect, gbound, sr, sexpect, sbound);
-        if (int rc = trace_arrays(c, sr.ox, sr.oy, sr.oz, sr.dx, sr.dy, sr.dz, (int)(SCAP < (size_t)N * 27 ? SCAP : (size_t)N * 27), scount, shits, sexpect, sbound, false)) return rc;
-        hipLaunchKernelGGL(k_bd_connect<1>, dim3((N + B - 1) / B), dim3(B), 0, st, bc, c->bdpt_items.as<bpixel>(), c->bdpt_state.as<BdStep>(), tm, P, N, frame0,
-                           sr, sexpect, sbound, c->bdpt_qidx.as<int>(), ibase, icount, scount, shits, c->bdpt_rad.as<float>(), 3 * NP, &ctr->rays_shadow);
-        for (int f = 0; f < F; f++) {                     // the running mean applies the frames in order
+        if (int rc = trace_arrays(c, sr.ox, sr.oy, sr.oz, sr.dx, sr.dy, sr.dz, (int)(SCAP < (size_t)N * 27 ? SCAP : (size_t)N * 27), scount, shits, sexpect, sbound, false, lane)) return rc;
+        hipLaunchKernelGGL(k_bd_connect<1>, dim3((N + B - 1) / B), dim3(B), 0, st, bc, items, state, tm, P, N, frame0,
+                           sr, sexpect, sbound, bl.qidx.as<int>(), ibase, icount, scount, shits, bl.rad.as<float>(), 3 * NP, &ctr->rays_shadow);
+        if (last_film) TIRT_HIP(hipStreamWaitEvent(st, last_film, 0));        // the running mean applies the frames in order
+        for (int f = 0; f < F; f++) {
             const float coff = 1.0f / ((float)(int)(frame0 + (uint32_t)f) + 1.0f);
-            hipLaunchKernelGGL(k_bdpt_film, dim3((unsigned)((3 * NP + 255) / 256)), dim3(256), 0, st, c->bdpt_rad.as<float>() + (size_t)f * 3 * NP,
+            hipLaunchKernelGGL(k_bdpt_film, dim3((unsigned)((3 * NP + 255) / 256)), dim3(256), 0, st, bl.rad.as<float>() + (size_t)f * 3 * NP,
                                c->hdr.as<float>(), 3 * NP, coff);
         }
+        if (NL > 1) { TIRT_HIP(hipEventRecord(bl.film_done, st)); last_film = bl.film_done; }
+    }
+    // what follows on the main stream (tone map, download, the next call) comes after both lanes
+    if (NL > 1) for (int l = 0; l < NL; l++) {
+        TIRT_HIP(hipEventRecord(c->bd[l].delta_done, c->lanes[l].stream));
+        TIRT_HIP(hipStreamWaitEvent(c->stream, c->bd[l].delta_done, 0));
     }
     TIRT_HIP(hipGetLastError());
     return TIRT_OK;

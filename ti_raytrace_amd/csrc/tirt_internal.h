@@ -221,8 +221,11 @@ struct tirt_ctx {
     tirt::DevBuf counters_mem, spill;            // used by the batch trace entry points (main stream)
 
     // BDPT_RGB: persistent per-pixel vertex arrays + per-frame radiance (splat target)
-    tirt::DevBuf bdpt_px, bdpt_rad;               // bdpt_px: per-pixel memory of the eye vertices' `delta` fields (what persists from frame to frame)
-    tirt::DevBuf bdpt_items, bdpt_state, bdpt_rays, bdpt_hits, bdpt_qidx, bdpt_ctr;   // wavefront batch: vertex arrays per (frame, pixel), step state, rays, hits
+    tirt::DevBuf bdpt_px;                         // bdpt_px: per-pixel memory of the eye vertices' `delta` fields (what persists from frame to frame)
+    // wavefront batch state (vertex arrays per (frame, pixel), step state, rays, hits, queue indices, counters, per-frame radiance) of the
+    // two BDPT lanes: consecutive batches alternate between them, on the streams of render lanes 0 and 1, so that the traversal
+    // launches of one batch (VALU-bound) run next to the vertex / connection kernels of the other (HBM-bound)
+    struct BdLane { tirt::DevBuf items, state, rays, hits, qidx, ctr, rad; hipEvent_t delta_done = nullptr, film_done = nullptr; } bd[2];
     size_t bdpt_batch_items = (size_t)8 << 20;   // option "bdpt_batch_items": (frame, pixel) items per wavefront batch
     int bdpt_bounded = 1;                          // option "bdpt_bounded": connection rays stop at their target distance
 
@@ -277,7 +280,7 @@ int launch_trace_batch(tirt_ctx *c, const float *rays, int nr, int stack_size, i
 int pt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed, int max_depth, int stack_size, int flags);
 int bdpt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed);
 int trace_arrays(tirt_ctx *c, const float *ox, const float *oy, const float *oz, const float *dx, const float *dy, const float *dz,
-                 int count, const int *count_ptr, float4 *hit, const int *expect, const float *bound, bool count_rays);
+                 int count, const int *count_ptr, float4 *hit, const int *expect, const float *bound, bool count_rays, int lane = -1);
 int ensure_counters(tirt_ctx *c);
 int ensure_shade_records(tirt_ctx *c);
 int sync_all(tirt_ctx *c);

@@ -592,26 +592,31 @@ int launch_trace_batch(tirt_ctx *c, const float *rays, int nr, int stack_size, i
 }
 
 // Closest hits (expect == nullptr) or bounded connection queries of `count` rays held in device arrays, hit records to
-// `hit` -- the traversal service of the BDPT wavefront (tirt_bdpt.hip).  Main stream, ordered traversal.
+// `hit` -- the traversal service of the BDPT wavefront (tirt_bdpt.hip).  Ordered traversal, on the main stream (lane < 0) or on
+// the stream of a render lane with that lane's ray-fetch cursors and spill buffer (two BDPT batches in flight).
 int trace_arrays(tirt_ctx *c, const float *ox, const float *oy, const float *oz, const float *dx, const float *dy, const float *dz,
-                 int count, const int *count_ptr, float4 *hit, const int *expect, const float *bound, bool count_rays)
+                 int count, const int *count_ptr, float4 *hit, const int *expect, const float *bound, bool count_rays, int lane)
 {
     if (count <= 0) return TIRT_OK;
-    hipStream_t st = c->stream;
+    hipStream_t st = lane < 0 ? c->stream : c->lanes[lane].stream;
+    DevBuf &spill = lane < 0 ? c->spill : c->lanes[lane].spill;
+    // (the lanes' counter buffers hold the per-bounce cursors of the path tracer as well: ensure() keeps a larger one)
+    DevBuf &fetch = lane < 0 ? c->counters_mem : c->lanes[lane].counters_mem;
     int spill_depth;
-    if (ensure_spill(c, c->spill, 64, spill_depth)) return TIRT_ERR_HIP;
-    if (c->counters_mem.ensure(sizeof(int) * TR_FETCH_STRIDE * TR_SLICES_MAX)) return TIRT_ERR_HIP;
-    TIRT_HIP(hipMemsetAsync(c->counters_mem.p, 0, sizeof(int) * TR_FETCH_STRIDE * TR_SLICES_MAX, st));
+    if (ensure_spill(c, spill, 64, spill_depth)) return TIRT_ERR_HIP;
+    if (fetch.ensure(sizeof(int) * TR_FETCH_STRIDE * TR_SLICES_MAX)) return TIRT_ERR_HIP;
+    TIRT_HIP(hipMemsetAsync(fetch.p, 0, sizeof(int) * TR_FETCH_STRIDE * TR_SLICES_MAX, st));
     TraceArgs a = {};
     a.bvh = bvh_view(c);
     a.ox = ox; a.oy = oy; a.oz = oz; a.dx = dx; a.dy = dy; a.dz = dz;
     a.count_ptr = count_ptr; a.count_fixed = count; a.hit = hit;      // count: the capacity when count_ptr is given (sizes the grid)
     a.sprim = expect; a.sdist = bound;
-    a.spill = c->spill.as<int>(); a.spill_depth = spill_depth;
+    a.spill = spill.as<int>(); a.spill_depth = spill_depth;
     a.ctr = c->dev_counters.as<DevCounters>(); a.per_ray_counts = nullptr; a.no_ray_count = count_rays ? 0 : 1;
-    a.fetch = c->counters_mem.as<int>();
+    a.fetch = fetch.as<int>();
     fill_tunables(c, a);
-    int grid = (count + TR_BLOCK - 1) / TR_BLOCK; if (grid > c->tr_grid_alone) grid = c->tr_grid_alone;
+    const int grid_cap = lane < 0 ? c->tr_grid_alone : c->tr_grid;          // next to another batch: leave it room (as pt_render does)
+    int grid = (count + TR_BLOCK - 1) / TR_BLOCK; if (grid > grid_cap) grid = grid_cap;
     return expect ? launch_trace<KIND_QUERY>(c, st, a, 0, grid) : launch_trace<KIND_CLOSEST>(c, st, a, 0, grid);
 }
 
