@@ -1776,6 +1776,10 @@ int orc_bdpt_render(const orc_scene *s, orc_bdpt *B, uint32_t frame_begin, int f
     int W = B->W, H = B->H;
     int32_t *stack = (int32_t *)malloc(sizeof(int32_t) * (size_t)(stack_size + 2));
     orc_stats st; memset(&st, 0, sizeof(st));
+    /* debugging aids (tools/dbg/bdpt_counts.py): ORC_BDPT_DUMP = file for the connection rays per pixel of the last frame,
+     * ORC_BDPT_PIXEL = pixel whose connections are printed */
+    const char *dbg_dump = getenv("ORC_BDPT_DUMP"), *dbg_pixel_s = getenv("ORC_BDPT_PIXEL");
+    const long dbg_pixel = dbg_pixel_s ? atol(dbg_pixel_s) : -1;
     for (int f = 0; f < frame_count; f++) {
         uint32_t frame = frame_begin + (uint32_t)f;
         memset(radiance, 0, sizeof(float) * (size_t)W * H * 3);
@@ -1798,7 +1802,7 @@ int orc_bdpt_render(const orc_scene *s, orc_bdpt *B, uint32_t frame_begin, int f
                     int nu, nv;
                     const uint64_t sh0__ = st.rays_shadow;
                     v3 r = bd_connect_path(s, B, P, i, j, e, l, frame, seed, stack, stack_size, &st, &nu, &nv);
-                    if (getenv("ORC_BDPT_PIXEL") && atol(getenv("ORC_BDPT_PIXEL")) == p && f == frame_count - 1) {
+                    if (dbg_pixel == p && f == frame_count - 1) {
                         fprintf(stderr, "pixel %ld frame %u e %d l %d: shadow rays %d, r = %g %g %g\n", p, frame, e, l, (int)(st.rays_shadow - sh0__), r.x, r.y, r.z);
                         if (e == 1 && l == 0) {
                             for (int k = 0; k < BD_EYE_MAX; k++) fprintf(stderr, "   eye[%d] type %d prim %d mat %d delta %d beta %g %g %g fpdf %g rpdf %g pos %g %g %g\n", k, P->eye[k].type, P->eye[k].prim, P->eye[k].mat, P->eye[k].delta, P->eye[k].beta.x, P->eye[k].beta.y, P->eye[k].beta.z, P->eye[k].fpdf, P->eye[k].rpdf, P->eye[k].pos.x, P->eye[k].pos.y, P->eye[k].pos.z);
@@ -1809,10 +1813,9 @@ int orc_bdpt_render(const orc_scene *s, orc_bdpt *B, uint32_t frame_begin, int f
                     if (q >= 0) { radiance[3 * q] += r.x; radiance[3 * q + 1] += r.y; radiance[3 * q + 2] += r.z; }
                 }
             }
-            /* debugging aid (tools/dbg/bdpt_counts.py): connection rays per pixel of the last frame, eye / light depths */
-            if (getenv("ORC_BDPT_DUMP") && f == frame_count - 1) {
+            if (dbg_dump && f == frame_count - 1) {
                 static FILE *fp = NULL;
-                if (p == 0) { if (fp) fclose(fp); fp = fopen(getenv("ORC_BDPT_DUMP"), "w"); }
+                if (p == 0) { if (fp) fclose(fp); fp = fopen(dbg_dump, "w"); }
                 if (fp) { fprintf(fp, "%ld %d %d %d\n", p, (int)(st.rays_shadow - shadow_before), eye_depth, light_depth); if (p == (long)W * H - 1) { fclose(fp); fp = NULL; } }
             }
         }
