@@ -701,7 +701,15 @@ int bdpt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t see
         if (FB > (frame_count + 1) / 2) FB = (frame_count + 1) / 2;
     }
     { const int nb = (frame_count + FB - 1) / FB; FB = (frame_count + nb - 1) / nb; }       // batches of equal size
-    const size_t NMAX = (size_t)FB * P;
+    // buffers for the batches of this call -- or of the whole job, when the caller said how many frames it has ("job_frames"): a
+    // frame-at-a-time caller then does not re-allocate as its calls grow
+    int FB_alloc = FB;
+    if (c->job_frames > frame_count) {
+        int fj = (int)(c->bdpt_batch_items / (NL > 1 ? 2 : 1) / (size_t)P); if (fj < 1) fj = 1;
+        if ((long)fj > (c->job_frames + 1) / 2) fj = (int)((c->job_frames + 1) / 2);
+        if (fj > FB_alloc) FB_alloc = fj;
+    }
+    const size_t NMAX = (size_t)FB_alloc * P;
     TIRT_REQUIRE(NMAX * BD_PAIRS < ((size_t)1 << 31), "tirt_bdpt_rgb_render: film too large for one frame per batch");
     const size_t SCAP = NMAX * 27;                               // at most 27 (e, l) pairs per item carry a connection ray (staging: [27][N])
     for (int l = 0; l < NL; l++) {
@@ -709,7 +717,7 @@ int bdpt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t see
         if (bl.items.ensure(sizeof(bpixel) * NMAX) || bl.state.ensure(sizeof(BdStep) * NMAX) ||
             bl.rays.ensure(sizeof(float) * (6 * 2 * NMAX + 16 * SCAP)) || bl.hits.ensure(sizeof(float4) * (2 * NMAX + SCAP)) ||
             bl.qidx.ensure(sizeof(int) * NMAX * (BD_PAIRS + 2)) || bl.ctr.ensure(256) ||
-            bl.rad.ensure(sizeof(float) * 3 * (size_t)NP * (size_t)FB)) return TIRT_ERR_HIP;
+            bl.rad.ensure(sizeof(float) * 3 * (size_t)NP * (size_t)FB_alloc)) return TIRT_ERR_HIP;
         if (!bl.delta_done) TIRT_HIP(hipEventCreateWithFlags(&bl.delta_done, hipEventDisableTiming));
         if (!bl.film_done) TIRT_HIP(hipEventCreateWithFlags(&bl.film_done, hipEventDisableTiming));
     }

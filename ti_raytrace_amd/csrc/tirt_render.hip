@@ -615,7 +615,7 @@ int trace_arrays(tirt_ctx *c, const float *ox, const float *oy, const float *oz,
     a.ctr = c->dev_counters.as<DevCounters>(); a.per_ray_counts = nullptr; a.no_ray_count = count_rays ? 0 : 1;
     a.fetch = fetch.as<int>();
     fill_tunables(c, a);
-    const int grid_cap = lane < 0 ? c->tr_grid_alone : c->tr_grid;          // next to another batch: leave it room (as pt_render does)
+    const int grid_cap = c->tr_grid_alone;          // also with two BDPT batches in flight: the other batch mostly runs its vertex / connection kernels (config 5: 384 blocks 2 047, 512 blocks 2 145 Mrays/s)
     int grid = (count + TR_BLOCK - 1) / TR_BLOCK; if (grid > grid_cap) grid = grid_cap;
     return expect ? launch_trace<KIND_QUERY>(c, st, a, 0, grid) : launch_trace<KIND_CLOSEST>(c, st, a, 0, grid);
 }

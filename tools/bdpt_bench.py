@@ -9,7 +9,7 @@ ex = scenes.veach_bdpt(size, size, spp, device_id=0)
 ex.build_scene(); ctx = ex.scene.ctx
 for kv in opts:
     k, v = kv.split("="); ctx.set_option(k, float(v))
-ctx.bdpt_rgb_render(0, 16, 1); ctx.sync()                       # warm-up (allocations), then a fresh film
+ctx.bdpt_rgb_render(0, spp, 1); ctx.sync()                      # warm-up with the job's own size (allocations), then a fresh film
 ctx.film_clear(); ctx.sync(); ctx.stats_reset()
 t0 = time.perf_counter()
 ctx.bdpt_rgb_render(0, spp, 1); ctx.sync()
