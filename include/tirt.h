@@ -88,7 +88,8 @@ int tirt_sync(tirt_ctx *ctx);
  *            bit-identical either way (tirt_traversal_tree_download); takes effect at the next tirt_lbvh_build
  *          "wide_collapse" (0/1, default 0) -- how the binary tree is grouped into 4-wide nodes: 0 = greedily by surface area, 1 = the
  *            grouping of least total node area (dynamic programme); same results, 1-9 % fewer node visits, no measurable gain
- *          "bdpt_batch_items" -- (frame, pixel) items per BDPT wavefront batch (default 8 Mi, ~3.7 KB of HBM each: 31 GB for a full batch; config 5: 1 Mi 1 649, 2 Mi 1 799, 4 Mi 1 887, 8 Mi 1 937, 16 Mi 1 953 Mrays/s)
+ *          "bdpt_batch_items" -- (frame, pixel) items per BDPT wavefront batch (default 8 Mi, ~3.7 KB of HBM each: 31 GB), shared by the two batches in flight on render lanes 0 and 1
+ *            (config 5 on one lane: 1 Mi 1 649, 2 Mi 1 799, 4 Mi 1 887, 8 Mi 1 937 Mrays/s; two lanes of 4 Mi: 2 230)
  *          (trace_lds_depth is checked against the LDS a block can have on the device) */
 int tirt_set_option(tirt_ctx *ctx, const char *name, double value);
 
