@@ -87,7 +87,7 @@ TD unsigned long long wave_sum(unsigned long long v)
 }
 
 #ifndef TR_MIN_WAVES
-#define TR_MIN_WAVES 4
+#define TR_MIN_WAVES 6        // 80 VGPRs: three 512-thread blocks per CU (their LDS: tirt_internal.h, TR_TOP_CAP)
 #endif
 template <int MODE, bool COUNT, int KIND>
 __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
