@@ -351,3 +351,26 @@ def test_example_loop_with_progressive_preview(gpu_ctx_ok, tmp_path):
     a = ex.integrator.hdr.to_numpy()
     ex2 = scenes.cornell_box(W, H, 6, device_id=0); ex2.build_scene(); ex2.integrator.render_frames(6)
     assert np.array_equal(a, ex2.integrator.hdr.to_numpy())
+
+
+def test_batch_planning_changes_no_bit(gpu_ctx_ok):
+    """tirt_internal.h plan_batches: with the "job_frames" hint a job is cut into few large wavefront batches (here 104 frames of a 512^2 film
+    = 27 M paths, above the 24 Mi-path threshold: 2 x 52 frames), without it into 32 Mi-path ones; calls
+    may arrive frame by frame, in chunks that do not divide the plan, or all at once, and the hint may be wrong.  Same film, bit for bit."""
+    W = H = 512
+    frames = 104
+    films = []
+    for hint, chunk in ((0, frames), (frames, 8), (frames, frames), (frames // 2, 13), (4 * frames, 5)):
+        ex = scenes.cornell_box(W, H, frames, device_id=0)
+        ex.build_scene()
+        ctx = ex.scene.ctx
+        ctx.set_option("job_frames", hint)
+        f = 0
+        while f < frames:
+            k = min(chunk, frames - f)
+            ctx.pt_rgb_render(f, k, 1, 15, 64, 0)
+            f += k
+        films.append(ctx.film_download(W, H)[0])
+        assert ctx.stats()["paths"] == frames * W * H
+    for f in films[1:]:
+        assert np.array_equal(f.view(np.uint32), films[0].view(np.uint32))
