@@ -62,7 +62,7 @@ def parse():
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--ntri", type=int, default=100000)
     ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--tile-size", type=int, default=4096)
+    ap.add_argument("--tile-size", type=int, default=0, help="pixels per film tile (0: PT_RGB.default_tile_size: 8 columns)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc child passes behind roofline.traffic")
@@ -242,7 +242,8 @@ def main():
     total_frames = (args.warmup + args.steps) * args.frames_per_step
     ex = scenes.synthetic(W, H, max(total_frames, 4), ntri=args.ntri, device_id=local_rank, seed=args.seed,
                           tile_rank=rank, tile_count=(args.emulate_world if args.emulate_world > 0 and world == 1 else world),
-                          tile_size=args.tile_size)
+                          tile_size=args.tile_size or None)
+    args.tile_size = ex.integrator.tile_size
     t0 = time.time()
     ctx = ex.scene.ctx
     opts = dict(kv.split("=") for kv in args.opt)

@@ -6,6 +6,7 @@ sub-path (<= 7 vertices), a light sub-path (<= 6), every (e, l) connection of to
 film.  Device side: ``csrc/tirt_bdpt.hip`` through ``tirt_bdpt_rgb_render``.
 """
 from .Scene import DeviceField
+from .PT_RGB import default_tile_size
 
 STOP_DEPTH = 10000
 MAX_DEPTH = 5
@@ -15,14 +16,14 @@ VERTEX_NONE, VERTEX_LIGHT, VERTEX_LENS, VERTEX_SURFACE = 0, 1, 2, 3
 
 
 class BDPT:
-    def __init__(self, imgSizeX, imgSizeY, cam, scene, stack_size, seed=1, tile_rank=0, tile_count=1, tile_size=4096):
+    def __init__(self, imgSizeX, imgSizeY, cam, scene, stack_size, seed=1, tile_rank=0, tile_count=1, tile_size=None):
         self.imgSizeX = imgSizeX
         self.imgSizeY = imgSizeY
         self.cam = cam
         self.scene = scene
         self.stack_size = stack_size
         self.seed = seed
-        self.tile_rank, self.tile_count, self.tile_size = tile_rank, tile_count, tile_size
+        self.tile_rank, self.tile_count, self.tile_size = tile_rank, tile_count, tile_size or default_tile_size(imgSizeY)
         self.hdr = DeviceField("hdr", scene, lambda: self._download(True))
         self.rgb_film = DeviceField("rgb_film", scene, lambda: self._download(False))
 

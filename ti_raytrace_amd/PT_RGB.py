@@ -12,9 +12,16 @@ from .Scene import DeviceField
 MAX_DEPTH = 15           # integrator/PT_RGB.py:21
 
 
+def default_tile_size(H):
+    """Pixels per tile of the multi-GPU film split (tiles go round-robin over the ranks).  8 whole columns when that is a handy size:
+    the device library then walks a tile in 8 x 8 pixel blocks (tirt_internal.h, local_to_pixel), which makes the 64 camera rays
+    of a wave a compact bundle; otherwise 4096 linear pixels."""
+    return 8 * H if (H % 8 == 0 and 4096 <= 8 * H <= 16384) else 4096
+
+
 class PathTrace:
     def __init__(self, imgSizeX, imgSizeY, cam, scene, stack_size,
-                 seed=1, tile_rank=0, tile_count=1, tile_size=4096, flags=0):
+                 seed=1, tile_rank=0, tile_count=1, tile_size=None, flags=0):
         self.imgSizeX = imgSizeX
         self.imgSizeY = imgSizeY
         self.cam = cam
@@ -23,7 +30,7 @@ class PathTrace:
         # extensions: counter-based RNG seed (the reference's ti.random() is unseeded) and
         # the pixel-tile shard this context renders (multi-GPU)
         self.seed = seed
-        self.tile_rank, self.tile_count, self.tile_size = tile_rank, tile_count, tile_size
+        self.tile_rank, self.tile_count, self.tile_size = tile_rank, tile_count, tile_size or default_tile_size(imgSizeY)
         self.flags = flags
         self.hdr = DeviceField("hdr", scene, lambda: self._download(True))
         self.rgb_film = DeviceField("rgb_film", scene, lambda: self._download(False))

@@ -566,6 +566,7 @@ int tirt_film_create(tirt_ctx *c, int W, int H, int tile_rank, int tile_count, i
     const long NP = (long)W * H;
     if (c->hdr.ensure(sizeof(float) * 3 * (size_t)NP) || c->rgb.ensure(sizeof(float) * 3 * (size_t)NP)) return TIRT_ERR_HIP;
     c->W = W; c->H = H; c->tile_rank = tile_rank; c->tile_count = tile_count; c->tile_size = tile_size;
+    c->tile_blocked = (H % 8 == 0 && tile_size % (8 * H) == 0 && ((long)W * H) % tile_size == 0) ? 1 : 0;       // local_to_pixel
     long ntiles = (NP + tile_size - 1) / tile_size, local = 0;
     for (long t = tile_rank; t < ntiles; t += tile_count) {
         long beg = t * tile_size, end = beg + tile_size; if (end > NP) end = NP;

@@ -131,11 +131,20 @@ struct PathState {
     float *fr, *fg, *fb;                         // final radiance per path id (read by k_film)
 };
 
-// pixel-tile shard of this context: local pixel k -> linear pixel index
-struct TileMap { int tile_rank, tile_count, tile_size, H; };
+// pixel-tile shard of this context: local pixel k -> linear pixel index (p = i * H + j: a tile is a run of whole or partial columns).
+// `blocked` (tiles of a multiple of 8 whole columns, H a multiple of 8, no partial tile): the local order inside a tile walks
+// 8 x 8 pixel blocks, so that the 64 camera rays of a wave form a compact bundle instead of a 1 x 64 strip -- the same rays, 5.5 %
+// faster through the tree (tools/exp/primary_order.py); which pixels a tile owns does not change.
+struct TileMap { int tile_rank, tile_count, tile_size, H, blocked; };
 TD int local_to_pixel(const TileMap &m, int k)
 {
     int lt = k / m.tile_size, within = k - lt * m.tile_size;
+    if (m.blocked) {
+        const int rows = m.H >> 3;                       // 8 x 8 blocks per column group
+        const int b = within >> 6, l = within & 63;
+        const int bc = b / rows, bj = b - bc * rows;
+        within = ((bc << 3) + (l >> 3)) * m.H + (bj << 3) + (l & 7);
+    }
     return (lt * m.tile_count + m.tile_rank) * m.tile_size + within;
 }
 
@@ -194,7 +203,7 @@ struct tirt_ctx {
     tirt::CameraView cam; float view[16]; bool cam_set = false;
 
     // film
-    int W = 0, H = 0, tile_rank = 0, tile_count = 1, tile_size = 4096;
+    int W = 0, H = 0, tile_rank = 0, tile_count = 1, tile_size = 4096, tile_blocked = 0;
     long npix_local = 0;
     tirt::DevBuf hdr, rgb;
 

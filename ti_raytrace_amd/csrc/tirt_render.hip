@@ -923,7 +923,7 @@ int pt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed,
         { int parts = c->split_lone < c->n_lanes ? c->split_lone : c->n_lanes; if (parts > frame_count) parts = frame_count; FB = (frame_count + parts - 1) / parts; }
     const SceneView sv = scene_view(c);
     const BvhView bv = bvh_view(c);
-    const TileMap tm = {c->tile_rank, c->tile_count, c->tile_size, c->H};
+    const TileMap tm = {c->tile_rank, c->tile_count, c->tile_size, c->H, c->tile_blocked};
     DevCounters *ctr = c->dev_counters.as<DevCounters>();
     const int B = 256;
     // everything queued on the main stream (uploads, film clear, tone map) precedes the lanes' work
