@@ -135,7 +135,9 @@ int tirt_camera_set(tirt_ctx *ctx, const float view[16], const float view_inv[16
 
 /* PathTrace.setup_data_cpu (integrator/PT_RGB.py:34-37): hdr + rgb_film, W*H*3 f32 each,
  * index (i*H + j)*3.  This context renders the pixels whose linear index p = i*H + j lies
- * in a tile (p / tile_size) with tile % tile_count == tile_rank (tile_count 1: all). */
+ * in a tile (p / tile_size) with tile % tile_count == tile_rank (tile_count 1: all).  A tile_size of a multiple of 8 whole
+ * columns (8 * H pixels; H a multiple of 8, W * H a multiple of tile_size) lets the device walk a tile in 8 x 8 pixel blocks
+ * -- the camera rays of a wave are then a compact bundle; any other tile_size works too. */
 int tirt_film_create(tirt_ctx *ctx, int W, int H, int tile_rank, int tile_count, int tile_size);
 int tirt_film_clear(tirt_ctx *ctx);
 
