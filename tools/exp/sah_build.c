@@ -44,7 +44,13 @@ static int build(int *idx, int cnt)
             if (bc[b]) { box_t t = bin[b]; float q[6] = {t.mn[0], t.mn[1], t.mn[2], t.mx[0], t.mx[1], t.mx[2]}; grow(&acc, q); }
             c += bc[b];
             if (c == 0 || rc[b + 1] == 0) continue;
+#ifdef COST_NODES
+            const float cost = area(&acc) * (2 * c - 1) + ra[b + 1] * (2 * rc[b + 1] - 1);      /* nodes of the two sub-trees instead of their leaves */
+#elif defined(COST_LOG)
+            const float cost = area(&acc) * c * (1.0f + 0.25f * log2f((float)c)) + ra[b + 1] * rc[b + 1] * (1.0f + 0.25f * log2f((float)rc[b + 1]));
+#else
             const float cost = area(&acc) * c + ra[b + 1] * rc[b + 1];
+#endif
             if (cost < best_cost) { best_cost = cost; best_axis = ax; best_split = b; }
         }
     }

@@ -66,6 +66,15 @@ def use(compact, csize, label):
     print("   films bit-identical:", same, "" if same else "differing pixels: %d" % int((a.view(np.uint32) != b.view(np.uint32)).any(axis=-1).sum()))
 
 use(compact, csize, "SAH")
+if os.environ.get("SAH_COST"):
+    for flag in os.environ["SAH_COST"].split(","):
+        sob = "/tmp/sah_build_%s.so" % flag
+        subprocess.check_call(["gcc", "-O2", "-D" + flag, "-shared", "-fPIC", "-o", sob, os.path.join(ROOT, "tools/exp/sah_build.c"), "-lm"])
+        l2 = C.CDLL(sob)
+        c2 = np.zeros((N, 9), np.float32); s2 = np.zeros(N, np.int32)
+        l2.sah_build(boxes.ctypes.data_as(C.c_void_p), n, c2.ctypes.data_as(C.c_void_p), s2.ctypes.data_as(C.c_void_p))
+        use(c2, s2, flag)
+    sys.exit(0)
 if os.environ.get("SAH_BINS"):
     for bins in [int(x) for x in os.environ["SAH_BINS"].split(",")]:
         sob = "/tmp/sah_build_%d.so" % bins
