@@ -5,8 +5,8 @@ import numpy as np
 from ti_raytrace_amd import scenes, _native
 from test_gpu_trace import _grazing_rays
 which = sys.argv[1] if len(sys.argv) > 1 else 'teapot'
-ex = {'teapot': scenes.single_model, 'veach': scenes.veach_bdpt, 'cornell': scenes.cornell_box}[which](32, 32, 4, device_id=0); ex.build_scene(); ctx = ex.scene.ctx
-n = 400000 // 14
+ex = {'teapot': scenes.single_model, 'veach': scenes.veach_bdpt, 'cornell': scenes.cornell_box, 'synthetic': scenes.synthetic}[which](32, 32, 4, device_id=0); ex.build_scene(); ctx = ex.scene.ctx
+n = (int(sys.argv[2]) if len(sys.argv) > 2 else 400000) // 14
 rays = _grazing_rays(ex, n, 41)
 a, ap, _ = ctx.trace_closest(rays, 64, 0)
 b, bp, _ = ctx.trace_closest(rays, 64, _native.TRAVERSE_EXHAUSTIVE)
