@@ -374,3 +374,25 @@ def test_batch_planning_changes_no_bit(gpu_ctx_ok):
         assert ctx.stats()["paths"] == frames * W * H
     for f in films[1:]:
         assert np.array_equal(f.view(np.uint32), films[0].view(np.uint32))
+
+
+def test_blocked_tile_order_changes_no_bit(gpu_ctx_ok):
+    """tirt_internal.h local_to_pixel: inside a tile of 8 whole columns the device walks 8 x 8 pixel blocks; any other tile size keeps the
+    linear order.  Same film, and the tiles of three ranks still re-assemble to it."""
+    W = H = 64
+    films = []
+    for tile_size in (8 * H, 100, 4096):                 # blocked | linear | blocked (the whole film is one tile)
+        ex = scenes.cornell_box(W, H, 4, device_id=0)
+        ex.integrator.tile_size = tile_size
+        ex.build_scene()
+        ex.integrator.render_frames(3)
+        films.append(ex.integrator.hdr.to_numpy().copy())
+    assert np.array_equal(films[0].view(np.uint32), films[1].view(np.uint32)) and np.array_equal(films[0].view(np.uint32), films[2].view(np.uint32))
+    total = np.zeros_like(films[0])
+    for rank in range(3):
+        ex = scenes.cornell_box(W, H, 4, device_id=0)
+        ex.integrator.tile_size = 8 * H; ex.integrator.tile_rank = rank; ex.integrator.tile_count = 3
+        ex.build_scene()
+        ex.integrator.render_frames(3)
+        total += ex.integrator.hdr.to_numpy()
+    assert np.array_equal(total.view(np.uint32), films[0].view(np.uint32))

@@ -139,3 +139,11 @@ def test_synthetic_scene_is_reproducible():
     ex = host_only(scenes.synthetic(16, 16, 4, ntri=50))
     assert ex.scene.primitive_count == 51 and ex.scene.light_np.tolist() == [50]
     assert ex.scene.primitive_np[50].tolist() == [2, 0, 1]
+
+
+def test_default_tile_size():
+    """PT_RGB.default_tile_size: 8 whole columns where that is between 4096 and 16384 pixels (the device then walks a tile in 8 x 8
+    pixel blocks), 4096 linear pixels otherwise."""
+    from ti_raytrace_amd.PT_RGB import default_tile_size
+    assert default_tile_size(1024) == 8192 and default_tile_size(512) == 4096 and default_tile_size(2048) == 16384
+    assert default_tile_size(4096) == 4096 and default_tile_size(100) == 4096 and default_tile_size(516) == 4096
