@@ -609,7 +609,10 @@ __global__ void k_bd_connect(BdCtx c, bpixel *items, const BdStep *steps, TileMa
             T.o = V(0.0f, 0.0f, 0.0f); T.d = T.o; T.expect = -3; T.bound = -1.0f;
             if (PHASE == 1 && valid) {
                 const int ql = qidx[(size_t)slot * (size_t)N + it];
-                if (ql >= 0) { const float4 hr = shits[ibase[it] + ql]; T.res.t = hr.x; T.res.u = hr.y; T.res.v = hr.z; T.res.prim = __float_as_int(hr.w); }
+                if (ql >= 0) {                               // k_bd_compact left the ray's place in the dense queue where its `expect` was staged
+                    const float4 hr = shits[sexpect[(size_t)ql * (size_t)N + it]];
+                    T.res.t = hr.x; T.res.u = hr.y; T.res.v = hr.z; T.res.prim = __float_as_int(hr.w);
+                }
             }
             int nu = 0, nv = 0;
             v3 r = V(0.0f, 0.0f, 0.0f);
@@ -644,22 +647,33 @@ __global__ void k_bd_connect(BdCtx c, bpixel *items, const BdStep *steps, TileMa
         int base = 0;
         if (lane == 63 && total) { base = atomicAdd(scount, total); atomicAdd(rays_shadow, (unsigned long long)total); }
         base = __shfl(base, 63, 64);
-        if (live) { ibase[it] = base + incl - (int)emitted; icount[it] = (int)emitted; }
+        if (live) { ibase[it] = base; icount[it] = (int)emitted; }          // the wave's place in the dense queue; k_bd_compact orders it slot by slot
     }
 }
 
-// staging slots [j][item] -> dense connection-ray queue
-__global__ void k_bd_compact(int N, const int *ibase, const int *icount, BdRays stage, const int *sexpect_in, const float *sbound_in,
+// staging slots [j][item] -> dense connection-ray queue.  A wave moves the rays of its 64 items slot by slot: the j-th rays of the
+// items that have one are read from 64 consecutive staging words and written to consecutive queue words (per item, ray after ray,
+// the writes were 4-byte scatters: 5.0 -> 1.x ms per 8 Mi items).  Where a ray went is left in its staged `expect` word for pass 1.
+__global__ void k_bd_compact(int N, const int *ibase, const int *icount, BdRays stage, int *sexpect_in, const float *sbound_in,
                              BdRays dense, int *sexpect, float *sbound)
 {
-    const int it = blockIdx.x * blockDim.x + threadIdx.x;
-    if (it >= N) return;
-    const int n = icount[it], base = ibase[it];
-    for (int j = 0; j < n; j++) {
-        const size_t k = (size_t)j * (size_t)N + it, q = (size_t)(base + j);
-        dense.ox[q] = stage.ox[k]; dense.oy[q] = stage.oy[k]; dense.oz[q] = stage.oz[k];
-        dense.dx[q] = stage.dx[k]; dense.dy[q] = stage.dy[k]; dense.dz[q] = stage.dz[k];
-        sexpect[q] = sexpect_in[k]; sbound[q] = sbound_in[k];
+    const int it = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
+    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const bool live = it < N;
+    const int n = live ? icount[it] : 0;
+    int off = live ? ibase[it] : 0;
+    off = __shfl(off, 0, 64);                           // lane 0 of a wave is live whenever any lane is
+    for (int j = 0; j < 27; j++) {
+        const unsigned long long m = __ballot(n > j);
+        if (m == 0ull) break;
+        if (n > j) {
+            const size_t k = (size_t)j * (size_t)N + it, q = (size_t)(off + __popcll(m & lt_mask));
+            dense.ox[q] = stage.ox[k]; dense.oy[q] = stage.oy[k]; dense.oz[q] = stage.oz[k];
+            dense.dx[q] = stage.dx[k]; dense.dy[q] = stage.dy[k]; dense.dz[q] = stage.dz[k];
+            sexpect[q] = sexpect_in[k]; sbound[q] = sbound_in[k];
+            sexpect_in[k] = (int)q;
+        }
+        off += __popcll(m);
     }
 }
 
@@ -775,7 +789,7 @@ int bdpt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t see
         hipLaunchKernelGGL(k_bd_compact, dim3((N + B - 1) / B), dim3(B), 0, st, N, ibase, icount, gr, gexpect, gbound, sr, sexpect, sbound);
         if (int rc = trace_arrays(c, sr.ox, sr.oy, sr.oz, sr.dx, sr.dy, sr.dz, (int)(SCAP < (size_t)N * 27 ? SCAP : (size_t)N * 27), scount, shits, sexpect, sbound, false, lane)) return rc;
         hipLaunchKernelGGL(k_bd_connect<1>, dim3((N + B - 1) / B), dim3(B), 0, st, bc, items, state, tm, P, N, frame0,
-                           sr, sexpect, sbound, bl.qidx.as<int>(), ibase, icount, scount, shits, bl.rad.as<float>(), 3 * NP, &ctr->rays_shadow);
+                           sr, gexpect /* staged `expect` words: now the rays' places in the queue */, sbound, bl.qidx.as<int>(), ibase, icount, scount, shits, bl.rad.as<float>(), 3 * NP, &ctr->rays_shadow);
         if (last_film) TIRT_HIP(hipStreamWaitEvent(st, last_film, 0));        // the running mean applies the frames in order
         for (int f = 0; f < F; f++) {
             const float coff = 1.0f / ((float)(int)(frame0 + (uint32_t)f) + 1.0f);
