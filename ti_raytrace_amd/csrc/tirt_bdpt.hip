@@ -653,7 +653,7 @@ __global__ void k_bd_connect(BdCtx c, bpixel *items, const BdStep *steps, TileMa
 
 // staging slots [j][item] -> dense connection-ray queue.  A wave moves the rays of its 64 items slot by slot: the j-th rays of the
 // items that have one are read from 64 consecutive staging words and written to consecutive queue words (per item, ray after ray,
-// the writes were 4-byte scatters: 5.0 -> 1.x ms per 8 Mi items).  Where a ray went is left in its staged `expect` word for pass 1.
+// the writes were 4-byte scatters: 5.0 -> 2.1 ms per 8 Mi items).  Where a ray went is left in its staged `expect` word for pass 1.
 __global__ void k_bd_compact(int N, const int *ibase, const int *icount, BdRays stage, int *sexpect_in, const float *sbound_in,
                              BdRays dense, int *sexpect, float *sbound)
 {
