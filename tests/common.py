@@ -41,3 +41,31 @@ def duplicate_code_scene(W=32, H=32, device_id=None):
 
 def rel_l2(a, b):
     return float(np.sqrt(((a.astype(np.float64) - b) ** 2).sum() / max((b.astype(np.float64) ** 2).sum(), 1e-30)))
+
+
+# ---- structure pins against the reference's gallery renders (tests/golden/gallery_*_blocks.npy) -------------------------
+def _srgb_to_linear(c):
+    c = np.asarray(c, np.float64)
+    return np.where(c <= 0.04045, c / 12.92, ((c + 0.055) / 1.055) ** 2.4)
+
+
+def gallery_structure(hdr_field, ref_blocks):
+    """Correlation of log block luminance between a linear film (field orientation [W,H,3]) and the 32x32 block means of a
+    gallery PNG, inside the sphere (radius 7 of 8 blocks) and over the background (outside the sphere and the light disc).
+    Log luminance because the gallery images went through an unrecorded tone curve: a monotone curve keeps the ordering and,
+    to first order, the correlation."""
+    img = np.nan_to_num(np.transpose(np.asarray(hdr_field, np.float64), (1, 0, 2))[::-1])
+    s = img.shape[0] // 32
+    ours = img.reshape(32, s, 32, s, 3).mean(axis=(1, 3))
+    w = np.array([0.2126, 0.7152, 0.0722])
+    lo = np.log(1e-3 + ours @ w)
+    lr = np.log(1e-3 + _srgb_to_linear(ref_blocks) @ w)
+    yy, xx = np.mgrid[0:32, 0:32] + 0.5
+    r2 = (xx - 16) ** 2 + (yy - 16) ** 2
+    inside = r2 < 7.0 ** 2
+    outside = (r2 > 9.5 ** 2) & (((xx - 16) ** 2 + (yy - 0.5) ** 2) > 4.0 ** 2)
+
+    def corr(a, b):
+        a = a - a.mean(); b = b - b.mean()
+        return float((a * b).sum() / np.sqrt((a * a).sum() * (b * b).sum()))
+    return corr(lo[inside], lr[inside]), corr(lo[outside], lr[outside])

@@ -29,3 +29,13 @@ for name in ("veach-bdpt512", "veach-pt512"):
     blocks = img.reshape(32, 16, 32, 16, 3).mean(axis=(1, 3)).astype(np.float32)
     np.save(name.replace("-", "_") + "_blocks.npy", blocks)
     print(name, blocks.shape, blocks.reshape(-1, 3).mean(0))
+# Gallery renders of example/single_model.py's sphere (image/glass.png, metal.png, non-metal.png; 512^2).  They predate the
+# committed example (measured on the images: sphere diameter 253 px = camera at 1.0 x |diagonal|, not 0.8; a light disc of
+# radius 37 px at 30 deg elevation = a sphere light near (0, 2, 0) r 0.3, not (0, 20, 0) r 5; background = the env seen
+# from yaw pi; a gentler tone curve than ACES(0.5 x)), so the tests that use these block means are STRUCTURE pins
+# (correlation of log block luminance), not radiometric ones.
+for name in ("glass", "metal", "non-metal"):
+    img = np.asarray(Image.open(REF + "/image/" + name + ".png").convert("RGB")).astype(np.float32) / 255.0
+    blocks = img.reshape(32, 16, 32, 16, 3).mean(axis=(1, 3)).astype(np.float32)
+    np.save("gallery_" + name.replace("-", "_") + "_blocks.npy", blocks)
+    print(name, blocks.shape, blocks.reshape(-1, 3).mean(0))

@@ -151,3 +151,65 @@ def test_oracle_threading_does_not_change_the_film(oracle_lib):
     c1, s1 = o.render(W, H, 0, 1, seed=3, p_begin=13, p_end=1207, tile_rank=1, tile_count=3, tile_size=50, nthreads=1)
     c2, s2 = o.render(W, H, 0, 1, seed=3, p_begin=13, p_end=1207, tile_rank=1, tile_count=3, tile_size=50, nthreads=5)
     assert np.array_equal(c1, c2) and s1 == s2 and s1["paths"] > 0
+
+
+def test_oracle_against_the_reference_gallery_spheres(oracle_lib):
+    """Structure pins on image/glass.png, metal.png, non-metal.png (example/single_model.py's sphere.obj and its two
+    commented material variants, :27-31).  The gallery renders predate the committed example (camera distance, light,
+    yaw and tone curve differ -- scenes.gallery_sphere states what was measured on the images), so what is compared is the
+    correlation of log block luminance, 128^2 x 64 spp against the 512^2 gallery image:
+      background (all three): the lat-long env lookup of PT_RGB.py:127-132 + Texture.texture2D through Camera's view matrix --
+        0.95 here, 0.24 from the opposite yaw, < 0.5 for any other atan2 argument order;
+      metal.png inside the sphere: Disney metal 1 / rough 0 = a mirror ball (brdf/Disney.py sample + evaluate_pdf) on smooth
+        normals (process_normal, Scene.py:754-798): 0.91;
+      non-metal.png inside: diffuse Disney under the env + the analytic sphere light (sample_li's sphere branch, quirks B2 / B3,
+        MIS): 0.93;
+      glass.png inside: 0.49 only, and no ior between 1.15 and 1.5 does better -- the gallery's glass is not the committed
+        Glass.sample + extinction roulette (B13); reported, asserted loosely.  Glass stays pinned by this oracle only."""
+    from common import gallery_structure
+    W = H = 128
+    got = {}
+    for variant in ("glass", "metal", "non-metal"):
+        ex = scenes.gallery_sphere(W, H, 64, variant=variant)
+        ex.scene.setup_data_cpu(); ex.frame_camera()
+        o = oa.OracleScene(ex.scene, ex.cam); o.lbvh_build(); o.process_normal(ex.scene.vertex_index_np)
+        hdr, st = o.render(W, H, 0, 64, seed=1)
+        ref = np.load(os.path.join(GOLD, "gallery_%s_blocks.npy" % variant.replace("-", "_")))
+        got[variant] = gallery_structure(hdr, ref)
+    print("gallery structure pins (inside, background):", {k: (round(a, 3), round(b, 3)) for k, (a, b) in got.items()})
+    for variant in got:
+        assert got[variant][1] > 0.92, (variant, got[variant])
+    assert got["metal"][0] > 0.85 and got["non-metal"][0] > 0.88, got
+    assert got["glass"][0] > 0.35, got
+    # negative control: the committed example's yaw 0 looks at another part of the env
+    ex = scenes.gallery_sphere(W, H, 16, variant="non-metal", yaw=0.0)
+    ex.scene.setup_data_cpu(); ex.frame_camera()
+    o = oa.OracleScene(ex.scene, ex.cam); o.lbvh_build(); o.process_normal(ex.scene.vertex_index_np)
+    hdr, _ = o.render(W, H, 0, 16, seed=1)
+    assert gallery_structure(hdr, np.load(os.path.join(GOLD, "gallery_non_metal_blocks.npy")))[1] < 0.5
+
+
+def test_libm_oracle_has_the_same_lbvh_and_hit_records_on_the_teapot():
+    """The oracle built on libm (-DORACLE_LIBM) instead of ti_raytrace_amd/csrc/tirt_math.h: everything that does not go through a
+    transcendental function must come out bit-identical -- the whole LBVH (Morton codes, sort, topology, boxes, flatten), the
+    smooth normals' finite entries and the 13-float closest-hit records of the Teapot's camera rays (t, position, both normals,
+    uv; sqrt and division are correctly rounded on both sides).  Only sin/cos/exp/log/pow/atan2/acos differ (<= 1 ulp), i.e. the
+    BSDF sampling and process_normal's acos-weighted angles."""
+    W = H = 64
+    ex = host_only(scenes.single_model(W, H, 4))
+    a = oa.OracleScene(ex.scene, ex.cam)
+    b = oa.OracleScene(ex.scene, ex.cam, libm=True)
+    assert a.L.orc_uses_libm() == 0 and b.L.orc_uses_libm() == 1
+    assert a.lbvh_build() == b.lbvh_build()
+    for x, y in zip(a.lbvh_get(), b.lbvh_get()):
+        assert np.array_equal(x, y)
+    rays = oa.camera_rays(ex.cam, W, H)
+    ha, pa, _ = a.closest_hit(rays)
+    hb, pb, _ = b.closest_hit(rays)
+    assert np.array_equal(pa, pb) and np.array_equal(ha, hb, equal_nan=True)
+    assert (pa >= 0).mean() > 0.2
+    # smooth normals go through acos: compare loosely, and count how many entries are even bit-identical
+    a.process_normal(ex.scene.vertex_index_np); b.process_normal(ex.scene.vertex_index_np)
+    va, vb = a.vertex(), b.vertex()
+    fin = np.isfinite(va).all(axis=1) & np.isfinite(vb).all(axis=1)
+    assert fin.mean() > 0.99 and np.abs(va[fin] - vb[fin]).max() < 1e-4

@@ -52,6 +52,45 @@ class single_model(Example.example):
         self.frame_camera(0.8)
 
 
+class gallery_sphere(Example.example):
+    """The scene of the reference's gallery renders image/glass.png, metal.png and non-metal.png: example/single_model.py
+    with sphere.obj and its three material variants (:27-31: glass ior 1.3 / extinction 5; Disney metal 1 rough 0; the
+    default Disney).  Those renders predate the committed example -- measured on the images: the sphere is 253 px wide
+    (camera at 1.0 x |diagonal|, the committed :46 says 0.8), the light disc has a radius of 37 px at 30 degrees
+    elevation (a sphere light near (0, 2, 0) r 0.3; Example.py:27-36 says (0, 20, 0) r 5) and the background is the env
+    map seen from yaw pi -- so this class takes those as parameters (defaults = the measured ones).  Used by the
+    structure pins of tests/test_oracle_golden.py and tests/test_gpu_gallery.py."""
+
+    def __init__(self, imgSizeX, imgSizeY, sample_count, variant="glass", cam_scale=1.0, yaw=3.14159265,
+                 light_pos=(0.0, 2.0, 0.0), light_radius=0.3, emission=50.0, device_id=None, **pt_kwargs):
+        Example.example.__init__(self, imgSizeX, imgSizeY, sample_count, device_id)
+        self.scene.add_obj(asset("model", "sphere.obj"))
+        m = self.scene.material_cpu[0]
+        if variant == "glass":
+            m.type = SCD.MAT_GLASS
+            m.setIor(1.3)
+            m.setExtinciton(5.0)
+        elif variant == "metal":
+            m.setMetal(1.0)
+            m.setRough(0.0)
+        elif variant != "non-metal":
+            raise ValueError(variant)
+        self.add_sphere_light(pos=light_pos, radius=light_radius, emission=emission)
+        self.scene.add_env(asset("image", "env.png"), 5.0)
+        self.cam_scale, self.cam_yaw = cam_scale, yaw
+        self.integrator = PT_RGB.PathTrace(imgSizeX, imgSizeY, self.cam, self.scene, 64, **pt_kwargs)
+
+    def frame_camera(self, scale_factor=None):
+        Example.example.frame_camera(self, self.cam_scale if scale_factor is None else scale_factor)
+        self.cam.set_view_point(self.cam_yaw, 0.0, 0.0, self.cam.scale)
+
+    def build_scene(self):
+        Example.example.build_scene(self)
+        self.scene.process_normal()
+        self.scene.total_area()
+        self.frame_camera()
+
+
 class veach_bdpt(Example.example):
     """example/veach_bdpt.py:12-35 (BASELINE config 5): bdpt.obj, BDPT_RGB, smooth normals,
     camera at 0.5 x |diagonal|."""
