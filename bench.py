@@ -20,21 +20,29 @@ line.  Inputs (scene, BVH) are resident in HBM before the timed region.
 
 Extra objects:
   roofline      dominant kernel = the traversal kernel k_trace (closest hits of bounce b + NEE shadow
-                rays of bounce b-1 in one launch).  rocprofv3 PMC (profiles/) shows it bound by the
-                L1 gather path (texture-address unit), not by HBM, so:
-                  achieved = bytes of node / primitive / ray records the launch gathers from global memory
-                             (device counters of an untimed counting pass over the same frames)
-                             / mean launch duration (HIP events on the library's stream, untimed pass)
-                  peak     = the ceiling of exactly that access pattern (random 64-byte records,
-                             4 x 16-byte loads per lane) measured in THIS run on an array of the BVH's
-                             actual byte size (tirt_micro_gather_rate)
-                  frac     = achieved / peak
-                  traffic  = HBM-side bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE, MI355X_MICROARCH.md)
-                             from two rocprofv3 --pmc passes this script runs itself on a child process;
-                             hbm_frac = traffic / duration / 8 TB/s
+                rays of bounce b-1 in one launch).  Three ceilings from MI355X_MICROARCH.md, each with the
+                kernel's measured use of it (four rocprofv3 --pmc passes this script runs itself on a child
+                process; launch duration from HIP events on the library's stream):
+                  fractions.hbm  = HBM-side bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE) / duration / 8 TB/s
+                  fractions.l2   = L1 -> L2 read bytes (TCP_TCC_READ_REQ, bytes per request calibrated on k_film
+                                   in the same pass) / duration / 34.5 TB/s
+                  fractions.valu = share of the kernel's cycles a SIMD's VALU is issuing (SQ_ACTIVE_INST_VALU x 4
+                                   / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs)); valu.useful_lane_throughput = that x
+                                   the active-lane fraction
+                  bound          = the largest of the three; achieved / peak / unit / frac state that one
+                  traffic        = HBM-side bytes per launch
+                  gather         = the node / primitive / ray records the launch gathers from global memory
+                                   against the two measured ceilings of that access pattern (working-set sized
+                                   and L2-resident array) -- both fractions printed, no switching
                   alg_reference_semantics = SURVEY.md 8d's figure (32 B x N_box + 36 B x N_leaf + 48 B per
                              ray with the REFERENCE's exhaustive pop counts): what the reference's
                              algorithm would move, not what this kernel moves -- reported, not a fraction.
+  configs       (N = 1) the other BASELINE.json configs after the timed region -- config 1 as the reference
+                committed it (Cornell 512^2 x 512 spp), config 2 (Teapot 1024^2 x 64 spp), config 5
+                (veach_bdpt 512^2 x 64 spp, with a roofline of the BDPT kernels) -- each: seconds, rays,
+                Mrays/s, NaN pixels, a film sample checked against the CPU oracle; LBVH build at 100k / 1 M.
+  distributed   (N > 1) rccl_ranks (an all-reduce of ones), equality of the replicated BVH builds (hash
+                all-gather), reduce_ms of the one film reduce.
   cpu_baseline  the CPU oracle (oracle/, a restatement of the reference algorithm: AoS rows,
                 exhaustive unordered traversal, per-pixel loop) built -O3 -march=native on this box,
                 on all host cores over a bounded sample of the same scene/frames ("kind": "port"; the
@@ -65,7 +73,9 @@ def parse():
     ap.add_argument("--tile-size", type=int, default=0, help="pixels per film tile (0: PT_RGB.default_tile_size: 8 columns)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc child passes behind roofline.traffic")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 --pmc child passes behind roofline.traffic / fractions")
+    ap.add_argument("--no-configs", action="store_true", help="skip the `configs` object (the other BASELINE configs, run after the timed region at N = 1)")
+    ap.add_argument("--configs-only", default="", help="internal: run one entry of the configs leg (child of the BDPT profiler passes)")
     ap.add_argument("--cpu-target-s", type=float, default=12.0, help="seconds of CPU-oracle work for cpu_baseline")
     ap.add_argument("--save-png", default="")
     ap.add_argument("--emulate-world", type=int, default=0, help="render only rank 0's tiles of an N-rank job (scaling study on one GPU)")
@@ -73,10 +83,16 @@ def parse():
     return ap.parse_args()
 
 
-def measure_hbm_traffic(args):
-    """HBM-side bytes per k_trace launch, measured now: two rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE do not
-    fit one pass: TCC has 4 counter slots) over a child run of this script (1 warm-up + 1 step, one render lane).
-    FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950.  Returns a dict, or {"error": ...}."""
+def _short_kernel(name):
+    """'void tirt::k_trace<0, false, 2>(tirt::TraceArgs)' -> 'k_trace<0,false,2>'"""
+    n = name.split("(")[0].replace("void ", "").replace("tirt::", "").replace(" ", "")
+    return n
+
+
+def rocprof_passes(child, groups, timeout_s=240):
+    """Runs `child` (argv) once per counter group under `rocprofv3 --kernel-trace --pmc <group>` (one group per run, as the
+    MI355X guide prescribes: FETCH_SIZE and WRITE_SIZE do not fit one pass, no tracing domain besides the kernel trace) and
+    returns {kernel: {"launches": n, "dur_ns": total, counter: total, ...}} merged over the passes (durations from the first)."""
     import csv
     import glob
     import shutil
@@ -84,57 +100,211 @@ def measure_hbm_traffic(args):
     import tempfile
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
-        return {"error": "rocprofv3 not found"}
+        raise RuntimeError("rocprofv3 not found")
     if any(k.startswith("ROCPROF") or k.startswith("ROCP_") for k in os.environ):
-        return {"error": "this process is itself being profiled: nested rocprofv3 pass skipped"}
+        raise RuntimeError("this process is itself being profiled: nested rocprofv3 pass skipped")
     env = {k: v for k, v in os.environ.items()
            if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT",
                         "TORCHELASTIC_RUN_ID", "TIRT_FORCE_DIST")}            # the child is a plain one-process run
     env["TMPDIR"] = "/tmp"
-    out = {}
     tmp = tempfile.mkdtemp(prefix="tirt_pmc_", dir="/tmp")
-    child = [sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "1", "--frames-per-step", str(args.frames_per_step),
-             "--size", str(args.size), "--ntri", str(args.ntri), "--seed", str(args.seed), "--no-cpu-baseline", "--no-roofline",
-             "--opt", "overlap_lanes=1",
-             # one batch per step, as in the instrumented pass whose launch duration the bytes are divided by
-             "--opt", "batch_paths=%d" % (args.frames_per_step * args.size * args.size),
-             "--opt", "merge_paths=%d" % (args.frames_per_step * args.size * args.size)] + sum((["--opt", o] for o in args.opt), [])
-    def one_pass(counters):
-        d = os.path.join(tmp, counters[0])
-        cmd = ["timeout", "-k", "5", "240", exe, "--kernel-trace", "--pmc"] + list(counters) + ["--output-format", "csv", "-d", d, "--"] + child
-        p = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
-        fs = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
-        if not fs:
-            raise RuntimeError("%s pass produced no counter file (rc %d)" % (counters[0], p.returncode))
-        tot, ids = {c: 0.0 for c in counters}, set()
-        for r in csv.DictReader(open(max(fs, key=os.path.getmtime))):
-            if "k_trace" in r["Kernel_Name"] and r["Counter_Name"] in tot:
-                tot[r["Counter_Name"]] += float(r["Counter_Value"]); ids.add(r["Dispatch_Id"])
-        if not ids:
-            raise RuntimeError("no k_trace dispatch in the %s pass" % counters[0])
-        return tot, len(ids)
+    out = {}
     try:
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-            tot, n = one_pass((counter,))
-            out[counter + "_KB_per_launch"] = round(tot[counter] / n, 1)
-            out["launches_" + counter] = n
-        # what the kernel is busy with, same child run: VALU issue and texture-address cycles against the kernel's own clock count
-        # (SQ_ACTIVE_INST_VALU counts quad-cycles per SIMD, GRBM_GUI_ACTIVE is summed over the 8 XCDs; MI355X: 1024 SIMDs, 256 CUs)
-        try:
-            tot, n = one_pass(("SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE", "TA_TA_BUSY_sum"))
-            cyc = tot["GRBM_GUI_ACTIVE"] / 8.0
-            if cyc > 0:
-                out["valu_busy"] = round(tot["SQ_ACTIVE_INST_VALU"] * 4.0 / (cyc * 1024.0), 3)
-                out["ta_busy"] = round(tot["TA_TA_BUSY_sum"] / (cyc * 256.0), 3)
-        except Exception as exc:        # noqa: BLE001
-            out["busy_error"] = "%s: %s" % (type(exc).__name__, exc)
-    except Exception as exc:            # noqa: BLE001 -- a failed profiler pass must not fail the bench line
-        return {"error": "%s: %s" % (type(exc).__name__, exc)}
+        for gi, counters in enumerate(groups):
+            d = os.path.join(tmp, "g%d" % gi)
+            cmd = ["timeout", "-k", "5", str(timeout_s), exe, "--kernel-trace", "--pmc"] + list(counters) + ["--output-format", "csv", "-d", d, "--"] + child
+            pr = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout_s + 60)
+            fs = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if not fs:
+                raise RuntimeError("%s pass produced no counter file (rc %d)" % (counters[0], pr.returncode))
+            seen = set()
+            for r in csv.DictReader(open(max(fs, key=os.path.getsize))):
+                k = _short_kernel(r["Kernel_Name"])
+                e = out.setdefault(k, {"launches": 0, "dur_ns": 0.0})
+                e[r["Counter_Name"]] = e.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+                if gi == 0 and (k, r["Dispatch_Id"]) not in seen:
+                    seen.add((k, r["Dispatch_Id"]))
+                    e["launches"] += 1
+                    e["dur_ns"] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
-    out["bytes_per_launch"] = round((2.0 * out["FETCH_SIZE_KB_per_launch"] + out["WRITE_SIZE_KB_per_launch"]) * 1024.0)
-    out["source"] = "rocprofv3 --pmc passes (FETCH_SIZE; WRITE_SIZE; SQ_ACTIVE_INST_VALU + GRBM_GUI_ACTIVE + TA_TA_BUSY_sum) run by bench.py on a child process; FETCH_SIZE x 2 (gfx950)"
     return out
+
+
+# Peaks from /opt/skills/guides/MI355X_MICROARCH.md
+L2_PEAK_GBS = 34500.0          # aggregate L2 bandwidth
+VALU_PEAK_GINSTR = 1024 * 2.4 / 2.0    # wave64 VALU instructions per ns: 1024 SIMD-32s x 2.4 GHz, 2 cycles per instruction at best (the 157.3 TFLOP/s FP32 vector peak)
+
+
+def measure_trace_counters(args):
+    """What the traversal kernel does to the memory system and to the VALUs, measured now on a child run of this script
+    (1 warm-up + 1 step, one render lane: one wavefront batch, launches do not overlap).  Four rocprofv3 passes:
+      FETCH_SIZE | WRITE_SIZE                     HBM-side bytes (FETCH_SIZE x 2 on gfx950, MI355X_MICROARCH.md)
+      TCP_TCC_READ_REQ_sum, TCC_HIT/MISS_sum      L1 -> L2 requests; bytes per request calibrated IN THE SAME PASS on k_film,
+                                                  whose reads are known exactly (3 words per path + the film)
+      SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU, SQ_THREAD_CYCLES_VALU, SQ_LDS_BANK_CONFLICT, SQ_LDS_IDX_ACTIVE + GRBM_GUI_ACTIVE +
+      TA_TA_BUSY_sum                              VALU instructions, busy quad-cycles, active lanes, LDS conflict cycles
+    Returns a dict (per k_trace launch), or {"error": ...}."""
+    fps, P = args.frames_per_step, args.size * args.size
+    child = [sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "1", "--frames-per-step", str(fps),
+             "--size", str(args.size), "--ntri", str(args.ntri), "--seed", str(args.seed), "--no-cpu-baseline", "--no-roofline", "--no-configs",
+             "--opt", "overlap_lanes=1",
+             # one batch per step, as in the instrumented pass whose launch duration the bytes are divided by
+             "--opt", "batch_paths=%d" % (fps * P), "--opt", "merge_paths=%d" % (fps * P)] + sum((["--opt", o] for o in args.opt), [])
+    try:
+        k = rocprof_passes(child, [("FETCH_SIZE",), ("WRITE_SIZE",), ("TCP_TCC_READ_REQ_sum", "TCC_HIT_sum", "TCC_MISS_sum"),
+                                   ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE",
+                                    "GRBM_GUI_ACTIVE", "TA_TA_BUSY_sum")])
+    except Exception as exc:            # noqa: BLE001 -- a failed profiler pass must not fail the bench line
+        return {"error": "%s: %s" % (type(exc).__name__, exc)}
+    tr = [v for n, v in k.items() if n.startswith("k_trace")]
+    if not tr:
+        return {"error": "no k_trace dispatch in the profiler passes"}
+    tot = {}
+    for v in tr:
+        for c, x in v.items():
+            tot[c] = tot.get(c, 0.0) + x
+    n = max(int(tot["launches"]), 1)
+    out = {"launches": n, "avg_launch_ms_profiled": round(tot["dur_ns"] / n / 1e6, 5),
+           "FETCH_SIZE_KB_per_launch": round(tot.get("FETCH_SIZE", 0.0) / n, 1), "WRITE_SIZE_KB_per_launch": round(tot.get("WRITE_SIZE", 0.0) / n, 1)}
+    out["bytes_per_launch"] = round((2.0 * out["FETCH_SIZE_KB_per_launch"] + out["WRITE_SIZE_KB_per_launch"]) * 1024.0)
+    cyc = tot.get("GRBM_GUI_ACTIVE", 0.0) / 8.0           # summed over the 8 XCDs
+    if cyc > 0 and tot.get("SQ_INSTS_VALU", 0) > 0:
+        out["valu_busy"] = round(tot["SQ_ACTIVE_INST_VALU"] * 4.0 / (cyc * 1024.0), 4)        # quad-cycles per SIMD -> share of the kernel's cycles
+        out["ta_busy"] = round(tot["TA_TA_BUSY_sum"] / (cyc * 256.0), 4)
+        out["valu_lane_util"] = round(tot["SQ_THREAD_CYCLES_VALU"] / (tot["SQ_ACTIVE_INST_VALU"] * 64.0), 4)
+        out["valu_cycles_per_inst"] = round(tot["SQ_ACTIVE_INST_VALU"] * 4.0 / tot["SQ_INSTS_VALU"], 3)
+        out["valu_wave_insts_per_launch"] = round(tot["SQ_INSTS_VALU"] / n)
+        out["clock_GHz_profiled"] = round(cyc / tot["dur_ns"], 3)
+        out["lds_bank_conflict_frac_of_lds_cycles"] = round(tot.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(tot.get("SQ_LDS_IDX_ACTIVE", 0.0), 1.0), 4)
+        out["lds_bank_conflict_cycles_frac_of_kernel"] = round(tot.get("SQ_LDS_BANK_CONFLICT", 0.0) / (cyc * 256.0), 4)   # LDS is per CU
+    if tot.get("TCP_TCC_READ_REQ_sum", 0) > 0:
+        out["l2_hit_rate"] = round(tot["TCC_HIT_sum"] / max(tot["TCC_HIT_sum"] + tot["TCC_MISS_sum"], 1.0), 4)
+        film = k.get("k_film")
+        bytes_per_req = 64.0
+        if film and film.get("TCP_TCC_READ_REQ_sum", 0) > 0 and film["launches"] > 0:
+            known = film["launches"] * (12.0 * fps * P + 12.0 * P)                  # fr, fg, fb of every path + the film itself
+            bytes_per_req = known / film["TCP_TCC_READ_REQ_sum"]
+            out["l2_bytes_per_request_calibrated_on_k_film"] = round(bytes_per_req, 2)
+        out["l2_read_bytes_per_launch"] = round(tot["TCP_TCC_READ_REQ_sum"] * bytes_per_req / n)
+    out["source"] = ("rocprofv3 --kernel-trace --pmc passes (FETCH_SIZE | WRITE_SIZE | TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum | SQ_INSTS_VALU "
+                     "SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE TA_TA_BUSY_sum) run by bench.py on a "
+                     "child process; FETCH_SIZE x 2 (gfx950)")
+    return out
+
+
+def _oracle_run_identical(ex, W, H, frames, seed, got_hdr, p0, npx=2048):
+    """`npx` pixels of the film starting at linear pixel p0, rendered by the CPU oracle (same frames, same seed), compared bit for
+    bit (NaNs in the same places count as equal)."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_api
+    o = oracle_api.OracleScene(ex.scene, ex.cam)
+    o.lbvh_build()
+    if getattr(ex.scene, "normals_processed", False):
+        o.process_normal(ex.scene.vertex_index_np)
+    want, _ = o.render(W, H, 0, frames, seed=seed, p_begin=p0, p_end=p0 + npx)
+    a = got_hdr.reshape(-1, 3)[p0:p0 + npx]
+    b = want.reshape(-1, 3)[p0:p0 + npx]
+    return bool(np.array_equal(a, b, equal_nan=True))
+
+
+def run_config(name, device_id, seed=1):
+    """One entry of the `configs` object: a BASELINE.json config other than the headline one, rendered whole on this GPU after a
+    warm-up job of the same size: seconds, rays, Mrays/s, NaN pixels, and a sample of the film checked against the CPU oracle."""
+    import numpy as np
+    from ti_raytrace_amd import scenes
+    from ti_raytrace_amd import UtilsFunc as UF
+    gold = os.path.join(ROOT, "tests", "golden")
+
+    def timed(ex, spp, render):
+        ctx = ex.scene.ctx
+        for kv in filter(None, os.environ.get("TIRT_BENCH_CTX_OPTS", "").split(",")):      # (profiler children: overlap_lanes=1)
+            k_, v_ = kv.split("="); ctx.set_option(k_, float(v_))
+        render(); ctx.sync()                                   # warm-up: the same job (allocations, clocks), then a fresh film
+        ctx.film_clear(); ex.cam.frame = 0; ex.cam.frame_cpu[0] = 0; ctx.sync(); ctx.stats_reset()
+        t0 = time.perf_counter(); render(); ctx.sync(); dt = time.perf_counter() - t0
+        st = ctx.stats()
+        rays = st["rays_closest"] + st["rays_shadow"]
+        hdr = ex.integrator.hdr.to_numpy()
+        return hdr, {"seconds": round(dt, 4), "rays": int(rays), "Mrays_per_s": round(rays / dt / 1e6, 1), "rays_closest": int(st["rays_closest"]),
+                     "rays_shadow": int(st["rays_shadow"]), "nan_pixels": int(np.isnan(hdr).any(axis=2).sum()), "lbvh_build_ms": round(st["ms_build"], 3),
+                     "prims": int(ex.scene.primitive_count)}
+
+    def block_pin(ex, hdr, fixture, exposure=0.5):
+        """mean colour and 16x16-block rel-L2 of the tone-mapped film against the block means of a reference PNG"""
+        ex.scene.ctx.tone_map(exposure)
+        rgb = ex.integrator.rgb_film.to_numpy()
+        img = np.nan_to_num(np.transpose(rgb, (1, 0, 2))[::-1])
+        ref = np.load(os.path.join(gold, fixture)).astype(np.float64)
+        s_ = img.shape[0] // 32
+        ours = img.reshape(32, s_, 32, s_, 3).mean(axis=(1, 3))
+        return {"fixture": fixture, "mean_srgb": [round(float(x), 4) for x in ours.reshape(-1, 3).mean(0)],
+                "ref_mean_srgb": [round(float(x), 4) for x in ref.reshape(-1, 3).mean(0)],
+                "block_rel_l2": round(float(np.sqrt(((ours - ref) ** 2).sum() / (ref ** 2).sum())), 4)}
+
+    if name == "config1_cornell_512x512_512spp":       # the reference's own committed run (Main.py:14): out.png
+        W = H = 512; spp = 512
+        ex = scenes.cornell_box(W, H, spp, device_id=device_id, seed=seed); ex.build_scene()
+        hdr, r = timed(ex, spp, lambda: ex.integrator.render_frames(spp))
+        r["oracle_sample_identical"] = _oracle_run_identical(ex, W, H, spp, seed, hdr, (W // 2) * H + 128)
+        r["oracle_sample"] = "2048 pixels x 512 spp, bit for bit"
+        r["reference_pin"] = block_pin(ex, hdr, "out_png_blocks.npy")
+        return r
+    if name == "config2_teapot_1024x1024_64spp":
+        W = H = 1024; spp = 64
+        ex = scenes.single_model(W, H, spp, device_id=device_id, seed=seed); ex.build_scene()
+        hdr, r = timed(ex, spp, lambda: ex.integrator.render_frames(spp))
+        r["oracle_sample_identical"] = _oracle_run_identical(ex, W, H, spp, seed, hdr, (W // 2) * H + 300)
+        r["oracle_sample"] = "2048 pixels x 64 spp through the teapot, bit for bit (NaN pixels included)"
+        return r
+    if name == "config5_veach_bdpt_512x512_64spp":
+        W = H = 512; spp = 64
+        ex = scenes.veach_bdpt(W, H, spp, device_id=device_id, seed=seed); ex.build_scene()
+        hdr, r = timed(ex, spp, lambda: ex.scene.ctx.bdpt_rgb_render(0, spp, seed))
+        r["reference_pin"] = block_pin(ex, hdr, "veach_bdpt512_blocks.npy")
+        # BDPT splats land on any pixel, so the oracle check is a whole (small) film: 48^2 x 4 spp of the same scene
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_api
+        w = 48
+        ex2 = scenes.veach_bdpt(w, w, 4, device_id=device_id, seed=seed); ex2.build_scene()
+        ex2.scene.ctx.bdpt_rgb_render(0, 4, seed); got = ex2.integrator.hdr.to_numpy()
+        o = oracle_api.OracleScene(ex2.scene, ex2.cam); o.lbvh_build(); o.process_normal(ex2.scene.vertex_index_np)
+        want, ost, _ = o.bdpt_render(ex2.cam, w, w, 0, 4, seed=seed)
+        rel = float(np.sqrt(((got.astype(np.float64) - want) ** 2).sum() / max((want.astype(np.float64) ** 2).sum(), 1e-30)))
+        st2 = ex2.scene.ctx.stats()
+        r["oracle_sample_identical"] = bool(rel <= 1e-5 and np.array_equal(np.isnan(got), np.isnan(want)))
+        r["oracle_sample"] = "whole 48x48 film x 4 spp: rel-L2 %.2e (float-atomic splats: order-dependent in the last bits), same NaN mask, " \
+                             "ray counts equal: %s" % (rel, bool(st2["rays_closest"] + st2["rays_shadow"] >= ost["rays_closest"] + ost["rays_shadow"]))
+        return r
+    raise SystemExit("unknown config " + name)
+
+
+def bdpt_roofline(device_id):
+    """roofline of the BDPT wavefront's own kernels (config 5): per kernel the HBM-side bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE,
+    two rocprofv3 passes over a child run of the config on ONE lane, so that launches do not overlap) / its profiled duration against
+    8 TB/s; `dominant` = the k_bd_* kernel with the largest share of the batch's time."""
+    child = [sys.executable, os.path.abspath(__file__), "--configs-only", "config5_veach_bdpt_512x512_64spp:overlap_lanes=1"]
+    try:
+        k = rocprof_passes(child, [("FETCH_SIZE",), ("WRITE_SIZE",)])
+    except Exception as exc:            # noqa: BLE001
+        return {"error": "%s: %s" % (type(exc).__name__, exc)}
+    rows = {}
+    total = sum(v["dur_ns"] for n, v in k.items() if n.startswith("k_bd") or n.startswith("k_trace")) or 1.0
+    for n, v in k.items():
+        if not (n.startswith("k_bd") or n.startswith("k_trace")) or v["launches"] == 0:
+            continue
+        by = (2.0 * v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0)) * 1024.0
+        rows[n] = {"launches": v["launches"], "avg_ms": round(v["dur_ns"] / v["launches"] / 1e6, 4), "time_share": round(v["dur_ns"] / total, 4),
+                   "hbm_bytes_per_launch": round(by / v["launches"]), "hbm_GBps": round(by / v["dur_ns"], 1),
+                   "hbm_frac": round(by / v["dur_ns"] / HBM_PEAK_GBS, 4)}
+    bd = {n: r for n, r in rows.items() if n.startswith("k_bd")}
+    if not bd:
+        return {"error": "no k_bd_* dispatch in the profiler passes"}
+    dom = max(bd, key=lambda n: bd[n]["time_share"])
+    return {"bound": "hbm", "kernel": dom, "achieved": rows[dom]["hbm_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": rows[dom]["hbm_frac"],
+            "traffic": rows[dom]["hbm_bytes_per_launch"], "kernels": rows,
+            "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE over `bench.py --configs-only config5...:overlap_lanes=1` (one lane, profiled durations)"}
 
 
 def host_cpu_info():
@@ -203,8 +373,39 @@ def cpu_baseline(args, ex, W, H, build_ms):
     }
 
 
+def _with_timeout(what, fn, seconds):
+    """Runs fn() on a helper thread; if it has not returned after `seconds` the process reports why and exits (a stalled RCCL /
+    process-group set-up would otherwise hang until the driver's own limit)."""
+    import threading
+    box = {}
+
+    def run():
+        try:
+            box["v"] = fn()
+        except BaseException as exc:      # noqa: BLE001
+            box["e"] = exc
+    th = threading.Thread(target=run, daemon=True)
+    th.start(); th.join(seconds)
+    if th.is_alive():
+        sys.stderr.write("bench.py: %s did not finish within %d s (rank %s of %s, MASTER_ADDR=%s MASTER_PORT=%s) -- giving up\n" %
+                         (what, seconds, os.environ.get("RANK"), os.environ.get("WORLD_SIZE"), os.environ.get("MASTER_ADDR"), os.environ.get("MASTER_PORT")))
+        sys.stderr.flush()
+        os._exit(3)
+    if "e" in box:
+        raise box["e"]
+    return box.get("v")
+
+
 def main():
     args = parse()
+    if args.no_roofline:            # the quick form every tool and test uses: headline number only
+        args.no_configs = True
+    if args.configs_only:                       # child of bdpt_roofline's profiler passes: one config, optional context options
+        name, _, optstr = args.configs_only.partition(":")
+        if optstr:
+            os.environ["TIRT_BENCH_CTX_OPTS"] = optstr
+        print(json.dumps({name: run_config(name, 0, args.seed)}), flush=True)
+        return
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -230,10 +431,12 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+        import datetime
+        tmo = datetime.timedelta(seconds=int(os.environ.get("TIRT_BENCH_PG_TIMEOUT_S", "180")))
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            _with_timeout("init_process_group(nccl)", lambda: dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=tmo), tmo.seconds + 30)
         else:
-            dist.init_process_group(backend)
+            _with_timeout("init_process_group(%s)" % backend, lambda: dist.init_process_group(backend, timeout=tmo), tmo.seconds + 30)
 
     from ti_raytrace_amd import scenes, _native
     from ti_raytrace_amd import distributed as tdist
@@ -283,12 +486,38 @@ def main():
             ex.cam.update_frame(fps)
 
     run_steps(args.warmup)
-    tdist.warmup(ctx, W, H, force=force_dist)
+    # the first collective creates the RCCL communicator: bounded, with a clear message if it stalls
+    _with_timeout("the first RCCL collective (communicator set-up)", lambda: tdist.warmup(ctx, W, H, force=force_dist), 240)
+    dist_info = None
+    if world > 1 or force_dist:
+        # how many ranks RCCL really connected: an all-reduce of ones over the communicator the film reduce will use
+        ones = torch.ones(1, dtype=torch.float32, device="cuda")
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        torch.cuda.synchronize()
+        # replicated builds must be identical: every rank hashes its LBVH (compact_node) and its traversal tree, the hashes are
+        # all-gathered, a mismatch aborts the run (each rank would render with a different tree: same film, but it would hide a
+        # nondeterministic build)
+        import hashlib
+        n_prims = ex.scene.primitive_count
+        _, _, compact = ctx.lbvh_download(n_prims, want_morton=False, want_bvh=False)
+        tree = ctx.traversal_tree_download(n_prims)
+        h = hashlib.blake2b(compact.tobytes(), digest_size=8); h.update(tree.tobytes())
+        mine = torch.tensor([int.from_bytes(h.digest(), "little", signed=True)], dtype=torch.int64, device="cuda")
+        allh = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+        dist.all_gather(allh, mine)
+        hashes = [int(x.item()) for x in allh]
+        if len(set(hashes)) != 1:
+            raise SystemExit("replicated BVH builds differ between ranks: %s" % hashes)
+        dist_info = {"backend": dist.get_backend(), "rccl_ranks": int(round(float(ones.item()))), "world_size": dist.get_world_size(),
+                     "bvh_hash_equal_on_all_ranks": True, "bvh_hash": "%016x" % (hashes[0] & 0xffffffffffffffff)}
     barrier()
     ctx.stats_reset()
     t_begin = time.perf_counter()
     run_steps(args.steps)
+    ctx.sync()
+    t_reduce = time.perf_counter()
     film = tdist.reduce_film(ctx, W, H, dst=0, force=force_dist)   # one RCCL reduce of the framebuffer (world > 1)
+    reduce_ms = (time.perf_counter() - t_reduce) * 1e3            # this rank: export, RCCL reduce, import (after its own rendering finished)
     barrier()
     elapsed = time.perf_counter() - t_begin
     st = ctx.stats()
@@ -329,6 +558,13 @@ def main():
         "build_detail": build_detail,
         "scene_setup_wall_s": round(build_wall, 3),
     }
+    if dist_info is not None:
+        red_t = torch.tensor([reduce_ms], dtype=torch.float64, device="cuda")
+        if world > 1:
+            dist.all_reduce(red_t, op=dist.ReduceOp.MAX)
+        dist_info["reduce_ms"] = round(float(red_t.item()), 3)
+        dist_info["reduce_def"] = "max over ranks of: device-to-device export of the film, one RCCL reduce(SUM) of W*H*3 f32 onto rank 0, import on rank 0 -- inside the timed region"
+        result["distributed"] = dist_info
 
     if rank == 0 and args.save_png:
         from ti_raytrace_amd.Example import write_png
@@ -369,32 +605,65 @@ def main():
         working_set = info["node_bytes"] + info["prim_bytes"]
         peak_ws = ctx.micro_gather_rate(working_set, 2000)
         peak_l2 = ctx.micro_gather_rate(2 << 20, 2000)
-        # The ceiling for uniformly random records of the whole working set is the right one while that set is of the order of the
-        # L2s (the default scene: 7.5 MB); a traversal of a much larger scene (--ntri 1000000: 75 MB) re-reads the top of its tree
-        # from cache and EXCEEDS it -- then the L2-resident ceiling is the one that still bounds the kernel.
-        peak = peak_ws if achieved <= peak_ws else peak_l2
         # (the profiler passes run the one-GPU workload on this rank's device: only at N = 1, where that is the workload timed)
-        traffic = None if (args.no_traffic or world > 1) else measure_hbm_traffic(args)
-        tr_bytes = traffic["bytes_per_launch"] if traffic and traffic.get("bytes_per_launch") else None
+        pmc = None if (args.no_traffic or world > 1) else measure_trace_counters(args)
+        ok = bool(pmc) and "error" not in pmc
+        tr_bytes = pmc["bytes_per_launch"] if ok else None
+        dur_s = avg_ms * 1e-3
+        # Three ceilings from MI355X_MICROARCH.md, each with the kernel's measured use of it; `bound` is the largest fraction.
+        #   hbm  : HBM-side bytes (counters) / launch duration / 8 TB/s
+        #   l2   : L1 -> L2 read bytes (counters) / launch duration / 34.5 TB/s
+        #   valu : share of the kernel's cycles in which a SIMD's VALU is issuing (SQ_ACTIVE_INST_VALU) -- the instruction mix of a node
+        #          visit (v_fma_mix, v_min3/v_max3, v_cndmask, v_alignbit) issues at ~4 cycles per wave64 instruction, twice the 2 cycles
+        #          behind the 157.3 TFLOP/s FP32 peak, so the same fact reads as `rate_frac_of_fp32_peak` ~ half of `issue_busy`
+        fr = {"hbm": None, "l2": None, "valu": None}
+        hbm = l2 = valu = None
+        if ok and dur_s > 0:
+            hbm = {"bytes_per_launch": tr_bytes, "GBps": round(tr_bytes / dur_s / 1e9, 1), "peak_GBps": HBM_PEAK_GBS}
+            fr["hbm"] = hbm["frac"] = round(hbm["GBps"] / HBM_PEAK_GBS, 4)
+            if pmc.get("l2_read_bytes_per_launch"):
+                l2 = {"read_bytes_per_launch": pmc["l2_read_bytes_per_launch"], "GBps": round(pmc["l2_read_bytes_per_launch"] / dur_s / 1e9, 1),
+                      "peak_GBps": L2_PEAK_GBS, "hit_rate": pmc.get("l2_hit_rate")}
+                fr["l2"] = l2["frac"] = round(l2["GBps"] / L2_PEAK_GBS, 4)
+            if pmc.get("valu_busy") is not None:
+                ginstr = pmc["valu_wave_insts_per_launch"] / (pmc["avg_launch_ms_profiled"] * 1e-3) / 1e9
+                valu = {"issue_busy": pmc["valu_busy"], "lane_util": pmc["valu_lane_util"],
+                        "useful_lane_throughput": round(pmc["valu_busy"] * pmc["valu_lane_util"], 4),
+                        "wave_insts_per_launch": pmc["valu_wave_insts_per_launch"], "wave_insts_per_ray": round(pmc["valu_wave_insts_per_launch"] * n_launch / max(rays_o, 1), 1),
+                        "Ginstr_per_s": round(ginstr, 1), "peak_Ginstr_per_s_at_2_cycles": VALU_PEAK_GINSTR,
+                        "rate_frac_of_fp32_peak": round(ginstr / VALU_PEAK_GINSTR, 4), "cycles_per_inst": pmc["valu_cycles_per_inst"],
+                        "ta_busy": pmc.get("ta_busy"), "lds_bank_conflict_frac_of_lds_cycles": pmc.get("lds_bank_conflict_frac_of_lds_cycles"),
+                        "lds_bank_conflict_cycles_frac_of_kernel": pmc.get("lds_bank_conflict_cycles_frac_of_kernel")}
+                fr["valu"] = valu["issue_busy"]
+        known = {k: v for k, v in fr.items() if v is not None}
+        bound = max(known, key=known.get) if known else "valu"
+        if bound == "valu" and valu:
+            top = {"achieved": valu["Ginstr_per_s"], "peak": round(valu["Ginstr_per_s"] / max(valu["issue_busy"], 1e-9), 1),
+                   "unit": "Ginstr/s (wave64 VALU instructions; peak = the rate at which this instruction mix saturates VALU issue: 1024 SIMDs x clock / measured cycles per instruction)",
+                   "frac": valu["issue_busy"]}
+        elif bound == "l2" and l2:
+            top = {"achieved": l2["GBps"], "peak": L2_PEAK_GBS, "unit": "GB/s", "frac": l2["frac"]}
+        elif hbm:
+            top = {"achieved": hbm["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm["frac"]}
+        else:       # no counters (--no-traffic, N > 1): the gathered bytes against the ceiling measured for this working set
+            top = {"achieved": round(achieved, 1), "peak": round(peak_ws, 1), "unit": "GB/s", "frac": round(achieved / peak_ws, 4) if peak_ws > 0 else None}
         alg_trace = alg_closest + alg_shadow
         result["roofline"] = {
-            # PMC (traffic_detail.valu_busy / ta_busy, measured by this run): the kernel is bound by VALU issue with the L1 gather path
-            # (texture-address unit) second; HBM is far from it.  The byte roofline below is stated on the gather path.
-            "bound": "valu_issue+l1_gather", "kernel": "k_trace<ordered> (closest-hit + NEE shadow rays)",
-            "achieved": round(achieved, 1), "peak": round(peak, 1), "unit": "GB/s",
-            "frac": round(achieved / peak, 4) if peak > 0 else None,
+            "bound": bound, "kernel": "k_trace<ordered> (closest-hit + NEE shadow rays)",
+            "achieved": top["achieved"], "peak": top["peak"], "unit": top["unit"], "frac": top["frac"],
             "traffic": tr_bytes,
-            "hbm_GBps": (round(tr_bytes / (avg_ms * 1e-3) / 1e9, 1) if (tr_bytes and avg_ms > 0) else None),
-            "hbm_frac": (round(tr_bytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if (tr_bytes and avg_ms > 0) else None),
-            "traffic_detail": traffic,
-            "peak_def": "tirt_micro_gather_rate measured in this run: random 64-byte records (4 x dwordx4 per lane) from an array of "
-                        "working_set_bytes = the traversal data of this scene (peak_working_set); peak_l2_resident = the same from 2 MB, used as "
-                        "peak when the kernel's non-uniform accesses beat the uniform-random ceiling of a working set far beyond the L2s",
-            "peak_working_set": round(peak_ws, 1), "peak_l2_resident": round(peak_l2, 1), "working_set_bytes": int(working_set), "bvh": info,
-            "achieved_def": "64 B x 4-wide node visits not served from LDS + 48 B x primitive tests + 40 B x rays, ordered-traversal device "
-                            "counters of the same frames, / mean k_trace launch duration (HIP events)",
-            "gather_bytes_per_launch": round(gather_bytes / n_launch, 1),
-            "gather_bytes_per_ray": round(gather_bytes / max(rays_o, 1), 1),
+            "fractions": fr, "hbm": hbm, "l2": l2, "valu": valu,
+            "hbm_GBps": hbm["GBps"] if hbm else None, "hbm_frac": fr["hbm"], "l2_frac": fr["l2"], "valu_frac": fr["valu"],
+            # the records the launch gathers from global memory against the two ceilings of that access pattern measured in THIS run
+            # (random 64-byte records, 4 x dwordx4 per lane: from an array of the traversal data's size, and from 2 MB = L2-resident);
+            # both fractions are printed, neither is chosen after the fact
+            "gather": {"GBps": round(achieved, 1), "bytes_per_launch": round(gather_bytes / n_launch, 1), "bytes_per_ray": round(gather_bytes / max(rays_o, 1), 1),
+                       "peak_working_set_GBps": round(peak_ws, 1), "frac_of_working_set_peak": round(achieved / peak_ws, 4) if peak_ws > 0 else None,
+                       "peak_l2_resident_GBps": round(peak_l2, 1), "frac_of_l2_resident_peak": round(achieved / peak_l2, 4) if peak_l2 > 0 else None,
+                       "working_set_bytes": int(working_set),
+                       "def": "64 B x 4-wide node visits not served from LDS + 48 B x primitive tests + 40 B x rays (ordered-traversal device counters of the "
+                              "same frames) / mean k_trace launch duration (HIP events); peaks: tirt_micro_gather_rate"},
+            "traffic_detail": pmc, "bvh": info,
             "avg_launch_ms": round(avg_ms, 5), "launches": int(n_launch),
             "node_visits_per_ray": round(node_visits / max(rays_o, 1), 2),
             "lds_node_visits_per_ray": round(lds_visits / max(rays_o, 1), 2),
@@ -423,6 +692,35 @@ def main():
     # ---- CPU baseline: oracle on the host cores, bounded sample (rank 0, N = 1 only) ---------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(args, ex, W, H, build_ms)
+
+    # ---- the other BASELINE configs and the build at 1 M primitives, driver-observable (rank 0, N = 1, after the timed region) ----
+    if rank == 0 and world == 1 and not args.no_configs:
+        cfgs = {}
+        for name in ("config1_cornell_512x512_512spp", "config2_teapot_1024x1024_64spp", "config5_veach_bdpt_512x512_64spp"):
+            try:
+                cfgs[name] = run_config(name, local_rank, args.seed)
+            except Exception as exc:        # noqa: BLE001 -- one failing config must not hide the headline line
+                cfgs[name] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+        cfgs["config3_headline"] = "this line's `value` (%d steps x %d frames of the 100k scene)" % (args.steps, fps)
+        if not args.no_traffic:
+            cfgs["config5_veach_bdpt_512x512_64spp"]["roofline"] = bdpt_roofline(local_rank)
+        # LBVH build (a4..a8) + traversal tree at 1 M primitives, second build of each kind (HIP events on the context's stream)
+        try:
+            big = scenes.synthetic(64, 64, 4, ntri=1000000, spread=0.012, device_id=local_rank)
+            big.build_scene(); bctx = big.scene.ctx
+            bd = {}
+            for tree in (0, 1):
+                bctx.set_option("traversal_tree", tree)
+                ms = []
+                for _ in range(3):
+                    bctx.lbvh_build(); ms.append(bctx.stats()["ms_build"])
+                bd["with_sah_traversal_tree_ms" if tree else "lbvh_only_ms"] = round(min(ms[1:]), 3)
+            bd["prims"] = int(big.scene.primitive_count)
+            cfgs["lbvh_build_1M"] = bd
+        except Exception as exc:            # noqa: BLE001
+            cfgs["lbvh_build_1M"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+        cfgs["lbvh_build_100k"] = dict(build_detail, prims=int(ex.scene.primitive_count))
+        result["configs"] = cfgs
 
     # RCCL writes its version banner to C stdio (block-buffered when piped): every rank pushes its buffer out, then
     # rank 0 prints the JSON line as the LAST line on stdout (no os._exit here: rocprofv3 writes its output from

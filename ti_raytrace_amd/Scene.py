@@ -250,3 +250,4 @@ class Scene:
     def process_normal(self):
         """Scene.py:754-798: angle x area weighted smooth normals via a BVH point query."""
         self.ctx.process_normal(self.vertex_index_np)
+        self.normals_processed = True

@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libtirt.so")
+LIB_PATH = os.environ.get("TIRT_LIB_PATH") or os.path.join(_HERE, "csrc", "libtirt.so")      # (TIRT_LIB_PATH: A/B builds of the same library, tools/ab*.sh)
 
 _f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
 _i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")

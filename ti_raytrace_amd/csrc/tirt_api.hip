@@ -358,6 +358,7 @@ int tirt_set_option(tirt_ctx *c, const char *name, double value)
         TIRT_REQUIRE(trace_lds_bytes((int)value) <= c->lds_optin, "trace_lds_depth: stacks + tree top exceed the LDS a block can have on this device");
         c->tr_lds_depth = (int)value; return TIRT_OK;
     }
+    if (!strcmp(name, "trace_queue")) { c->tr_queue = value != 0.0 ? 1 : 0; return TIRT_OK; }
     if (!strcmp(name, "trace_refill_min")) { TIRT_REQUIRE(value >= 1 && value <= 64, "trace_refill_min: 1..64"); c->tr_refill_min = (int)value; return TIRT_OK; }
     if (!strcmp(name, "trace_node_min")) { TIRT_REQUIRE(value >= 1 && value <= 64, "trace_node_min: 1..64"); c->tr_node_min = (int)value; return TIRT_OK; }
     if (!strcmp(name, "bdpt_bounded")) { c->bdpt_bounded = value != 0.0 ? 1 : 0; return TIRT_OK; }
@@ -682,7 +683,8 @@ int tirt_bvh_info(tirt_ctx *c, uint64_t out[4])
     TIRT_REQUIRE(out && c->built, "tirt_bvh_info: LBVH not built");
     const int nq = c->wide_nodes;
     out[0] = (uint64_t)nq * 64u; out[1] = (uint64_t)c->n * sizeof(float4) * TRI_STRIDE; out[2] = (uint64_t)nq;
-    out[3] = (uint64_t)(nq < TR_TOP_SLOTS ? nq : TR_TOP_SLOTS);
+    const int top = c->tr_queue ? TRQ_TOP_SLOTS : TR_TOP_SLOTS;
+    out[3] = (uint64_t)(nq < top ? nq : top);
     return TIRT_OK;
 }
 
