@@ -550,7 +550,7 @@ def main():
                         "(%d steps x %d frames), max_depth 15, render seed %d" %
                         (args.ntri, W, H, args.steps * fps, args.steps, fps, args.seed),
             "parallelism": "pixel tiles of %d round-robin over %d GPU(s), replicated BVH, one RCCL film reduce" % (args.tile_size, world),
-            "traversal": "ordered+t-culled over 4-wide nodes collapsed from a device-built binned-SAH tree; every hit verified against the reference's LBVH (bit-identical to its exhaustive order)",
+            "traversal": "ordered+t-culled over 4-wide nodes collapsed from a device-built binned-SAH tree; every hit verified against the reference's LBVH (bit-identical to its exhaustive order except for rays lying in a triangle's plane to fp32 rounding, DESIGN.md section 2: none in a render)",
         },
         "rays": {"closest": int(rays_closest), "shadow": int(rays_shadow), "paths": int(paths),
                  "rays_per_path": round((rays_closest + rays_shadow) / max(paths, 1.0), 3)},

@@ -87,7 +87,9 @@ int tirt_sync(tirt_ctx *ctx);
  *            (tile_count >= 6) and whose whole job is one batch runs it as that many smaller batches on as many lanes
  *          "traversal_tree" (0/1, default 1) -- the tree tirt_lbvh_build collapses into the 4-wide traversal nodes: 1 = a binned-SAH
  *            tree over the same primitives built on the device after the LBVH, 0 = the reference's LBVH itself; results are
- *            bit-identical either way (tirt_traversal_tree_download); takes effect at the next tirt_lbvh_build
+ *            bit-identical either way (tirt_traversal_tree_download) -- except for rays that lie, to fp32 rounding, IN the plane of a
+ *            triangle: there the reference's Moller-Trumbore divides by a determinant of rounding noise and which "hit" such a ray
+ *            gets depends on the visiting order (none in any render); takes effect at the next tirt_lbvh_build
  *          "wide_collapse" (0/1, default 0) -- how the binary tree is grouped into 4-wide nodes: 0 = greedily by surface area, 1 = the
  *            grouping of least total node area (dynamic programme); same results, 1-9 % fewer node visits, no measurable gain
  *          "bdpt_batch_items" -- (frame, pixel) items per BDPT wavefront batch (default 8 Mi, ~3.7 KB of HBM each: 31 GB), shared by the two batches in flight on render lanes 0 and 1
@@ -163,7 +165,10 @@ int tirt_film_download(tirt_ctx *ctx, float *hdr, float *rgb);
 int tirt_film_export_device(tirt_ctx *ctx, void *dev_dst);
 int tirt_film_import_device(tirt_ctx *ctx, const void *dev_src);
 
-/* Scene.closet_hit / closet_hit_shadow on a batch of rays (Scene.py:702-744, 671-699):
+/* Scene.closet_hit / closet_hit_shadow on a batch of rays (Scene.py:702-744, 671-699).  The default (ordered) traversal returns the
+ * reference's hit bit for bit for every ray but the in-plane rays named under "traversal_tree" above; rays that start more than 8
+ * scene extents away are traced without distance culling (from there the reference's own distances are rounding noise), so they
+ * are the reference's too (tests/test_gpu_trace.py::test_ordered_equals_exhaustive_on_two_million_stress_rays).
  * rays[nr*6] = origin, direction.  out_hit[nr*13] = t, pos3, gnormal3, normal3, tex3;
  * out_prim[nr]; counts[nr*2] = N_box, N_leaf per ray (NULL unless TIRT_COUNT_NODES). */
 int tirt_trace_closest(tirt_ctx *ctx, const float *rays, int nr, int stack_size, int flags,

@@ -90,6 +90,15 @@ def test_headline_100k_primary_rays(gpu_ctx_ok):
     n, frac, cnt = check_scene(ex, 256, 256, max_rays=30000)
     print("100k scene: hit fraction %.3f, exhaustive N_box %.1f N_leaf %.1f per primary ray" % (frac, cnt[0], cnt[1]))
     assert 0.3 < frac < 0.95
+    # The ordered traversal culls: for rays that start near the scene (camera rays) it must test far fewer boxes and primitives than
+    # the reference's exhaustive order -- a bounded check that a regression in the culling (margins, cull distance, tree quality) trips.
+    # (Far-away origins are exempt by design: wide grid margin, no distance culling beyond TR_FAR_RHO extents.)
+    rays = oa.camera_rays(ex.cam, 256, 256)[::3]
+    _, _, oc = ex.scene.ctx.trace_closest(rays, 64, _native.TRAVERSE_ORDERED | _native.COUNT_NODES)
+    _, _, ec = ex.scene.ctx.trace_closest(rays, 64, _native.TRAVERSE_EXHAUSTIVE | _native.COUNT_NODES)
+    on, ol = oc.mean(axis=0); en, el = ec.mean(axis=0)
+    print("camera rays: ordered %.1f box tests / %.2f primitive tests per ray, reference order %.1f / %.2f" % (on, ol, en, el))
+    assert ol <= 0.5 * el and on <= 0.6 * en and ol < 12.0 and on < 160.0
 
 
 def test_deep_duplicate_chain_uses_the_spill_stack(gpu_ctx_ok):

@@ -35,6 +35,7 @@ class BDPT:
         pass
 
     def setup_data_gpu(self):
+        self.scene.ctx.set_option("bdpt_stack_size", max(16, int(self.stack_size)))
         self.scene.ctx.film_create(self.imgSizeX, self.imgSizeY, self.tile_rank, self.tile_count, self.tile_size)
         self.cam.attach(self.scene.ctx)
 

@@ -1,6 +1,7 @@
 // tirt_api.hip -- the C-ABI of include/tirt.h: context, uploads/downloads, camera, film,
 // tone map, Scene.process_normal / total_area kernels, known-answer-test kernels, stats.
 #include "tirt_internal.h"
+#include <stddef.h>
 #include <mutex>
 #include <string.h>
 
@@ -358,6 +359,7 @@ int tirt_set_option(tirt_ctx *c, const char *name, double value)
         TIRT_REQUIRE(trace_lds_bytes((int)value) <= c->lds_optin, "trace_lds_depth: stacks + tree top exceed the LDS a block can have on this device");
         c->tr_lds_depth = (int)value; return TIRT_OK;
     }
+    if (!strcmp(name, "bdpt_stack_size")) { TIRT_REQUIRE(value >= 16 && value <= 4096, "bdpt_stack_size: 16..4096"); c->bdpt_stack = (int)value; return TIRT_OK; }
     if (!strcmp(name, "trace_queue")) { c->tr_queue = value != 0.0 ? 1 : 0; return TIRT_OK; }
     if (!strcmp(name, "trace_refill_min")) { TIRT_REQUIRE(value >= 1 && value <= 64, "trace_refill_min: 1..64"); c->tr_refill_min = (int)value; return TIRT_OK; }
     if (!strcmp(name, "trace_node_min")) { TIRT_REQUIRE(value >= 1 && value <= 64, "trace_node_min: 1..64"); c->tr_node_min = (int)value; return TIRT_OK; }
@@ -736,6 +738,9 @@ int tirt_stats(tirt_ctx *c, tirt_stats_t *out)
     out->launches_shade = c->launches_shade;
     if (h.stack_overflow > 0) {      // results are wrong (subtrees were dropped): the statistics are filled in, the call reports it
         set_error("traversal stack overflow on " + std::to_string((unsigned long long)h.stack_overflow) + " rays: raise stack_size");
+        // reported once: the counter is cleared, so that later tirt_stats calls of unrelated consumers do not keep failing
+        TIRT_HIP(hipMemsetAsync((char *)c->dev_counters.p + offsetof(DevCounters, stack_overflow), 0, sizeof(h.stack_overflow), c->stream));
+        TIRT_HIP(hipStreamSynchronize(c->stream));
         return TIRT_ERR_STACK;
     }
     return TIRT_OK;

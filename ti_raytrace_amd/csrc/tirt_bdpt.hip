@@ -715,14 +715,10 @@ int bdpt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t see
         if (FB > (frame_count + 1) / 2) FB = (frame_count + 1) / 2;
     }
     { const int nb = (frame_count + FB - 1) / FB; FB = (frame_count + nb - 1) / nb; }       // batches of equal size
-    // buffers for the batches of this call -- or of the whole job, when the caller said how many frames it has ("job_frames"): a
-    // frame-at-a-time caller then does not re-allocate as its calls grow
-    int FB_alloc = FB;
-    if (c->job_frames > frame_count) {
-        int fj = (int)(c->bdpt_batch_items / (NL > 1 ? 2 : 1) / (size_t)P); if (fj < 1) fj = 1;
-        if ((long)fj > (c->job_frames + 1) / 2) fj = (int)((c->job_frames + 1) / 2);
-        if (fj > FB_alloc) FB_alloc = fj;
-    }
+    // buffers for the batches of THIS call (a frame-at-a-time caller gets one-frame buffers; DevBuf::ensure only ever grows, so a caller
+    // whose calls grow re-allocates a few times at most).  Round 2 reserved for the whole job from the "job_frames" hint -- 31 GB for
+    // an example loop that renders one frame per call and never merges calls.
+    const int FB_alloc = FB;
     const size_t NMAX = (size_t)FB_alloc * P;
     TIRT_REQUIRE(NMAX * BD_PAIRS < ((size_t)1 << 31), "tirt_bdpt_rgb_render: film too large for one frame per batch");
     const size_t SCAP = NMAX * 27;                               // at most 27 (e, l) pairs per item carry a connection ray (staging: [27][N])

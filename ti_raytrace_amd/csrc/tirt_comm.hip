@@ -6,7 +6,14 @@
 // libtirt.so itself does not depend on it.
 #include "tirt_internal.h"
 #include <dlfcn.h>
-#include <rccl/rccl.h>
+
+// The few RCCL declarations this file needs (librccl is dlopen'ed: building libtirt.so must not require the RCCL headers).
+// Values as in rccl.h / nccl.h 2.x, which are ABI: ncclSuccess = 0, ncclFloat32 = 7, ncclSum = 0.
+typedef struct ncclComm *ncclComm_t;
+typedef int ncclResult_t;
+typedef int ncclDataType_t;
+typedef int ncclRedOp_t;
+enum { ncclSuccess = 0, ncclFloat = 7, ncclSum = 0 };
 
 namespace tirt {
 
@@ -74,7 +81,7 @@ int tirt_comm_init(tirt_ctx **ctxs, int ndev)
 
 int tirt_film_reduce(tirt_ctx **ctxs, int ndev, int root)
 {
-    TIRT_REQUIRE(ctxs && ndev >= 1 && root >= 0 && root < ndev, "tirt_film_reduce: bad arguments");
+    TIRT_REQUIRE(ctxs && ndev >= 1 && root >= 0 && root < ndev && ctxs[0], "tirt_film_reduce: bad arguments");
     const size_t count = 3 * (size_t)ctxs[0]->W * (size_t)ctxs[0]->H;
     for (int i = 0; i < ndev; i++) {
         tirt_ctx *c = ctxs[i];
@@ -86,11 +93,15 @@ int tirt_film_reduce(tirt_ctx **ctxs, int ndev, int root)
     }
     // every context holds zeros outside its own tiles (tirt_film_create): the sum is the full film
     TIRT_NCCL(g_rccl.GroupStart());
-    for (int i = 0; i < ndev; i++) {
+    ncclResult_t bad = ncclSuccess;
+    for (int i = 0; i < ndev && bad == ncclSuccess; i++) {
         tirt_ctx *c = ctxs[i];
-        TIRT_NCCL(g_rccl.Reduce(c->hdr.p, c->hdr.p, count, ncclFloat, ncclSum, root, (ncclComm_t)c->comm, c->stream));
+        bad = g_rccl.Reduce(c->hdr.p, c->hdr.p, count, ncclFloat, ncclSum, root, (ncclComm_t)c->comm, c->stream);
     }
-    TIRT_NCCL(g_rccl.GroupEnd());
+    // the group is closed whatever happened inside it: an open group would swallow every later collective
+    const ncclResult_t end = g_rccl.GroupEnd();
+    if (bad != ncclSuccess) { set_error(std::string("ncclReduce: ") + g_rccl.GetErrorString(bad)); return TIRT_ERR_HIP; }
+    if (end != ncclSuccess) { set_error(std::string("ncclGroupEnd: ") + g_rccl.GetErrorString(end)); return TIRT_ERR_HIP; }
     for (int i = 0; i < ndev; i++) { TIRT_HIP(hipSetDevice(ctxs[i]->device)); TIRT_HIP(hipStreamSynchronize(ctxs[i]->stream)); }
     return TIRT_OK;
 }

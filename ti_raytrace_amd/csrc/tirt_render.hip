@@ -1104,7 +1104,7 @@ int trace_arrays(tirt_ctx *c, const float *ox, const float *oy, const float *oz,
     // (the lanes' counter buffers hold the per-bounce cursors of the path tracer as well: ensure() keeps a larger one)
     DevBuf &fetch = lane < 0 ? c->counters_mem : c->lanes[lane].counters_mem;
     int spill_depth;
-    if (ensure_spill(c, spill, 64, spill_depth)) return TIRT_ERR_HIP;
+    if (ensure_spill(c, spill, c->bdpt_stack, spill_depth)) return TIRT_ERR_HIP;      // (the integrator's stack_size: option "bdpt_stack_size")
     if (fetch.ensure(sizeof(int) * TR_FETCH_STRIDE * TR_SLICES_MAX)) return TIRT_ERR_HIP;
     TIRT_HIP(hipMemsetAsync(fetch.p, 0, sizeof(int) * TR_FETCH_STRIDE * TR_SLICES_MAX, st));
     TraceArgs a = {};
