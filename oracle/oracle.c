@@ -40,11 +40,13 @@
 #define m_pow powf
 #define m_atan2 atan2f
 #define m_acos acosf
+#define m_tan tanf
 #else
 #define m_sin tm_sin
 #define m_cos tm_cos
 #define m_exp tm_exp
 #define m_pow tm_pow
+#define m_tan tm_tan
 #define m_atan2 tm_atan2
 #define m_acos tm_acos
 #endif
@@ -58,6 +60,8 @@
 #define NOD_VEC 11   /* SceneData.py:37 */
 #define CPN_VEC 9    /* SceneData.py:38 */
 #define SHAPE_SPHERE 1          /* SceneData.py:41 */
+#define SHAPE_SPOT 3            /* SceneData.py:43: emitter at a point, cone of half-angles (x1 full, x2 cut-off), never intersected */
+#define SHAPE_LASER 4           /* SceneData.py:44: parallel beam of a radius along the shape normal, never intersected */
 #define PRIMITIVE_TRI 1         /* SceneData.py:47 */
 #define MAT_DISNEY 0            /* SceneData.py:50 */
 #define MAT_GLASS 1
@@ -933,9 +937,53 @@ static void get_prim_random_point_normal(const orc_scene *s, int index, float a,
             v3 centre = V(sh[1], sh[2], sh[3]);
             normal = uniform_sample_sphere(a, b);
             pos = vadd(centre, vscale(normal, r));
+        } else if ((int)sh[0] == SHAPE_SPOT || (int)sh[0] == SHAPE_LASER) {      /* Scene.py:413-418 */
+            normal = V(sh[7], sh[8], sh[9]);
+            pos = V(sh[1], sh[2], sh[3]);
         }
     }
     *pos_o = pos; *nor_o = vnormalized(normal);
+}
+
+/* Scene.py:491-516: what sample_li adds for the two shape emitters that have no surface -- the factor `visable` on the emission
+ * (spot: 1 inside the cone of half-angle x1, falling linearly to 0 at x2, measured between the light's normal and the direction to
+ * the shaded point; laser: 1 within `radius` of the beam's axis, else 0) and, for the laser, light_choice_pdf = 1 / light_count. */
+static float light_shape_visible(const orc_scene *s, int light_prim, v3 light_dir, v3 light_normal, float light_dist, float *choice_pdf)
+{
+    float visable = 1.0f;
+    const int32_t *pr = s->primitive + (size_t)light_prim * PRI_VEC;
+    if (pr[0] != PRIMITIVE_TRI) {
+        const float *sh = s->shape + (size_t)pr[1] * SHA_VEC;
+        const int st = (int)sh[0];
+        if (st == SHAPE_SPOT) {
+            const float NdotL = fabs_(vdot(light_dir, light_normal));
+            const float x1 = sh[4], x2 = sh[5];
+            const float x = m_acos(NdotL);
+            if (x > x2) visable = 0.0f;
+            else if (x > x1) visable *= 1.0f - (x - x1) / (x2 - x1);
+        } else if (st == SHAPE_LASER) {
+            *choice_pdf = 1.0f / (float)s->light_count;
+            const float proj = vdot(light_dir, light_normal) * light_dist;
+            const float r = m_sqrt(light_dist * light_dist - proj * proj);
+            if (r > sh[4]) visable = 0.0f;
+        }
+    }
+    return visable;
+}
+
+/* UtilsFunc.py:321-345 */
+static void map_to_disk(float u1, float u2, float *r_o, float *phi_o)
+{
+    float phi = 0.0f, r = 0.0f;
+    const float a = 2.0f * u1 - 1.0f, b = 2.0f * u2 - 1.0f;
+    if (a > -b) {
+        if (a > b) { r = a; phi = (M_PIf / 4.0f) * (b / a); }
+        else { r = b; phi = (M_PIf / 4.0f) * (2.0f - a / b); }
+    } else {
+        if (a < b) { r = -a; phi = (M_PIf / 4.0f) * (4.0f + b / a); }
+        else { r = -b; phi = (b == 0.0f) ? 0.0f : (M_PIf / 4.0f) * (6.0f - a / b); }
+    }
+    *r_o = r; *phi_o = phi;
 }
 
 /* texture/Texture.py:41-69 */
@@ -1046,6 +1094,7 @@ static v3 pt_rgb_pixel(const orc_scene *s, int i, int j, int H, uint32_t frame, 
                     v3 light_dir = vsub(h.pos, light_pos);
                     float light_dist = vnorm(light_dir);
                     light_dir = vdivs(light_dir, light_dist);
+                    light_emission = vscale(light_emission, light_shape_visible(s, light_prim, light_dir, light_normal, light_dist, &light_choice_pdf));
                     /* PT_RGB.py:101-109 */
                     float NdotL_surface = vdot(fnormal, light_dir);
                     float NdotL_light = vdot(light_normal, light_dir);
@@ -1468,7 +1517,7 @@ static int bd_eye_path(const orc_scene *s, bpixel *P, int i, int j, int H, uint3
     return depth;
 }
 
-/* Scene.py:430-474 (sphere / triangle lights) */
+/* Scene.py:430-474 */
 static void bd_sample_light(const orc_scene *s, uint32_t seed, uint32_t pixel, uint32_t frame,
                             v3 *pos, v3 *nor, v3 *dir, v3 *emission, int *prim, float *choice_pdf, float *dir_pdf)
 {
@@ -1487,6 +1536,31 @@ static void bd_sample_light(const orc_scene *s, uint32_t seed, uint32_t pixel, u
     *dir_pdf = cosine_hemisphere_pdf(ld.z);
     *dir = inverse_transform(ld, lnor);
     *pos = lpos; *nor = lnor; *emission = V(lm[2], lm[3], lm[4]); *prim = lp;
+    const int32_t *pr = s->primitive + (size_t)lp * PRI_VEC;
+    if (pr[0] != PRIMITIVE_TRI) {                                   /* Scene.py:449-472 */
+        const float *sh = s->shape + (size_t)pr[1] * SHA_VEC;
+        const int st = (int)sh[0];
+        if (st == SHAPE_SPOT) {
+            const float scale = sh[6];
+            *dir_pdf = 1.0f;
+            float r, phi;
+            map_to_disk(tm_rand(seed, pixel, frame, BD_DIM_LSTART + 5), tm_rand(seed, pixel, frame, BD_DIM_LSTART + 6), &r, &phi);
+            const float r1 = scale * m_tan(sh[4]), r2 = scale * m_tan(sh[5]);
+            r *= r2;
+            if (r > r1) *emission = vscale(*emission, 1.0f - (r - r1) / (r2 - r1));
+            const v3 sp = V(r * m_cos(phi), r * m_sin(phi), m_sqrt(fmax_(0.0f, scale * scale - r * r)));
+            *dir = inverse_transform(sp, lnor);
+        } else if (st == SHAPE_LASER) {
+            *choice_pdf = 1.0f / (float)s->light_count;
+            const float r = sh[4];
+            const float phi = tm_rand(seed, pixel, frame, BD_DIM_LSTART + 5) * M_PIf * 2.0f;
+            v3 sp = V(r * m_cos(phi), r * m_sin(phi), 0.0f);
+            sp = inverse_transform(sp, lnor);
+            *dir = lnor;
+            *dir_pdf = 1.0f;
+            *pos = vadd(lpos, sp);
+        }
+    }
 }
 
 /* BDPT_RGB.py:200-294 */
@@ -1717,6 +1791,7 @@ static v3 bd_connect_path(const orc_scene *s, const orc_bdpt *B, bpixel *P, int 
             v3 wi = vsub(surface, light_pos);
             float light_dist = vnorm(wi);
             wi = vdivs(wi, light_dist);
+            light_emission = vscale(light_emission, light_shape_visible(s, light_prim, wi, light_normal, light_dist, &light_choice_pdf));
             float NdotLl = vdot(wi, light_normal);
             float NdotLe = vdot(wi, eye[e - 1].snormal);
             int shadow_prim;

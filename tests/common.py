@@ -39,6 +39,38 @@ def duplicate_code_scene(W=32, H=32, device_id=None):
     return ex
 
 
+def spot_laser_scene(W, H, kinds=("spot", "laser"), device_id=None, integrator="pt", with_quad_light=True):
+    """Cornell box plus the two shape emitters that have no surface (SceneData.SHPAE_SPOT / SHPAE_LASER; the reference uses them in
+    example/prism_rainbow.py:39-50 and samples them in Scene.sample_li / sample_light, Scene.py:449-472, 491-516): a spot light under
+    the ceiling shining down (full intensity within 0.3 rad, fading out to 0.6 rad) and a laser beam of radius 40 aimed at the floor."""
+    from ti_raytrace_amd import BDPT_RGB
+    ex = Example.example(W, H, 4, device_id)
+    ex.scene.add_obj(scenes.asset("model", "cornell_box.obj"))
+    if not with_quad_light:                       # the box's own emissive quad becomes a grey Disney surface
+        for m in ex.scene.material_cpu:
+            if m.type == SCD.MAT_LIGHT:
+                m.type = SCD.MAT_DISNEY; m.setMetal(0.0); m.setRough(0.5); m.setColor([0.7, 0.7, 0.7, 1.0])
+    for kind in kinds:
+        sh = SCD.Shape()
+        mat = SCD.Material(); mat.type = SCD.MAT_LIGHT
+        if kind == "spot":
+            sh.type = SCD.SHPAE_SPOT
+            sh.pos = [278.0, 520.0, -280.0]
+            sh.setXita(0.3, 0.6); sh.setScale(1.0); sh.setNormal([0.0, -1.0, 0.0])
+            mat.setColor([3.0e6, 3.0e6, 2.0e6])
+        else:
+            sh.type = SCD.SHPAE_LASER
+            sh.pos = [120.0, 400.0, -100.0]
+            sh.setRadius(40.0); sh.setNormal([0.25, -0.9, -0.35])
+            mat.setColor([40.0, 10.0, 10.0])
+        ex.scene.add_shape(sh, mat)
+    if integrator == "bdpt":
+        ex.integrator = BDPT_RGB.BDPT(W, H, ex.cam, ex.scene, 64)
+    else:
+        ex.integrator = PT_RGB.PathTrace(W, H, ex.cam, ex.scene, 64)
+    return ex
+
+
 def rel_l2(a, b):
     return float(np.sqrt(((a.astype(np.float64) - b) ** 2).sum() / max((b.astype(np.float64) ** 2).sum(), 1e-30)))
 

@@ -270,18 +270,50 @@ def test_env_lit_scene_without_emitters(gpu_ctx_ok):
         ctx.bdpt_rgb_render(0, 1, 1)
 
 
-def test_spot_and_laser_emitters_are_refused(gpu_ctx_ok):
-    ctx = _native.Context(0)
-    v = np.zeros((3, 9), np.float32); v[1, 0] = 1; v[2, 1] = 1
-    m = np.zeros((2, 10), np.float32); m[1, 0] = 2
-    prim = np.array([[1, 0, 0], [2, 0, 1]], np.int32)
-    for shape_type in (3, 4):
-        s = np.zeros((1, 10), np.float32); s[0, 0] = shape_type; s[0, 4] = 1.0
-        with pytest.raises(_native.TirtError, match="spot / laser"):
-            ctx.scene_upload(v, prim, m, s, np.array([1], np.int32), 1, -np.ones(3), np.ones(3))
-    s = np.zeros((1, 10), np.float32); s[0, 0] = 1; s[0, 4] = 1.0
-    ctx.scene_upload(v, prim, m, s, np.array([1], np.int32), 1, -np.ones(3), np.ones(3))
-    ctx.close()
+@pytest.mark.parametrize("kinds,quad", [(("spot",), False), (("laser",), False), (("spot", "laser"), True)])
+def test_spot_and_laser_emitters(gpu_ctx_ok, kinds, quad):
+    """The two shape emitters without a surface (Scene.sample_li's SPOT / LASER branches, Scene.py:491-516; their point and normal,
+    :413-418; area, :344-349): PT_RGB films bit-identical to the oracle, same ray counts; they light the scene (the spot's cone
+    and the laser's disc on the floor) and are never hit themselves (intersect_prim returns INF for them, Scene.py:597-598)."""
+    from common import spot_laser_scene
+    W = H = 64
+    ex = spot_laser_scene(W, H, kinds, device_id=0, with_quad_light=quad)
+    ex.build_scene(); ex.scene.total_area(); ex.frame_camera(0.8)
+    ctx = ex.scene.ctx
+    o = oa.OracleScene(ex.scene, ex.cam); o.lbvh_build()
+    _, _, compact = o.lbvh_get()
+    assert np.array_equal(compact, ex.scene.bvh.compact_node.to_numpy())      # their leaf boxes are the reference's (0,0,0)-(0,0,0)
+    ctx.stats_reset()
+    ex.integrator.render_frames(6)
+    got = ex.integrator.hdr.to_numpy()
+    want, ost = o.render(W, H, 0, 6, seed=ex.integrator.seed)
+    st = ctx.stats()
+    assert np.array_equal(got, want, equal_nan=True), rel_l2(got, want)
+    assert st["rays_closest"] == ost["rays_closest"] and st["rays_shadow"] == ost["rays_shadow"] and st["rays_shadow"] > 0
+    assert np.isfinite(got).all() and got.mean() > 0.0
+    if not quad:          # nothing else emits: everything the film shows was lit through sample_li's shape branch
+        lit = (got.sum(axis=2) > 0).mean()
+        print("%s only: %.1f %% of the pixels lit, mean %.4f" % (kinds[0], 100 * lit, got.mean()))
+        assert 0.02 < lit < 0.98
+
+
+def test_spot_and_laser_emitters_bdpt(gpu_ctx_ok):
+    """Scene.sample_light's SPOT / LASER branches (Scene.py:449-472: the spot's direction through UF.mapToDisk and tan of its two
+    angles, the laser's disc of start points) start BDPT's light sub-paths: film within 1e-5 of the oracle's (float-atomic splats),
+    same ray counts."""
+    from common import spot_laser_scene
+    W = H = 40
+    ex = spot_laser_scene(W, H, ("spot", "laser"), device_id=0, integrator="bdpt")
+    ex.build_scene(); ex.scene.total_area(); ex.frame_camera(0.8)
+    ctx = ex.scene.ctx
+    o = oa.OracleScene(ex.scene, ex.cam); o.lbvh_build()
+    ctx.stats_reset()
+    ex.integrator.render_frames(3)
+    got = ex.integrator.hdr.to_numpy()
+    want, ost, _ = o.bdpt_render(ex.cam, W, H, 0, 3, seed=ex.integrator.seed)
+    st = ctx.stats()
+    assert rel_l2(got, want) <= 1e-5 and np.array_equal(np.isnan(got), np.isnan(want))
+    assert st["rays_closest"] == ost["rays_closest"] and st["rays_shadow"] == ost["rays_shadow"]
 
 
 def test_config2_full_size_tile_sample_against_the_oracle(gpu_ctx_ok):

@@ -213,3 +213,31 @@ def test_libm_oracle_has_the_same_lbvh_and_hit_records_on_the_teapot():
     va, vb = a.vertex(), b.vertex()
     fin = np.isfinite(va).all(axis=1) & np.isfinite(vb).all(axis=1)
     assert fin.mean() > 0.99 and np.abs(va[fin] - vb[fin]).max() < 1e-4
+
+
+def test_oracle_spot_and_laser_emitters(oracle_lib):
+    """The oracle's restatement of the shape emitters without a surface (Scene.py:344-349, 413-418, 449-472, 491-516) behaves as
+    the reference's formulas say: a spot light under the ceiling lights the floor inside its cone at full strength up to x1, fading
+    to nothing at x2; a laser lights a disc of its radius around its axis and nothing else; neither is ever hit by a ray."""
+    from common import spot_laser_scene
+    W = H = 48
+    for kind in ("spot", "laser"):
+        ex = spot_laser_scene(W, H, (kind,), with_quad_light=False)
+        ex.scene.setup_data_cpu(); ex.frame_camera(0.8)
+        o = oa.OracleScene(ex.scene, ex.cam); o.lbvh_build()
+        # rays aimed at the emitter itself fly through it (intersect_prim: INF for these shapes)
+        n = ex.scene.primitive_count
+        pos = ex.scene.shape_np[-1, 1:4].astype(np.float64)
+        org = np.array([278.0, 273.0, 700.0])
+        d = pos - org; d /= np.linalg.norm(d)
+        _, prim, _ = o.closest_hit(np.concatenate([org, d])[None].astype(np.float32))
+        assert prim[0] != n - 1
+        hdr, st = o.render(W, H, 0, 8, seed=1)
+        assert np.isfinite(hdr).all() and st["rays_shadow"] > 0
+        lit = hdr.sum(axis=2) > 0
+        assert 0.02 < lit.mean() < 0.98, lit.mean()
+    # the spot's fall-off, point by point, against the formula: directly below at full strength, beyond x2 nothing
+    ex = spot_laser_scene(W, H, ("spot",), with_quad_light=False)
+    ex.scene.setup_data_cpu(); ex.frame_camera(0.8)
+    sh = ex.scene.shape_np[-1]
+    assert int(sh[0]) == 3 and np.allclose(sh[4:7], [0.3, 0.6, 1.0]) and np.allclose(sh[7:10], [0, -1, 0])

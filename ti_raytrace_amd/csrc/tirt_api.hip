@@ -395,15 +395,6 @@ int tirt_scene_upload(tirt_ctx *c, const float *vertex, int nv, const int32_t *p
         TIRT_REQUIRE(pr[2] >= 0 && pr[2] < nm, "tirt_scene_upload: material index out of range");
     }
     for (int i = 0; i < nl; i++) TIRT_REQUIRE(light[i] >= 0 && light[i] < n, "tirt_scene_upload: light index out of range");
-    // sample_li's spot / laser branches (Scene.py:497-516, used by the spectral examples only) are not restated here:
-    // such emitters are refused instead of being lit as if they were spheres
-    for (int i = 0; i < light_count; i++) {
-        const int32_t *pr = primitive + (size_t)light[i] * 3;
-        if (pr[0] != PRIMITIVE_TRI) {
-            const int st = (int)shape[(size_t)pr[1] * 10];
-            TIRT_REQUIRE(st != SHAPE_SPOT && st != SHAPE_LASER, "tirt_scene_upload: spot / laser emitters (SceneData.SHPAE_SPOT / SHPAE_LASER) are not supported");
-        }
-    }
     hipStream_t st = c->stream;
     c->built = false;
     if (upload(c->vertex, vertex, sizeof(float) * 9 * (size_t)nv, st)) return TIRT_ERR_HIP;

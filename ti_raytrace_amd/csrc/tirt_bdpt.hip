@@ -288,12 +288,13 @@ TD v3 bd_connect_path(const BdCtx &c, const bpixel *P, bvert &sample, int i, int
             v3 light_pos, light_normal;
             get_prim_random_point_normal(s, light_prim, tm_rand(c.seed, pixel, frame, d0 + 1), tm_rand(c.seed, pixel, frame, d0 + 2), light_pos, light_normal);
             const float *lm = mat_row(s, s.primitive[(size_t)light_prim * PRI_VEC + 2]);
-            const v3 light_emission = V(lm[2], lm[3], lm[4]);
-            const float light_choice_pdf = 1.0f / ((float)s.light_count * get_prim_area(s, light_prim));
+            v3 light_emission = V(lm[2], lm[3], lm[4]);
+            float light_choice_pdf = 1.0f / ((float)s.light_count * get_prim_area(s, light_prim));
             light_normal = normalized(light_normal);
             v3 wi = surface - light_pos;
             const float light_dist = norm(wi);
             wi = wi / light_dist;
+            light_emission = light_emission * light_shape_visible(s, light_prim, wi, light_normal, light_dist, light_choice_pdf);   // spot / laser (Scene.py:491-516)
             const float NdotLl = dot(wi, light_normal);
             const float NdotLe = dot(wi, EV.snormal);
             const SimpleHit sh = bd_trace(T, surface, -wi, light_prim, c.bounded ? light_dist : -1.0f);
@@ -386,12 +387,37 @@ __global__ void k_bd_init(BdCtx c, bpixel *items, BdStep *steps, BdRays rays, in
         v3 lpos, lnor;
         get_prim_random_point_normal(s, lp, tm_rand(c.seed, pixel, frame, BD_DIM_LSTART + 1), tm_rand(c.seed, pixel, frame, BD_DIM_LSTART + 2), lpos, lnor);
         const float *lm = mat_row(s, s.primitive[(size_t)lp * PRI_VEC + 2]);
-        const v3 emission = V(lm[2], lm[3], lm[4]);
-        const float choice_pdf = 1.0f / ((float)s.light_count * get_prim_area(s, lp));
+        v3 emission = V(lm[2], lm[3], lm[4]);
+        float choice_pdf = 1.0f / ((float)s.light_count * get_prim_area(s, lp));
         lnor = normalized(lnor);
         const v3 ld = cosine_sample_hemisphere(tm_rand(c.seed, pixel, frame, BD_DIM_LSTART + 3), tm_rand(c.seed, pixel, frame, BD_DIM_LSTART + 4));
-        const float dir_pdf = cosine_hemisphere_pdf(ld.z);
-        const v3 ldir = inverse_transform(ld, lnor);
+        float dir_pdf = cosine_hemisphere_pdf(ld.z);
+        v3 ldir = inverse_transform(ld, lnor);
+        const int *lpr = s.primitive + (size_t)lp * PRI_VEC;
+        if (lpr[0] != PRIMITIVE_TRI) {                                  // Scene.py:449-472: the two shape emitters without a surface
+            const float *sh = s.shape + (size_t)lpr[1] * SHA_VEC;
+            const int st = (int)sh[0];
+            if (st == SHAPE_SPOT) {
+                const float scale = sh[6];
+                dir_pdf = 1.0f;
+                float r, phi;
+                map_to_disk(tm_rand(c.seed, pixel, frame, BD_DIM_LSTART + 5), tm_rand(c.seed, pixel, frame, BD_DIM_LSTART + 6), r, phi);
+                const float r1 = scale * tm_tan(sh[4]), r2 = scale * tm_tan(sh[5]);
+                r *= r2;
+                if (r > r1) emission = emission * (1.0f - (r - r1) / (r2 - r1));
+                const v3 sp = V(r * tm_cos(phi), r * tm_sin(phi), tm_sqrt(maxf(0.0f, scale * scale - r * r)));
+                ldir = inverse_transform(sp, lnor);
+            } else if (st == SHAPE_LASER) {
+                choice_pdf = 1.0f / (float)s.light_count;
+                const float r = sh[4];
+                const float phi = tm_rand(c.seed, pixel, frame, BD_DIM_LSTART + 5) * PI_UF * 2.0f;
+                v3 sp = V(r * tm_cos(phi), r * tm_sin(phi), 0.0f);
+                sp = inverse_transform(sp, lnor);
+                ldir = lnor;
+                dir_pdf = 1.0f;
+                lpos = lpos + sp;
+            }
+        }
         const float light_pdf = choice_pdf;
         light[0].pos = lpos; light[0].normal = lnor; light[0].beta = emission / light_pdf;
         light[0].fpdf = light_pdf; light[0].rpdf = 0.0f; light[0].wo = ldir; light[0].type = VERTEX_LIGHT;

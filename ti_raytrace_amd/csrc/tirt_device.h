@@ -419,9 +419,51 @@ TD void get_prim_random_point_normal(const SceneView &s, int index, float a, flo
             float r = sh[4];
             normal = uniform_sample_sphere(a, b);
             pos = V(sh[1], sh[2], sh[3]) + normal * r;
+        } else if ((int)sh[0] == SHAPE_SPOT || (int)sh[0] == SHAPE_LASER) {      // Scene.py:413-418: the shape's own point and normal
+            normal = V(sh[7], sh[8], sh[9]);
+            pos = V(sh[1], sh[2], sh[3]);
         }
     }
     nor = normalized(normal);
+}
+// ---- Scene.py:491-516: what sample_li adds for the two shape emitters that have no surface -- the factor `visable` on the
+// emission (spot: 1 inside the cone of half-angle x1, falling linearly to 0 at x2, measured between the light's normal and the
+// direction to the shaded point; laser: 1 within `radius` of the beam's axis, else 0) and, for the laser, light_choice_pdf =
+// 1 / light_count ----
+TD float light_shape_visible(const SceneView &s, int light_prim, v3 light_dir, v3 light_normal, float light_dist, float &choice_pdf)
+{
+    float visable = 1.0f;
+    const int *pr = s.primitive + (size_t)light_prim * PRI_VEC;
+    if (pr[0] != PRIMITIVE_TRI) {
+        const float *sh = s.shape + (size_t)pr[1] * SHA_VEC;
+        const int st = (int)sh[0];
+        if (st == SHAPE_SPOT) {
+            const float NdotL = absf(dot(light_dir, light_normal));
+            const float x1 = sh[4], x2 = sh[5];
+            const float x = tm_acos(NdotL);
+            if (x > x2) visable = 0.0f;
+            else if (x > x1) visable *= 1.0f - (x - x1) / (x2 - x1);
+        } else if (st == SHAPE_LASER) {
+            choice_pdf = 1.0f / (float)s.light_count;
+            const float proj = dot(light_dir, light_normal) * light_dist;
+            const float r = tm_sqrt(light_dist * light_dist - proj * proj);
+            if (r > sh[4]) visable = 0.0f;
+        }
+    }
+    return visable;
+}
+// ---- UtilsFunc.py:321-345 ----
+TD void map_to_disk(float u1, float u2, float &r, float &phi)
+{
+    phi = 0.0f; r = 0.0f;
+    const float a = 2.0f * u1 - 1.0f, b = 2.0f * u2 - 1.0f;
+    if (a > -b) {
+        if (a > b) { r = a; phi = (PI_UF / 4.0f) * (b / a); }
+        else { r = b; phi = (PI_UF / 4.0f) * (2.0f - a / b); }
+    } else {
+        if (a < b) { r = -a; phi = (PI_UF / 4.0f) * (4.0f + b / a); }
+        else { r = -b; phi = (b == 0.0f) ? 0.0f : (PI_UF / 4.0f) * (6.0f - a / b); }
+    }
 }
 // ---- Scene.py:353-377 ------------------------------------------------------------------------------------
 TD float get_prim_angle(const SceneView &s, int index, v3 v)

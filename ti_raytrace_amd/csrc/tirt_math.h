@@ -183,6 +183,9 @@ TM_HD float tm_cos(float x)
 }
 
 /* sin and cos of the same angle from ONE range reduction; bit-identical to tm_sin / tm_cos */
+/* tan as the quotient of the two correctly rounded values above (<= 1.5 ulp; the reference's ts.tan is LLVM's tanf) -- only
+ * Scene.sample_light's spot branch uses it (Scene.py:458-459) */
+TM_HD float tm_tan(float x) { return tm_sin(x) / tm_cos(x); }
 TM_HD void tm_sincos(float x, float *s, float *c)
 {
     if (x != x || x > 1.0e6f || x < -1.0e6f) { *s = tm_nan(); *c = tm_nan(); return; }

@@ -1234,13 +1234,14 @@ __global__ __launch_bounds__(SH_BLOCK, SH_MIN_WAVES) void k_shade(PathState ps, 
                         get_prim_random_point_normal(sc, light_prim, ra, rb, light_pos, light_normal);
                         const int lmat = sc.primitive[(size_t)light_prim * PRI_VEC + 2];
                         const float *lm = sc.material + (size_t)lmat * MAT_VEC;
-                        const v3 light_emission = V(lm[2], lm[3], lm[4]);
+                        const v3 light_emission0 = V(lm[2], lm[3], lm[4]);
                         const float light_area = get_prim_area(sc, light_prim);
-                        const float light_choice_pdf = 1.0f / ((float)sc.light_count * light_area);
+                        float light_choice_pdf = 1.0f / ((float)sc.light_count * light_area);
                         light_normal = normalized(light_normal);
                         v3 light_dir = h.pos - light_pos;
                         const float light_dist = norm(light_dir);
                         light_dir = light_dir / light_dist;
+                        const v3 light_emission = light_emission0 * light_shape_visible(sc, light_prim, light_dir, light_normal, light_dist, light_choice_pdf);   // spot / laser (Scene.py:491-516)
                         const float NdotL_surface = dot(fnormal, light_dir);            // PT_RGB.py:101-109
                         const float NdotL_light = dot(light_normal, light_dir);
                         if ((NdotL_surface < 0.0f) & (NdotL_light > 0.0f)) {
