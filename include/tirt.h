@@ -156,6 +156,27 @@ int tirt_pt_rgb_render(tirt_ctx *ctx, uint32_t frame_begin, int frame_count, uin
  * PT_RGB (with tiles, every context accumulates splats into its full-size film: sum-reduce). */
 int tirt_bdpt_rgb_render(tirt_ctx *ctx, uint32_t frame_begin, int frame_count, uint32_t seed);
 
+/* ---- spectral path: integrator/PT_Spec.py (hero-wavelength path tracer) -----------------------------
+ * tirt_spec_table_build: spectrum/JakobSpecTable.py:1-439 on the device -- the RGB -> sigmoid-spectrum coefficient table that
+ *   Rgb2Spec.load_table reads from spectrum/spec_table (a file the reference repository lacks).  cie_xyz [n*3] and d65 [n] for
+ *   360..830 nm in 1 nm steps (n = 471; spectrum/ciexyz31_1.csv, spectrum/Illuminantd65.csv from 360 nm on);
+ *   scale_out [res], coeff_out [3*res^3*3] in the order of the table file (res = 64 there).
+ * tirt_spectral_upload: what PathTrace.setup_data_cpu / setup_data_gpu place (PT_Spec.py:56-99): the CIE 1931 observer rows
+ *   (sensor [n_sensor*3], wavelengths s_min..s_max, step s_range), four tabulated spectra back to back in `spd` (D65 after
+ *   normalize_spec, white, red, green: Spectrum.load_table; sizes spd_n, ranges spd_min / spd_max / spd_range), the Rgb2Spec table
+ *   (tbl_scale [res], tbl_data [3*res^3*3]), and the sky (Sky.configs [11*9], Sky.radiances [11], Sky.sun_dir; sky/Sky.py:76-172).
+ * tirt_pt_spec_render: PathTrace.render x frame_count (PT_Spec.py:181-279; MAX_DEPTH 10 there); film, camera, tiling, deferred
+ *   submission and flags as tirt_pt_rgb_render. */
+typedef struct {
+    const float *sensor; int n_sensor; float s_min, s_max, s_range;
+    const float *spd; int spd_n[4]; float spd_min[4], spd_max[4], spd_range[4];
+    const float *tbl_scale, *tbl_data; int tbl_res;
+    const float *sky_cfg, *sky_rad; float sun_dir[3];
+} tirt_spectral_t;
+int tirt_spec_table_build(tirt_ctx *ctx, int res, const float *cie_xyz, const float *d65, int n, float *scale_out, float *coeff_out);
+int tirt_spectral_upload(tirt_ctx *ctx, const tirt_spectral_t *tables);
+int tirt_pt_spec_render(tirt_ctx *ctx, uint32_t frame_begin, int frame_count, uint32_t seed, int max_depth, int stack_size, int flags);
+
 /* UtilsFunc.tone_map(exposure, hdr, rgb_film) (UtilsFunc.py:583-586) */
 int tirt_tone_map(tirt_ctx *ctx, float exposure);
 /* field.to_numpy(): either pointer may be NULL */

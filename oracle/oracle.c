@@ -1148,9 +1148,364 @@ static v3 pt_rgb_pixel(const orc_scene *s, int i, int j, int H, uint32_t frame, 
     return radiance;
 }
 
+/* =====================================================================================================================
+ * PT_Spec: the hero-wavelength spectral path tracer, integrator/PT_Spec.py:44-279, with
+ * spectrum/Spectrum.py (tabulated spectra), spectrum/HeroSample.py (four wavelengths 100 nm apart per path),
+ * spectrum/Rgb2Spec.py (Jakob-Hanika sigmoid spectra from a 3 x 64^3 coefficient table), sky/Sky.py (the analytic sky
+ * dome that is PT_Spec's environment) and brdf/Glass.py:36-59 (dispersion).  Tables arrive as the host prepared them
+ * (ti_raytrace_amd/Spectrum.py, Rgb2Spec.py, Sky.py: the same arrays go to the device).
+ * ===================================================================================================================== */
+#define MAT_SPECTRAL 10         /* SceneData.py:53 */
+#define HERO_N 4                /* spectrum/HeroSample.py:5-8 */
+static const float HERO_LAMBDA_MIN = 360.0f, HERO_LAMBDA_STEP = (760.0f - 360.0f) / 4.0f;
+#define TM_DIM_SPEC_LAMBDA 4000u         /* the path's hero wavelength (PT_Spec.py:191); bounce dims as PT_RGB, slot 7 = get_rnd_hero */
+#define TM_SLOT_HERO 7
+
+typedef struct { float v[HERO_N]; } v4s;
+typedef struct { const float *data; int n; float lmin, lmax, lrange; } orc_spd;
+typedef struct {
+    float *sensor; int n_sensor; float s_min, s_max, s_range;       /* CIE 1931 observer, [n][3] (PT_Spec.py:56-77) */
+    orc_spd spd[4]; float *spd_mem;                                  /* d65 (normalised), white, red, green */
+    float *tbl_scale, *tbl_data; int tbl_res;                       /* Rgb2Spec */
+    float sky_cfg[11 * 9], sky_rad[11], sun_dir[3];                 /* Sky.configs / radiances / sun_dir */
+} orc_spec;
+
+orc_spec *orc_spec_create(const float *sensor, int n_sensor, float s_min, float s_max, float s_range,
+                          const float *spd_concat, const int *spd_n, const float *spd_lmin, const float *spd_lmax, const float *spd_lrange,
+                          const float *tbl_scale, const float *tbl_data, int tbl_res,
+                          const float *sky_cfg, const float *sky_rad, const float *sun_dir)
+{
+    orc_spec *sp = (orc_spec *)calloc(1, sizeof(orc_spec));
+    sp->sensor = (float *)malloc(sizeof(float) * 3 * (size_t)n_sensor); memcpy(sp->sensor, sensor, sizeof(float) * 3 * (size_t)n_sensor);
+    sp->n_sensor = n_sensor; sp->s_min = s_min; sp->s_max = s_max; sp->s_range = s_range;
+    int tot = 0; for (int k = 0; k < 4; k++) tot += spd_n[k];
+    sp->spd_mem = (float *)malloc(sizeof(float) * (size_t)tot); memcpy(sp->spd_mem, spd_concat, sizeof(float) * (size_t)tot);
+    int off = 0;
+    for (int k = 0; k < 4; k++) { sp->spd[k].data = sp->spd_mem + off; sp->spd[k].n = spd_n[k]; sp->spd[k].lmin = spd_lmin[k]; sp->spd[k].lmax = spd_lmax[k]; sp->spd[k].lrange = spd_lrange[k]; off += spd_n[k]; }
+    sp->tbl_res = tbl_res;
+    sp->tbl_scale = (float *)malloc(sizeof(float) * (size_t)tbl_res); memcpy(sp->tbl_scale, tbl_scale, sizeof(float) * (size_t)tbl_res);
+    size_t nt = (size_t)9 * tbl_res * tbl_res * tbl_res;
+    sp->tbl_data = (float *)malloc(sizeof(float) * nt); memcpy(sp->tbl_data, tbl_data, sizeof(float) * nt);
+    memcpy(sp->sky_cfg, sky_cfg, sizeof(sp->sky_cfg)); memcpy(sp->sky_rad, sky_rad, sizeof(sp->sky_rad)); memcpy(sp->sun_dir, sun_dir, sizeof(sp->sun_dir));
+    return sp;
+}
+void orc_spec_destroy(orc_spec *sp) { if (sp) { free(sp->sensor); free(sp->spd_mem); free(sp->tbl_scale); free(sp->tbl_data); free(sp); } }
+
+static float fractf_(float x) { return x - tm_floor(x); }                     /* taichi_glsl fract */
+/* spectrum/Spectrum.py:44-52 (the weight is fract(offset), not fract(offset / range): kept; data[idx + 1] at Lambda == lambda_max
+ * would be one past the table -- read as the last entry here) */
+static float spd_sample(const orc_spd *d, float Lambda)
+{
+    float ret = 0.0f;
+    if ((Lambda >= d->lmin) & (Lambda <= d->lmax)) {
+        const float offset = Lambda - d->lmin;
+        const int idx = (int)(offset / d->lrange);
+        const float w = fractf_(offset);
+        const int i1 = idx + 1 < d->n ? idx + 1 : d->n - 1;
+        ret = mixf(d->data[idx], d->data[i1], w);
+    }
+    return ret;
+}
+/* spectrum/HeroSample.py:10-16 */
+static v4s hero_sample(const orc_spd *d, float Lambda0)
+{ v4s r; for (int i = 0; i < HERO_N; i++) r.v[i] = spd_sample(d, Lambda0 + (float)i * HERO_LAMBDA_STEP); return r; }
+/* integrator/PT_Spec.py:131-139 */
+static v3 sensor_sample(const orc_spec *sp, float Lambda)
+{
+    v3 ret = V(0, 0, 0);
+    if ((Lambda >= sp->s_min) & (Lambda <= sp->s_max)) {
+        const float offset = Lambda - sp->s_min;
+        const int idx = (int)(offset / sp->s_range);
+        const float w = fractf_(offset);
+        const int i1 = idx + 1 < sp->n_sensor ? idx + 1 : sp->n_sensor - 1;
+        const float *a = sp->sensor + 3 * (size_t)idx, *b = sp->sensor + 3 * (size_t)i1;
+        ret = V(mixf(a[0], b[0], w), mixf(a[1], b[1], w), mixf(a[2], b[2], w));
+    }
+    return ret;
+}
+/* spectrum/Rgb2Spec.py:83-99 */
+static int r2s_find_interval(const orc_spec *sp, int size, float x)
+{
+    int left = 0, last_interval = size - 2;
+    size = last_interval;
+    while (size > 0) {
+        const int half = size >> 1, middle = left + half + 1;
+        if (sp->tbl_scale[middle] <= x) { left = middle; size -= half + 1; }
+        else size = half;
+    }
+    return left < last_interval ? left : last_interval;
+}
+static float r2s_tri(const orc_spec *sp, int i, float x0, float y0, float z0)     /* :77-80 */
+{
+    const int dx = 3, dy = 3 * sp->tbl_res, dz = 3 * sp->tbl_res * sp->tbl_res;
+    const float *t = sp->tbl_data;
+    return mixf(mixf(mixf(t[i], t[i + dx], x0), mixf(t[i + dy], t[i + dy + dx], x0), y0),
+                mixf(mixf(t[i + dz], t[i + dz + dx], x0), mixf(t[i + dy + dz], t[i + dx + dy + dz], x0), y0), z0);
+}
+/* spectrum/Rgb2Spec.py:101-137 (fetch) with get_max_component (:50-74) */
+static v3 r2s_fetch(const orc_spec *sp, v3 rgb)
+{
+    rgb = V(clampf(rgb.x, 0.0f, 1.0f), clampf(rgb.y, 0.0f, 1.0f), clampf(rgb.z, 0.0f, 1.0f));
+    int index = 0;
+    float x = rgb.x, y = rgb.y, z = rgb.z;
+    if (rgb.y > rgb.x) {
+        if (rgb.z > rgb.y) index = 2;
+        else { index = 1; x = rgb.z; y = rgb.x; z = rgb.y; }
+    } else {
+        if (rgb.z > rgb.x) index = 2;
+        else { index = 0; x = rgb.y; y = rgb.z; z = rgb.x; }
+    }
+    z = fmax_(0.00001f, z);
+    const float scale = (float)(sp->tbl_res - 1) / z;
+    x *= scale; y *= scale;
+    const int res = sp->tbl_res;
+    const int xi = (int)fmin_(x, (float)(res - 2)), yi = (int)fmin_(y, (float)(res - 2));
+    const int zi = r2s_find_interval(sp, res, z);
+    const int offset = (((index * res + zi) * res + yi) * res + xi) * 3;
+    const float x0 = x - (float)xi, y0 = y - (float)yi;
+    const float z0 = (z - sp->tbl_scale[zi]) / (sp->tbl_scale[zi + 1] - sp->tbl_scale[zi]);
+    return V(r2s_tri(sp, offset, x0, y0, z0), r2s_tri(sp, offset + 1, x0, y0, z0), r2s_tri(sp, offset + 2, x0, y0, z0));
+}
+static float r2s_eval(v3 c, float Lambda)                                       /* :139-143, fma(a,b,c) = a*b + c */
+{
+    const float x = (c.x * Lambda + c.y) * Lambda + c.z;
+    const float y = 1.0f / m_sqrt(x * x + 1.0f);
+    return (0.5f * x) * y + 0.5f;
+}
+/* spectrum/HeroSample.py:46-58 */
+static v4s srgb_to_spec(const orc_spec *sp, v3 srgb, float Lambda0)
+{
+    const v3 coff = r2s_fetch(sp, srgb_to_lrgb(srgb));
+    v4s r; for (int i = 0; i < HERO_N; i++) r.v[i] = r2s_eval(coff, Lambda0 + (float)i * HERO_LAMBDA_STEP);
+    return r;
+}
+static v4s v4_mul(v4s a, v4s b) { v4s r; for (int i = 0; i < HERO_N; i++) r.v[i] = a.v[i] * b.v[i]; return r; }
+static v4s v4_scale(v4s a, float k) { v4s r; for (int i = 0; i < HERO_N; i++) r.v[i] = a.v[i] * k; return r; }
+static v4s v4_add(v4s a, v4s b) { v4s r; for (int i = 0; i < HERO_N; i++) r.v[i] = a.v[i] + b.v[i]; return r; }
+static v4s v4_divs(v4s a, float k) { v4s r; for (int i = 0; i < HERO_N; i++) r.v[i] = a.v[i] / k; return r; }
+/* integrator/PT_Spec.py:102-109 */
+static v4s emission_to_rad(const orc_spec *sp, v3 emission, float Lambda)
+{
+    const float scale = vnorm(emission);
+    v4s ret; for (int i = 0; i < HERO_N; i++) ret.v[i] = 0.0f;
+    if (scale > 0.0f) ret = srgb_to_spec(sp, vdivs(emission, scale), Lambda);
+    return v4_scale(ret, scale);
+}
+/* integrator/PT_Spec.py:111-127 */
+static v4s get_spec_power(const orc_scene *s, const orc_spec *sp, int mat_id, float Lambda)
+{
+    const float *m = s->material + (size_t)mat_id * MAT_VEC;
+    const int mat_type = (int)m[0], mat_tex = (int)m[1];
+    v4s ret; for (int i = 0; i < HERO_N; i++) ret.v[i] = 0.0f;
+    if (mat_type == MAT_SPECTRAL) {
+        if (mat_tex == 0) ret = hero_sample(&sp->spd[1], Lambda);
+        if (mat_tex == 1) ret = hero_sample(&sp->spd[2], Lambda);
+        if (mat_tex == 2) ret = hero_sample(&sp->spd[3], Lambda);
+    } else ret = srgb_to_spec(sp, V(m[2], m[3], m[4]), Lambda);
+    return ret;
+}
+/* sky/Sky.py:176-186, 232-246, 248-255: the sky dome without the sun's disc (solar_radiance_internal2 is commented out there) */
+static float sky_internal(const orc_spec *sp, int wl, float theta, float gamma)
+{
+    const float *c = sp->sky_cfg + 9 * wl;
+    const float expM = m_exp(c[4] * gamma);
+    const float rayM = m_cos(gamma) * m_cos(gamma);
+    const float mieM = (1.0f + m_cos(gamma) * m_cos(gamma)) / m_pow((1.0f + c[8] * c[8]) - 2.0f * c[8] * m_cos(gamma), 1.5f);
+    const float zenith = m_sqrt(m_cos(theta));
+    return (1.0f + c[0] * m_exp(c[1] / (m_cos(theta) + 0.01f))) *
+           ((((c[2] + c[3] * expM) + c[5] * rayM) + c[6] * mieM) + c[7] * zenith);
+}
+static float sky_radiance(const orc_spec *sp, float theta, float gamma, float wavelength)
+{
+    float ret = 0.0f;
+    if ((wavelength >= 320.0f) & (wavelength <= 720.0f)) {
+        const int low_wl = (int)((wavelength - 320.0f) / 40.0f);
+        float result = 0.0f;
+        if ((low_wl >= 0) & (low_wl < 11)) {
+            const float interp = fractf_((wavelength - 320.0f) / 40.0f);
+            const float val_low = sky_internal(sp, low_wl, theta, gamma) * sp->sky_rad[low_wl];
+            if (interp < 1e-6f) result = val_low;
+            else {
+                result = (1.0f - interp) * val_low;
+                if (low_wl + 1 < 11) result += interp * sky_internal(sp, low_wl + 1, theta, gamma) * sp->sky_rad[low_wl + 1];
+            }
+        }
+        ret = result;
+    }
+    return ret;
+}
+/* brdf/Glass.py:36-59 with UF.get_glass_ior (UtilsFunc.py:481-484, BK7 Sellmeier) */
+static float get_glass_ior(float Lambda)
+{
+    Lambda = Lambda / 1000.0f;
+    const float L2 = Lambda * Lambda;
+    return m_sqrt(((1.0f + 1.03961212f * L2 / (L2 - 0.00600069867f)) + 0.231792344f * L2 / (L2 - 0.0200179144f)) + 1.01046945f * L2 / (L2 - 103.560653f));
+}
+static v3 glass_sample_lambda(v3 dir, v3 N, float Lambda, float probability, float *f_or_b)
+{
+    v3 w_out = dir;
+    float cos_theta_i = vdot(w_out, N);
+    const float ior = get_glass_ior(Lambda);
+    float eta = ior;
+    *f_or_b = 1.0f;
+    float R = probability + 1.0f;
+    if (cos_theta_i > 0.0f) N = vneg(N);
+    else { cos_theta_i = -cos_theta_i; eta = 1.0f / ior; }
+    float suc;
+    v3 next_dir = refract_(w_out, N, eta, &suc);
+    if (suc > 0.0f) R = schlick(cos_theta_i, ior);
+    if (probability < R) next_dir = reflect_(w_out, N);
+    else *f_or_b = -1.0f;
+    return next_dir;
+}
+
+/* integrator/PT_Spec.py:181-279: one pixel-sample; returns the four hero radiances and the hero wavelength */
+static v4s pt_spec_pixel(const orc_scene *s, const orc_spec *sp, int i, int j, int H, uint32_t frame, uint32_t seed,
+                         int max_depth, int32_t *stack, int stack_size, orc_stats *st, float *Lambda_out)
+{
+    uint32_t pixel = (uint32_t)(i * H + j);
+    v3 next_origin = V(s->eye[0], s->eye[1], s->eye[2]);
+    float jx = 0.0f, jy = 0.0f;
+    if (frame != 0) {
+        jx = tm_rand(seed, pixel, frame, TM_DIM_JX) - 0.5f;
+        jy = tm_rand(seed, pixel, frame, TM_DIM_JY) - 0.5f;
+    }
+    v3 next_dir;
+    {
+        float x = ((float)i + jx - s->cx) / s->fx;
+        float y = ((float)j + jy - s->cy) / s->fy;
+        float z = -1.0f, w = 0.0f;
+        const float *M = s->view_inv;
+        float wx = ((M[0] * x + M[1] * y) + M[2] * z) + M[3] * w;
+        float wy = ((M[4] * x + M[5] * y) + M[6] * z) + M[7] * w;
+        float wz = ((M[8] * x + M[9] * y) + M[10] * z) + M[11] * w;
+        next_dir = vnormalized(V(wx, wy, wz));
+    }
+    const float Lambda = HERO_LAMBDA_MIN + HERO_LAMBDA_STEP * tm_rand(seed, pixel, frame, TM_DIM_SPEC_LAMBDA);
+    *Lambda_out = Lambda;
+    int depth = 0;
+    float light_pdf = 1.0f, brdf_pdf = 1.0f, f_or_b = 1.0f, brdf = 1.0f;
+    v4s throughout, radiance;
+    for (int k = 0; k < HERO_N; k++) { throughout.v[k] = 1.0f; radiance.v[k] = 0.0f; }
+    const v4s light_rad = hero_sample(&sp->spd[0], Lambda);          /* the same for every vertex of the path (:212) */
+    if (st) st->paths++;
+    while (depth < max_depth) {
+        v3 origin = next_origin, direction = next_dir;
+        uint32_t dim0 = TM_DIM_BOUNCE0 + TM_DIMS_PER_BOUNCE * (uint32_t)depth;
+        hit_t h = closet_hit(s, origin, direction, stack, stack_size, st);
+        if (h.t < INF_VALUE) {
+            v3 normal = h.nor;
+            v3 fnormal = vscale(h.nor, signf(vdot(vneg(direction), h.gnor)));
+            int mat_id = s->primitive[(size_t)h.prim * PRI_VEC + 2];
+            const float *m = s->material + (size_t)mat_id * MAT_VEC;
+            v3 mat_color = V(m[2], m[3], m[4]);
+            int mat_type = (int)m[0];
+            /* :213 -- the "tint" is the colour of the material that was HIT, also where the NEE sample below uses it */
+            const v4s light_tint = emission_to_rad(sp, mat_color, Lambda);
+            if (mat_type == MAT_LIGHT) {
+                const float fCosTheta = vdot(direction, normal);
+                if (fCosTheta < 0.0f) {
+                    const float area = get_prim_area(s, h.prim);
+                    light_pdf = (h.t * h.t) / (area * fCosTheta);
+                    (void)light_pdf;       /* perfect_spec is reset to 1 at the top of every iteration (:214): the MIS branch is dead */
+                    radiance = v4_add(radiance, v4_mul(v4_mul(throughout, light_rad), light_tint));
+                }
+                break;
+            } else {
+                if (st) st->shaded++;
+                const v4s reflect_spec = get_spec_power(s, sp, mat_id, Lambda);
+                if (mat_type == MAT_GLASS) {
+                    int index = (int)(tm_rand(seed, pixel, frame, dim0 + TM_SLOT_HERO) * (float)HERO_N);     /* HeroSample.py:33-35 */
+                    const float rnd_lambda = Lambda + (float)index * HERO_LAMBDA_STEP;
+                    next_dir = glass_sample_lambda(direction, normal, rnd_lambda, tm_rand(seed, pixel, frame, dim0 + TM_SLOT_GLASS), &f_or_b);
+                    brdf = 1.0f; brdf_pdf = 1.0f;
+                } else {
+                    if (s->light_count > 0) {
+                    int lidx = (int)(tm_rand(seed, pixel, frame, dim0 + TM_SLOT_LIGHT) * (float)s->light_count);
+                    if (lidx >= s->light_count) lidx = s->light_count - 1;
+                    int light_prim = s->light[lidx];
+                    float ra = tm_rand(seed, pixel, frame, dim0 + TM_SLOT_LA);
+                    float rb = tm_rand(seed, pixel, frame, dim0 + TM_SLOT_LB);
+                    v3 light_pos, light_normal;
+                    get_prim_random_point_normal(s, light_prim, ra, rb, &light_pos, &light_normal);
+                    float light_area = get_prim_area(s, light_prim);
+                    float light_choice_pdf = 1.0f / ((float)s->light_count * light_area);
+                    light_normal = vnormalized(light_normal);
+                    v3 light_dir = vsub(h.pos, light_pos);
+                    float light_dist = vnorm(light_dir);
+                    light_dir = vdivs(light_dir, light_dist);
+                    (void)light_shape_visible(s, light_prim, light_dir, light_normal, light_dist, &light_choice_pdf);   /* only its pdf reaches :245 */
+                    float NdotL_surface = vdot(fnormal, light_dir);
+                    float NdotL_light = vdot(light_normal, light_dir);
+                    if ((NdotL_surface < 0.0f) & (NdotL_light > 0.0f)) {
+                        int shadow_prim;
+                        (void)closet_hit_shadow(s, light_pos, light_dir, stack, stack_size, &shadow_prim, st);
+                        if (shadow_prim == h.prim) {
+                            brdf = disney_evaluate_pdf(s, fnormal, vneg(direction), vneg(light_dir), mat_id, &brdf_pdf);
+                            light_pdf = light_dist * light_dist * light_choice_pdf / NdotL_light;
+                            if (brdf_pdf > 0.0f) {
+                                const float w = power_heuristic(light_pdf, brdf_pdf) / fmax_(0.0001f, light_pdf);
+                                v4s c = v4_scale(light_rad, w);
+                                c = v4_mul(c, light_tint);
+                                c = v4_mul(c, throughout);
+                                c = v4_mul(c, reflect_spec);
+                                c = v4_scale(c, brdf);
+                                c = v4_scale(c, fabs_(NdotL_surface));
+                                radiance = v4_add(radiance, c);
+                            }
+                        }
+                    }
+                    }
+                    float rnd[3] = { tm_rand(seed, pixel, frame, dim0 + TM_SLOT_LOBE),
+                                     tm_rand(seed, pixel, frame, dim0 + TM_SLOT_R1),
+                                     tm_rand(seed, pixel, frame, dim0 + TM_SLOT_R2) };
+                    next_dir = disney_sample(s, direction, fnormal, mat_id, rnd);
+                    f_or_b = 1.0f;
+                    brdf = disney_evaluate_pdf(s, fnormal, next_dir, vneg(direction), mat_id, &brdf_pdf);      /* (N, V = next_dir, L = -direction): :251 */
+                    brdf *= fabs_(vdot(normal, next_dir));
+                }
+                next_origin = offset_ray(h.pos, vscale(fnormal, signf(f_or_b)));
+                if ((brdf_pdf > 0.0f) & (fmax_(throughout.v[2], fmax_(throughout.v[0], throughout.v[1])) > 0.0f)) {
+                    throughout = v4_mul(throughout, v4_divs(v4_scale(reflect_spec, brdf), brdf_pdf));
+                    depth += 1;
+                } else break;
+            }
+        } else {
+            /* :267-274: the analytic sky */
+            const float dis = m_sqrt(direction.x * direction.x + direction.z * direction.z);
+            const float beta = m_atan2(direction.y, dis);
+            const float gamma = m_acos(vdot(direction, V(sp->sun_dir[0], sp->sun_dir[1], sp->sun_dir[2])));
+            const float theta = clampf(0.5f * PI_SCENE - beta, 0.0f, 0.5f * PI_SCENE);
+            v4s ibl;
+            for (int k = 0; k < HERO_N; k++) ibl.v[k] = sky_radiance(sp, theta, gamma, Lambda + (float)k * HERO_LAMBDA_STEP);
+            radiance = v4_add(radiance, v4_mul(v4_mul(throughout, ibl), light_rad));
+            break;
+        }
+    }
+    return radiance;
+}
+/* integrator/PT_Spec.py:141-158 AddSplat: hero radiances -> CIE XYZ -> linear sRGB, mixed into hdr */
+static void spec_add_splat(const orc_spec *sp, v4s spec, float Lambda0, float coff, float *px)
+{
+    float xf[HERO_N], yf[HERO_N], zf[HERO_N];
+    for (int k = 0; k < HERO_N; k++) {
+        const v3 xyz = sensor_sample(sp, Lambda0 + (float)k * HERO_LAMBDA_STEP);
+        xf[k] = xyz.x * spec.v[k]; yf[k] = xyz.y * spec.v[k]; zf[k] = xyz.z * spec.v[k];
+    }
+    const float range = sp->s_max - sp->s_min;
+    float X = 0.0f, Y = 0.0f, Z = 0.0f;
+    for (int k = 0; k < HERO_N; k++) { X += xf[k] * range / (float)HERO_N; Y += yf[k] * range / (float)HERO_N; Z += zf[k] * range / (float)HERO_N; }
+    /* UtilsFunc.py:42 xyz_to_srgb @ xyz */
+    const float r = ((float)3.240479 * X + (float)-1.537150 * Y) + (float)-0.498535 * Z;
+    const float g = ((float)-0.969256 * X + (float)1.875991 * Y) + (float)0.041556 * Z;
+    const float b = ((float)0.055648 * X + (float)-0.204043 * Y) + (float)1.057311 * Z;
+    px[0] = mixf(px[0], r, coff); px[1] = mixf(px[1], g, coff); px[2] = mixf(px[2], b, coff);
+}
+
 typedef struct {
     const orc_scene *s; int W, H; uint32_t frame_begin; int frame_count; uint32_t seed;
     int max_depth, stack_size; float *hdr;
+    const orc_spec *spec;           /* non-NULL: PT_Spec instead of PT_RGB */
     long p_begin, p_end;            /* linear pixel range [p_begin, p_end), p = i*H + j */
     int tile_rank, tile_count, tile_size;
     orc_stats st;
@@ -1166,10 +1521,16 @@ static void *render_worker(void *arg)
         float *px = jb->hdr + (size_t)p * 3;
         for (int f = 0; f < jb->frame_count; f++) {
             uint32_t frame = jb->frame_begin + (uint32_t)f;
-            v3 rad = pt_rgb_pixel(jb->s, i, j, jb->H, frame, jb->seed, jb->max_depth, stack, jb->stack_size, &jb->st);
-            /* PT_RGB.py:134-136 */
             float ff = (float)(int32_t)frame;
             float coff = 1.0f / (ff + 1.0f);
+            if (jb->spec) {
+                float Lambda;
+                v4s sr = pt_spec_pixel(jb->s, jb->spec, i, j, jb->H, frame, jb->seed, jb->max_depth, stack, jb->stack_size, &jb->st, &Lambda);
+                spec_add_splat(jb->spec, sr, Lambda, coff, px);
+                continue;
+            }
+            v3 rad = pt_rgb_pixel(jb->s, i, j, jb->H, frame, jb->seed, jb->max_depth, stack, jb->stack_size, &jb->st);
+            /* PT_RGB.py:134-136 */
             px[0] = rad.x * coff + px[0] * (1.0f - coff);
             px[1] = rad.y * coff + px[1] * (1.0f - coff);
             px[2] = rad.z * coff + px[2] * (1.0f - coff);
@@ -1203,10 +1564,10 @@ static void *thread_main(void *arg)
 /* hdr: [W*H*3], index (i*H + j)*3, read-modify-written (running mean, PT_RGB.py:134-136).
  * Pixels are visited for linear index p in [p_begin, p_end) whose tile (p / tile_size) %
  * tile_count == tile_rank (tile_count <= 1: all).  stats may be NULL. */
-int orc_pt_rgb_render(const orc_scene *s, int W, int H, uint32_t frame_begin, int frame_count,
-                      uint32_t seed, int max_depth, int stack_size, float *hdr,
-                      long p_begin, long p_end, int tile_rank, int tile_count, int tile_size,
-                      int nthreads, orc_stats *stats)
+static int render_common(const orc_scene *s, const orc_spec *spec, int W, int H, uint32_t frame_begin, int frame_count,
+                         uint32_t seed, int max_depth, int stack_size, float *hdr,
+                         long p_begin, long p_end, int tile_rank, int tile_count, int tile_size,
+                         int nthreads, orc_stats *stats)
 {
     if (p_end > (long)W * H) p_end = (long)W * H;
     if (p_begin < 0) p_begin = 0;
@@ -1222,7 +1583,7 @@ int orc_pt_rgb_render(const orc_scene *s, int W, int H, uint32_t frame_begin, in
     for (int t = 0; t < nthreads; t++) {
         render_job *jb = &tc[t].proto;
         jb->s = s; jb->W = W; jb->H = H; jb->frame_begin = frame_begin; jb->frame_count = frame_count;
-        jb->seed = seed; jb->max_depth = max_depth; jb->stack_size = stack_size; jb->hdr = hdr;
+        jb->seed = seed; jb->max_depth = max_depth; jb->stack_size = stack_size; jb->hdr = hdr; jb->spec = spec;
         jb->tile_rank = tile_rank; jb->tile_count = tile_count; jb->tile_size = tile_size > 0 ? tile_size : 1;
         tc[t].p_begin = p_begin; tc[t].total = total; tc[t].chunks = chunks; tc[t].next = &next;
     }
@@ -1248,6 +1609,200 @@ int orc_pt_rgb_render(const orc_scene *s, int W, int H, uint32_t frame_begin, in
     free(tc);
     return 0;
 }
+int orc_pt_rgb_render(const orc_scene *s, int W, int H, uint32_t frame_begin, int frame_count,
+                      uint32_t seed, int max_depth, int stack_size, float *hdr,
+                      long p_begin, long p_end, int tile_rank, int tile_count, int tile_size,
+                      int nthreads, orc_stats *stats)
+{ return render_common(s, NULL, W, H, frame_begin, frame_count, seed, max_depth, stack_size, hdr, p_begin, p_end, tile_rank, tile_count, tile_size, nthreads, stats); }
+/* PT_Spec.render x frame_count (integrator/PT_Spec.py:181-279, MAX_DEPTH 10): same film conventions as orc_pt_rgb_render */
+int orc_pt_spec_render(const orc_scene *s, const orc_spec *spec, int W, int H, uint32_t frame_begin, int frame_count,
+                       uint32_t seed, int max_depth, int stack_size, float *hdr,
+                       long p_begin, long p_end, int tile_rank, int tile_count, int tile_size,
+                       int nthreads, orc_stats *stats)
+{ return render_common(s, spec, W, H, frame_begin, frame_count, seed, max_depth, stack_size, hdr, p_begin, p_end, tile_rank, tile_count, tile_size, nthreads, stats); }
+/* =====================================================================================================================
+ * spectrum/JakobSpecTable.py:1-439 -- the offline optimiser behind spectrum/spec_table (the reference repository lacks the
+ * table itself: .MISSING_LARGE_BLOBS).  For every cell of a 3 x res^3 grid over RGB (largest component l, its value through
+ * scale[k], the two others as fractions i, j of it) three sigmoid-polynomial coefficients are fitted by Gauss-Newton in CIE
+ * Lab under D65, warm-started along k.  Double precision throughout, as the reference (ti.init(default_fp=ti.f64)).
+ * cie_xyz: [n][3] and d65: [n] for 360..830 nm in 1 nm steps (n = 471), as float32 (the reference loads them through float32
+ * numpy arrays, :386-388).  scale_out: [res], coeff_out: [3*res^3*3] as float32 (the table file holds %.9g of the doubles).
+ * ===================================================================================================================== */
+typedef struct { int n; double rgb_tbl[471][3], lam[471], wp[3]; } spt_ctx;
+static double spt_sqr(double x) { return x * x; }
+static double spt_smoothstep(double x) { return x * x * (3.0 - 2.0 * x); }
+static double spt_sigmoid(double x) { return 0.5 * x / tm_sqrtd(1.0 + x * x) + 0.5; }
+static double spt_f(double t)                                     /* :88-97; pow(t, 1/3) = exp(log(t) / 3) with the shared double kernels */
+{
+    const double delta = 6.0 / 29.0;
+    return (t > delta * delta * delta) ? tm_expd(tm_logd(t) * (1.0 / 3.0)) : t / (delta * delta * 3.0) + (4.0 / 29.0);
+}
+static void spt_cie_lab(const spt_ctx *c, const double p[3], double out[3])   /* :99-105 */
+{
+    const double X = (0.412453 * p[0] + 0.357580 * p[1]) + 0.180423 * p[2];
+    const double Y = (0.212671 * p[0] + 0.715160 * p[1]) + 0.072169 * p[2];
+    const double Z = (0.019334 * p[0] + 0.119193 * p[1]) + 0.950227 * p[2];
+    out[0] = 116.0 * spt_f(Y / c->wp[1]) - 16.0;
+    out[1] = 500.0 * (spt_f(X / c->wp[0]) - spt_f(Y / c->wp[1]));
+    out[2] = 200.0 * (spt_f(Y / c->wp[1]) - spt_f(Z / c->wp[2]));
+}
+static void spt_residual(const spt_ctx *c, const double co[3], const double rgb[3], double out[3])   /* :260-277 */
+{
+    double acc[3] = {0.0, 0.0, 0.0};
+    for (int i = 0; i < c->n; i++) {
+        const double L = (c->lam[i] - 360.0) / (830.0 - 360.0);
+        double x = co[0];
+        x = x * L + co[1];
+        x = x * L + co[2];
+        const double sg = spt_sigmoid(x);
+        acc[0] += c->rgb_tbl[i][0] * sg; acc[1] += c->rgb_tbl[i][1] * sg; acc[2] += c->rgb_tbl[i][2] * sg;
+    }
+    double a[3], b[3];
+    spt_cie_lab(c, rgb, a); spt_cie_lab(c, acc, b);
+    out[0] = a[0] - b[0]; out[1] = a[1] - b[1]; out[2] = a[2] - b[2];
+}
+/* :107-209 LUPDecompose, as written there: the pivot search of the SECOND column looks at column 0 again (A[k,0], :170) -- kept */
+static int spt_lup(double A[3][3], int P[4])
+{
+    const double Tol = 1e-15;
+    int ret = 1;
+    P[0] = 0; P[1] = 1; P[2] = 2; P[3] = 3;
+    double maxA = 0.0; int imax = 0;
+    for (int k = 0; k < 3; k++) { const double a = A[k][0] < 0 ? -A[k][0] : A[k][0]; if (a > maxA) { maxA = a; imax = k; } }
+    if (maxA < Tol) ret = 0;
+    if (imax != 0) {
+        const int o = imax;           /* swap rows 0 and imax, and the permutation */
+        for (int q = 0; q < 3; q++) { const double t = A[0][q]; A[0][q] = A[o][q]; A[o][q] = t; }
+        { const int t = P[0]; P[0] = P[o]; P[o] = t; }
+        P[3] += 1;
+    }
+    A[1][0] /= A[0][0]; A[1][1] -= A[1][0] * A[0][1]; A[1][2] -= A[1][0] * A[0][2];
+    A[2][0] /= A[0][0]; A[2][1] -= A[2][0] * A[0][1]; A[2][2] -= A[2][0] * A[0][2];
+    maxA = 0.0; imax = 1;
+    for (int k = 1; k < 3; k++) { const double a = A[k][0] < 0 ? -A[k][0] : A[k][0]; if (a > maxA) { maxA = a; imax = k; } }
+    if (maxA < Tol) ret = 0;
+    if (imax != 1) {
+        for (int q = 0; q < 3; q++) { const double t = A[1][q]; A[1][q] = A[2][q]; A[2][q] = t; }
+        { const int t = P[1]; P[1] = P[2]; P[2] = t; }
+        P[3] += 1;
+    }
+    A[2][1] /= A[1][1]; A[2][2] -= A[2][1] * A[1][2];
+    if ((A[2][2] < 0 ? -A[2][2] : A[2][2]) < Tol) ret = 0;
+    return ret;
+}
+static void spt_solve(double A[3][3], const int P[4], const double b[3], double x[3])     /* :212-257 */
+{
+    x[0] = b[P[0]];
+    x[1] = b[P[1]]; x[1] -= A[1][0] * x[0];
+    x[2] = b[P[2]]; x[2] -= A[2][0] * x[0]; x[2] -= A[2][1] * x[1];
+    x[2] = x[2] / A[2][2];
+    x[1] -= A[1][2] * x[2]; x[1] = x[1] / A[1][1];
+    x[0] -= A[0][1] * x[1]; x[0] -= A[0][2] * x[2]; x[0] = x[0] / A[0][0];
+}
+static int spt_gauss_newton(const spt_ctx *c, const double rgb[3], double co[3])         /* :301-332 */
+{
+    const double EPS = 1e-4;
+    int rv = 1;
+    for (int it = 0; it < 15; it++) {
+        double res[3], J[3][3];
+        spt_residual(c, co, rgb, res);
+        for (int i = 0; i < 3; i++) {
+            double tmp[3] = {co[0], co[1], co[2]}, r0[3], r1[3];
+            tmp[i] -= EPS; spt_residual(c, tmp, rgb, r0);
+            tmp[0] = co[0]; tmp[1] = co[1]; tmp[2] = co[2];
+            tmp[i] += EPS; spt_residual(c, tmp, rgb, r1);
+            for (int q = 0; q < 3; q++) J[q][i] = (r1[q] - r0[q]) / (2.0 * EPS);
+        }
+        int P[4];
+        rv = spt_lup(J, P);
+        if (rv != 1) break;
+        double x[3];
+        spt_solve(J, P, res, x);
+        co[0] -= x[0]; co[1] -= x[1]; co[2] -= x[2];
+        const double r = (res[0] * res[0] + res[1] * res[1]) + res[2] * res[2];
+        if (r < 0.000001) break;
+        const double m01 = co[0] > co[1] ? co[0] : co[1], cm = m01 > co[2] ? m01 : co[2];
+        if (cm > 200.0) { const double k = 200.0 / cm; co[0] *= k; co[1] *= k; co[2] *= k; }
+    }
+    return rv;
+}
+static void spt_get_rgb(const double *scale, int k, double x, double y, int l, double rgb[3])   /* :51-67 */
+{
+    const double b = scale[k];
+    rgb[0] = rgb[1] = rgb[2] = 0.0;
+    if (l == 0) { rgb[0] = b; rgb[1] = x * b; rgb[2] = y * b; }
+    else if (l == 1) { rgb[1] = b; rgb[2] = x * b; rgb[0] = y * b; }
+    else { rgb[2] = b; rgb[0] = x * b; rgb[1] = y * b; }
+}
+static void spt_write(float *out, long idx, const double co[3])                               /* :69-77 */
+{
+    const double c0 = 360.0, c1 = 1.0 / (830.0 - 360.0);
+    out[3 * idx + 0] = (float)(co[0] * spt_sqr(c1));
+    out[3 * idx + 1] = (float)(co[1] * c1 - 2 * co[0] * c0 * spt_sqr(c1));
+    out[3 * idx + 2] = (float)(co[2] - co[1] * c0 * c1 + co[0] * spt_sqr(c0 * c1));
+}
+typedef struct { const spt_ctx *c; const double *scale; int res, l, j0, j1; float *out; } spt_job;
+static void *spt_worker(void *arg)
+{
+    spt_job *jb = (spt_job *)arg;
+    const int res = jb->res;
+    for (int j = jb->j0; j < jb->j1; j++) for (int i = 0; i < res; i++) {                    /* sovle(l), :345-375 */
+        const double x = (double)i / (double)(res - 1), y = (double)j / (double)(res - 1);
+        double co[3] = {0.0, 0.0, 0.0}, rgb[3];
+        for (int k = res / 5; k < res; k++) {
+            spt_get_rgb(jb->scale, k, x, y, jb->l, rgb);
+            if (spt_gauss_newton(jb->c, rgb, co) != 1) break;
+            spt_write(jb->out, (((long)jb->l * res + k) * res + j) * res + i, co);
+        }
+        co[0] = co[1] = co[2] = 0.0;
+        for (int k = res / 5; k >= 0; k--) {
+            spt_get_rgb(jb->scale, k, x, y, jb->l, rgb);
+            if (spt_gauss_newton(jb->c, rgb, co) != 1) break;
+            spt_write(jb->out, (((long)jb->l * res + k) * res + j) * res + i, co);
+        }
+    }
+    return NULL;
+}
+int orc_spec_table_build(int res, const float *cie_xyz, const float *d65, int n, float *scale_out, float *coeff_out, int nthreads)
+{
+    if (n != 471 || res < 5 || res > 64) return -1;
+    spt_ctx *c = (spt_ctx *)calloc(1, sizeof(spt_ctx));
+    c->n = n;
+    const double h = (830.0 - 360.0) / (double)(n - 1);
+    double wp[3] = {0.0, 0.0, 0.0};
+    for (int i = 0; i < n; i++) {                                                             /* pre_compute, :334-343 */
+        double weight = 3.0 / 8.0 * h;
+        if ((i == 0) | (i == n - 1)) weight = weight;
+        else if ((i - 1) % 3 == 2) weight = weight * 2.0;
+        else weight = weight * 3.0;
+        const double X = (double)cie_xyz[3 * i], Y = (double)cie_xyz[3 * i + 1], Z = (double)cie_xyz[3 * i + 2], D = (double)d65[i];
+        c->lam[i] = 360.0 + (double)i;
+        c->rgb_tbl[i][0] = (((3.240479 * X + -1.537150 * Y) + -0.498535 * Z) * D) * weight;
+        c->rgb_tbl[i][1] = (((-0.969256 * X + 1.875991 * Y) + 0.041556 * Z) * D) * weight;
+        c->rgb_tbl[i][2] = (((0.055648 * X + -0.204043 * Y) + 1.057311 * Z) * D) * weight;
+        wp[0] += (X * D) * weight; wp[1] += (Y * D) * weight; wp[2] += (Z * D) * weight;
+    }
+    double scale[64];
+    for (int i = 0; i < res; i++) { scale[i] = spt_smoothstep(spt_smoothstep((double)i / (double)(res - 1))); scale_out[i] = (float)scale[i]; }
+    /* :413-417: white point and rgb table normalised by the white point's Y */
+    for (int i = 0; i < n; i++) { c->rgb_tbl[i][0] /= wp[1]; c->rgb_tbl[i][1] /= wp[1]; c->rgb_tbl[i][2] /= wp[1]; }
+    c->wp[0] = wp[0] / wp[1]; c->wp[2] = wp[2] / wp[1]; c->wp[1] = wp[1] / wp[1];
+    memset(coeff_out, 0, sizeof(float) * 9 * (size_t)res * res * res);
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > res) nthreads = res;
+    for (int l = 0; l < 3; l++) {
+        pthread_t th[64]; spt_job jb[64];
+        for (int t = 0; t < nthreads; t++) {
+            jb[t].c = c; jb[t].scale = scale; jb[t].res = res; jb[t].l = l; jb[t].out = coeff_out;
+            jb[t].j0 = res * t / nthreads; jb[t].j1 = res * (t + 1) / nthreads;
+            pthread_create(&th[t], NULL, spt_worker, &jb[t]);
+        }
+        for (int t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
+    }
+    free(c);
+    return 0;
+}
+
 /* UtilsFunc.py:583-586; in/out: [npix*3] */
 void orc_tone_map(float exposure, const float *in, float *out, long npix)
 {

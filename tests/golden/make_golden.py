@@ -39,3 +39,7 @@ for name in ("glass", "metal", "non-metal"):
     blocks = img.reshape(32, 16, 32, 16, 3).mean(axis=(1, 3)).astype(np.float32)
     np.save("gallery_" + name.replace("-", "_") + "_blocks.npy", blocks)
     print(name, blocks.shape, blocks.reshape(-1, 3).mean(0))
+# image/spectral-cornellbox.png: the reference's gallery render of example/spectral_box.py (PT_Spec); tests/test_spectral.py says why
+# it can only be a structure pin
+img = np.asarray(Image.open(REF + "/image/spectral-cornellbox.png").convert("RGB")).astype(np.float32) / 255.0
+np.save("spectral_cornellbox_blocks.npy", img.reshape(32, 16, 32, 16, 3).mean(axis=(1, 3)).astype(np.float32))

@@ -97,6 +97,15 @@ def load(libm=False, native=False):
         L.orc_kat_rand.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
         L.orc_kat_math.argtypes = [C.c_int, _f32p, _f32p, _f32p, C.c_int]
         L.orc_uses_libm.restype = C.c_int
+        L.orc_spec_table_build.restype = C.c_int
+        L.orc_spec_table_build.argtypes = [C.c_int, _f32p, _f32p, C.c_int, _f32p, _f32p, C.c_int]
+        L.orc_spec_create.restype = _vp
+        L.orc_spec_create.argtypes = [_f32p, C.c_int, C.c_float, C.c_float, C.c_float, _f32p, _i32p, _f32p, _f32p, _f32p,
+                                      _f32p, _f32p, C.c_int, _f32p, _f32p, _f32p]
+        L.orc_spec_destroy.argtypes = [_vp]
+        L.orc_pt_spec_render.restype = C.c_int
+        L.orc_pt_spec_render.argtypes = [_vp, _vp, C.c_int, C.c_int, C.c_uint32, C.c_int, C.c_uint32, C.c_int, C.c_int,
+                                         _f32p, C.c_long, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(OrcStats)]
         _libs[name] = L
     return _libs[name]
 
@@ -205,6 +214,28 @@ class OracleScene:
         self.L.orc_bdpt_render(self.h, state, frame_begin, frame_count, seed, stack_size, rad.reshape(-1), hdr.reshape(-1), C.byref(st))
         return hdr, st.as_dict(), state
 
+    def set_spectral(self, t):
+        """t: PT_Spec.PathTrace.tables() -- the same arrays the device gets"""
+        f = lambda k: np.ascontiguousarray(t[k], np.float32)
+        self.spec = self.L.orc_spec_create(f("sensor"), int(t["n_sensor"]), t["s_min"], t["s_max"], t["s_range"], f("spd"),
+                                           np.asarray(t["spd_n"], np.int32), np.asarray(t["spd_min"], np.float32),
+                                           np.asarray(t["spd_max"], np.float32), np.asarray(t["spd_range"], np.float32),
+                                           f("tbl_scale"), f("tbl_data"), int(t["tbl_res"]), f("sky_cfg"), f("sky_rad"),
+                                           np.asarray(t["sun_dir"], np.float32))
+
+    def spec_render(self, W, H, frame_begin, frame_count, seed=1, max_depth=10, stack_size=64, hdr=None,
+                    p_begin=0, p_end=None, tile_rank=0, tile_count=1, tile_size=4096, nthreads=None):
+        if hdr is None:
+            hdr = np.zeros((W, H, 3), np.float32)
+        if p_end is None:
+            p_end = W * H
+        if nthreads is None:
+            nthreads = os.cpu_count() or 1
+        st = OrcStats()
+        self.L.orc_pt_spec_render(self.h, self.spec, W, H, frame_begin, frame_count, seed, max_depth, stack_size,
+                                  hdr.reshape(-1), p_begin, p_end, tile_rank, tile_count, tile_size, nthreads, C.byref(st))
+        return hdr, st.as_dict()
+
     def tone_map(self, exposure, hdr):
         out = np.zeros_like(hdr)
         self.L.orc_tone_map(exposure, np.ascontiguousarray(hdr.reshape(-1)), out.reshape(-1), hdr.size // 3)
@@ -215,6 +246,17 @@ class OracleScene:
 
     def process_normal(self, vertex_index):
         self.L.orc_process_normal(self.h, np.ascontiguousarray(vertex_index, np.int32))
+
+
+def spec_table_build(res, cie_xyz, d65, nthreads=None, libm=False):
+    """spectrum/JakobSpecTable.py in the oracle (double precision, pthreads): (scale[res], coeff[3*res^3*3]) as float32."""
+    L = load(libm)
+    scale = np.zeros(res, np.float32)
+    coeff = np.zeros(9 * res ** 3, np.float32)
+    rc = L.orc_spec_table_build(res, np.ascontiguousarray(cie_xyz, np.float32).reshape(-1), np.ascontiguousarray(d65, np.float32),
+                                int(np.asarray(d65).size), scale, coeff, nthreads or (os.cpu_count() or 1))
+    assert rc == 0
+    return scale, coeff
 
 
 def camera_rays(cam, W, H, pixels=None):

@@ -99,6 +99,20 @@ SIGNATURES = {
     "tirt_obj_material_vertices": (C.c_int, [_vp, C.c_int, np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS"), C.c_longlong]),
 }
 
+class SpectralTables(C.Structure):
+    """tirt_spectral_t (include/tirt.h)"""
+    _fields_ = [("sensor", C.c_void_p), ("n_sensor", C.c_int), ("s_min", C.c_float), ("s_max", C.c_float), ("s_range", C.c_float),
+                ("spd", C.c_void_p), ("spd_n", C.c_int * 4), ("spd_min", C.c_float * 4), ("spd_max", C.c_float * 4), ("spd_range", C.c_float * 4),
+                ("tbl_scale", C.c_void_p), ("tbl_data", C.c_void_p), ("tbl_res", C.c_int),
+                ("sky_cfg", C.c_void_p), ("sky_rad", C.c_void_p), ("sun_dir", C.c_float * 3)]
+
+
+SIGNATURES.update({
+    "tirt_spec_table_build": (C.c_int, [_vp, C.c_int, _f32p, _f32p, C.c_int, _f32p, _f32p]),
+    "tirt_spectral_upload": (C.c_int, [_vp, C.POINTER(SpectralTables)]),
+    "tirt_pt_spec_render": (C.c_int, [_vp, C.c_uint32, C.c_int, C.c_uint32, C.c_int, C.c_int, C.c_int]),
+})
+
 _lib = None
 
 
@@ -238,6 +252,31 @@ class Context:
 
     def bdpt_rgb_render(self, frame_begin, frame_count, seed):
         check(lib().tirt_bdpt_rgb_render(self.handle, int(frame_begin), int(frame_count), int(seed)))
+
+    def pt_spec_render(self, frame_begin, frame_count, seed, max_depth=10, stack_size=64, flags=0):
+        check(lib().tirt_pt_spec_render(self.handle, int(frame_begin), int(frame_count), int(seed),
+                                        int(max_depth), int(stack_size), int(flags)))
+
+    def spec_table_build(self, res, cie_xyz, d65):
+        cie_xyz = np.ascontiguousarray(cie_xyz, np.float32).reshape(-1)
+        d65 = np.ascontiguousarray(d65, np.float32)
+        scale = np.zeros(res, np.float32)
+        coeff = np.zeros(9 * res * res * res, np.float32)
+        check(lib().tirt_spec_table_build(self.handle, int(res), cie_xyz, d65, int(d65.size), scale, coeff))
+        return scale, coeff
+
+    def spectral_upload(self, t):
+        """t: the dict of PT_Spec.PathTrace.tables()"""
+        keep = [np.ascontiguousarray(t[k], np.float32) for k in ("sensor", "spd", "tbl_scale", "tbl_data", "sky_cfg", "sky_rad")]
+        st = SpectralTables()
+        st.sensor, st.spd, st.tbl_scale, st.tbl_data, st.sky_cfg, st.sky_rad = [a.ctypes.data for a in keep]
+        st.n_sensor = int(t["n_sensor"]); st.s_min = t["s_min"]; st.s_max = t["s_max"]; st.s_range = t["s_range"]
+        for k in range(4):
+            st.spd_n[k] = int(t["spd_n"][k]); st.spd_min[k] = t["spd_min"][k]; st.spd_max[k] = t["spd_max"][k]; st.spd_range[k] = t["spd_range"][k]
+        st.tbl_res = int(t["tbl_res"])
+        for k in range(3):
+            st.sun_dir[k] = t["sun_dir"][k]
+        check(lib().tirt_spectral_upload(self.handle, C.byref(st)))
 
     def tone_map(self, exposure):
         check(lib().tirt_tone_map(self.handle, float(exposure)))

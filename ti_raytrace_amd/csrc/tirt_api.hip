@@ -1,6 +1,7 @@
 // tirt_api.hip -- the C-ABI of include/tirt.h: context, uploads/downloads, camera, film,
 // tone map, Scene.process_normal / total_area kernels, known-answer-test kernels, stats.
 #include "tirt_internal.h"
+#include "tirt_spectral.h"
 #include <stddef.h>
 #include <mutex>
 #include <string.h>
@@ -34,7 +35,8 @@ int flush_pending(tirt_ctx *c)
 {
     if (!c->pend.valid) return 0;
     c->pend.valid = false;
-    return pt_render(c, c->pend.begin, c->pend.count, c->pend.seed, c->pend.max_depth, c->pend.stack_size, c->pend.flags);
+    return pt_render(c, c->pend.begin, c->pend.count, c->pend.seed, c->pend.max_depth, c->pend.stack_size, c->pend.flags,
+                     c->pend.spectral ? (const SpecView *)c->spec_view : nullptr);
 }
 int sync_all(tirt_ctx *c)
 {
@@ -310,6 +312,8 @@ void tirt_destroy(tirt_ctx *c)
         if (L.film_done) (void)hipEventDestroy(L.film_done);
         if (L.stream) (void)hipStreamDestroy(L.stream);
     }
+    c->spec_mem.release();
+    if (c->spec_view) { delete (SpecView *)c->spec_view; c->spec_view = nullptr; }
     if (c->ev_main) (void)hipEventDestroy(c->ev_main);
     (void)hipEventDestroy(c->ev0); (void)hipEventDestroy(c->ev1);
     (void)hipStreamDestroy(c->stream);
@@ -585,25 +589,35 @@ int tirt_film_clear(tirt_ctx *c)
     return TIRT_OK;
 }
 
-int tirt_pt_rgb_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed, int max_depth, int stack_size, int flags)
+static int submit_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed, int max_depth, int stack_size, int flags, bool spectral)
 {
-    CTX_NOFLUSH(c);
-    TIRT_REQUIRE(c->built, "tirt_pt_rgb_render: LBVH not built");
-    TIRT_REQUIRE(c->cam_set, "tirt_pt_rgb_render: camera not set");
-    TIRT_REQUIRE(c->hdr.p && c->npix_local >= 0, "tirt_pt_rgb_render: film not created");
-    TIRT_REQUIRE(frame_count >= 0 && max_depth >= 1 && max_depth <= 4096, "tirt_pt_rgb_render: bad frame_count/max_depth");
+    TIRT_REQUIRE(c->built, "render: LBVH not built");
+    TIRT_REQUIRE(c->cam_set, "render: camera not set");
+    TIRT_REQUIRE(c->hdr.p && c->npix_local >= 0, "render: film not created");
+    TIRT_REQUIRE(frame_count >= 0 && max_depth >= 1 && max_depth <= 4096, "render: bad frame_count/max_depth");
     if (frame_count == 0) return TIRT_OK;
     auto &p = c->pend;
     if (p.valid && p.begin + (uint32_t)p.count == frame_begin && p.seed == seed && p.max_depth == max_depth &&
-        p.stack_size == stack_size && p.flags == flags) {
+        p.stack_size == stack_size && p.flags == flags && p.spectral == spectral) {
         p.count += frame_count;
     } else {
         if (int rc = flush_pending(c)) return rc;
         p.valid = true; p.begin = frame_begin; p.count = frame_count; p.seed = seed;
-        p.max_depth = max_depth; p.stack_size = stack_size; p.flags = flags;
+        p.max_depth = max_depth; p.stack_size = stack_size; p.flags = flags; p.spectral = spectral;
     }
     if ((size_t)p.count * (size_t)(c->npix_local > 0 ? c->npix_local : 1) >= effective_merge_paths(c)) return flush_pending(c);
     return TIRT_OK;
+}
+int tirt_pt_rgb_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed, int max_depth, int stack_size, int flags)
+{
+    CTX_NOFLUSH(c);
+    return submit_render(c, frame_begin, frame_count, seed, max_depth, stack_size, flags, false);
+}
+int tirt_pt_spec_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed, int max_depth, int stack_size, int flags)
+{
+    CTX_NOFLUSH(c);
+    TIRT_REQUIRE(c->spec_set && c->spec_view, "tirt_pt_spec_render: spectral tables not uploaded (tirt_spectral_upload)");
+    return submit_render(c, frame_begin, frame_count, seed, max_depth, stack_size, flags, true);
 }
 
 int tirt_bdpt_rgb_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed)

@@ -133,6 +133,7 @@ struct PathState {
     int *sdst;                                   // where the contribution goes: >= 0 index in the next
                                                  // PathSoA (path continues), < 0: ~slot in the final radiance
     float *fr, *fg, *fb;                         // final radiance per path id (read by k_film)
+    float *scw, *fw;                             // PT_Spec: fourth hero-wavelength component of the shadow-ray contribution / of the final radiance
 };
 
 // pixel-tile shard of this context: local pixel k -> linear pixel index (p = i * H + j: a tile is a run of whole or partial columns).
@@ -227,7 +228,7 @@ struct tirt_ctx {
     bool grid_user = false;                        // trace_grid / shade_grid were set through tirt_set_option
     bool batch_user = false, merge_user = false;   // batch_paths / merge_paths were set through tirt_set_option: no automatic sizing
     long job_frames = 0;                           // option "job_frames": expected frames of the whole job (0 = unknown); bounds the head-room
-    struct { bool valid = false; uint32_t begin = 0; int count = 0; uint32_t seed = 0; int max_depth = 0, stack_size = 0, flags = 0; } pend;
+    struct { bool valid = false; uint32_t begin = 0; int count = 0; uint32_t seed = 0; int max_depth = 0, stack_size = 0, flags = 0; bool spectral = false; } pend;
     // traversal tunables (options "trace_lds_depth", "trace_refill_min", "trace_node_min", "trace_grid",
     // "trace_slices" = number of ray-fetch cursors, "shade_grid" = persistent blocks of k_shade)
     int tr_lds_depth = 16, tr_refill_min = 18, tr_node_min = 38, tr_grid = 384, tr_slice_log2 = 5, sh_grid = 1024;
@@ -245,6 +246,9 @@ struct tirt_ctx {
     size_t bdpt_batch_items = (size_t)8 << 20;   // option "bdpt_batch_items": (frame, pixel) items per wavefront batch
     int bdpt_stack = 64;                           // option "bdpt_stack_size": traversal stack entries of BDPT's rays (BDPT.__init__'s stack_size; LDS part + paged spill)
     int bdpt_bounded = 1;                          // option "bdpt_bounded": connection rays stop at their target distance
+
+    // PT_Spec tables (tirt_spectral_upload): CIE observer, spectra, Rgb2Spec table, sky configuration -- one buffer, views in spec_host
+    tirt::DevBuf spec_mem; bool spec_set = false; void *spec_view = nullptr;      // spec_view: a heap tirt::SpecView (tirt_spectral.h) with device pointers
 
     // batch trace scratch
     tirt::DevBuf tr_rays, tr_out, tr_prim, tr_counts;
@@ -294,7 +298,8 @@ int exp_wide_from_tree(tirt_ctx *c, const float *compact_host, const int *csize_
 #endif
 int launch_trace_batch(tirt_ctx *c, const float *rays, int nr, int stack_size, int flags, bool shadow,
                        float *out_f, int32_t *out_prim, int32_t *counts);
-int pt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed, int max_depth, int stack_size, int flags);
+struct SpecView;
+int pt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed, int max_depth, int stack_size, int flags, const SpecView *spec = nullptr);   // spec != nullptr: PT_Spec
 int bdpt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed);
 int trace_arrays(tirt_ctx *c, const float *ox, const float *oy, const float *oz, const float *dx, const float *dy, const float *dz,
                  int count, const int *count_ptr, float4 *hit, const int *expect, const float *bound, bool count_rays, int lane = -1);

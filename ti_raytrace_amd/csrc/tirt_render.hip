@@ -30,6 +30,7 @@
 // first and keeps the first-found candidate on `t < hit_t`): the candidate with the larger
 // compact-node index wins.
 #include "tirt_internal.h"
+#include "tirt_spectral.h"
 
 namespace tirt {
 
@@ -47,6 +48,7 @@ struct TraceArgs {
     float4 *hit;                                 // KIND_CLOSEST output, index q: (t, u, v, bits prim)
     // KIND_SHADOW_ACC: contribution of ray q goes to (rr,rg,rb)[sdst[q]] or (fr,fg,fb)[~sdst[q]]
     const int *sprim, *sdst; const float *sdist, *scr, *scg, *scb; float *rr, *rg, *rb, *fr, *fg, *fb;
+    const float *scw; float *rw, *fw;            // PT_Spec: the fourth hero wavelength's contribution / radiance (nullptr for the RGB integrators)
     int *spill; int spill_depth;                 // global stack tail: [entry][global thread]
     // KIND_MIXED: the shadow rays live in their own arrays; indices [count, count + scount) are shadow rays
     const float *sox, *soy, *soz, *sdx, *sdy, *sdz; const int *scount_ptr;
@@ -460,6 +462,7 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
                 float *pg = dst >= 0 ? a.rg + dst : a.fg + ~dst;
                 float *pb = dst >= 0 ? a.rb + dst : a.fb + ~dst;
                 *pr = *pr + a.scr[q]; *pg = *pg + a.scg[q]; *pb = *pb + a.scb[q];
+                if (a.scw) { float *pw = dst >= 0 ? a.rw + dst : a.fw + ~dst; *pw = *pw + a.scw[q]; }
             }
             if (COUNT) {
                 if (MAY_SHADOW && is_sh) { sum_box_s += nbox; sum_leaf_s += nleaf; }
@@ -933,6 +936,7 @@ __global__ __launch_bounds__(TR_BLOCK, TRQ_MIN_WAVES) void k_trace_q(TraceArgs a
                 float *pg = dst >= 0 ? a.rg + dst : a.fg + ~dst;
                 float *pb = dst >= 0 ? a.rb + dst : a.fb + ~dst;
                 *pr = *pr + a.scr[q]; *pg = *pg + a.scg[q]; *pb = *pb + a.scb[q];
+                if (a.scw) { float *pw = dst >= 0 ? a.rw + dst : a.fw + ~dst; *pw = *pw + a.scw[q]; }
             }
             if (COUNT) {
                 if (MAY_SHADOW && is_sh) { sum_box_s += nbox; sum_leaf_s += nleaf; }
@@ -1366,6 +1370,197 @@ __global__ void k_film(PathState ps, TileMap tm, int P, int F, uint32_t frame_be
     px[0] = r; px[1] = g; px[2] = b;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// PT_Spec (integrator/PT_Spec.py:181-279) on the same wavefront: k_generate and the traversal launches are PT_RGB's, the
+// shading kernel and the film update are spectral.  Path state in the same PathSoA arrays: throughput[4] in (tr, tg, tb, brdf_pdf),
+// radiance[4] in (rr, rg, rb, flags) -- PT_Spec carries no brdf_pdf and no perfect_spec flag from one bounce to the next (its
+// `perfect_spec` is reset to 1 at the top of every loop iteration, PT_Spec.py:214, so the emission hit is never MIS-weighted) --;
+// the hero wavelength is not stored: Lambda = 360 + 100 * rand(pixel, frame, TM_DIM_SPEC_LAMBDA) is recomputed where it is needed.
+// Reference behaviours kept: the NEE sample is tinted with the colour of the surface that was HIT (`light_tint` of :213), not with
+// the light's emission; Disney.evaluate_pdf for the continuation is called with (N, V = next_dir, L = -direction) (:251).
+__global__ __launch_bounds__(SH_BLOCK, 4) void k_shade_spec(PathState ps, PathSoA in, PathSoA out, SceneView sc, SpecView sp, TileMap tm, int P,
+                                                   uint32_t frame_begin, uint32_t seed, int bounce, int last_bounce,
+                                                   const int *count_ptr, int count_fixed, unsigned long long *append_ctr,
+                                                   DevCounters *ctr, v3 eye, float *scw, float *fw)
+{
+    __shared__ unsigned s_wcnt[2][SH_BLOCK / 64];
+    __shared__ unsigned long long s_base[2];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const int count = count_ptr ? *count_ptr : count_fixed;
+    const int total = gridDim.x * blockDim.x;
+    const int rounds = (count + total - 1) / total;
+    unsigned long long n_shaded = 0;
+    float *in_tw = in.brdf_pdf, *in_rw = (float *)in.flags, *out_tw = out.brdf_pdf, *out_rw = (float *)out.flags;
+    for (int it = 0; it < rounds; it++) {
+        const int q = it * total + blockIdx.x * blockDim.x + threadIdx.x;
+        bool live = q < count, want_next = false, want_shadow = false;
+        int slot = 0;
+        f4s radiance = f4_set(0.0f), next_thr = radiance, sh_c = radiance;
+        v3 next_o = V(0.0f, 0.0f, 0.0f), next_d = next_o, sh_o = next_o, sh_d = next_o;
+        float sh_dist = 0.0f; int sh_expect = -2;
+        if (live) {
+            const bool first = bounce == 0;
+            slot = first ? q : in.slot[q];
+            const int f = slot / P, k = slot - f * P;
+            const uint32_t pixel = (uint32_t)local_to_pixel(tm, k);
+            const uint32_t frame = frame_begin + (uint32_t)f;
+            const uint32_t dim0 = TM_DIM_BOUNCE0 + TM_DIMS_PER_BOUNCE * (uint32_t)bounce;
+            const float Lambda = HERO_LAMBDA_MIN + HERO_LAMBDA_STEP * tm_rand(seed, pixel, frame, TM_DIM_SPEC_LAMBDA);     // PT_Spec.py:191
+            const v3 origin = first ? eye : V(in.ox[q], in.oy[q], in.oz[q]);
+            const v3 direction = V(in.dx[q], in.dy[q], in.dz[q]);
+            const float4 hrec = ps.hit[q];
+            const float t = hrec.x;
+            f4s throughout = f4_set(1.0f);
+            if (!first) {
+                throughout.v[0] = in.tr[q]; throughout.v[1] = in.tg[q]; throughout.v[2] = in.tb[q]; throughout.v[3] = in_tw[q];
+                radiance.v[0] = in.rr[q]; radiance.v[1] = in.rg[q]; radiance.v[2] = in.rb[q]; radiance.v[3] = in_rw[q];
+            }
+            const f4s light_rad = hero_sample(sp.spd[0], Lambda);                                   // :212
+            if (t < INF_VALUE) {
+                const int prim_id = __float_as_int(hrec.w);
+                int mat_id;
+                const HitAttr h = hit_attributes_rec(sc.shade_rec, origin, direction, prim_id, t, hrec.y, hrec.z, mat_id);
+                const v3 normal = h.nor;
+                const v3 fnormal = normal * signf(dot(-direction, h.gnor));
+                const float *m = sc.material + (size_t)mat_id * MAT_VEC;
+                const v3 mat_color = V(m[2], m[3], m[4]);
+                const int mat_type = (int)m[0];
+                const f4s light_tint = emission_to_rad(sp, mat_color, Lambda);                      // :213 (the HIT material's colour)
+                if (mat_type == MAT_LIGHT) {                                                        // :216-226
+                    const float fCosTheta = dot(direction, normal);
+                    if (fCosTheta < 0.0f) radiance = radiance + ((throughout * light_rad) * light_tint);
+                } else {
+                    n_shaded++;
+                    const f4s reflect_spec = get_spec_power(sp, m, Lambda);
+                    v3 next_dir; float f_or_b = 1.0f, brdf = 1.0f, brdf_pdf = 1.0f;
+                    if (mat_type == MAT_GLASS) {                                                    // :234-238
+                        const int index = (int)(tm_rand(seed, pixel, frame, dim0 + TM_SLOT_HERO) * (float)HERO_N);
+                        const float rnd_lambda = Lambda + (float)index * HERO_LAMBDA_STEP;
+                        next_dir = glass_sample_lambda(direction, normal, rnd_lambda, tm_rand(seed, pixel, frame, dim0 + TM_SLOT_GLASS), f_or_b);
+                    } else {
+                        if (sc.light_count > 0) {                                                   // :240-249, Scene.sample_li
+                            int lidx = (int)(tm_rand(seed, pixel, frame, dim0 + TM_SLOT_LIGHT) * (float)sc.light_count);
+                            if (lidx >= sc.light_count) lidx = sc.light_count - 1;
+                            const int light_prim = sc.light[lidx];
+                            const float ra = tm_rand(seed, pixel, frame, dim0 + TM_SLOT_LA);
+                            const float rb = tm_rand(seed, pixel, frame, dim0 + TM_SLOT_LB);
+                            v3 light_pos, light_normal;
+                            get_prim_random_point_normal(sc, light_prim, ra, rb, light_pos, light_normal);
+                            const float light_area = get_prim_area(sc, light_prim);
+                            float light_choice_pdf = 1.0f / ((float)sc.light_count * light_area);
+                            light_normal = normalized(light_normal);
+                            v3 light_dir = h.pos - light_pos;
+                            const float light_dist = norm(light_dir);
+                            light_dir = light_dir / light_dist;
+                            (void)light_shape_visible(sc, light_prim, light_dir, light_normal, light_dist, light_choice_pdf);      // only its pdf is used by :245
+                            const float NdotL_surface = dot(fnormal, light_dir);
+                            const float NdotL_light = dot(light_normal, light_dir);
+                            if ((NdotL_surface < 0.0f) & (NdotL_light > 0.0f)) {
+                                want_shadow = true;
+                                float e_pdf;
+                                const float e_brdf = disney_evaluate_pdf(m, fnormal, -direction, -light_dir, e_pdf);
+                                const float light_pdf = light_dist * light_dist * light_choice_pdf / NdotL_light;
+                                f4s c = f4_set(0.0f);
+                                int expect = -2;
+                                if (e_pdf > 0.0f) {
+                                    const float w = power_heuristic(light_pdf, e_pdf) / maxf(0.0001f, light_pdf);
+                                    c = light_rad * w;
+                                    c = c * light_tint;
+                                    c = c * throughout;
+                                    c = c * reflect_spec;
+                                    c = c * e_brdf;
+                                    c = c * absf(NdotL_surface);
+                                    expect = prim_id;
+                                }
+                                sh_o = light_pos; sh_d = light_dir; sh_c = c; sh_expect = expect; sh_dist = light_dist;
+                            }
+                        }
+                        next_dir = disney_sample(m, direction, fnormal, tm_rand(seed, pixel, frame, dim0 + TM_SLOT_LOBE),
+                                                 tm_rand(seed, pixel, frame, dim0 + TM_SLOT_R1), tm_rand(seed, pixel, frame, dim0 + TM_SLOT_R2));
+                        f_or_b = 1.0f;
+                        brdf = disney_evaluate_pdf(m, fnormal, next_dir, -direction, brdf_pdf);     // (N, V = next_dir, L = -direction): :251
+                        brdf *= absf(dot(normal, next_dir));
+                    }
+                    const v3 next_origin = offset_ray(h.pos, fnormal * signf(f_or_b));             // :254
+                    if ((brdf_pdf > 0.0f) & (maxf(throughout.v[2], maxf(throughout.v[0], throughout.v[1])) > 0.0f)) {      // :256-258
+                        throughout = throughout * ((reflect_spec * brdf) / brdf_pdf);
+                        want_next = !last_bounce;
+                        next_o = next_origin; next_d = next_dir; next_thr = throughout;
+                    }
+                }
+            } else {                                                                                // :262-270: the analytic sky
+                const float dis = tm_sqrt(direction.x * direction.x + direction.z * direction.z);
+                const float beta = tm_atan2(direction.y, dis);
+                const float gamma = tm_acos(dot(direction, V(sp.sun_dir[0], sp.sun_dir[1], sp.sun_dir[2])));
+                const float theta = clampf(0.5f * PI_SCENE - beta, 0.0f, 0.5f * PI_SCENE);
+                f4s ibl;
+                for (int w = 0; w < HERO_N; w++) ibl.v[w] = sky_radiance(sp, theta, gamma, Lambda + (float)w * HERO_LAMBDA_STEP);
+                radiance = radiance + ((throughout * ibl) * light_rad);
+            }
+        }
+        const int par = it & 1;
+        const unsigned long long nmask = __ballot(want_next), smask = __ballot(want_shadow);
+        if (lane == 0) s_wcnt[par][wid] = (unsigned)__popcll(nmask) | ((unsigned)__popcll(smask) << 16);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned tn = 0, tsd = 0;
+#pragma unroll
+            for (int w = 0; w < SH_BLOCK / 64; w++) { tn += s_wcnt[par][w] & 0xffffu; tsd += s_wcnt[par][w] >> 16; }
+            s_base[par] = (tn | tsd) ? atomicAdd(append_ctr, (unsigned long long)tn | ((unsigned long long)tsd << 32)) : 0ull;
+        }
+        __syncthreads();
+        unsigned pn = 0, psd = 0;
+#pragma unroll
+        for (int w = 0; w < SH_BLOCK / 64; w++) if (w < wid) { pn += s_wcnt[par][w] & 0xffffu; psd += s_wcnt[par][w] >> 16; }
+        const unsigned long long bb = s_base[par];
+        const int qn = (int)(unsigned)(bb & 0xffffffffull) + (int)pn + __popcll(nmask & lt_mask);
+        const int qs = (int)(unsigned)(bb >> 32) + (int)psd + __popcll(smask & lt_mask);
+        if (want_next) {
+            out.ox[qn] = next_o.x; out.oy[qn] = next_o.y; out.oz[qn] = next_o.z;
+            out.dx[qn] = next_d.x; out.dy[qn] = next_d.y; out.dz[qn] = next_d.z;
+            out.tr[qn] = next_thr.v[0]; out.tg[qn] = next_thr.v[1]; out.tb[qn] = next_thr.v[2]; out_tw[qn] = next_thr.v[3];
+            out.rr[qn] = radiance.v[0]; out.rg[qn] = radiance.v[1]; out.rb[qn] = radiance.v[2]; out_rw[qn] = radiance.v[3];
+            out.slot[qn] = slot;
+        } else if (live) {
+            ps.fr[slot] = radiance.v[0]; ps.fg[slot] = radiance.v[1]; ps.fb[slot] = radiance.v[2]; fw[slot] = radiance.v[3];
+        }
+        if (want_shadow) {
+            ps.sox[qs] = sh_o.x; ps.soy[qs] = sh_o.y; ps.soz[qs] = sh_o.z;
+            ps.sdx[qs] = sh_d.x; ps.sdy[qs] = sh_d.y; ps.sdz[qs] = sh_d.z;
+            ps.scr[qs] = sh_c.v[0]; ps.scg[qs] = sh_c.v[1]; ps.scb[qs] = sh_c.v[2]; scw[qs] = sh_c.v[3];
+            ps.sprim[qs] = sh_expect; ps.sdist[qs] = sh_dist;
+            ps.sdst[qs] = want_next ? qn : ~slot;
+        }
+    }
+    __shared__ unsigned long long s_shaded;
+    if (threadIdx.x == 0) s_shaded = 0ull;
+    __syncthreads();
+    n_shaded = wave_sum(n_shaded);
+    if ((threadIdx.x & 63) == 0 && n_shaded) atomicAdd(&s_shaded, n_shaded);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_shaded) atomicAdd(&ctr->shaded, s_shaded);
+}
+
+// integrator/PT_Spec.py:141-158 (AddSplat) + :273-274, frames applied in order
+__global__ void k_film_spec(PathState ps, const float *fw, SpecView sp, TileMap tm, int P, int F, uint32_t frame_begin, uint32_t seed, float *hdr)
+{
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= P) return;
+    const int p = local_to_pixel(tm, k);
+    float *px = hdr + (size_t)p * 3;
+    float r = px[0], g = px[1], b = px[2];
+    for (int f = 0; f < F; f++) {
+        const int s = f * P + k;
+        const uint32_t frame = frame_begin + (uint32_t)f;
+        const float coff = 1.0f / ((float)(int)frame + 1.0f);
+        const float Lambda = HERO_LAMBDA_MIN + HERO_LAMBDA_STEP * tm_rand(seed, (uint32_t)p, frame, TM_DIM_SPEC_LAMBDA);
+        f4s spec; spec.v[0] = ps.fr[s]; spec.v[1] = ps.fg[s]; spec.v[2] = ps.fb[s]; spec.v[3] = fw[s];
+        spec_add_splat(sp, spec, Lambda, coff, r, g, b);
+    }
+    px[0] = r; px[1] = g; px[2] = b;
+}
+
 // Per-batch device counters of a lane: one packed append counter per bounce (low word: paths that go on
 // to bounce b+1, high word: shadow rays of bounce b), each in its own 128-byte line, then the sliced
 // ray-fetch cursors of the max_depth + 1 traversal launches.
@@ -1373,7 +1568,7 @@ constexpr size_t LINE = 128;
 static size_t lane_counter_bytes(int max_depth)
 { return LINE * (size_t)(max_depth + 1) + sizeof(int) * TR_FETCH_STRIDE * TR_SLICES_MAX * (size_t)(max_depth + 1); }
 
-constexpr int PATH_WORDS = 2 * 15 + 4 + 12 + 3;      // two PathSoA + hit record + shadow ray + final radiance
+constexpr int PATH_WORDS = 2 * 15 + 4 + 12 + 3 + 2;  // two PathSoA + hit record + shadow ray + final radiance + the two fourth-wavelength words of PT_Spec
 static size_t path_state_bytes(size_t S) { return sizeof(float) * PATH_WORDS * ((S + 3) & ~(size_t)3); }
 static int ensure_paths(Lane &L, size_t S, int max_depth)
 {
@@ -1394,13 +1589,14 @@ static int ensure_paths(Lane &L, size_t S, int max_depth)
         p.sox = nxt(); p.soy = nxt(); p.soz = nxt(); p.sdx = nxt(); p.sdy = nxt(); p.sdz = nxt();
         p.scr = nxt(); p.scg = nxt(); p.scb = nxt(); p.sprim = (int *)nxt(); p.sdist = nxt(); p.sdst = (int *)nxt();
         p.fr = nxt(); p.fg = nxt(); p.fb = nxt();
+        p.scw = nxt(); p.fw = nxt();
         L.path_capacity = S_user;
     }
     if (L.counters_mem.ensure(lane_counter_bytes(max_depth))) return TIRT_ERR_HIP;
     return 0;
 }
 
-int pt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed, int max_depth, int stack_size, int flags)
+int pt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed, int max_depth, int stack_size, int flags, const SpecView *spec)
 {
     TIRT_REQUIRE(c->built, "tirt_pt_rgb_render: LBVH not built");
     TIRT_REQUIRE(c->cam_set, "tirt_pt_rgb_render: camera not set");
@@ -1509,6 +1705,7 @@ int pt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed,
             a.sox = L.ps.sox; a.soy = L.ps.soy; a.soz = L.ps.soz; a.sdx = L.ps.sdx; a.sdy = L.ps.sdy; a.sdz = L.ps.sdz;
             a.sprim = L.ps.sprim; a.sdst = L.ps.sdst; a.sdist = L.ps.sdist; a.scr = L.ps.scr; a.scg = L.ps.scg; a.scb = L.ps.scb;
             a.rr = in.rr; a.rg = in.rg; a.rb = in.rb; a.fr = L.ps.fr; a.fg = L.ps.fg; a.fb = L.ps.fb;
+            if (spec) { a.scw = L.ps.scw; a.rw = (float *)in.flags; a.fw = L.ps.fw; }
             a.scount_ptr = (b == 0) ? nullptr : cnt_shadow(b - 1);
             fill_tunables(c, a);
             stamp(evc, true);
@@ -1517,6 +1714,11 @@ int pt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed,
             c->launches_trace_closest++;
 
             stamp(evh, true);
+            if (spec)
+                hipLaunchKernelGGL(k_shade_spec, dim3(grid_shade), dim3(SH_BLOCK), 0, st, L.ps, in, out, sv, *spec, tm, P, f0, seed, b,
+                                   (b == max_depth - 1) ? 1 : 0, (b == 0) ? (const int *)nullptr : cnt_path(b), S,
+                                   append_ctr(b), ctr, eye_v, L.ps.scw, L.ps.fw);
+            else
             hipLaunchKernelGGL(k_shade, dim3(grid_shade), dim3(SH_BLOCK), 0, st, L.ps, in, out, sv, tm, P, f0, seed, b,
                                (b == max_depth - 1) ? 1 : 0, (b == 0) ? (const int *)nullptr : cnt_path(b), S,
                                append_ctr(b), ctr, eye_v);
@@ -1530,6 +1732,7 @@ int pt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed,
                 sa.count_ptr = cnt_shadow(b); sa.count_fixed = 0;
                 sa.sprim = L.ps.sprim; sa.sdst = L.ps.sdst; sa.sdist = L.ps.sdist; sa.scr = L.ps.scr; sa.scg = L.ps.scg; sa.scb = L.ps.scb;
                 sa.rr = out.rr; sa.rg = out.rg; sa.rb = out.rb; sa.fr = L.ps.fr; sa.fg = L.ps.fg; sa.fb = L.ps.fb;
+                if (spec) { sa.scw = L.ps.scw; sa.rw = (float *)out.flags; sa.fw = L.ps.fw; }
                 sa.spill = L.spill.as<int>(); sa.spill_depth = spill_depth; sa.ctr = ctr; sa.per_ray_counts = nullptr;
                 sa.fetch = fetch(max_depth);
                 fill_tunables(c, sa);
@@ -1541,7 +1744,8 @@ int pt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed,
         }
         // the running mean is order dependent: this batch's film update follows the previous batch's
         if (c->last_film) TIRT_HIP(hipStreamWaitEvent(st, c->last_film, 0));
-        hipLaunchKernelGGL(k_film, dim3((P + B - 1) / B), dim3(B), 0, st, L.ps, tm, P, F, f0, c->hdr.as<float>());
+        if (spec) hipLaunchKernelGGL(k_film_spec, dim3((P + B - 1) / B), dim3(B), 0, st, L.ps, L.ps.fw, *spec, tm, P, F, f0, seed, c->hdr.as<float>());
+        else hipLaunchKernelGGL(k_film, dim3((P + B - 1) / B), dim3(B), 0, st, L.ps, tm, P, F, f0, c->hdr.as<float>());
         TIRT_HIP(hipEventRecord(L.film_done, st));
         L.film_recorded = true;
         c->last_film = L.film_done;

@@ -7,7 +7,7 @@ import os
 
 import numpy as np
 
-from . import Example, PT_RGB, BDPT_RGB
+from . import Example, PT_RGB, BDPT_RGB, PT_Spec
 from . import SceneData as SCD
 
 ASSETS = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "assets")
@@ -108,6 +108,44 @@ class veach_bdpt(Example.example):
         self.scene.process_normal()
         self.scene.total_area()
         self.frame_camera(0.5)
+
+
+class spectral_box(Example.example):
+    """example/spectral_box.py:12-43: the Cornell box through PT_Spec, its three diffuse materials turned into tabulated
+    reflectance spectra (MAT_SPECTRAL with alebdoTex 0 / 1 / 2 = white / red / green, spectrum/*-spec.csv), D65 emitter."""
+
+    def __init__(self, imgSizeX, imgSizeY, sample_count, device_id=None, **kwargs):
+        Example.example.__init__(self, imgSizeX, imgSizeY, sample_count, device_id)
+        self.scene.add_obj(asset("model", "cornell_box.obj"))
+        self.integrator = PT_Spec.PathTrace(imgSizeX, imgSizeY, self.cam, self.scene, 64, **kwargs)
+        for k in range(3):
+            self.scene.material_cpu[k].type = SCD.MAT_SPECTRAL
+            self.scene.material_cpu[k].alebdoTex = k
+
+    def build_scene(self):
+        Example.example.build_scene(self)
+        self.scene.process_normal()
+        self.scene.total_area()
+        self.frame_camera(0.8)
+
+
+class sky_dome(Example.example):
+    """example/sky_dome.py:11-39: a mirror ball (sphere.obj, Disney metal 1 / rough 0) under the analytic sky, PT_Spec."""
+
+    def __init__(self, imgSizeX, imgSizeY, sample_count, device_id=None, **kwargs):
+        Example.example.__init__(self, imgSizeX, imgSizeY, sample_count, device_id)
+        self.scene.add_obj(asset("model", "sphere.obj"))
+        self.scene.material_cpu[0].setMetal(1.0)
+        self.scene.material_cpu[0].setRough(0.0)
+        self.add_sphere_light()
+        self.integrator = PT_Spec.PathTrace(imgSizeX, imgSizeY, self.cam, self.scene, 64, **kwargs)
+
+    def build_scene(self):
+        Example.example.build_scene(self)
+        self.scene.process_normal()
+        self.scene.total_area()
+        self.scene.env_power = 0.0
+        self.frame_camera(2.0)
 
 
 # ---- synthetic scene -------------------------------------------------------------------------
