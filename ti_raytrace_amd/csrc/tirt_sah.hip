@@ -17,15 +17,20 @@
 // and centroid bounds, (B) 32 bins per axis by centroid (integer-keyed min / max / count atomics in LDS), (C) the cheapest
 // of the 3 x 31 candidate planes by area(L) * n_L + area(R) * n_R, (D) a stable partition of the range into the other
 // index buffer.  All centroids in one bin on every axis (duplicates), or a tree deeper than 64 levels: the range is halved.
-// Three sizes of node, so that the top of the tree is as parallel as its bottom:
-//   mini   (<= SAH_MINI primitives)   16 lanes per node, everything in registers, EXACT sweep over the sorted centroids of
-//                                     each axis instead of bins (every lane prices the split behind its own primitive) k_sah_mini
+// Sizes of node, so that the top of the tree is as parallel as its bottom:
+//   subtree (<= SAH_SUB primitives)   the WHOLE subtree is finished by one wave in one launch at the end (k_sah_subtree): its nodes of more
+//                                     than SAH_MINI primitives with the binned sweep below, smaller ones 16 lanes per node, everything in
+//                                     registers, with an EXACT sweep over the sorted centroids of each axis instead of bins (every lane
+//                                     prices the split behind its own primitive)
 //   small  (<= SAH_LARGE)             one wave per node, 16 nodes per block                     k_sah_level<1>
 //   large  (<= SAH_HUGE)              one 1024-thread block per node                            k_sah_level<16>
 //   huge                              a block per SAH_CHUNK primitives, three launches per level: bins of the chunks merged
 //                                     into the node's with global atomics (k_sah_huge_bin), plane + per-chunk output offsets
 //                                     from the chunks' bin counts (k_sah_huge_eval), partition + the bounds of huge children
 //                                     (k_sah_huge_part)
+// Where the time goes at 100 001 primitives (rocprofv3 timeline, profiles/r03_build_timeline.txt): six levels with huge nodes 0.47 ms
+// (k_sah_huge_eval alone 24 us per level: one wave per node), k_sah_level<16> 0.27 ms, k_sah_level<1> 0.31 ms over six levels (LDS-atomic
+// binning of up to 512 primitives by one wave), k_sah_subtree 0.20 ms (a wave's serial chain through six levels), two counter reads 0.19 ms.
 // The next level's task lists are appended with one atomic per block and list (same-address atomics: ~11 ns each).
 #include "tirt_internal.h"
 #include "tirt_device.h"
@@ -35,6 +40,7 @@ namespace tirt {
 constexpr int SAH_BINS = 32;
 constexpr int SAH_BIN_WORDS = 3 * SAH_BINS * 7;      // per node: [axis][bin][min x y z, max x y z, count]
 constexpr int SAH_MINI = 16;              // at most this many primitives: a quarter of a wave works on the node, in registers, with an exact sweep
+constexpr int SAH_SUB = 64;               // at most this many primitives: the whole subtree is finished by ONE wave in one launch (k_sah_subtree)
 constexpr int SAH_LARGE = 512;            // more primitives than this: a whole block works on the node
 constexpr int SAH_HUGE = 8192;            // more than this: a block per chunk
 constexpr int SAH_CHUNK = 1024;
@@ -193,8 +199,8 @@ template <int WPT>
 __global__ __launch_bounds__(SAH_BLOCK) void k_sah_level(const float4 *__restrict__ sbox, const int *__restrict__ sorted_prims,
                                                          const int *__restrict__ idx_in, int *__restrict__ idx_out,
                                                          const SahTask *__restrict__ tasks, const int *__restrict__ task_count,
-                                                         SahTask *next_small, SahTask *next_large, SahTask *next_mini, int *next_count /* [0] small, [1] large, [4] mini */,
-                                                         float *compact, int *csize, int *parent, int *prim_slot, int halve)
+                                                         SahTask *next_small, SahTask *next_large, SahTask *sub_list, int *next_count /* [0] small, [1] large */, int *sub_count,
+                                                         float *compact, int *csize, int *parent, int *prim_slot, int halve, int level)
 {
     constexpr int TPB = 16 / WPT;            // tasks per block
     constexpr int G = 64 * WPT;              // threads per task
@@ -305,121 +311,203 @@ __global__ __launch_bounds__(SAH_BLOCK) void k_sah_level(const float4 *__restric
     // ---- next level's lists: one atomic per block and list --------------------------------------------
     if (threadIdx.x == 0) {
         int ns = 0, nlg = 0, nm = 0;
-        for (int s = 0; s < TPB; s++) for (int k = 0; k < 2; k++) { const int c = s_child[s][k].count; if (c > SAH_LARGE) nlg++; else if (c > SAH_MINI) ns++; else if (c >= 2) nm++; }
+        for (int s = 0; s < TPB; s++) for (int k = 0; k < 2; k++) { const int c = s_child[s][k].count; if (c > SAH_LARGE) nlg++; else if (c > SAH_SUB) ns++; else if (c >= 2) nm++; }
         s_base[0] = ns ? atomicAdd(&next_count[0], ns) : 0;
         s_base[1] = nlg ? atomicAdd(&next_count[1], nlg) : 0;
-        s_base[2] = nm ? atomicAdd(&next_count[4], nm) : 0;
+        s_base[2] = nm ? atomicAdd(sub_count, nm) : 0;
         for (int s = 0; s < TPB; s++) for (int k = 0; k < 2; k++) {
             const int c = s_child[s][k].count;
             if (c > SAH_LARGE) next_large[s_base[1]++] = s_child[s][k];
-            else if (c > SAH_MINI) next_small[s_base[0]++] = s_child[s][k];
-            else if (c >= 2) next_mini[s_base[2]++] = s_child[s][k];
+            else if (c > SAH_SUB) next_small[s_base[0]++] = s_child[s][k];
+            else if (c >= 2) { SahTask t = s_child[s][k]; t.pad = level + 1; sub_list[s_base[2]++] = t; }      // its range sits in the buffer level + 1 reads
         }
     }
 }
 
-// Mini nodes: 16 lanes per node (4 nodes per wave, 16 per 256-thread block), one primitive per lane, no LDS, no barriers until the
-// children are appended.  Every lane prices the split "everything up to my centroid goes left" on each axis (ties by position: a
-// total order, so duplicates still split) from the 16 boxes passed around by shuffles; the cheapest wins.
-__global__ __launch_bounds__(256) void k_sah_mini(const float4 *__restrict__ sbox, const int *__restrict__ sorted_prims,
-                                                  const int *__restrict__ idx_in, int *__restrict__ idx_out,
-                                                  const SahTask *__restrict__ tasks, const int *__restrict__ task_count,
-                                                  SahTask *next_mini, int *next_count /* [4] mini */,
-                                                  float *compact, int *csize, int *parent, int *prim_slot, int halve)
+// ---- whole subtrees of at most SAH_SUB primitives: one wave each, one launch -------------------------------------------------
+// The bottom of the tree holds most of its nodes and, level by level, most of the launches (round 2: ten levels of k_sah_level<1> +
+// k_sah_mini below 512 primitives, 0.7 of the 1.3 ms of a 100k-primitive build, nearly all of it launch latency).  A task of this list
+// is finished where it is picked up: the wave keeps the subtree's open nodes of one level in LDS, splits them -- nodes of more
+// than SAH_MINI primitives one after the other with the binned sweep of k_sah_level<1> (all 64 lanes on one node), smaller ones
+// four at a time with the exact sweep of k_sah_mini (16 lanes each) -- and goes on with their children until none is left.  Same
+// per-node decisions as the level-by-level kernels (same bins, same tie rules, same forced halving from level 64 on), hence the
+// same tree; a node's range lives in the index buffer of its level's parity, as there.
+constexpr int SAH_SUB_WAVES = 4;              // waves (tasks) per block
+constexpr int SAH_SUB_LIST = SAH_SUB / 2;     // open nodes of one level of a subtree: each holds two primitives or more
+__global__ __launch_bounds__(64 * SAH_SUB_WAVES) void k_sah_subtree(const float4 *__restrict__ sbox, const int *__restrict__ sorted_prims, int *idx_a, int *idx_b,
+                                                                   const SahTask *__restrict__ tasks, const int *__restrict__ task_count,
+                                                                   float *compact, int *csize, int *parent, int *prim_slot)
 {
-    __shared__ SahTask s_child[16][2];
-    __shared__ int s_base;
-    const int ntask = *task_count;
-    if ((int)blockIdx.x * 16 >= ntask) return;
-    const int lane = threadIdx.x & 63, gl = lane & 15, gbase = lane & 48;           // lane within its group, first lane of the group
-    const int slot = threadIdx.x >> 4;
-    const int ti = blockIdx.x * 16 + slot;
-    SahTask t = {0, 0, 0, 0};
-    if (ti < ntask) t = tasks[ti];
-    const int start = t.start, count = t.count, pre = t.pre;
-    const bool active = gl < count;
-    int p = 0; float4 a = make_float4(3.0e38f, 3.0e38f, 3.0e38f, 0.0f), b = make_float4(-3.0e38f, -3.0e38f, -3.0e38f, 0.0f);
-    if (active) { p = idx_in[start + gl]; a = sbox[2 * (size_t)p]; b = sbox[2 * (size_t)p + 1]; }
-    const float c0 = 0.5f * (a.x + b.x), c1 = 0.5f * (a.y + b.y), c2 = 0.5f * (a.z + b.z);
-    // candidate of this lane on each axis: left = { j : (c_j, j) <= (c_i, i) }
-    float lmn[3][3], lmx[3][3], rmn[3][3], rmx[3][3]; int nl3[3] = {0, 0, 0};
+    __shared__ unsigned s_bin[SAH_SUB_WAVES][3][SAH_BINS][7];
+    __shared__ SahTask s_list[SAH_SUB_WAVES][2][SAH_SUB_LIST];
+    __shared__ int s_n[SAH_SUB_WAVES][2];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int ti = blockIdx.x * SAH_SUB_WAVES + wave;
+    if (ti >= *task_count) return;                               // wave-uniform; no block-wide barrier below
+    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#define SAH_WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+    if (lane == 0) { s_list[wave][0][0] = tasks[ti]; s_n[wave][0] = 1; s_n[wave][1] = 0; }
+    SAH_WSYNC();
+    int level = tasks[ti].pad;                                   // the level that READS this range: idx[level & 1]
+    for (int cur = 0;; cur ^= 1, level++) {
+        const int n_open = s_n[wave][cur];
+        if (n_open == 0) break;
+        const int *idx_in = (level & 1) ? idx_b : idx_a;
+        int *idx_out = (level & 1) ? idx_a : idx_b;
+        const bool halve = level >= SAH_FORCE_HALVING_AFTER;
+        if (lane == 0) s_n[wave][cur ^ 1] = 0;
+        SAH_WSYNC();
+        // ---- nodes of more than SAH_MINI primitives: the whole wave on one node (k_sah_level<1>'s steps A-D) ----
+        for (int k = 0; k < n_open; k++) {
+            const SahTask t = s_list[wave][cur][k];
+            if (t.count <= SAH_MINI) continue;                   // wave-uniform
+            const int start = t.start, count = t.count, pre = t.pre;
+            float r[12]; sah_bounds_init(r);
+            int p = 0; float4 a = make_float4(0, 0, 0, 0), b = a;
+            const bool active = lane < count;                    // count <= 64: one primitive per lane
+            if (active) { p = idx_in[start + lane]; a = sbox[2 * (size_t)p]; b = sbox[2 * (size_t)p + 1]; sah_bounds_add(r, a, b); }
+            sah_wave_bounds(r);
+            float scale[3];
+            const float cmin[3] = {r[6], r[7], r[8]};
 #pragma unroll
-    for (int ax = 0; ax < 3; ax++)
-#pragma unroll
-        for (int k = 0; k < 3; k++) { lmn[ax][k] = 3.0e38f; lmx[ax][k] = -3.0e38f; rmn[ax][k] = 3.0e38f; rmx[ax][k] = -3.0e38f; }
-    float box[6] = {3.0e38f, 3.0e38f, 3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
-    for (int j = 0; j < SAH_MINI; j++) {
-        if (j >= count) break;                                       // group-uniform (count is), but other groups of the wave may go on: shuffles below are executed by all
-        const int src = gbase + j;
-        const float ax_ = __shfl(a.x, src, 64), ay_ = __shfl(a.y, src, 64), az_ = __shfl(a.z, src, 64);
-        const float bx_ = __shfl(b.x, src, 64), by_ = __shfl(b.y, src, 64), bz_ = __shfl(b.z, src, 64);
-        const float cj[3] = {0.5f * (ax_ + bx_), 0.5f * (ay_ + by_), 0.5f * (az_ + bz_)};
-        const float ci[3] = {c0, c1, c2};
-        const float mn[3] = {ax_, ay_, az_}, mx[3] = {bx_, by_, bz_};
-#pragma unroll
-        for (int k = 0; k < 3; k++) { box[k] = fminf(box[k], mn[k]); box[3 + k] = fmaxf(box[3 + k], mx[k]); }
-#pragma unroll
-        for (int ax = 0; ax < 3; ax++) {
-            const bool left = (cj[ax] < ci[ax]) || (cj[ax] == ci[ax] && j <= gl);
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-                if (left) { lmn[ax][k] = fminf(lmn[ax][k], mn[k]); lmx[ax][k] = fmaxf(lmx[ax][k], mx[k]); }
-                else { rmn[ax][k] = fminf(rmn[ax][k], mn[k]); rmx[ax][k] = fmaxf(rmx[ax][k], mx[k]); }
+            for (int x = 0; x < 3; x++) { const float ext = r[9 + x] - r[6 + x]; scale[x] = ext > 0.0f ? (float)SAH_BINS / ext : 0.0f; }
+            for (int q = lane; q < 3 * SAH_BINS; q += 64) {
+                unsigned *bb = &s_bin[wave][0][0][0] + q * 7;
+                bb[0] = bb[1] = bb[2] = 0xffffffffu; bb[3] = bb[4] = bb[5] = 0u; bb[6] = 0u;
             }
-            nl3[ax] += left ? 1 : 0;
+            SAH_WSYNC();
+            if (!halve && active) sah_bin_add(s_bin[wave], a, b, cmin, scale);
+            SAH_WSYNC();
+            int axis, plane, nl;
+            sah_pick(s_bin[wave], count, halve, lane, axis, plane, nl);
+            const int nr = count - nl;
+            bool left = false;
+            if (active) {
+                if (axis < 0) left = lane < nl;
+                else {
+                    const float sel_min = axis == 0 ? r[6] : (axis == 1 ? r[7] : r[8]), sel_scale = axis == 0 ? scale[0] : (axis == 1 ? scale[1] : scale[2]);
+                    const float c = axis == 0 ? 0.5f * (a.x + b.x) : (axis == 1 ? 0.5f * (a.y + b.y) : 0.5f * (a.z + b.z));
+                    left = sah_bin(c, sel_min, sel_scale) <= plane;
+                }
+            }
+            const unsigned long long ml = __ballot(active && left), mr = __ballot(active && !left);
+            if (active) {
+                const int dst = left ? start + __popcll(ml & lt_mask) : start + nl + __popcll(mr & lt_mask);
+                idx_out[dst] = p;
+                if ((left && nl == 1) || (!left && nr == 1)) sah_write_leaf(compact, csize, prim_slot, left ? pre + 1 : pre + 2 * nl, dst, sorted_prims[p], a, b);
+            }
+            if (lane == 0) {
+                sah_write_inner(compact, csize, parent, pre, pre + 2 * nl, count, r);
+                int at = s_n[wave][cur ^ 1];
+                if (nl >= 2) s_list[wave][cur ^ 1][at++] = SahTask{start, nl, pre + 1, 0};
+                if (nr >= 2) s_list[wave][cur ^ 1][at++] = SahTask{start + nl, nr, pre + 2 * nl, 0};
+                s_n[wave][cur ^ 1] = at;
+            }
+            SAH_WSYNC();
         }
-    }
-    float best = 3.0e38f; int best_id = 0x7fffffff;
-    if (active && !halve) {
+        // ---- nodes of at most SAH_MINI primitives: four at a time, 16 lanes each (k_sah_mini's exact sweep) ----
+        const int gl = lane & 15, gbase = lane & 48, grp = lane >> 4;
+        // the mini nodes of this level, in list order: group g of a round takes the g-th remaining one
+        int taken = 0;
+        for (;;) {
+            // find the next four mini tasks at or after position `taken` (wave-uniform scan of at most SAH_SUB_LIST entries)
+            int pos[4] = {-1, -1, -1, -1}; int found = 0, scan = taken;
+            for (; scan < n_open && found < 4; scan++) if (s_list[wave][cur][scan].count <= SAH_MINI) pos[found++] = scan;
+            if (found == 0) break;
+            taken = scan;
+            const int my = grp == 0 ? pos[0] : (grp == 1 ? pos[1] : (grp == 2 ? pos[2] : pos[3]));
+            SahTask t = {0, 0, 0, 0};
+            if (my >= 0) t = s_list[wave][cur][my];
+            const int start = t.start, count = t.count, pre = t.pre;
+            const bool active = gl < count;
+            int p = 0; float4 a = make_float4(3.0e38f, 3.0e38f, 3.0e38f, 0.0f), b = make_float4(-3.0e38f, -3.0e38f, -3.0e38f, 0.0f);
+            if (active) { p = idx_in[start + gl]; a = sbox[2 * (size_t)p]; b = sbox[2 * (size_t)p + 1]; }
+            const float c0 = 0.5f * (a.x + b.x), c1 = 0.5f * (a.y + b.y), c2 = 0.5f * (a.z + b.z);
+            float lmn[3][3], lmx[3][3], rmn[3][3], rmx[3][3]; int nl3[3] = {0, 0, 0};
 #pragma unroll
-        for (int ax = 0; ax < 3; ax++) {
-            const int nl_ = nl3[ax], nr_ = count - nl_;
-            if (nr_ <= 0) continue;
-            const float cost = sah_half_area(lmx[ax][0] - lmn[ax][0], lmx[ax][1] - lmn[ax][1], lmx[ax][2] - lmn[ax][2]) * (float)nl_ +
-                               sah_half_area(rmx[ax][0] - rmn[ax][0], rmx[ax][1] - rmn[ax][1], rmx[ax][2] - rmn[ax][2]) * (float)nr_;
-            const int id = ax * SAH_MINI + gl;
-            if (cost < best || (cost == best && id < best_id)) { best = cost; best_id = id; }
-        }
-    }
+            for (int ax = 0; ax < 3; ax++)
 #pragma unroll
-    for (int o = 8; o >= 1; o >>= 1) {
-        const float ob = __shfl_xor(best, o, 64); const int oi = __shfl_xor(best_id, o, 64);
-        if (ob < best || (ob == best && oi < best_id)) { best = ob; best_id = oi; }
-    }
-    // the winner's key, from its lane; left = keys up to it
-    bool left = false;
-    if (best_id != 0x7fffffff) {
-        const int ax = best_id / SAH_MINI, wl = best_id - ax * SAH_MINI;
-        const float mine = ax == 0 ? c0 : (ax == 1 ? c1 : c2);
-        const float key = __shfl(mine, gbase + wl, 64);
-        left = active && ((mine < key) || (mine == key && gl <= wl));
-    } else left = active && gl < count / 2;                                          // forced halving (level >= 64), or no task
-    if (best_id != 0x7fffffff) { /* the shuffle above must be executed by the whole group: it is (best_id is group-uniform) */ }
-    const unsigned long long gm = 0xffffull << gbase;
-    const unsigned long long ml = __ballot(left) & gm, mr = __ballot(active && !left) & gm;
-    const unsigned long long below = (1ull << lane) - 1ull;
-    const int nl = __popcll(ml), nr = __popcll(mr);
-    if (active) {
-        const int dst = left ? start + __popcll(ml & below) : start + nl + __popcll(mr & below);
-        idx_out[dst] = p;
-        if ((left && nl == 1) || (!left && nr == 1)) sah_write_leaf(compact, csize, prim_slot, left ? pre + 1 : pre + 2 * nl, dst, sorted_prims[p], a, b);
-    }
-    if (gl == 0) {
-        s_child[slot][0].count = 0; s_child[slot][1].count = 0;
-        if (count >= 2) {
-            sah_write_inner(compact, csize, parent, pre, pre + 2 * nl, count, box);
-            if (nl >= 2) s_child[slot][0] = SahTask{start, nl, pre + 1, 0};
-            if (nr >= 2) s_child[slot][1] = SahTask{start + nl, nr, pre + 2 * nl, 0};
+                for (int q = 0; q < 3; q++) { lmn[ax][q] = 3.0e38f; lmx[ax][q] = -3.0e38f; rmn[ax][q] = 3.0e38f; rmx[ax][q] = -3.0e38f; }
+            float box[6] = {3.0e38f, 3.0e38f, 3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
+            int cmax = count;                                    // the longest of the four groups sets the trip count: shuffles are executed by all
+#pragma unroll
+            for (int o = 32; o >= 16; o >>= 1) { const int v = __shfl_xor(cmax, o, 64); cmax = v > cmax ? v : cmax; }
+            for (int j = 0; j < cmax; j++) {
+                const int src = gbase + j;
+                const float ax_ = __shfl(a.x, src, 64), ay_ = __shfl(a.y, src, 64), az_ = __shfl(a.z, src, 64);
+                const float bx_ = __shfl(b.x, src, 64), by_ = __shfl(b.y, src, 64), bz_ = __shfl(b.z, src, 64);
+                if (j >= count) continue;                        // group-uniform
+                const float cj[3] = {0.5f * (ax_ + bx_), 0.5f * (ay_ + by_), 0.5f * (az_ + bz_)};
+                const float ci[3] = {c0, c1, c2};
+                const float mn[3] = {ax_, ay_, az_}, mx[3] = {bx_, by_, bz_};
+#pragma unroll
+                for (int q = 0; q < 3; q++) { box[q] = fminf(box[q], mn[q]); box[3 + q] = fmaxf(box[3 + q], mx[q]); }
+#pragma unroll
+                for (int ax = 0; ax < 3; ax++) {
+                    const bool lft = (cj[ax] < ci[ax]) || (cj[ax] == ci[ax] && j <= gl);
+#pragma unroll
+                    for (int q = 0; q < 3; q++) {
+                        if (lft) { lmn[ax][q] = fminf(lmn[ax][q], mn[q]); lmx[ax][q] = fmaxf(lmx[ax][q], mx[q]); }
+                        else { rmn[ax][q] = fminf(rmn[ax][q], mn[q]); rmx[ax][q] = fmaxf(rmx[ax][q], mx[q]); }
+                    }
+                    nl3[ax] += lft ? 1 : 0;
+                }
+            }
+            float best = 3.0e38f; int best_id = 0x7fffffff;
+            if (active && !halve) {
+#pragma unroll
+                for (int ax = 0; ax < 3; ax++) {
+                    const int nl_ = nl3[ax], nr_ = count - nl_;
+                    if (nr_ <= 0) continue;
+                    const float cost = sah_half_area(lmx[ax][0] - lmn[ax][0], lmx[ax][1] - lmn[ax][1], lmx[ax][2] - lmn[ax][2]) * (float)nl_ +
+                                       sah_half_area(rmx[ax][0] - rmn[ax][0], rmx[ax][1] - rmn[ax][1], rmx[ax][2] - rmn[ax][2]) * (float)nr_;
+                    const int id = ax * SAH_MINI + gl;
+                    if (cost < best || (cost == best && id < best_id)) { best = cost; best_id = id; }
+                }
+            }
+#pragma unroll
+            for (int o = 8; o >= 1; o >>= 1) {
+                const float ob = __shfl_xor(best, o, 64); const int oi = __shfl_xor(best_id, o, 64);
+                if (ob < best || (ob == best && oi < best_id)) { best = ob; best_id = oi; }
+            }
+            // the winner's key, from its lane (every lane executes the shuffle; groups without a winner read lane gbase)
+            const int wax = best_id != 0x7fffffff ? best_id / SAH_MINI : 0, wl = best_id != 0x7fffffff ? best_id - wax * SAH_MINI : 0;
+            const float mine = wax == 0 ? c0 : (wax == 1 ? c1 : c2);
+            const float key = __shfl(mine, gbase + wl, 64);
+            bool left;
+            if (best_id != 0x7fffffff) left = active && ((mine < key) || (mine == key && gl <= wl));
+            else left = active && gl < count / 2;                // forced halving, or no task in this group
+            const unsigned long long gm = 0xffffull << gbase;
+            const unsigned long long ml = __ballot(left) & gm, mr = __ballot(active && !left) & gm;
+            const unsigned long long below = (1ull << lane) - 1ull;
+            const int nl = __popcll(ml), nr = __popcll(mr);
+            if (active) {
+                const int dst = left ? start + __popcll(ml & below) : start + nl + __popcll(mr & below);
+                idx_out[dst] = p;
+                if ((left && nl == 1) || (!left && nr == 1)) sah_write_leaf(compact, csize, prim_slot, left ? pre + 1 : pre + 2 * nl, dst, sorted_prims[p], a, b);
+            }
+            if (gl == 0 && count >= 2) sah_write_inner(compact, csize, parent, pre, pre + 2 * nl, count, box);
+            // children: the four group leaders append in group order (one lane does it, reading the others' results by shuffle)
+            const int g_nl[4] = {__shfl(nl, 0, 64), __shfl(nl, 16, 64), __shfl(nl, 32, 64), __shfl(nl, 48, 64)};
+            const int g_cnt[4] = {__shfl(count, 0, 64), __shfl(count, 16, 64), __shfl(count, 32, 64), __shfl(count, 48, 64)};
+            const int g_start[4] = {__shfl(start, 0, 64), __shfl(start, 16, 64), __shfl(start, 32, 64), __shfl(start, 48, 64)};
+            const int g_pre[4] = {__shfl(pre, 0, 64), __shfl(pre, 16, 64), __shfl(pre, 32, 64), __shfl(pre, 48, 64)};
+            if (lane == 0) {
+                int at = s_n[wave][cur ^ 1];
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    if (g_cnt[g] < 2) continue;
+                    const int l_ = g_nl[g], r_ = g_cnt[g] - l_;
+                    if (l_ >= 2) s_list[wave][cur ^ 1][at++] = SahTask{g_start[g], l_, g_pre[g] + 1, 0};
+                    if (r_ >= 2) s_list[wave][cur ^ 1][at++] = SahTask{g_start[g] + l_, r_, g_pre[g] + 2 * l_, 0};
+                }
+                s_n[wave][cur ^ 1] = at;
+            }
+            SAH_WSYNC();
         }
+        SAH_WSYNC();
     }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int nm = 0;
-        for (int s = 0; s < 16; s++) for (int k = 0; k < 2; k++) if (s_child[s][k].count >= 2) nm++;
-        s_base = nm ? atomicAdd(&next_count[4], nm) : 0;
-        int at = s_base;
-        for (int s = 0; s < 16; s++) for (int k = 0; k < 2; k++) if (s_child[s][k].count >= 2) next_mini[at++] = s_child[s][k];
-    }
+#undef SAH_WSYNC
 }
 
 // ---- huge nodes: level counters lc[] = (small, large, huge, chunks) ---------------------------------------------------
@@ -461,8 +549,8 @@ __global__ __launch_bounds__(SAH_CHUNK) void k_sah_huge_bin(const float4 *__rest
 // plane of a huge node, output offsets of its chunks, its row, its children
 __global__ __launch_bounds__(64) void k_sah_huge_eval(SahHuge *huge, const int *__restrict__ lc, const unsigned *__restrict__ hbins, const int *__restrict__ chunk_cnt,
                                                        int *chunk_base, SahHuge *next_huge, unsigned *next_hbins, int *next_chunk_task,
-                                                       SahTask *next_small, SahTask *next_large, SahTask *next_mini, int *nc /* next level's counters */,
-                                                       float *compact, int *csize, int *parent, int halve)
+                                                       SahTask *next_small, SahTask *next_large, SahTask *sub_list, int *nc /* next level's counters */, int *sub_count,
+                                                       float *compact, int *csize, int *parent, int halve, int level)
 {
     __shared__ unsigned s_bin[3][SAH_BINS][7];
     const int slot = blockIdx.x, lane = threadIdx.x;
@@ -504,8 +592,8 @@ __global__ __launch_bounds__(64) void k_sah_huge_eval(SahHuge *huge, const int *
                 next_huge[s] = n;
                 child_slot[side] = s; child_first[side] = fc;
             } else if (t.count > SAH_LARGE) next_large[atomicAdd(&nc[1], 1)] = t;
-            else if (t.count > SAH_MINI) next_small[atomicAdd(&nc[0], 1)] = t;
-            else if (t.count >= 2) next_mini[atomicAdd(&nc[4], 1)] = t;
+            else if (t.count > SAH_SUB) next_small[atomicAdd(&nc[0], 1)] = t;
+            else if (t.count >= 2) { SahTask u = t; u.pad = level + 1; sub_list[atomicAdd(sub_count, 1)] = u; }
         }
         h->axis = axis; h->plane = plane; h->nl = nl; h->child[0] = child_slot[0]; h->child[1] = child_slot[1];
     }
@@ -581,10 +669,10 @@ int sah_build(tirt_ctx *c, const int *sorted_prims)
 {
     const int n = c->n, N = 2 * n - 1;
     hipStream_t st = c->stream;
-    const size_t small_cap = (size_t)n / SAH_MINI + 2, large_cap = (size_t)n / SAH_LARGE + 2, huge_cap = (size_t)n / SAH_HUGE + 2, mini_cap = (size_t)n / 2 + 2;
+    const size_t small_cap = (size_t)n / SAH_SUB + 2, large_cap = (size_t)n / SAH_LARGE + 2, huge_cap = (size_t)n / SAH_HUGE + 2, sub_cap = (size_t)n / 2 + 2;
     const size_t chunk_cap = (size_t)n / SAH_CHUNK + huge_cap + 2;
-    // scratch: two task lists of each size, huge node records + their bins, chunk tables
-    const size_t task_bytes = sizeof(SahTask) * 2 * (small_cap + large_cap + mini_cap);
+    // scratch: two task lists of each size, the list of whole subtrees, huge node records + their bins, chunk tables
+    const size_t task_bytes = sizeof(SahTask) * (2 * (small_cap + large_cap) + sub_cap);
     const size_t huge_bytes = sizeof(SahHuge) * 2 * huge_cap + sizeof(unsigned) * 2 * huge_cap * SAH_BIN_WORDS;
     const size_t chunk_bytes = sizeof(int) * chunk_cap * (2 /* task, both levels */ + 3 * SAH_BINS + 2);
     if (c->sah_compact.ensure(sizeof(float) * (size_t)N * CPN_VEC) || c->sah_csize.ensure(sizeof(int) * (size_t)N) || c->sah_parent.ensure(sizeof(int) * (size_t)N) ||
@@ -595,12 +683,13 @@ int sah_build(tirt_ctx *c, const int *sorted_prims)
     int *idx[2] = {c->sah_idx.as<int>(), c->sah_idx.as<int>() + n};
     SahTask *small[2] = {c->sah_tasks.as<SahTask>(), c->sah_tasks.as<SahTask>() + small_cap};
     SahTask *large[2] = {small[1] + small_cap, small[1] + small_cap + large_cap};
-    SahTask *mini[2] = {large[1] + large_cap, large[1] + large_cap + mini_cap};
-    SahHuge *huge[2] = {(SahHuge *)(mini[1] + mini_cap), (SahHuge *)(mini[1] + mini_cap) + huge_cap};
+    SahTask *sub = large[1] + large_cap;
+    SahHuge *huge[2] = {(SahHuge *)(sub + sub_cap), (SahHuge *)(sub + sub_cap) + huge_cap};
     unsigned *hbins[2] = {(unsigned *)(huge[1] + huge_cap), (unsigned *)(huge[1] + huge_cap) + huge_cap * SAH_BIN_WORDS};
     int *chunk_task[2] = {(int *)(hbins[1] + huge_cap * SAH_BIN_WORDS), (int *)(hbins[1] + huge_cap * SAH_BIN_WORDS) + chunk_cap};
     int *chunk_cnt = chunk_task[1] + chunk_cap, *chunk_base = chunk_cnt + chunk_cap * 3 * SAH_BINS;
-    int *counts = c->sah_counts.as<int>();                 // counts[SAH_CNT * level + (0 small | 1 large | 2 huge | 3 chunks | 4 mini)]
+    int *counts = c->sah_counts.as<int>();                 // counts[SAH_CNT * level + (0 small | 1 large | 2 huge | 3 chunks)]
+    int *sub_count = counts + SAH_CNT * (SAH_MAX_LEVELS + 1);      // (a row of its own behind the levels')
     float *compact = c->sah_compact.as<float>(); int *csize = c->sah_csize.as<int>(), *parent = c->sah_parent.as<int>(), *prim_slot = c->prim_slot.as<int>();
 
     TIRT_HIP(hipMemsetAsync(counts, 0, sizeof(int) * SAH_CNT * (SAH_MAX_LEVELS + 2), st));
@@ -609,53 +698,63 @@ int sah_build(tirt_ctx *c, const int *sorted_prims)
     for (int k = 0; k < 12; k++) root_huge.bounds[k] = ((k < 3) || (k >= 6 && k < 9)) ? 0xffffffffu : 0u;
     TIRT_HIP(hipMemcpyAsync(huge[0], &root_huge, sizeof(root_huge), hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_sah_prim_boxes, dim3((n + 255) / 256), dim3(256), 0, st, sv, sorted_prims, sbox, idx[0], huge[0], hbins[0]);
-    const SahTask root = {0, n, 0, 0};
+    const SahTask root = {0, n, 0, 0};                     // (pad = the level that reads it: 0)
     int first_counts[SAH_CNT] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int first_sub = 0;
     if (n > SAH_HUGE) {
         first_counts[2] = 1; first_counts[3] = (n + SAH_CHUNK - 1) / SAH_CHUNK;
         TIRT_HIP(hipMemsetAsync(chunk_task[0], 0, sizeof(int) * (size_t)first_counts[3], st));       // every chunk belongs to slot 0
     } else if (n > SAH_LARGE) { first_counts[1] = 1; TIRT_HIP(hipMemcpyAsync(large[0], &root, sizeof(root), hipMemcpyHostToDevice, st)); }
-    else if (n > SAH_MINI) { first_counts[0] = 1; TIRT_HIP(hipMemcpyAsync(small[0], &root, sizeof(root), hipMemcpyHostToDevice, st)); }
-    else { first_counts[4] = 1; TIRT_HIP(hipMemcpyAsync(mini[0], &root, sizeof(root), hipMemcpyHostToDevice, st)); }
+    else if (n > SAH_SUB) { first_counts[0] = 1; TIRT_HIP(hipMemcpyAsync(small[0], &root, sizeof(root), hipMemcpyHostToDevice, st)); }
+    else if (n >= 2) { first_sub = 1; TIRT_HIP(hipMemcpyAsync(sub, &root, sizeof(root), hipMemcpyHostToDevice, st)); }
     TIRT_HIP(hipMemcpyAsync(counts, first_counts, sizeof(first_counts), hipMemcpyHostToDevice, st));
+    if (first_sub) TIRT_HIP(hipMemcpyAsync(sub_count, &first_sub, sizeof(int), hipMemcpyHostToDevice, st));
 
-    bool any_huge = n > SAH_HUGE, any_large = n > SAH_LARGE, any_small = n > SAH_MINI;
-    int level = 0, host_counts[SAH_CNT * (SAH_MAX_LEVELS + 2)];
-    for (;;) {
-        // a blocking read of the counters ends a round of levels: the first round is as long as a balanced tree is deep plus a
-        // few levels (an idle level costs two empty launches, a read ~50 us), later ones 8 levels
+    // Levels are launched in rounds, a blocking read of the counters ends a round (~50 us; an idle level costs its empty launches).
+    // Round 1: as many levels as a balanced tree needs to get every node below SAH_HUGE, plus two -- after it the three launches per
+    // level of the huge nodes are usually over --; round 2: down to SAH_SUB, plus three; further rounds of 8 levels for what is left
+    // of an unbalanced tree.  What falls below SAH_SUB on the way is not split level by level: it waits in the `sub` list for the
+    // one launch of k_sah_subtree at the end.
+    bool any_huge = n > SAH_HUGE, any_large = n > SAH_LARGE, any_small = n > SAH_SUB;
+    int level = 0, host_counts[SAH_CNT * (SAH_MAX_LEVELS + 2)], round_no = 0;
+    auto levels_to = [&](long target) { int k = 0; for (long m = n; m > target; m = (m + 1) / 2) k++; return k; };
+    while (any_huge || any_large || any_small) {
         int round = 8;
-        if (level == 0) { round = 10; for (long k = 1; k < n; k *= 2) round++; }
+        if (round_no == 0) round = any_huge ? levels_to(SAH_HUGE) + 2 : levels_to(SAH_SUB) + 3;
+        else if (round_no == 1) { round = levels_to(SAH_SUB) + 3 - level; if (round < 4) round = 4; }
+        round_no++;
         const int until = (level + round < SAH_MAX_LEVELS) ? level + round : SAH_MAX_LEVELS;
         for (; level < until; level++) {
             const int in = level & 1, out = in ^ 1, halve = level >= SAH_FORCE_HALVING_AFTER ? 1 : 0;
             int *lc = counts + SAH_CNT * level, *nc = counts + SAH_CNT * (level + 1);
             long cap = 1; for (int k = 0; k < level && cap < n; k++) cap *= 2;              // a level holds at most 2^level nodes
             const long cap_small = cap < (long)small_cap ? cap : (long)small_cap, cap_large = cap < (long)large_cap ? cap : (long)large_cap;
-            const long cap_huge = cap < (long)huge_cap ? cap : (long)huge_cap, cap_mini = cap < (long)mini_cap ? cap : (long)mini_cap;
+            const long cap_huge = cap < (long)huge_cap ? cap : (long)huge_cap;
             if (any_huge) {
                 hipLaunchKernelGGL(k_sah_huge_bin, dim3((unsigned)chunk_cap), dim3(SAH_CHUNK), 0, st, sbox, idx[in], huge[in], lc, chunk_task[in], hbins[in], chunk_cnt, halve);
                 hipLaunchKernelGGL(k_sah_huge_eval, dim3((unsigned)cap_huge), dim3(64), 0, st, huge[in], lc, hbins[in], chunk_cnt, chunk_base, huge[out], hbins[out], chunk_task[out],
-                                   small[out], large[out], mini[out], nc, compact, csize, parent, halve);
+                                   small[out], large[out], sub, nc, sub_count, compact, csize, parent, halve, level);
                 hipLaunchKernelGGL(k_sah_huge_part, dim3((unsigned)chunk_cap), dim3(SAH_CHUNK), 0, st, sbox, sorted_prims, idx[in], idx[out], huge[in], lc, chunk_task[in], chunk_base,
                                    huge[out], compact, csize, prim_slot);
             }
             if (any_large)
                 hipLaunchKernelGGL(k_sah_level<16>, dim3((unsigned)cap_large), dim3(SAH_BLOCK), 0, st, sbox, sorted_prims, idx[in], idx[out], large[in], lc + 1,
-                                   small[out], large[out], mini[out], nc, compact, csize, parent, prim_slot, halve);
+                                   small[out], large[out], sub, nc, sub_count, compact, csize, parent, prim_slot, halve, level);
             if (any_small)
                 hipLaunchKernelGGL(k_sah_level<1>, dim3((unsigned)((cap_small + 15) / 16)), dim3(SAH_BLOCK), 0, st, sbox, sorted_prims, idx[in], idx[out], small[in], lc,
-                                   small[out], large[out], mini[out], nc, compact, csize, parent, prim_slot, halve);
-            hipLaunchKernelGGL(k_sah_mini, dim3((unsigned)((cap_mini + 15) / 16)), dim3(256), 0, st, sbox, sorted_prims, idx[in], idx[out], mini[in], lc + 4,
-                               mini[out], nc, compact, csize, parent, prim_slot, halve);
+                                   small[out], large[out], sub, nc, sub_count, compact, csize, parent, prim_slot, halve, level);
         }
         TIRT_HIP(hipMemcpyAsync(host_counts, counts, sizeof(host_counts), hipMemcpyDeviceToHost, st));
         TIRT_HIP(hipStreamSynchronize(st));
         const int *lc = host_counts + SAH_CNT * level;
-        if (lc[0] == 0 && lc[1] == 0 && lc[2] == 0 && lc[4] == 0) break;
         any_huge = lc[2] > 0; any_large = any_huge || lc[1] > 0; any_small = any_large || lc[0] > 0;
-        TIRT_REQUIRE(level < SAH_MAX_LEVELS, "tirt_lbvh_build: traversal tree deeper than 160 levels");
+        TIRT_REQUIRE(level < SAH_MAX_LEVELS || !(any_small), "tirt_lbvh_build: traversal tree deeper than 160 levels");
     }
+    int n_sub = first_sub;
+    if (round_no > 0) n_sub = host_counts[SAH_CNT * (SAH_MAX_LEVELS + 1)];
+    if (n_sub > 0)
+        hipLaunchKernelGGL(k_sah_subtree, dim3((unsigned)((n_sub + SAH_SUB_WAVES - 1) / SAH_SUB_WAVES)), dim3(64 * SAH_SUB_WAVES), 0, st, sbox, sorted_prims, idx[0], idx[1],
+                           sub, sub_count, compact, csize, parent, prim_slot);
     c->sah_levels = level;
     TIRT_HIP(hipGetLastError());
     return TIRT_OK;
