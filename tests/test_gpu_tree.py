@@ -28,7 +28,7 @@ def prim_boxes(sc):
     return box
 
 
-def check_tree(rows, box):
+def check_tree(rows, box, shape_prims=None):
     n = box.shape[0]
     N = 2 * n - 1
     assert rows.shape == (N, 9)
@@ -36,7 +36,17 @@ def check_tree(rows, box):
     assert leaf.sum() == n and ((rows[:, 0] == 0.0) | leaf).all()
     prims = rows[leaf, 1].astype(np.int64)
     assert np.array_equal(np.sort(prims), np.arange(n)), "every primitive in exactly one leaf"
-    assert np.array_equal(rows[leaf, 2:8], box[prims]), "leaf boxes are the primitives' boxes"
+    tri = np.ones(n, bool) if shape_prims is None else ~np.isin(np.arange(n), shape_prims)
+    lb, pb = rows[leaf, 2:8], box[prims]
+    assert np.array_equal(lb[tri[prims]], pb[tri[prims]]), "leaf boxes are the triangles' boxes"
+    sh = ~tri[prims]          # analytic spheres: the tree holds their box padded by what the reference's sphere test can be off by (tirt_internal.h, sphere_pad)
+    if sh.any():
+        assert (lb[sh, :3] <= pb[sh, :3]).all() and (lb[sh, 3:] >= pb[sh, 3:]).all()
+        r = 0.5 * (pb[sh, 3] - pb[sh, 0])
+        diag = np.linalg.norm(rows[0, 5:8] - rows[0, 2:5])         # (the padded root: an upper bound of the scene diagonal the pad is sized by)
+        pad_max = 1.0e-3 * r + 2.4e-7 * (16.0 * diag) ** 2 / r
+        assert (np.abs(lb[sh] - pb[sh]) <= 1.01 * pad_max[:, None] + 1e-6).all(), "padded by no more than sphere_pad"
+
     # pre-order: subtree sizes bottom-up (children have larger indices than their parent)
     size = np.ones(N, np.int64)
     right = rows[:, 1].astype(np.int64)
@@ -65,7 +75,7 @@ def test_traversal_tree_is_a_tree(gpu_ctx_ok, make):
     ex = make(); ex.build_scene()
     sc = ex.scene
     rows = sc.ctx.traversal_tree_download(sc.primitive_count)
-    check_tree(rows, prim_boxes(sc))
+    check_tree(rows, prim_boxes(sc), np.flatnonzero(sc.primitive_np[:, 0] != 1))
     # with the option off the rows are the reference's compact_node
     ex2 = make(); ex2.scene.ctx.set_option("traversal_tree", 0); ex2.build_scene()
     lb = ex2.scene.ctx.traversal_tree_download(sc.primitive_count)
@@ -76,7 +86,7 @@ def test_traversal_tree_is_a_tree(gpu_ctx_ok, make):
 def test_traversal_tree_headline_scene(gpu_ctx_ok):
     ex = scenes.synthetic(64, 64, 4, device_id=0); ex.build_scene()
     sc = ex.scene
-    size = check_tree(sc.ctx.traversal_tree_download(sc.primitive_count), prim_boxes(sc))
+    size = check_tree(sc.ctx.traversal_tree_download(sc.primitive_count), prim_boxes(sc), np.flatnonzero(sc.primitive_np[:, 0] != 1))
     # a top-down SAH tree of 100 001 primitives is shallow: depth well below the 64 levels after which ranges are halved
     depth = np.zeros(size.shape[0], np.int32)
     rows = sc.ctx.traversal_tree_download(sc.primitive_count)
@@ -159,7 +169,7 @@ def test_traversal_tree_on_hostile_distributions(gpu_ctx_ok, kind):
         tris = np.concatenate([a, b], axis=0)
     ex = _custom_scene(tris); ex.build_scene()
     sc = ex.scene
-    check_tree(sc.ctx.traversal_tree_download(sc.primitive_count), prim_boxes(sc))
+    check_tree(sc.ctx.traversal_tree_download(sc.primitive_count), prim_boxes(sc), np.flatnonzero(sc.primitive_np[:, 0] != 1))
     o = oa.OracleScene(sc, ex.cam); o.lbvh_build()
     lo, hi = np.asarray(tris).reshape(-1, 3).min(axis=0), np.asarray(tris).reshape(-1, 3).max(axis=0)
     org = r.uniform(lo - 0.1 * (hi - lo) - 1e-3, hi + 0.1 * (hi - lo) + 1e-3, (6000, 3))

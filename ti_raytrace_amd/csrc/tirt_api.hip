@@ -24,11 +24,12 @@ BvhView bvh_view(const tirt_ctx *c)
 {
     BvhView b;
     b.wnode = c->wnode.as<float4>(); b.tri = c->tri.as<float4>();
-    b.cnode = c->cnode.as<uint4>(); b.top_count = c->wide_nodes < TR_TOP_SLOTS ? c->wide_nodes : TR_TOP_SLOTS; b.compact = c->compact.as<float>(); b.cparent = c->cparent.as<int>();
+    b.cnode = c->cnode.as<uint4>(); b.top_count = c->wide_nodes + c->n_far_nodes < TR_TOP_SLOTS ? c->wide_nodes + c->n_far_nodes : TR_TOP_SLOTS; b.compact = c->compact.as<float>(); b.cparent = c->cparent.as<int>();
     for (int k = 0; k < 3; k++) { b.grid_min[k] = c->grid_min[k]; b.cell[k] = c->grid_cell[k]; b.inv_cell[k] = c->grid_inv_cell[k]; b.inv_extent[k] = c->grid_inv_extent[k]; }
     for (int k = 0; k < 3; k++) { b.root_min[k] = c->root_min[k]; b.root_max[k] = c->root_max[k]; }
     b.root_code = c->root_code;
     b.root_qcode = c->root_code;        // >= 0: wide node 0
+    b.far_qcode = c->n_far_nodes ? c->wide_nodes : c->root_code;
     return b;
 }
 int flush_pending(tirt_ctx *c)
@@ -399,6 +400,11 @@ int tirt_scene_upload(tirt_ctx *c, const float *vertex, int nv, const int32_t *p
         TIRT_REQUIRE(pr[2] >= 0 && pr[2] < nm, "tirt_scene_upload: material index out of range");
     }
     for (int i = 0; i < nl; i++) TIRT_REQUIRE(light[i] >= 0 && light[i] < n, "tirt_scene_upload: light index out of range");
+    c->sphere_prims.clear();
+    for (int i = 0; i < n; i++) {
+        const int32_t *pr = primitive + (size_t)i * 3;
+        if (pr[0] != PRIMITIVE_TRI && (int)shape[(size_t)pr[1] * 10] == SHAPE_SPHERE) c->sphere_prims.push_back(i);
+    }
     hipStream_t st = c->stream;
     c->built = false;
     if (upload(c->vertex, vertex, sizeof(float) * 9 * (size_t)nv, st)) return TIRT_ERR_HIP;

@@ -111,6 +111,9 @@ struct BvhView {
     float root_min[3], root_max[3];
     int root_code;                // two-child layout: compact index 0, or the leaf code of a one-primitive scene
     int root_qcode;               // 4-wide layout: node 0, or the same leaf code
+    // Analytic spheres whose slot in the 4-wide nodes is their own (padded) box instead of the whole grid (TIRT_SPHERE_PAD, tirt_sah.hip):
+    // a ray that starts too far away for that box to be safe (cull_far < 0, k_trace) gets these leaves pushed at its start.
+    int far_qcode;                // where a far-origin ray starts: root_qcode, or the first of the chain nodes that hold the padded analytic spheres beside the root (lbvh_build)
 };
 
 // Wavefront state, struct-of-arrays in HBM.  Live paths are kept DENSE: every bounce the shade
@@ -199,6 +202,8 @@ struct tirt_ctx {
     int wide_nodes = 0;                            // number of 4-wide nodes
     tirt::DevBuf sah_compact, sah_csize, sah_parent, wide_dp, sah_box, sah_idx, sah_tasks, sah_counts;   // traversal tree (tirt_sah.hip): `compact`-layout rows + subtree sizes, build scratch
     int use_sah = 1, sah_levels = 0, built_sah = 0;
+    std::vector<int> sphere_prims;                  // primitive ids of the analytic spheres (tirt_scene_upload)
+    int n_far_nodes = 0;                      // chain nodes behind the wide tree (cnode[wide_nodes ...]): the entry of far-origin rays when the spheres' slots carry padded boxes (lbvh_build)
     int wide_dp_on = 0;                            // option "wide_collapse": 0 = greedy by surface area (default), 1 = cost-optimal grouping of the binary tree into 4-wide nodes (dynamic programme; 1-9 % fewer visits, same rays/s)               // option "traversal_tree": 1 = binned-SAH tree (default), 0 = the reference's LBVH
     float grid_min[3] = {0, 0, 0}, grid_cell[3] = {1, 1, 1}, grid_inv_cell[3] = {1, 1, 1}, grid_inv_extent[3] = {1, 1, 1};
     size_t lds_optin = 65536;                      // hipDeviceAttributeMaxSharedMemoryPerBlock (opt-in) of this device
@@ -292,7 +297,13 @@ inline BatchPlan plan_batches(const tirt_ctx *c)
 }
 inline size_t effective_batch_paths(const tirt_ctx *c) { return plan_batches(c).batch; }
 inline size_t effective_merge_paths(const tirt_ctx *c) { return (c->merge_user || c->merge_paths == 0) ? c->merge_paths : effective_batch_paths(c); }
-int sah_build(tirt_ctx *c, const int *sorted_prims);      // tirt_sah.hip
+int sah_build(tirt_ctx *c, const int *sorted_prims, float sphere_pad_abs);      // tirt_sah.hip
+// Box of an analytic sphere in the TRAVERSAL tree: centre -+ (r + pad).  The reference's sphere test (Scene.py:565-596) answers from
+// dis_cp = sqrt(|oc|^2 - (d.oc)^2) < r, a difference of squares of the origin's distance: its error is ~2.4e-7 |oc|^2 / r, so a ray may be
+// given a "hit" although it passes the sphere at r + that.  pad = 1e-3 r + pad_abs / r with pad_abs = 2.4e-7 R^2, R = 16 scene diagonals: safe
+// for every origin within TR_FAR_RHO root-box extents of the grid; rays from further away have the spheres pushed explicitly (BvhView).
+inline float sphere_pad_abs(float diag) { const float R = 16.0f * diag; return 2.4e-7f * R * R; }
+TD float sphere_pad(float r, float pad_abs) { return 1.0e-3f * r + pad_abs / (r > 1.0e-20f ? r : 1.0e-20f); }
 #ifdef TIRT_EXPERIMENTS
 int exp_wide_from_tree(tirt_ctx *c, const float *compact_host, const int *csize_host);     // tools/exp/sah_tree.py
 #endif

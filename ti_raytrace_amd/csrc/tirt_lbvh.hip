@@ -500,7 +500,7 @@ __global__ void k_wide_dp(int N, const float *compact, const int *parent, int *f
 
 // level_off[L] / level_cnt[L]: first wide index and number of wide nodes of level L; queue holds the binary roots (compact
 // indices) of all wide nodes in breadth-first order (queue[w] for wide node w)
-__global__ void k_wide_level(SceneView s, const int *prim_slot, const float *compact, const int *csize, const int *dp_dec, int level, int *level_off, int *level_cnt, int *queue, uint4 *cnode, float pad, GridMap gm)
+__global__ void k_wide_level(SceneView s, const int *prim_slot, const float *compact, const int *csize, const int *dp_dec, int level, int *level_off, int *level_cnt, int *queue, uint4 *cnode, float pad, GridMap gm, int shapes_boxed)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
     const int n_in = level_cnt[level], off = level_off[level];
@@ -568,7 +568,7 @@ __global__ void k_wide_level(SceneView s, const int *prim_slot, const float *com
             if ((((int)cn[0]) & 1) == 1) code = child_code(s, prim_slot, cn, cand[c]);
             else { queue[next_off + pos] = cand[c]; code = next_off + pos; pos++; }
             const bool leaf = code < 0;
-            const bool shape = leaf && (((~code) >> 30) & 1) != 0;
+            const bool shape = !shapes_boxed && leaf && (((~code) >> 30) & 1) != 0;      // (shapes_boxed: the tree's rows hold the spheres' padded boxes, tirt_sah.hip)
             const float p = leaf ? pad : 0.0f;
             for (int a = 0; a < 3; a++)
                 wd[3 * c + a] = shape ? (TR_H_NEG | (TR_H_POS << 16))
@@ -584,7 +584,7 @@ __global__ void k_wide_level(SceneView s, const int *prim_slot, const float *com
 
 // The level loop of the wide build over a binary tree in `compact` layout (pre-order, left child = self + 1) with subtree
 // sizes `csize`; ends with c->ev1 recorded after the last level.
-static int build_wide(tirt_ctx *c, const float *compact, const int *csize, const int *parent, float pad, const GridMap &gm)
+static int build_wide(tirt_ctx *c, const float *compact, const int *csize, const int *parent, float pad, const GridMap &gm, int shapes_boxed = 0)
 {
     const int n = c->n, N = 2 * n - 1;
     hipStream_t st = c->stream;
@@ -611,7 +611,7 @@ static int build_wide(tirt_ctx *c, const float *compact, const int *csize, const
             long cap = 1; for (int k = 0; k < level && cap < n; k++) cap *= 4;             // a level holds at most 4^level nodes
             if (cap > n) cap = n;
             hipLaunchKernelGGL(k_wide_level, dim3((unsigned)((cap + 127) / 128)), dim3(128), 0, st, sv, c->prim_slot.as<int>(), compact, csize, dp_dec, level, lv_off, lv_cnt,
-                               c->wide_queue.as<int>(), c->cnode.as<uint4>(), pad, gm);
+                               c->wide_queue.as<int>(), c->cnode.as<uint4>(), pad, gm, shapes_boxed);
         }
         TIRT_HIP(hipEventRecord(c->ev1, st));
         TIRT_HIP(hipMemcpyAsync(host_lv, c->wide_levels.p, sizeof(host_lv), hipMemcpyDeviceToHost, st));
@@ -663,7 +663,7 @@ int lbvh_build(tirt_ctx *c)
     // 4-wide nodes: fewer than n of them; indices are used as 32-bit byte offsets / 64
     TIRT_REQUIRE(n <= (1 << 24), "tirt_lbvh_build: more than 16 Mi primitives");
     constexpr int WIDE_LEVELS_MAX = 2048;
-    if (c->cnode.ensure(sizeof(uint4) * 4 * (size_t)n) || c->wide_queue.ensure(sizeof(int) * (size_t)n) ||
+    if (c->cnode.ensure(sizeof(uint4) * 4 * ((size_t)n + 4)) || c->wide_queue.ensure(sizeof(int) * (size_t)n) ||
         c->wide_levels.ensure(sizeof(int) * 2 * (WIDE_LEVELS_MAX + 2)) || c->cparent.ensure(sizeof(int) * (size_t)N) ||
         c->csize.ensure(sizeof(int) * (size_t)N)) return TIRT_ERR_HIP;
     (void)st0;
@@ -716,15 +716,19 @@ int lbvh_build(tirt_ctx *c)
     // surface-area collapse of the binary tree into 4-wide nodes, one launch per level of the wide tree (k_wide_level)
     c->wide_nodes = 0;
     const float *tree = c->compact.as<float>(); const int *tree_size = c->csize.as<int>(), *tree_parent = c->cparent.as<int>();
+    // analytic spheres get their own padded box in the traversal tree when there are few of them (far-origin rays enter through chain nodes that
+    // hold them with whole-grid boxes: BvhView::far_qcode); otherwise, and on the reference's LBVH, their 4-wide slots span the whole grid as before
+    const int shapes_boxed = (n >= 2 && c->use_sah && c->sphere_prims.size() <= 8) ? 1 : 0;
+    c->n_far_nodes = 0;
     if (n >= 2 && c->use_sah) {          // walk a better tree than the reference's (tirt_sah.hip); the hits stay the reference's (k_trace)
-        if (int rc = sah_build(c, va)) return rc;                                  // also fills prim_slot
+        if (int rc = sah_build(c, va, shapes_boxed ? sphere_pad_abs(diag) : -1.0f)) return rc;                                  // also fills prim_slot
         tree = c->sah_compact.as<float>(); tree_size = c->sah_csize.as<int>(); tree_parent = c->sah_parent.as<int>();
         c->built_sah = 1;
     } else hipLaunchKernelGGL(k_slot_sorted, dim3((n + B - 1) / B), dim3(B), 0, st, n, va, c->prim_slot.as<int>());
     hipLaunchKernelGGL(k_wnodes, dim3((N + B - 1) / B), dim3(B), 0, st, sv, c->prim_slot.as<int>(), N, c->compact.as<float>(), c->wnode.as<float4>(), pad);
     hipLaunchKernelGGL(k_tris, dim3((n + B - 1) / B), dim3(B), 0, st, sv, c->leaf_compact.as<int>(), c->prim_slot.as<int>(), c->tri.as<float4>());
     if (n >= 2) {
-        if (int rc = build_wide(c, tree, tree_size, tree_parent, pad, gm)) return rc;
+        if (int rc = build_wide(c, tree, tree_size, tree_parent, pad, gm, shapes_boxed)) return rc;
     } else TIRT_HIP(hipEventRecord(c->ev1, st));
     if (n == 1) {
         int prim = 0, is_shape = 0;
@@ -734,6 +738,31 @@ int lbvh_build(tirt_ctx *c)
         is_shape = (pr0 == PRIMITIVE_TRI) ? 0 : 1;
         c->root_code = ~(prim | (is_shape << 30));
     } else c->root_code = 0;
+    if (shapes_boxed && !c->sphere_prims.empty()) {
+        // the entry of far-origin rays: up to three chain nodes behind the wide tree, [root, sphere, sphere, sphere | next chain node],
+        // every slot with the whole grid as its box (k_trace's refill; a sphere's leaf code is ~(record index | shape bit))
+        int slots[8];
+        const int ns = (int)c->sphere_prims.size();
+        for (int k = 0; k < ns; k++)
+            TIRT_HIP(hipMemcpyAsync(&slots[k], c->prim_slot.as<int>() + c->sphere_prims[k], sizeof(int), hipMemcpyDeviceToHost, st));
+        TIRT_HIP(hipStreamSynchronize(st));
+        int codes[12], nc = 0, nodes = 0;
+        unsigned wd[3 * 16];
+        codes[nc++] = 0;                                   // the root of the wide tree
+        for (int k = 0; k < ns; k++) codes[nc++] = ~(slots[k] | (1 << 30));
+        for (int at = 0; at < nc; nodes++) {
+            unsigned *w = wd + 16 * nodes;
+            const int left = nc - at, take = left <= 4 ? left : 3;      // a full node keeps its last slot for the link
+            for (int s = 0; s < 4; s++) {
+                const bool used = s < take || (s == 3 && left > 4);
+                for (int a = 0; a < 3; a++) w[3 * s + a] = used ? (TR_H_NEG | (TR_H_POS << 16)) : (TR_H_POS | (TR_H_NEG << 16));
+                w[12 + s] = s < take ? (unsigned)codes[at + s] : (used ? (unsigned)(c->wide_nodes + nodes + 1) : (unsigned)TR_EMPTY);
+            }
+            at += take;
+        }
+        c->n_far_nodes = nodes;
+        TIRT_HIP(hipMemcpyAsync(c->cnode.as<uint4>() + (size_t)c->wide_nodes * 4, wd, sizeof(unsigned) * 16 * (size_t)nodes, hipMemcpyHostToDevice, st));
+    }
     TIRT_HIP(hipStreamSynchronize(st));
     float ms = 0.0f;
     TIRT_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));

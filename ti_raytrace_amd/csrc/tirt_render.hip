@@ -254,7 +254,9 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
                 }
                 if (BOUNDED && t_bound > 0.0f && cull_far > 0.0f) { cull_far = t_bound * 1.01f; settle = t_bound * 0.99f; }
                 lim = __builtin_fminf(__builtin_fminf(hit_t * 1.0001f, __builtin_fabsf(cull_far)), INF_VALUE);      // (v_min: a canonical value, so the node loop does not re-canonicalise it every step)
-                cur = (MODE == TIRT_TRAVERSE_EXHAUSTIVE) ? b.root_code : b.root_qcode;
+                // (a far-origin ray cannot trust the padded boxes of the analytic spheres: it starts at a chain node that holds the root and
+                // those spheres with whole-grid boxes, BvhView::far_qcode, and so tests them whatever their boxes say -- as the reference does)
+                cur = (MODE == TIRT_TRAVERSE_EXHAUSTIVE) ? b.root_code : (cull_far < 0.0f ? b.far_qcode : b.root_qcode);
                 if (cur >= 0) {
                     float tn;
                     if (!slabs(r, b.root_min[0], b.root_min[1], b.root_min[2], b.root_max[0], b.root_max[1], b.root_max[2], tn)) cur = TR_SENT;
@@ -394,12 +396,18 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
             const bool is_tri = ((code >> 30) & 1) == 0;
             const v3 pa = V(ta.x, ta.y, ta.z), pb = V(tb.x, tb.y, tb.z), pc = V(tc.x, tc.y, tc.z);
             float t, u, v;
+            bool sph = false;
             if (is_tri) {
                 t = intersect_tri_packed(o, d, pa, pb - pa, pc - pa, u, v);          // E1 = v2 - v1, E2 = v3 - v1 (Scene.py:608-609)
             } else {
-                float cc; u = 0.0f; v = 0.0f;
-                t = ((int)tb.y == SHAPE_SPHERE) ? intersect_sphere(o, d, pa, tb.x, cc) : INF_VALUE;
+                // Analytic sphere (Scene.py:565-596).  Its root is t = (-b - sqrt(b^2 - 4ac)) / 2 / a with b = -2 (d . oc), a = d . d > 0: for
+                // d . oc <= 0 the numerator is a non-positive number minus a square root -- t <= 0, or NaN -- and such a t is never a
+                // candidate (0 < t < hit_t).  Exactly so in fp32 (signs, no rounding involved), so the two square roots and two divisions
+                // (~80 instructions, which the whole wave would issue for one lane) are only run for rays that head towards the centre.
+                u = 0.0f; v = 0.0f; t = INF_VALUE;
+                if ((int)tb.y == SHAPE_SPHERE) { const v3 oc = pa - o; sph = dot(d, oc) > 0.0f; }
             }
+            if (wave_any(sph)) { if (sph) { float cc; t = intersect_sphere(o, d, pa, tb.x, cc); } }
             const int leaf = __float_as_int(ta.w);
             if (from_pend) pend = 0; else TR_POP(cur);
             // reference: accept iff 0 < t < hit_t (so never t >= INF_VALUE); equal-t candidates: see header
@@ -686,7 +694,9 @@ __global__ __launch_bounds__(TR_BLOCK, TRQ_MIN_WAVES) void k_trace_q(TraceArgs a
                 }
                 if (BOUNDED && t_bound > 0.0f && cull_far > 0.0f) { cull_far = t_bound * 1.01f; settle = t_bound * 0.99f; }
                 lim = __builtin_fminf(__builtin_fminf(hit_t * 1.0001f, __builtin_fabsf(cull_far)), INF_VALUE);      // (v_min: a canonical value, so the node loop does not re-canonicalise it every step)
-                cur = (MODE == TIRT_TRAVERSE_EXHAUSTIVE) ? b.root_code : b.root_qcode;
+                // (a far-origin ray cannot trust the padded boxes of the analytic spheres: it starts at a chain node that holds the root and
+                // those spheres with whole-grid boxes, BvhView::far_qcode, and so tests them whatever their boxes say -- as the reference does)
+                cur = (MODE == TIRT_TRAVERSE_EXHAUSTIVE) ? b.root_code : (cull_far < 0.0f ? b.far_qcode : b.root_qcode);
                 if (cur >= 0) {
                     float tn;
                     if (!slabs(r, b.root_min[0], b.root_min[1], b.root_min[2], b.root_max[0], b.root_max[1], b.root_max[2], tn)) cur = TR_SENT;
@@ -853,8 +863,8 @@ __global__ __launch_bounds__(TR_BLOCK, TRQ_MIN_WAVES) void k_trace_q(TraceArgs a
                 if (is_tri) {
                     t = intersect_tri_packed(o, d, pa, pb - pa, pc - pa, u, v);          // E1 = v2 - v1, E2 = v3 - v1 (Scene.py:608-609)
                 } else {
-                    float cc; u = 0.0f; v = 0.0f;
-                    t = ((int)tb.y == SHAPE_SPHERE) ? intersect_sphere(o, d, pa, tb.x, cc) : INF_VALUE;
+                    float cc; u = 0.0f; v = 0.0f; t = INF_VALUE;
+                    if ((int)tb.y == SHAPE_SPHERE) { const v3 oc = pa - o; if (dot(d, oc) > 0.0f) t = intersect_sphere(o, d, pa, tb.x, cc); }      // (see k_trace)
                 }
                 const int leaf = __float_as_int(ta.w);
                 // reference: accept iff 0 < t < hit_t (so never t >= INF_VALUE); equal-t candidates: see header

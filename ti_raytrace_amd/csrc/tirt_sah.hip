@@ -159,7 +159,7 @@ TD void sah_write_inner(float *compact, int *csize, int *parent, int row_index, 
 
 // Boxes in Morton order (accel/LBvh.py:397-426: triangle min / max, sphere centre -+ r), the identity index array, the
 // bounds of everything (root of a huge scene) and the root's empty bins.
-__global__ __launch_bounds__(256) void k_sah_prim_boxes(SceneView s, const int *sorted_prims, float4 *sbox, int *idx0, SahHuge *root, unsigned *root_bins)
+__global__ __launch_bounds__(256) void k_sah_prim_boxes(SceneView s, const int *sorted_prims, float4 *sbox, int *idx0, SahHuge *root, unsigned *root_bins, float sph_pad_abs)
 {
     __shared__ unsigned s_b[12];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -177,7 +177,10 @@ __global__ __launch_bounds__(256) void k_sah_prim_boxes(SceneView s, const int *
             mx = V(fmaxf(fmaxf(a.x, b.x), c.x), fmaxf(fmaxf(a.y, b.y), c.y), fmaxf(fmaxf(a.z, b.z), c.z));
         } else {
             const float *sh = s.shape + (size_t)pr[1] * SHA_VEC;
-            mn = V(sh[1] - sh[4], sh[2] - sh[4], sh[3] - sh[4]); mx = V(sh[1] + sh[4], sh[2] + sh[4], sh[3] + sh[4]);
+            // analytic sphere: its box in THIS tree is padded by what the reference's sphere test can be off by (sphere_pad, tirt_internal.h;
+            // sph_pad_abs < 0: no padding -- the 4-wide slots of shapes then span the whole grid, as in round 2).  Spot / laser shapes are never hit.
+            const float rr = ((int)sh[0] == SHAPE_SPHERE && sph_pad_abs >= 0.0f) ? sh[4] + sphere_pad(sh[4], sph_pad_abs) : sh[4];
+            mn = V(sh[1] - rr, sh[2] - rr, sh[3] - rr); mx = V(sh[1] + rr, sh[2] + rr, sh[3] + rr);
         }
         const float4 a = make_float4(mn.x, mn.y, mn.z, 0.0f), b = make_float4(mx.x, mx.y, mx.z, 0.0f);
         sbox[2 * (size_t)i] = a; sbox[2 * (size_t)i + 1] = b;
@@ -665,7 +668,7 @@ __global__ __launch_bounds__(SAH_CHUNK) void k_sah_huge_part(const float4 *__res
 
 // Builds the tree over the primitives in the order `sorted_prims` (Morton order: neighbours in the array are neighbours in
 // space, so the box reads of the first levels are streams) into c->sah_compact / c->sah_csize.  Work on c->stream.
-int sah_build(tirt_ctx *c, const int *sorted_prims)
+int sah_build(tirt_ctx *c, const int *sorted_prims, float sph_pad_abs)
 {
     const int n = c->n, N = 2 * n - 1;
     hipStream_t st = c->stream;
@@ -697,7 +700,7 @@ int sah_build(tirt_ctx *c, const int *sorted_prims)
     root_huge.count = n; root_huge.child[0] = root_huge.child[1] = -1;
     for (int k = 0; k < 12; k++) root_huge.bounds[k] = ((k < 3) || (k >= 6 && k < 9)) ? 0xffffffffu : 0u;
     TIRT_HIP(hipMemcpyAsync(huge[0], &root_huge, sizeof(root_huge), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_sah_prim_boxes, dim3((n + 255) / 256), dim3(256), 0, st, sv, sorted_prims, sbox, idx[0], huge[0], hbins[0]);
+    hipLaunchKernelGGL(k_sah_prim_boxes, dim3((n + 255) / 256), dim3(256), 0, st, sv, sorted_prims, sbox, idx[0], huge[0], hbins[0], sph_pad_abs);
     const SahTask root = {0, n, 0, 0};                     // (pad = the level that reads it: 0)
     int first_counts[SAH_CNT] = {0, 0, 0, 0, 0, 0, 0, 0};
     int first_sub = 0;
