@@ -582,11 +582,11 @@ def main():
         c = ctx.stats()
         alg_closest = 32.0 * c["box_closest"] + 36.0 * c["leaf_closest"] + 48.0 * c["rays_closest"]
         alg_shadow = 32.0 * c["box_shadow"] + 36.0 * c["leaf_shadow"] + 48.0 * c["rays_shadow"]
+        ctx.set_option("time_kernels", 1)            # per-kernel HIP events; runs the batches on ONE lane (no overlap)
         ctx.stats_reset()
         ctx.pt_rgb_render(f0, probe_frames, args.seed, 15, 64, _native.TRAVERSE_ORDERED | _native.COUNT_NODES)
         ctx.sync()
         co = ctx.stats()
-        ctx.set_option("time_kernels", 1)            # per-kernel HIP events; runs the batches on ONE lane (no overlap)
         ctx.stats_reset()
         ctx.pt_rgb_render(f0, probe_frames, args.seed, 15, 64, 0)
         ctx.sync()
@@ -674,7 +674,12 @@ def main():
                                   "node_lane_util": round(co["diag_lanes_node"] / max(co["diag_it_node"] * 64.0, 1), 4),
                                   "leaf_iters_per_ray": round(co["diag_it_leaf"] * 64.0 / max(rays_o, 1), 2),
                                   "leaf_lane_util": round(co["diag_lanes_leaf"] / max(co["diag_it_leaf"] * 64.0, 1), 4),
-                                  "refills_per_wave_ray": round(co["diag_refills"] * 64.0 / max(rays_o, 1), 3)},
+                                  "refills_per_wave_ray": round(co["diag_refills"] * 64.0 / max(rays_o, 1), 3),
+                                  # timeline of the (counting) launches: a wave's mean lifetime against the launch it ran in, and the share of the
+                                  # waves' lifetimes spent after the ray queue ran dry (each wave only finishing the rays it holds: the tail)
+                                  "wave_life_over_launch": round(co["diag_wave_ticks"] * 1.0e-5 / max(co["diag_waves"], 1) /
+                                                                 max((co["ms_trace_closest"] + co["ms_trace_shadow"]) / max(co["launches_trace_closest"] + co["launches_trace_shadow"], 1), 1e-9), 4),
+                                  "drain_share_of_wave_life": round(co["diag_drain_ticks"] / max(co["diag_wave_ticks"], 1), 4)},
             # SURVEY.md 8d's algorithmic bytes on the REFERENCE's traversal semantics (exhaustive pop counts): what the
             # reference's algorithm would move for these rays -- the ordered traversal moves far less, so this is NOT a
             # fraction of any roofline of this kernel

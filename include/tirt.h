@@ -54,6 +54,9 @@ typedef struct {
     /* wave-occupancy diagnostics of the traversal kernels (TIRT_COUNT_NODES only): per-wave
      * loop trips and the number of busy lanes summed over those trips (64 = full wave) */
     uint64_t diag_it_node, diag_lanes_node, diag_it_leaf, diag_lanes_leaf, diag_refills, diag_it_outer;
+    /* timeline of the traversal waves (TIRT_COUNT_NODES only), 100 MHz ticks: their lifetimes summed, the part of a lifetime after the wave
+     * found the ray queue empty (it only finishes the rays it holds), and how many waves ran */
+    uint64_t diag_wave_ticks, diag_drain_ticks, diag_waves;
 } tirt_stats_t;
 
 const char *tirt_last_error(void);
@@ -215,6 +218,12 @@ int tirt_comm_destroy(tirt_ctx **ctxs, int ndev);
  *   `working_set_bytes`; returns the rate in GB/s (best of 3 launches). */
 int tirt_bvh_info(tirt_ctx *ctx, uint64_t out[4]);
 int tirt_micro_gather_rate(tirt_ctx *ctx, uint64_t working_set_bytes, int iters, double *gbps_out);
+
+/* Diagnostics of the traversal kernel's schedule.  tirt_set_option(ctx, "trace_timeline", k) arms the k-th counting launch (TIRT_COUNT_NODES)
+ * from then on (-1 disarms); that launch records, per wave, four 64-bit words: start, the moment the wave found the ray queue empty (0: never),
+ * end -- all in ticks of the device's 100 MHz wall clock -- and the wave's hardware id (HW_ID in the low word, XCC_ID in the high word).
+ * tirt_trace_timeline copies up to max_waves records to `out` and reports how many the launch had.  (No reference counterpart: bench / tools.) */
+int tirt_trace_timeline(tirt_ctx *ctx, uint64_t *out, int max_waves, int *n_waves);
 
 /* Fills *out.  Returns TIRT_ERR_STACK (with *out filled in) when stack_overflow > 0: rays dropped subtrees, what was
  * rendered since the last tirt_stats_reset is wrong -- the reference prints "overflow, need larger stack" (Scene.py:741). */

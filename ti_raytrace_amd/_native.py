@@ -40,7 +40,7 @@ class Stats(C.Structure):
                                   "ms_trace_shadow", "ms_shade")] + [
         (n, C.c_uint64) for n in ("launches_trace_closest", "launches_trace_shadow",
                                   "launches_shade", "diag_it_node", "diag_lanes_node", "diag_it_leaf",
-                                  "diag_lanes_leaf", "diag_refills", "diag_it_outer")]
+                                  "diag_lanes_leaf", "diag_refills", "diag_it_outer", "diag_wave_ticks", "diag_drain_ticks", "diag_waves")]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -87,6 +87,7 @@ SIGNATURES = {
     "tirt_comm_destroy": (C.c_int, [C.POINTER(_vp), C.c_int]),
     "tirt_bvh_info": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
     "tirt_micro_gather_rate": (C.c_int, [_vp, C.c_uint64, C.c_int, C.POINTER(C.c_double)]),
+    "tirt_trace_timeline": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.c_int, C.POINTER(C.c_int)]),
     "tirt_stats": (C.c_int, [_vp, C.POINTER(Stats)]),
     "tirt_stats_reset": (C.c_int, [_vp]),
     "tirt_kat_math": (C.c_int, [_vp, C.c_int, _f32p, _f32p, _f32p, C.c_int]),
@@ -317,6 +318,13 @@ class Context:
         out = (C.c_uint64 * 4)()
         check(lib().tirt_bvh_info(self.handle, out))
         return {"node_bytes": int(out[0]), "prim_bytes": int(out[1]), "nodes": int(out[2]), "nodes_in_lds": int(out[3])}
+
+    def trace_timeline(self, max_waves=1 << 16):
+        """Per-wave [start, queue empty, end, hw id] of the launch armed by set_option("trace_timeline", k): (n, 4) uint64."""
+        import numpy as np
+        out = np.zeros((max_waves, 4), np.uint64); n = C.c_int(0)
+        check(lib().tirt_trace_timeline(self.handle, out.ctypes.data_as(C.POINTER(C.c_uint64)), int(max_waves), C.byref(n)))
+        return out[:min(n.value, max_waves)]
 
     def micro_gather_rate(self, working_set_bytes, iters=2000):
         v = C.c_double(0.0)

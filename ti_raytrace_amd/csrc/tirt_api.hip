@@ -284,6 +284,11 @@ int tirt_create(int device_id, tirt_ctx **out)
     int optin = 0;
     if (hipDeviceGetAttribute(&optin, hipDeviceAttributeSharedMemPerBlockOptin, device_id) == hipSuccess && optin > 0) c->lds_optin = (size_t)optin;
     else { (void)hipGetLastError(); if (hipDeviceGetAttribute(&optin, hipDeviceAttributeMaxSharedMemoryPerBlock, device_id) == hipSuccess && optin > 0) c->lds_optin = (size_t)optin; }
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && cus > 0) {
+        const int g = 5 * cus < 2048 ? 5 * cus : 2048;            // five 256-thread k_trace blocks per CU (tirt_internal.h, TR_TOP_CAP)
+        c->tr_grid = g; c->tr_grid_alone = g;
+    } else (void)hipGetLastError();
     *out = c;
     return TIRT_OK;
 }
@@ -299,7 +304,7 @@ void tirt_destroy(tirt_ctx *c)
                       &c->keys_b, &c->vals_a, &c->vals_b, &c->hist, &c->morton_sorted, &c->bvh_node, &c->compact, &c->parent,
                       &c->flag, &c->subtree, &c->build_status, &c->leaf_compact, &c->wnode, &c->tri, &c->prim_slot, &c->cnode, &c->cparent, &c->csize, &c->wide_queue, &c->wide_levels, &c->sah_compact, &c->sah_csize, &c->sah_parent, &c->wide_dp, &c->sah_box, &c->sah_idx, &c->sah_tasks, &c->sah_counts, &c->hdr, &c->rgb,
                       &c->counters_mem, &c->spill, &c->tr_rays,
-                      &c->tr_out, &c->tr_prim, &c->tr_counts, &c->dev_counters, &c->bdpt_px};
+                      &c->tr_out, &c->tr_prim, &c->tr_counts, &c->dev_counters, &c->bdpt_px, &c->timeline};
     for (DevBuf *b : bufs) b->release();
     for (auto &bl : c->bd) {
         DevBuf *bb[] = {&bl.items, &bl.state, &bl.rays, &bl.hits, &bl.qidx, &bl.ctr, &bl.rad};
@@ -366,6 +371,7 @@ int tirt_set_option(tirt_ctx *c, const char *name, double value)
     }
     if (!strcmp(name, "bdpt_stack_size")) { TIRT_REQUIRE(value >= 16 && value <= 4096, "bdpt_stack_size: 16..4096"); c->bdpt_stack = (int)value; return TIRT_OK; }
     if (!strcmp(name, "trace_queue")) { c->tr_queue = value != 0.0 ? 1 : 0; return TIRT_OK; }
+    if (!strcmp(name, "trace_timeline")) { c->timeline_arm = (int)value; c->timeline_waves = 0; return TIRT_OK; }
     if (!strcmp(name, "trace_refill_min")) { TIRT_REQUIRE(value >= 1 && value <= 64, "trace_refill_min: 1..64"); c->tr_refill_min = (int)value; return TIRT_OK; }
     if (!strcmp(name, "trace_node_min")) { TIRT_REQUIRE(value >= 1 && value <= 64, "trace_node_min: 1..64"); c->tr_node_min = (int)value; return TIRT_OK; }
     if (!strcmp(name, "bdpt_bounded")) { c->bdpt_bounded = value != 0.0 ? 1 : 0; return TIRT_OK; }
@@ -743,6 +749,7 @@ int tirt_stats(tirt_ctx *c, tirt_stats_t *out)
     out->shaded = h.shaded; out->paths = h.paths; out->stack_overflow = h.stack_overflow;
     out->diag_it_node = h.it_node; out->diag_lanes_node = h.lanes_node; out->diag_it_leaf = h.it_leaf;
     out->diag_lanes_leaf = h.lanes_leaf; out->diag_refills = h.refills; out->diag_it_outer = h.it_outer;
+    out->diag_wave_ticks = h.wave_ticks; out->diag_drain_ticks = h.drain_ticks; out->diag_waves = h.waves;
     out->ms_build = c->ms_build; out->ms_render = c->ms_render;
     out->ms_trace_closest = c->ms_trace_closest; out->ms_trace_shadow = c->ms_trace_shadow; out->ms_shade = c->ms_shade;
     out->launches_trace_closest = c->launches_trace_closest; out->launches_trace_shadow = c->launches_trace_shadow;
@@ -754,6 +761,17 @@ int tirt_stats(tirt_ctx *c, tirt_stats_t *out)
         TIRT_HIP(hipStreamSynchronize(c->stream));
         return TIRT_ERR_STACK;
     }
+    return TIRT_OK;
+}
+
+int tirt_trace_timeline(tirt_ctx *c, uint64_t *out, int max_waves, int *n_waves)
+{
+    CTX(c);
+    TIRT_REQUIRE(out && n_waves && max_waves >= 0, "tirt_trace_timeline: null / negative arguments");
+    if (sync_all(c)) return TIRT_ERR_HIP;
+    const int n = c->timeline_waves < max_waves ? c->timeline_waves : max_waves;
+    if (n > 0) TIRT_HIP(hipMemcpy(out, c->timeline.p, sizeof(uint64_t) * 4 * (size_t)n, hipMemcpyDeviceToHost));
+    *n_waves = c->timeline_waves;
     return TIRT_OK;
 }
 

@@ -65,13 +65,17 @@ constexpr int TR_EMPTY = (int)0x80000001;
 #define TR_TOP_LEVELS_N 5
 #endif
 constexpr int TR_TOP_LEVELS = TR_TOP_LEVELS_N;           // levels of 4-wide nodes that get a breadth-first slot
-// (336, not the 341 of five full levels: 32 KB of stacks + 336 x 64 B is 53 KB, and THREE 512-thread blocks then fit the 160 KB of a CU --
-// six waves per SIMD at 80 VGPRs instead of four: +0.8 %)
+// How many tree-top records: a k_trace block is 256 threads (one wave per SIMD) with 16 KB of stacks, and FIVE of them are to fit a CU's
+// 160 KB of LDS: five traversal waves per SIMD at 80 VGPRs leave 112 of the SIMD's 512 registers, which is what lets a k_shade wave (96) of
+// the batch running next door live beside them.  LDS is handed out in 2 KB-ish granules: 16 KB + 224 x 64 B = 30 KB per block is safely five per CU.
+// (Measured with the wave timeline of tools/timeline.py, round 3: the earlier 512-thread blocks with 32 KB + 336 records = 53 KB were believed to fit
+// three to a CU and fitted two -- four waves per SIMD, latency-bound at 0.81 VALU issue; three of them (320 records) traverse 13 % faster on
+// their own but take 480 registers and shut the shading kernels out, so the whole job got slower.  Five per SIMD + shading beside: +5 % whole job.)
 #ifndef TR_TOP_CAP
-#define TR_TOP_CAP 336
+#define TR_TOP_CAP 224
 #endif
 constexpr int TR_TOP_FULL = ((1 << (2 * TR_TOP_LEVELS)) - 1) / 3;
-constexpr int TR_TOP_SLOTS = TR_TOP_FULL < TR_TOP_CAP ? TR_TOP_FULL : TR_TOP_CAP;   // the first 336 nodes in breadth-first order: five levels but five nodes
+constexpr int TR_TOP_SLOTS = TR_TOP_FULL < TR_TOP_CAP ? TR_TOP_FULL : TR_TOP_CAP;   // the first 224 nodes in breadth-first order: four levels and the start of the fifth
 #ifndef TRQ_TOP_N
 #define TRQ_TOP_N 176
 #endif
@@ -94,7 +98,7 @@ constexpr int TRQ_TOP_SLOTS = TRQ_TOP_N;            // k_trace_q (leaf queue per
 constexpr float TR_GRID_HALF = 30000.0f;      // the padded root box spans cells -30000 .. +30000
 constexpr unsigned TR_H_POS = 0x7b53u, TR_H_NEG = 0xfb53u;      // fp16 +-60000
 #ifndef TR_BLOCK_SIZE
-#define TR_BLOCK_SIZE 512
+#define TR_BLOCK_SIZE 256
 #endif
 constexpr int TR_BLOCK = TR_BLOCK_SIZE;                  // threads per persistent k_trace block
 constexpr int TIRT_MAX_DEVICES = 64;
@@ -161,6 +165,9 @@ struct DevCounters {          // lives in device memory; accumulated by the kern
     unsigned long long shaded, paths, stack_overflow;
     // wave-occupancy diagnostics of k_trace (TIRT_COUNT_NODES only): loop trips and busy lanes
     unsigned long long it_node, lanes_node, it_leaf, lanes_leaf, refills, it_outer;
+    // timeline of k_trace's waves in 100 MHz ticks (TIRT_COUNT_NODES only): lifetimes summed, the part of them after the wave found the ray
+    // queue empty (the drain) and the number of waves: against the launches' own time these say how much of a launch is its tail
+    unsigned long long wave_ticks, drain_ticks, waves;
 };
 
 // One in-flight wavefront batch: its own stream, path state, queues and counters.  The lanes
@@ -203,6 +210,7 @@ struct tirt_ctx {
     tirt::DevBuf sah_compact, sah_csize, sah_parent, wide_dp, sah_box, sah_idx, sah_tasks, sah_counts;   // traversal tree (tirt_sah.hip): `compact`-layout rows + subtree sizes, build scratch
     int use_sah = 1, sah_levels = 0, built_sah = 0;
     std::vector<int> sphere_prims;                  // primitive ids of the analytic spheres (tirt_scene_upload)
+    tirt::DevBuf timeline; int timeline_arm = -1, timeline_waves = 0;      // diagnostics: option "trace_timeline", tirt_trace_timeline
     int n_far_nodes = 0;                      // chain nodes behind the wide tree (cnode[wide_nodes ...]): the entry of far-origin rays when the spheres' slots carry padded boxes (lbvh_build)
     int wide_dp_on = 0;                            // option "wide_collapse": 0 = greedy by surface area (default), 1 = cost-optimal grouping of the binary tree into 4-wide nodes (dynamic programme; 1-9 % fewer visits, same rays/s)               // option "traversal_tree": 1 = binned-SAH tree (default), 0 = the reference's LBVH
     float grid_min[3] = {0, 0, 0}, grid_cell[3] = {1, 1, 1}, grid_inv_cell[3] = {1, 1, 1}, grid_inv_extent[3] = {1, 1, 1};
@@ -236,10 +244,10 @@ struct tirt_ctx {
     struct { bool valid = false; uint32_t begin = 0; int count = 0; uint32_t seed = 0; int max_depth = 0, stack_size = 0, flags = 0; bool spectral = false; } pend;
     // traversal tunables (options "trace_lds_depth", "trace_refill_min", "trace_node_min", "trace_grid",
     // "trace_slices" = number of ray-fetch cursors, "shade_grid" = persistent blocks of k_shade)
-    int tr_lds_depth = 16, tr_refill_min = 18, tr_node_min = 38, tr_grid = 384, tr_slice_log2 = 5, sh_grid = 1024;
+    int tr_lds_depth = 16, tr_refill_min = 18, tr_node_min = 38, tr_grid = 1280, tr_slice_log2 = 5, sh_grid = 1024;
     int tr_queue = 0;                              // option "trace_queue": 1 = the ordered traversal runs k_trace_q (per-wave leaf queue, tirt_render.hip: an experiment, 4 % slower); 0 = k_trace
-    int tr_grid_alone = 768;                      // "trace_grid_alone": persistent blocks of a batch submitted to an idle GPU (three per CU);
-                                                  // tr_grid (1.5 per CU) leaves LDS for the traversal kernel of the batch running next to it
+    int tr_grid_alone = 1280;                     // "trace_grid_alone" / "trace_grid": persistent k_trace blocks of a batch submitted to an idle / a busy GPU. Both five per CU
+                                                  // (tirt_create scales them by the device's CU count): blocks of the next batch's launch move in as this one's drain
     tirt::DevBuf counters_mem, spill;            // used by the batch trace entry points (main stream)
 
     // BDPT_RGB: persistent per-pixel vertex arrays + per-frame radiance (splat target)

@@ -62,6 +62,7 @@ struct TraceArgs {
     int refill_min;                              // re-fetch rays when this many lanes of a wave are idle
     int node_min;                                // leave the inner-node loop below this many busy lanes
     DevCounters *ctr; int2 *per_ray_counts;
+    unsigned long long *timeline;        // diagnostics (option "trace_timeline"): per wave [start, queue found empty, end, hardware id] of this launch
     int no_ray_count;                            // the caller counts its rays itself (queues with dead entries)
 };
 
@@ -90,7 +91,7 @@ TD unsigned long long wave_sum(unsigned long long v)
 }
 
 #ifndef TR_MIN_WAVES
-#define TR_MIN_WAVES 6        // 80 VGPRs: three 512-thread blocks per CU (their LDS: tirt_internal.h, TR_TOP_CAP)
+#define TR_MIN_WAVES 6        // 80 VGPRs: five 256-thread blocks per CU and room for a shading wave per SIMD (tirt_internal.h, TR_TOP_CAP)
 #endif
 template <int MODE, bool COUNT, int KIND>
 __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
@@ -135,6 +136,8 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
     float gAx = 0.0f, gAy = 0.0f, gAz = 0.0f, gBnx = 0.0f, gBny = 0.0f, gBnz = 0.0f, gBfx = 0.0f, gBfy = 0.0f, gBfz = 0.0f;
     int grotx = 0, groty = 0, grotz = 0;
     bool exhausted = false;
+    unsigned long long tk_start = 0, tk_exh = 0;
+    if (COUNT) tk_start = wall_clock64();
     const int S_LOG = a.slice_log2, S_MASK = (1 << S_LOG) - 1;
     int home = (int)((blockIdx.x * (TR_BLOCK / 64) + (tid >> 6)) & S_MASK), tried = 0;      // wave-uniform
     const int full_chunks = count >> 6;
@@ -202,7 +205,7 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
             const int my = v < len ? (((((v >> 6) << S_LOG) + home) << 6) | (v & 63)) : count;
             if (base + n_idle >= len) {                                    // slice drained: move on
                 home = (home + 1) & S_MASK;
-                if (++tried > S_MASK) exhausted = true;
+                if (++tried > S_MASK) { exhausted = true; if (COUNT) tk_exh = wall_clock64(); }
             }
             if (!have && my < count) {
                 q = my;
@@ -493,6 +496,14 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
             atomicAdd(&a.ctr->it_node, d_it_node); atomicAdd(&a.ctr->lanes_node, d_lanes_node);
             atomicAdd(&a.ctr->it_leaf, d_it_leaf); atomicAdd(&a.ctr->lanes_leaf, d_lanes_leaf);
             atomicAdd(&a.ctr->refills, d_refills);
+            const unsigned long long tk_end = wall_clock64();
+            atomicAdd(&a.ctr->wave_ticks, tk_end - tk_start); atomicAdd(&a.ctr->drain_ticks, tk_end - (tk_exh ? tk_exh : tk_end)); atomicAdd(&a.ctr->waves, 1ull);
+            if (a.timeline) {
+                // HW_ID (wave, SIMD, CU, shader array, shader engine) and XCC_ID of the CU this wave ran on
+                const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+                unsigned long long *rec = a.timeline + (size_t)(gtid >> 6) * 4;
+                rec[0] = tk_start; rec[1] = tk_exh; rec[2] = tk_end; rec[3] = (unsigned long long)hw | ((unsigned long long)xcc << 32);
+            }
         }
         if (n_over) atomicAdd(&a.ctr->stack_overflow, n_over);
         if (gtid == 0 && !a.no_ray_count) {
@@ -978,6 +989,18 @@ __global__ __launch_bounds__(TR_BLOCK, TRQ_MIN_WAVES) void k_trace_q(TraceArgs a
     }
 }
 
+// diagnostics: option "trace_timeline" = k >= 0 arms the k-th counting launch from now on; it writes [start, queue empty, end, hw id] per wave
+static unsigned long long *timeline_for(tirt_ctx *c, int flags, int grid)
+{
+    if (c->timeline_arm < 0 || !(flags & TIRT_COUNT_NODES)) return nullptr;
+    if (c->timeline_arm-- != 0) return nullptr;
+    c->timeline_waves = grid * (TR_BLOCK / 64);
+    if (c->timeline.ensure(sizeof(unsigned long long) * 4 * (size_t)c->timeline_waves)) { c->timeline_waves = 0; return nullptr; }
+    hipMemsetAsync(c->timeline.p, 0, sizeof(unsigned long long) * 4 * (size_t)c->timeline_waves, c->stream);
+    hipStreamSynchronize(c->stream);
+    return c->timeline.as<unsigned long long>();
+}
+
 template <int MODE, bool COUNT, int KIND>
 static int launch_trace_as(tirt_ctx *c, hipStream_t stream, const TraceArgs &a, dim3 g, dim3 b, size_t lds)
 {
@@ -1093,6 +1116,7 @@ int launch_trace_batch(tirt_ctx *c, const float *rays, int nr, int stack_size, i
     a.fetch = c->counters_mem.as<int>();
     fill_tunables(c, a);
     int grid = (nr + TR_BLOCK - 1) / TR_BLOCK; if (grid > c->tr_grid) grid = c->tr_grid;
+    a.timeline = timeline_for(c, flags, grid);
     if (int rc = launch_trace<KIND_CLOSEST>(c, st, a, flags, grid)) return rc;
     hipLaunchKernelGGL(k_hit_attr, dim3((nr + B - 1) / B), dim3(B), 0, st, scene_view(c), nr, ox, oy, oz, dx, dy, dz, hit, attr, ht,
                        c->tr_prim.as<int>());
@@ -1718,6 +1742,7 @@ int pt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed,
             if (spec) { a.scw = L.ps.scw; a.rw = (float *)in.flags; a.fw = L.ps.fw; }
             a.scount_ptr = (b == 0) ? nullptr : cnt_shadow(b - 1);
             fill_tunables(c, a);
+            a.timeline = timeline_for(c, flags, grid_full);
             stamp(evc, true);
             if (int rc = (b == 0) ? launch_trace<KIND_CLOSEST>(c, st, a, flags, grid_full) : launch_trace<KIND_MIXED>(c, st, a, flags, grid_full)) return rc;
             stamp(evc, false);
