@@ -178,6 +178,12 @@ def measure_trace_counters(args):
         out["clock_GHz_profiled"] = round(cyc / tot["dur_ns"], 3)
         out["lds_bank_conflict_frac_of_lds_cycles"] = round(tot.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(tot.get("SQ_LDS_IDX_ACTIVE", 0.0), 1.0), 4)
         out["lds_bank_conflict_cycles_frac_of_kernel"] = round(tot.get("SQ_LDS_BANK_CONFLICT", 0.0) / (cyc * 256.0), 4)   # LDS is per CU
+        # every kernel of the wavefront loop, both profiled steps: what one step asks of the VALUs (for `whole_job` in the roofline object)
+        per = {}
+        for name, v in k.items():
+            if name.startswith(("k_trace", "k_shade", "k_generate", "k_film")) and v.get("SQ_INSTS_VALU", 0) > 0:
+                per[name] = round(v["SQ_INSTS_VALU"] / 2.0)
+        out["valu_wave_insts_per_step_by_kernel"] = per
     if tot.get("TCP_TCC_READ_REQ_sum", 0) > 0:
         out["l2_hit_rate"] = round(tot["TCC_HIT_sum"] / max(tot["TCC_HIT_sum"] + tot["TCC_MISS_sum"], 1.0), 4)
         film = k.get("k_film")
@@ -635,6 +641,21 @@ def main():
                         "ta_busy": pmc.get("ta_busy"), "lds_bank_conflict_frac_of_lds_cycles": pmc.get("lds_bank_conflict_frac_of_lds_cycles"),
                         "lds_bank_conflict_cycles_frac_of_kernel": pmc.get("lds_bank_conflict_cycles_frac_of_kernel")}
                 fr["valu"] = valu["issue_busy"]
+                per = pmc.get("valu_wave_insts_per_step_by_kernel") or {}
+                if per and pmc.get("clock_GHz_profiled"):
+                    # The timed region runs several batches at once (traversal of one beside the shading of another): is the WHOLE JOB
+                    # bound by VALU issue?  All VALU wave-instructions a step needs (profiler pass, every kernel of the loop) x the measured
+                    # cycles per instruction / (1024 SIMDs x the clock measured in that pass) = the time the VALUs need for a step if they
+                    # never idle, against the step time of the timed region.
+                    need_ms = sum(per.values()) * pmc["valu_cycles_per_inst"] / (1024.0 * pmc["clock_GHz_profiled"] * 1e9) * 1e3
+                    valu["whole_job"] = {"valu_wave_insts_per_step": int(sum(per.values())), "by_kernel": per,
+                                         "valu_issue_ms_per_step": round(need_ms, 3), "ms_per_step_timed": round(result["ms_per_step"], 3),
+                                         "issue_busy": round(need_ms / result["ms_per_step"], 4),
+                                         # (the clock of the timed region itself is not measured: at the 2.4 GHz peak clock the same instructions need less time)
+                                         "clock_GHz_profiled": pmc["clock_GHz_profiled"],
+                                         "issue_busy_if_timed_region_ran_at_2.4_GHz": round(need_ms * pmc["clock_GHz_profiled"] / 2.4 / result["ms_per_step"], 4),
+                                         "def": "sum over the loop's kernels of SQ_INSTS_VALU per step x measured cycles per instruction / (1024 SIMDs x "
+                                                "measured clock), divided by the timed ms_per_step (batches overlapped)"}
         known = {k: v for k, v in fr.items() if v is not None}
         bound = max(known, key=known.get) if known else "valu"
         if bound == "valu" and valu:
