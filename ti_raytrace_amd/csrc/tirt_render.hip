@@ -93,6 +93,14 @@ TD unsigned long long wave_sum(unsigned long long v)
 #ifndef TR_MIN_WAVES
 #define TR_MIN_WAVES 6        // 80 VGPRs: five 256-thread blocks per CU and room for a shading wave per SIMD (tirt_internal.h, TR_TOP_CAP)
 #endif
+// The arguments a ray only needs when it is fetched, written back or paged (40 pointers, the grid constants) are NOT read from the by-value
+// argument: held in SGPRs across the whole walk they overflow the scalar register file, and the compiler parks them in VGPR lanes --
+// v_writelane / v_readlane, VALU instructions, ~245 of them per refill of a kernel that is bound by VALU issue.  They are read from the
+// kernel-argument segment where they are needed instead (scalar loads: no VALU), through a pointer the optimiser cannot see through, so
+// that it can neither hoist the loads out of the persistent loop nor keep their results alive across it.
+typedef const __attribute__((address_space(4))) TraceArgs *cold_args_t;
+#define TR_COLD(ca) cold_args_t ca = (cold_args_t)__builtin_amdgcn_kernarg_segment_ptr(); asm volatile("" : "+s"(ca))
+
 template <int MODE, bool COUNT, int KIND>
 __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
 {
@@ -171,9 +179,10 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
     }
 #define TR_PAGE_OUT()                                                                                \
     do {                                                                                             \
-        if ((paged + 1) * TR_PAGE <= a.spill_depth) {                                                \
+        TR_COLD(ca);                                                                                 \
+        if ((paged + 1) * TR_PAGE <= ca->spill_depth) {                                                \
             for (int k__ = 0; k__ < TR_PAGE; k__++)                                                  \
-                a.spill[(size_t)(paged * TR_PAGE + k__) * gstride + gtid] = LDS_AT(sa_bottom + (unsigned)(k__ + 1) * ENTRY); \
+                ca->spill[(size_t)(paged * TR_PAGE + k__) * gstride + gtid] = LDS_AT(sa_bottom + (unsigned)(k__ + 1) * ENTRY); \
             for (unsigned e__ = sa_bottom + (TR_PAGE + 1) * ENTRY; e__ <= sa; e__ += ENTRY)          \
                 LDS_AT(e__ - TR_PAGE * ENTRY) = LDS_AT(e__);                                         \
             sa -= TR_PAGE * ENTRY; paged++;                                                          \
@@ -181,9 +190,10 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
     } while (0)
 #define TR_PAGE_IN()                                                                                 \
     do {                                                                                             \
+        TR_COLD(ca);                                                                                 \
         paged--;                                                                                     \
         for (int k__ = 0; k__ < TR_PAGE; k__++)                                                      \
-            LDS_AT(sa_bottom + (unsigned)(k__ + 1) * ENTRY) = a.spill[(size_t)(paged * TR_PAGE + k__) * gstride + gtid]; \
+            LDS_AT(sa_bottom + (unsigned)(k__ + 1) * ENTRY) = ca->spill[(size_t)(paged * TR_PAGE + k__) * gstride + gtid]; \
         sa = sa_bottom + TR_PAGE * ENTRY;                                                            \
     } while (0)
 #define TR_POP(dst) do { dst = LDS_AT(sa); sa -= ENTRY; } while (0)
@@ -192,6 +202,24 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
         // ---- refill idle lanes -------------------------------------------------------------
         const unsigned long long idle = ballot64(!have);
         if (idle != 0ull && !exhausted && (__popcll(idle) >= a.refill_min || idle == ~0ull)) {
+            TR_COLD(ca);
+            // (all of them read here, in one batch of scalar loads with one wait: left to itself the compiler loads each where it is used,
+            // a chain of a dozen dependent round trips per refill)
+            int *const c_fetch = ca->fetch;
+            const float *const c_ox = ca->ox, *const c_oy = ca->oy, *const c_oz = ca->oz, *const c_dx = ca->dx, *const c_dy = ca->dy, *const c_dz = ca->dz;
+            const float *const c_sox = MAY_SHADOW ? ca->sox : nullptr, *const c_soy = MAY_SHADOW ? ca->soy : nullptr, *const c_soz = MAY_SHADOW ? ca->soz : nullptr;
+            const float *const c_sdx = MAY_SHADOW ? ca->sdx : nullptr, *const c_sdy = MAY_SHADOW ? ca->sdy : nullptr, *const c_sdz = MAY_SHADOW ? ca->sdz : nullptr;
+            const int *const c_sprim = MAY_SHADOW ? ca->sprim : nullptr; const float *const c_sdist = MAY_SHADOW ? ca->sdist : nullptr;
+            const float c_gm0 = ca->bvh.grid_min[0], c_gm1 = ca->bvh.grid_min[1], c_gm2 = ca->bvh.grid_min[2];
+            const float c_ie0 = ca->bvh.inv_extent[0], c_ie1 = ca->bvh.inv_extent[1], c_ie2 = ca->bvh.inv_extent[2];
+            const float c_ic0 = ca->bvh.inv_cell[0], c_ic1 = ca->bvh.inv_cell[1], c_ic2 = ca->bvh.inv_cell[2];
+            const float c_ce0 = ca->bvh.cell[0], c_ce1 = ca->bvh.cell[1], c_ce2 = ca->bvh.cell[2];
+            const float c_rn0 = ca->bvh.root_min[0], c_rn1 = ca->bvh.root_min[1], c_rn2 = ca->bvh.root_min[2];
+            const float c_rx0 = ca->bvh.root_max[0], c_rx1 = ca->bvh.root_max[1], c_rx2 = ca->bvh.root_max[2];
+            const int c_root = ca->bvh.root_code, c_rootq = ca->bvh.root_qcode, c_farq = ca->bvh.far_qcode;
+            asm volatile("" :: "s"(c_fetch), "s"(c_ox), "s"(c_oy), "s"(c_oz), "s"(c_dx), "s"(c_dy), "s"(c_dz), "s"(c_gm0), "s"(c_gm1), "s"(c_gm2), "s"(c_ie0), "s"(c_ie1), "s"(c_ie2),
+                         "s"(c_ic0), "s"(c_ic1), "s"(c_ic2), "s"(c_ce0), "s"(c_ce1), "s"(c_ce2), "s"(c_rn0), "s"(c_rn1), "s"(c_rn2), "s"(c_rx0), "s"(c_rx1), "s"(c_rx2));
+            if (MAY_SHADOW) asm volatile("" :: "s"(c_sox), "s"(c_soy), "s"(c_soz), "s"(c_sdx), "s"(c_sdy), "s"(c_sdz), "s"(c_sprim), "s"(c_sdist));
             const int n_idle = __popcll(idle);
             if (COUNT) d_refills++;
             const int leader = __ffsll((long long)idle) - 1;
@@ -199,7 +227,7 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
             const int len = (((full_chunks >> S_LOG) + (home < (full_chunks & S_MASK) ? 1 : 0)) << 6) +
                             (home == (full_chunks & S_MASK) ? (count & 63) : 0);
             int base = 0;
-            if (lane == leader) base = atomicAdd(a.fetch + home * TR_FETCH_STRIDE, n_idle);
+            if (lane == leader) base = atomicAdd(c_fetch + home * TR_FETCH_STRIDE, n_idle);
             base = __shfl(base, leader, 64);
             const int v = base + __popcll(idle & lt_mask);                // index within the slice
             const int my = v < len ? (((((v >> 6) << S_LOG) + home) << 6) | (v & 63)) : count;
@@ -211,9 +239,9 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
                 q = my;
                 if (KIND == KIND_MIXED) { is_sh = my >= count_c; if (is_sh) q = my - count_c; }
                 const bool mixed_sh = (KIND == KIND_MIXED) && is_sh;
-                const v3 o = mixed_sh ? V(a.sox[q], a.soy[q], a.soz[q])
-                                      : ((KIND == KIND_CLOSEST && a.ox == nullptr) ? V(a.eye[0], a.eye[1], a.eye[2]) : V(a.ox[q], a.oy[q], a.oz[q]));
-                const v3 d = mixed_sh ? V(a.sdx[q], a.sdy[q], a.sdz[q]) : V(a.dx[q], a.dy[q], a.dz[q]);
+                const v3 o = mixed_sh ? V(c_sox[q], c_soy[q], c_soz[q])
+                                      : ((KIND == KIND_CLOSEST && c_ox == nullptr) ? V(ca->eye[0], ca->eye[1], ca->eye[2]) : V(c_ox[q], c_oy[q], c_oz[q]));
+                const v3 d = mixed_sh ? V(c_sdx[q], c_sdy[q], c_sdz[q]) : V(c_dx[q], c_dy[q], c_dz[q]);
                 r = make_ray(o, d);
                 par = ray_has_parallel_axis(r);
                 hit_t = INF_VALUE; hit_u = 0.0f; hit_v = 0.0f; hit_prim = -1; hit_leaf = -1;
@@ -221,16 +249,16 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
                 cull_far = 3.0e38f; settle = -1.0f; expect = -3;
                 float t_bound = -1.0f;
                 if (MAY_SHADOW && is_sh) {
-                    expect = a.sprim[q];
-                    if (BOUNDED) t_bound = a.sdist[q];
+                    expect = c_sprim[q];
+                    if (BOUNDED) t_bound = c_sdist[q];
                 }
                 if (MODE != TIRT_TRAVERSE_EXHAUSTIVE) {
                     // margin in cells, the same on all axes: 0.25 + 0.25 per root-box extent between the origin and the
                     // grid (largest axis).  It has to cover (i) the rounding of q * gA + gB (<= 0.016 cells per extent of
                     // distance) and (ii) what the reference's primitive tests accept outside a leaf box: Moller-Trumbore
                     // works on o - v0 and is off by ~5e-7 of the origin's distance IN EVERY DIRECTION (0.03 cells per extent)
-                    const float relx__ = b.grid_min[0] - o.x, rely__ = b.grid_min[1] - o.y, relz__ = b.grid_min[2] - o.z;
-                    const float rho__ = maxf(maxf(absf(relx__) * b.inv_extent[0], absf(rely__) * b.inv_extent[1]), absf(relz__) * b.inv_extent[2]);
+                    const float relx__ = c_gm0 - o.x, rely__ = c_gm1 - o.y, relz__ = c_gm2 - o.z;
+                    const float rho__ = maxf(maxf(absf(relx__) * c_ie0, absf(rely__) * c_ie1), absf(relz__) * c_ie2);
                     const float mc__ = 0.25f + 0.25f * rho__;
                     // From far away the reference's Moller-Trumbore returns distances that are rounding noise (its o - v0 carries
                     // |o - v0| * 2^-24, divided by a determinant of the order of the triangle's area): a small or edge-on triangle
@@ -242,10 +270,10 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
 #define TR_GRID_AXIS(rel, dd, idd, k, gA, gBn, gBf, grot)                                            \
                     do {                                                                             \
                         if (absf(dd) < 0.000001f) {      /* the reference's parallel case: origin inside the slab or no hit */ \
-                            const float og__ = -(rel) * b.inv_cell[k];                               \
+                            const float og__ = -(rel) * (k == 0 ? c_ic0 : (k == 1 ? c_ic1 : c_ic2));                               \
                             gA = 1.0e30f; gBn = (-og__ - (mc__ + 1.0f)) * 1.0e30f; gBf = (-og__ + (mc__ + 1.0f)) * 1.0e30f; grot = 0; \
                         } else {                                                                     \
-                            gA = b.cell[k] * (idd);                                                  \
+                            gA = (k == 0 ? c_ce0 : (k == 1 ? c_ce1 : c_ce2)) * (idd);                                                  \
                             const float gB__ = (rel) * (idd);                                        \
                             const float m__ = mc__ * absf(gA);                                       \
                             gBn = gB__ - m__; gBf = gB__ + m__; grot = gA < 0.0f ? 16 : 0;           \
@@ -259,10 +287,10 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
                 lim = __builtin_fminf(__builtin_fminf(hit_t * 1.0001f, __builtin_fabsf(cull_far)), INF_VALUE);      // (v_min: a canonical value, so the node loop does not re-canonicalise it every step)
                 // (a far-origin ray cannot trust the padded boxes of the analytic spheres: it starts at a chain node that holds the root and
                 // those spheres with whole-grid boxes, BvhView::far_qcode, and so tests them whatever their boxes say -- as the reference does)
-                cur = (MODE == TIRT_TRAVERSE_EXHAUSTIVE) ? b.root_code : (cull_far < 0.0f ? b.far_qcode : b.root_qcode);
+                cur = (MODE == TIRT_TRAVERSE_EXHAUSTIVE) ? c_root : (cull_far < 0.0f ? c_farq : c_rootq);
                 if (cur >= 0) {
                     float tn;
-                    if (!slabs(r, b.root_min[0], b.root_min[1], b.root_min[2], b.root_max[0], b.root_max[1], b.root_max[2], tn)) cur = TR_SENT;
+                    if (!slabs(r, c_rn0, c_rn1, c_rn2, c_rx0, c_rx1, c_rx2, tn)) cur = TR_SENT;
                 }
                 // A ray with a NaN component passes every `slabs` test (all comparisons are false)
                 // and fails every primitive test, in the reference as well: it walks the whole tree
@@ -465,50 +493,59 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
 
         // ---- finished rays write back and free their lane ---------------------------------------
         if (have && cur == TR_SENT && pend == 0) {
+            TR_COLD(ca);
+            float4 *const c_hit = ca->hit;
+            const int *const c_sdst = MAY_SHADOW ? ca->sdst : nullptr;
+            float *const c_rr = MAY_SHADOW ? ca->rr : nullptr, *const c_rg = MAY_SHADOW ? ca->rg : nullptr, *const c_rb = MAY_SHADOW ? ca->rb : nullptr;
+            float *const c_fr = MAY_SHADOW ? ca->fr : nullptr, *const c_fg = MAY_SHADOW ? ca->fg : nullptr, *const c_fb = MAY_SHADOW ? ca->fb : nullptr;
+            const float *const c_scr = MAY_SHADOW ? ca->scr : nullptr, *const c_scg = MAY_SHADOW ? ca->scg : nullptr, *const c_scb = MAY_SHADOW ? ca->scb : nullptr;
+            const float *const c_scw = MAY_SHADOW ? ca->scw : nullptr;
+            if (MAY_SHADOW) asm volatile("" :: "s"(c_hit), "s"(c_sdst), "s"(c_rr), "s"(c_rg), "s"(c_rb), "s"(c_fr), "s"(c_fg), "s"(c_fb), "s"(c_scr), "s"(c_scg), "s"(c_scb), "s"(c_scw));      // one batch of scalar loads (as in the refill)
             if (!(MAY_SHADOW && is_sh) || KIND == KIND_QUERY) {
-                a.hit[q] = make_float4(hit_t, hit_u, hit_v, __int_as_float(hit_prim));
+                c_hit[q] = make_float4(hit_t, hit_u, hit_v, __int_as_float(hit_prim));
             } else if (hit_prim == expect) {                 // integrator/PT_RGB.py:105-109
-                const int dst = a.sdst[q];
-                float *pr = dst >= 0 ? a.rr + dst : a.fr + ~dst;
-                float *pg = dst >= 0 ? a.rg + dst : a.fg + ~dst;
-                float *pb = dst >= 0 ? a.rb + dst : a.fb + ~dst;
-                *pr = *pr + a.scr[q]; *pg = *pg + a.scg[q]; *pb = *pb + a.scb[q];
-                if (a.scw) { float *pw = dst >= 0 ? a.rw + dst : a.fw + ~dst; *pw = *pw + a.scw[q]; }
+                const int dst = c_sdst[q];
+                float *pr = dst >= 0 ? c_rr + dst : c_fr + ~dst;
+                float *pg = dst >= 0 ? c_rg + dst : c_fg + ~dst;
+                float *pb = dst >= 0 ? c_rb + dst : c_fb + ~dst;
+                *pr = *pr + c_scr[q]; *pg = *pg + c_scg[q]; *pb = *pb + c_scb[q];
+                if (c_scw) { float *pw = dst >= 0 ? ca->rw + dst : ca->fw + ~dst; *pw = *pw + c_scw[q]; }
             }
             if (COUNT) {
                 if (MAY_SHADOW && is_sh) { sum_box_s += nbox; sum_leaf_s += nleaf; }
                 else { sum_box += nbox; sum_leaf += nleaf; }
-                if (a.per_ray_counts) a.per_ray_counts[q] = make_int2((int)nbox, (int)nleaf);
+                if (ca->per_ray_counts) ca->per_ray_counts[q] = make_int2((int)nbox, (int)nleaf);
             }
             if (n_overflow) n_over++;
             have = false; sa = sa_bottom;
         }
     }
-    if (a.ctr) {
+    TR_COLD(ca);
+    if (ca->ctr) {
         if (COUNT) {
             sum_box = wave_sum(sum_box); sum_leaf = wave_sum(sum_leaf);
             sum_box_s = wave_sum(sum_box_s); sum_leaf_s = wave_sum(sum_leaf_s);
-            if (lane == 0 && (sum_box | sum_leaf)) { atomicAdd(&a.ctr->box_closest, sum_box); atomicAdd(&a.ctr->leaf_closest, sum_leaf); }
-            if (lane == 0 && (sum_box_s | sum_leaf_s)) { atomicAdd(&a.ctr->box_shadow, sum_box_s); atomicAdd(&a.ctr->leaf_shadow, sum_leaf_s); }
+            if (lane == 0 && (sum_box | sum_leaf)) { atomicAdd(&ca->ctr->box_closest, sum_box); atomicAdd(&ca->ctr->leaf_closest, sum_leaf); }
+            if (lane == 0 && (sum_box_s | sum_leaf_s)) { atomicAdd(&ca->ctr->box_shadow, sum_box_s); atomicAdd(&ca->ctr->leaf_shadow, sum_leaf_s); }
         }
-        if (COUNT) { d_outer = wave_sum(d_outer); if (lane == 0) atomicAdd(&a.ctr->it_outer, d_outer); }   // lane-visits of LDS-resident (top) nodes
+        if (COUNT) { d_outer = wave_sum(d_outer); if (lane == 0) atomicAdd(&ca->ctr->it_outer, d_outer); }   // lane-visits of LDS-resident (top) nodes
         if (COUNT && lane == 0) {
-            atomicAdd(&a.ctr->it_node, d_it_node); atomicAdd(&a.ctr->lanes_node, d_lanes_node);
-            atomicAdd(&a.ctr->it_leaf, d_it_leaf); atomicAdd(&a.ctr->lanes_leaf, d_lanes_leaf);
-            atomicAdd(&a.ctr->refills, d_refills);
+            atomicAdd(&ca->ctr->it_node, d_it_node); atomicAdd(&ca->ctr->lanes_node, d_lanes_node);
+            atomicAdd(&ca->ctr->it_leaf, d_it_leaf); atomicAdd(&ca->ctr->lanes_leaf, d_lanes_leaf);
+            atomicAdd(&ca->ctr->refills, d_refills);
             const unsigned long long tk_end = wall_clock64();
-            atomicAdd(&a.ctr->wave_ticks, tk_end - tk_start); atomicAdd(&a.ctr->drain_ticks, tk_end - (tk_exh ? tk_exh : tk_end)); atomicAdd(&a.ctr->waves, 1ull);
-            if (a.timeline) {
+            atomicAdd(&ca->ctr->wave_ticks, tk_end - tk_start); atomicAdd(&ca->ctr->drain_ticks, tk_end - (tk_exh ? tk_exh : tk_end)); atomicAdd(&ca->ctr->waves, 1ull);
+            if (ca->timeline) {
                 // HW_ID (wave, SIMD, CU, shader array, shader engine) and XCC_ID of the CU this wave ran on
                 const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
-                unsigned long long *rec = a.timeline + (size_t)(gtid >> 6) * 4;
+                unsigned long long *rec = ca->timeline + (size_t)(gtid >> 6) * 4;
                 rec[0] = tk_start; rec[1] = tk_exh; rec[2] = tk_end; rec[3] = (unsigned long long)hw | ((unsigned long long)xcc << 32);
             }
         }
-        if (n_over) atomicAdd(&a.ctr->stack_overflow, n_over);
-        if (gtid == 0 && !a.no_ray_count) {
-            if (count_c) atomicAdd(&a.ctr->rays_closest, (unsigned long long)count_c);
-            if (count_s) atomicAdd(&a.ctr->rays_shadow, (unsigned long long)count_s);
+        if (n_over) atomicAdd(&ca->ctr->stack_overflow, n_over);
+        if (gtid == 0 && !ca->no_ray_count) {
+            if (count_c) atomicAdd(&ca->ctr->rays_closest, (unsigned long long)count_c);
+            if (count_s) atomicAdd(&ca->ctr->rays_shadow, (unsigned long long)count_s);
         }
     }
 }
