@@ -1233,7 +1233,14 @@ __global__ void k_generate(PathSoA ps, CameraView cam, TileMap tm, int P, int S,
 #ifndef SH_MIN_WAVES
 #define SH_MIN_WAVES 5
 #endif
-__global__ __launch_bounds__(SH_BLOCK, SH_MIN_WAVES) void k_shade(PathState ps, PathSoA in, PathSoA out, SceneView sc, TileMap tm, int P,
+// The 78 array pointers of the path state are the first kernel argument and are never read from it directly: each of the three places
+// that needs some of them (a path's state in, the survivor's state out, the shadow ray out) reads those from the kernel-argument segment in
+// one batch of scalar loads -- as k_trace does (TR_COLD), and for the same reason: kept in SGPRs across the loop they overflow the scalar
+// register file and come back through v_readlane, 700 VALU instructions of the 4 476 in this kernel.
+struct ShadeArgs { PathState ps; PathSoA in, out; };
+typedef const __attribute__((address_space(4))) ShadeArgs *cold_shade_t;
+#define SH_COLD(ca) cold_shade_t ca = (cold_shade_t)__builtin_amdgcn_kernarg_segment_ptr(); asm volatile("" : "+s"(ca))
+__global__ __launch_bounds__(SH_BLOCK, SH_MIN_WAVES) void k_shade(ShadeArgs paths_in_kernarg_segment, SceneView sc, TileMap tm, int P,
                                                    uint32_t frame_begin, uint32_t seed, int bounce, int last_bounce,
                                                    const int *count_ptr, int count_fixed, unsigned long long *append_ctr,
                                                    DevCounters *ctr, v3 eye)
@@ -1255,19 +1262,26 @@ __global__ __launch_bounds__(SH_BLOCK, SH_MIN_WAVES) void k_shade(PathState ps, 
         float next_pdf = 0.0f, sh_dist = 0.0f; int next_spec = 0, sh_expect = -2;
         if (live) {
             const bool first = bounce == 0;          // camera rays: constant state, see k_generate
-            slot = first ? q : in.slot[q];
+            SH_COLD(ca);
+            const int *const c_slot = ca->in.slot; const uint32_t *const c_flags = ca->in.flags; const float4 *const c_hit = ca->ps.hit;
+            const float *const c_ox = ca->in.ox, *const c_oy = ca->in.oy, *const c_oz = ca->in.oz, *const c_dx = ca->in.dx, *const c_dy = ca->in.dy, *const c_dz = ca->in.dz;
+            const float *const c_tr = ca->in.tr, *const c_tg = ca->in.tg, *const c_tb = ca->in.tb, *const c_rr = ca->in.rr, *const c_rg = ca->in.rg, *const c_rb = ca->in.rb;
+            const float *const c_pdf = ca->in.brdf_pdf;
+            asm volatile("" :: "s"(c_slot), "s"(c_flags), "s"(c_hit), "s"(c_ox), "s"(c_oy), "s"(c_oz), "s"(c_dx), "s"(c_dy), "s"(c_dz), "s"(c_tr), "s"(c_tg), "s"(c_tb),
+                         "s"(c_rr), "s"(c_rg), "s"(c_rb), "s"(c_pdf));
+            slot = first ? q : c_slot[q];
             const int f = slot / P, k = slot - f * P;
             const uint32_t pixel = (uint32_t)local_to_pixel(tm, k);
             const uint32_t frame = frame_begin + (uint32_t)f;
             const uint32_t dim0 = TM_DIM_BOUNCE0 + TM_DIMS_PER_BOUNCE * (uint32_t)bounce;
-            const v3 origin = first ? eye : V(in.ox[q], in.oy[q], in.oz[q]);
-            const v3 direction = V(in.dx[q], in.dy[q], in.dz[q]);
-            const float4 hrec = ps.hit[q];
+            const v3 origin = first ? eye : V(c_ox[q], c_oy[q], c_oz[q]);
+            const v3 direction = V(c_dx[q], c_dy[q], c_dz[q]);
+            const float4 hrec = c_hit[q];
             const float t = hrec.x;
-            v3 throughout = first ? V(1.0f, 1.0f, 1.0f) : V(in.tr[q], in.tg[q], in.tb[q]);
-            radiance = first ? V(0.0f, 0.0f, 0.0f) : V(in.rr[q], in.rg[q], in.rb[q]);
-            float brdf_pdf = first ? 1.0f : in.brdf_pdf[q];
-            int perfect_spec = first ? 1 : (int)(in.flags[q] & 1u);
+            v3 throughout = first ? V(1.0f, 1.0f, 1.0f) : V(c_tr[q], c_tg[q], c_tb[q]);
+            radiance = first ? V(0.0f, 0.0f, 0.0f) : V(c_rr[q], c_rg[q], c_rb[q]);
+            float brdf_pdf = first ? 1.0f : c_pdf[q];
+            int perfect_spec = first ? 1 : (int)(c_flags[q] & 1u);
             if (t < INF_VALUE) {
                 const int prim_id = __float_as_int(hrec.w);
                 int mat_id;
@@ -1396,20 +1410,34 @@ __global__ __launch_bounds__(SH_BLOCK, SH_MIN_WAVES) void k_shade(PathState ps, 
         const int qn = (int)(unsigned)(bb & 0xffffffffull) + (int)pn + __popcll(nmask & lt_mask);
         const int qs = (int)(unsigned)(bb >> 32) + (int)psd + __popcll(smask & lt_mask);
         if (want_next) {
-            out.ox[qn] = next_o.x; out.oy[qn] = next_o.y; out.oz[qn] = next_o.z;
-            out.dx[qn] = next_d.x; out.dy[qn] = next_d.y; out.dz[qn] = next_d.z;
-            out.tr[qn] = next_thr.x; out.tg[qn] = next_thr.y; out.tb[qn] = next_thr.z;
-            out.rr[qn] = radiance.x; out.rg[qn] = radiance.y; out.rb[qn] = radiance.z;
-            out.brdf_pdf[qn] = next_pdf; out.flags[qn] = (uint32_t)next_spec; out.slot[qn] = slot;
+            SH_COLD(ca);
+            float *const o_ox = ca->out.ox, *const o_oy = ca->out.oy, *const o_oz = ca->out.oz, *const o_dx = ca->out.dx, *const o_dy = ca->out.dy, *const o_dz = ca->out.dz;
+            float *const o_tr = ca->out.tr, *const o_tg = ca->out.tg, *const o_tb = ca->out.tb, *const o_rr = ca->out.rr, *const o_rg = ca->out.rg, *const o_rb = ca->out.rb;
+            float *const o_pdf = ca->out.brdf_pdf; uint32_t *const o_flags = ca->out.flags; int *const o_slot = ca->out.slot;
+            asm volatile("" :: "s"(o_ox), "s"(o_oy), "s"(o_oz), "s"(o_dx), "s"(o_dy), "s"(o_dz), "s"(o_tr), "s"(o_tg), "s"(o_tb), "s"(o_rr), "s"(o_rg), "s"(o_rb),
+                         "s"(o_pdf), "s"(o_flags), "s"(o_slot));
+            o_ox[qn] = next_o.x; o_oy[qn] = next_o.y; o_oz[qn] = next_o.z;
+            o_dx[qn] = next_d.x; o_dy[qn] = next_d.y; o_dz[qn] = next_d.z;
+            o_tr[qn] = next_thr.x; o_tg[qn] = next_thr.y; o_tb[qn] = next_thr.z;
+            o_rr[qn] = radiance.x; o_rg[qn] = radiance.y; o_rb[qn] = radiance.z;
+            o_pdf[qn] = next_pdf; o_flags[qn] = (uint32_t)next_spec; o_slot[qn] = slot;
         } else if (live) {
-            ps.fr[slot] = radiance.x; ps.fg[slot] = radiance.y; ps.fb[slot] = radiance.z;
+            SH_COLD(ca);
+            float *const f_r = ca->ps.fr, *const f_g = ca->ps.fg, *const f_b = ca->ps.fb;
+            asm volatile("" :: "s"(f_r), "s"(f_g), "s"(f_b));
+            f_r[slot] = radiance.x; f_g[slot] = radiance.y; f_b[slot] = radiance.z;
         }
         if (want_shadow) {
-            ps.sox[qs] = sh_o.x; ps.soy[qs] = sh_o.y; ps.soz[qs] = sh_o.z;
-            ps.sdx[qs] = sh_d.x; ps.sdy[qs] = sh_d.y; ps.sdz[qs] = sh_d.z;
-            ps.scr[qs] = sh_c.x; ps.scg[qs] = sh_c.y; ps.scb[qs] = sh_c.z;
-            ps.sprim[qs] = sh_expect; ps.sdist[qs] = sh_dist;
-            ps.sdst[qs] = want_next ? qn : ~slot;
+            SH_COLD(ca);
+            float *const s_ox = ca->ps.sox, *const s_oy = ca->ps.soy, *const s_oz = ca->ps.soz, *const s_dx = ca->ps.sdx, *const s_dy = ca->ps.sdy, *const s_dz = ca->ps.sdz;
+            float *const s_cr = ca->ps.scr, *const s_cg = ca->ps.scg, *const s_cb = ca->ps.scb, *const s_dist = ca->ps.sdist;
+            int *const s_prim = ca->ps.sprim, *const s_dst = ca->ps.sdst;
+            asm volatile("" :: "s"(s_ox), "s"(s_oy), "s"(s_oz), "s"(s_dx), "s"(s_dy), "s"(s_dz), "s"(s_cr), "s"(s_cg), "s"(s_cb), "s"(s_dist), "s"(s_prim), "s"(s_dst));
+            s_ox[qs] = sh_o.x; s_oy[qs] = sh_o.y; s_oz[qs] = sh_o.z;
+            s_dx[qs] = sh_d.x; s_dy[qs] = sh_d.y; s_dz[qs] = sh_d.z;
+            s_cr[qs] = sh_c.x; s_cg[qs] = sh_c.y; s_cb[qs] = sh_c.z;
+            s_prim[qs] = sh_expect; s_dist[qs] = sh_dist;
+            s_dst[qs] = want_next ? qn : ~slot;
         }
     }
     // statistics: one global atomic per block (through LDS), not per wave -- same-address atomics retire at ~11 ns
@@ -1791,7 +1819,7 @@ int pt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed,
                                    (b == max_depth - 1) ? 1 : 0, (b == 0) ? (const int *)nullptr : cnt_path(b), S,
                                    append_ctr(b), ctr, eye_v, L.ps.scw, L.ps.fw);
             else
-            hipLaunchKernelGGL(k_shade, dim3(grid_shade), dim3(SH_BLOCK), 0, st, L.ps, in, out, sv, tm, P, f0, seed, b,
+            hipLaunchKernelGGL(k_shade, dim3(grid_shade), dim3(SH_BLOCK), 0, st, ShadeArgs{L.ps, in, out}, sv, tm, P, f0, seed, b,
                                (b == max_depth - 1) ? 1 : 0, (b == 0) ? (const int *)nullptr : cnt_path(b), S,
                                append_ctr(b), ctr, eye_v);
             stamp(evh, false);
