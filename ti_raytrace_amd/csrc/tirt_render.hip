@@ -288,7 +288,11 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
                 // (a far-origin ray cannot trust the padded boxes of the analytic spheres: it starts at a chain node that holds the root and
                 // those spheres with whole-grid boxes, BvhView::far_qcode, and so tests them whatever their boxes say -- as the reference does)
                 cur = (MODE == TIRT_TRAVERSE_EXHAUSTIVE) ? c_root : (cull_far < 0.0f ? c_farq : c_rootq);
-                if (cur >= 0) {
+                // The reference's first step: the root box.  The ordered walk only needs it as a shortcut -- a candidate is accepted after the boxes
+                // of ALL its ancestors, the root's included, have been seen to pass `slabs` (leaf phase) --, and it is a shortcut for rays that
+                // start outside the scene (camera rays: KIND_CLOSEST).  Bounce and shadow rays start on a surface inside the root box and pass it:
+                // for them the test (~30 instructions per refill, at a fifth of the lanes) is skipped and the rare outsider spends one node step instead.
+                if ((MODE == TIRT_TRAVERSE_EXHAUSTIVE || KIND == KIND_CLOSEST) && cur >= 0) {
                     float tn;
                     if (!slabs(r, c_rn0, c_rn1, c_rn2, c_rx0, c_rx1, c_rx2, tn)) cur = TR_SENT;
                 }
