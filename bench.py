@@ -283,6 +283,25 @@ def run_config(name, device_id, seed=1):
         r["oracle_sample"] = "whole 48x48 film x 4 spp: rel-L2 %.2e (float-atomic splats: order-dependent in the last bits), same NaN mask, " \
                              "ray counts equal: %s" % (rel, bool(st2["rays_closest"] + st2["rays_shadow"] >= ost["rays_closest"] + ost["rays_shadow"]))
         return r
+    if name == "spectral_cornell_512x512_64spp":       # example/spectral_box.py through PT_Spec (hero wavelengths), rgb2spec table built on this GPU
+        W = H = 512; spp = 64
+        t0 = time.perf_counter()
+        ex = scenes.spectral_box(W, H, spp, device_id=device_id, seed=seed); ex.build_scene(); ex.scene.ctx.sync()
+        t_setup = time.perf_counter() - t0
+        hdr, r = timed(ex, spp, lambda: ex.integrator.render_frames(spp))
+        r["setup_seconds_incl_rgb2spec_table_64cubed"] = round(t_setup, 3)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_api
+        o = oracle_api.OracleScene(ex.scene, ex.cam); o.lbvh_build()
+        if getattr(ex.scene, "normals_processed", False):
+            o.process_normal(ex.scene.vertex_index_np)
+        o.set_spectral(ex.integrator.tables())
+        p0 = (W // 2) * H + 128
+        want, _ = o.spec_render(W, H, 0, spp, seed=ex.integrator.seed, p_begin=p0, p_end=p0 + 1024)
+        r["oracle_sample_identical"] = bool(np.array_equal(hdr.reshape(-1, 3)[p0:p0 + 1024], want.reshape(-1, 3)[p0:p0 + 1024], equal_nan=True))
+        r["oracle_sample"] = "1024 pixels x 64 spp, bit for bit"
+        r["reference_pin"] = "structure pin against image/spectral-cornellbox.png: tests/test_spectral.py (the gallery render is of an earlier scene set-up; no radiometric pin)"
+        return r
     raise SystemExit("unknown config " + name)
 
 
@@ -722,7 +741,7 @@ def main():
     # ---- the other BASELINE configs and the build at 1 M primitives, driver-observable (rank 0, N = 1, after the timed region) ----
     if rank == 0 and world == 1 and not args.no_configs:
         cfgs = {}
-        for name in ("config1_cornell_512x512_512spp", "config2_teapot_1024x1024_64spp", "config5_veach_bdpt_512x512_64spp"):
+        for name in ("config1_cornell_512x512_512spp", "config2_teapot_1024x1024_64spp", "config5_veach_bdpt_512x512_64spp", "spectral_cornell_512x512_64spp"):
             try:
                 cfgs[name] = run_config(name, local_rank, args.seed)
             except Exception as exc:        # noqa: BLE001 -- one failing config must not hide the headline line

@@ -292,3 +292,31 @@ def test_ordered_equals_exhaustive_on_two_million_stress_rays(gpu_ctx_ok):
             total += rays.shape[0]
     print("ordered vs exhaustive: %d rays, %d mismatches" % (total, bad))
     assert total >= 1900000 and bad == 0
+
+
+def test_wave_timeline_of_a_counting_launch(gpu_ctx_ok):
+    """tirt_trace_timeline (diagnostics, no reference counterpart): the armed counting launch records one (start, queue empty, end, hardware id)
+    row per wave; five 256-thread blocks per CU means 20 waves on every CU, all alive together (round 3: the 512-thread blocks fitted two per CU)."""
+    from ti_raytrace_amd import scenes, _native
+    ex = scenes.synthetic(512, 512, 8, ntri=20000, device_id=0, seed=3)
+    ctx = ex.scene.ctx
+    ex.build_scene(); ctx.sync()
+    ctx.set_option("time_kernels", 1)
+    ctx.set_option("trace_timeline", 0)
+    ctx.pt_rgb_render(0, 8, 1, 15, 64, _native.TRAVERSE_ORDERED | _native.COUNT_NODES); ctx.sync()
+    tl = ctx.trace_timeline()
+    ctx.set_option("time_kernels", 0); ctx.set_option("trace_timeline", -1)
+    assert len(tl) > 0 and len(tl) % 4 == 0
+    start, exh, end = tl[:, 0].astype(np.int64), tl[:, 1].astype(np.int64), tl[:, 2].astype(np.int64)
+    assert (end >= start).all() and ((exh == 0) | ((exh >= start) & (exh <= end))).all()
+    span = end.max() - start.min()
+    life = (end - start).mean()
+    hw = tl[:, 3]
+    cu = ((hw >> np.uint64(32)) & np.uint64(0xf)) * np.uint64(1 << 16) + (hw & np.uint64(0xff00))          # XCC id, then CU / SH / SE bits of HW_ID
+    per_cu = np.unique(cu, return_counts=True)[1]
+    print("timeline: %d waves on %d CUs (waves per CU %d..%d), span %.1f us, mean wave life %.2f of the span" % (
+        len(tl), len(per_cu), per_cu.min(), per_cu.max(), span * 1e-2, life / max(span, 1)))
+    st = ctx.stats()
+    assert st["diag_waves"] >= len(tl) and st["diag_wave_ticks"] > 0
+    if len(tl) == 5 * 4 * len(per_cu):                 # a full grid: every CU runs its five blocks at once
+        assert per_cu.min() == per_cu.max() == 20 and life > 0.4 * span          # (a small job: its tail is a large part of the launch)
