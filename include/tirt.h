@@ -86,7 +86,7 @@ int tirt_sync(tirt_ctx *ctx);
  *            not allocate 32 Mi-path lanes).  Set it before the first render call of the job
  *          "batch_paths" -- pixel-samples kept in flight per wavefront batch (default 32 Mi, or planned from "job_frames";
  *            196 B of HBM each, lanes hold 1.5 x that)
- *          "split_lone_batch" (0 = off, or the number of parts 2..8; default 2) -- a context that owns 1/6 or less of the film
+ *          "split_lone_batch" (0 = off, or the number of parts 2..8; default 0 since round 3) -- a context that owns 1/6 or less of the film
  *            (tile_count >= 6) and whose whole job is one batch runs it as that many smaller batches on as many lanes
  *          "traversal_tree" (0/1, default 1) -- the tree tirt_lbvh_build collapses into the 4-wide traversal nodes: 1 = a binned-SAH
  *            tree over the same primitives built on the device after the LBVH, 0 = the reference's LBVH itself; results are

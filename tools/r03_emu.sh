@@ -1,9 +1,10 @@
 cd $GRAFT_REPO_ROOT
-run() { O=""; for kv in "$@"; do O="$O --opt $kv"; done
-  v=$(timeout 300 python bench.py --no-cpu-baseline --no-roofline --emulate-world 8 $O 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])")
-  echo "$* : $v"; }
-run
-for b in 4194304 6291456 8388608 12582912 16777216; do run batch_paths=$b merge_paths=$b; done
-run batch_paths=4194304 merge_paths=4194304 overlap_lanes=6
-run batch_paths=8388608 merge_paths=8388608 overlap_lanes=3
-run batch_paths=2097152 merge_paths=2097152 overlap_lanes=8
+for n in 1 2 4 8; do timeout 300 python bench.py --no-cpu-baseline --no-roofline --emulate-world $n 2>/dev/null | tail -1; done > gpurun_out/r03h_emulated_rank_scaling.log
+for s in 4 8 16 32; do timeout 300 python bench.py --no-cpu-baseline --no-roofline --emulate-world 8 --steps $s 2>/dev/null | tail -1; done > gpurun_out/r03h_emulated_8_ranks_steps_4_8_16_32.log
+python - <<PY
+import json
+for f in ("gpurun_out/r03h_emulated_rank_scaling.log","gpurun_out/r03h_emulated_8_ranks_steps_4_8_16_32.log"):
+    for l in open(f):
+        d=json.loads(l); print(f[-40:], d['steps'], d['value'], d['ms_per_step'])
+PY
+timeout 900 python -m pytest tests/test_gpu_render.py tests/test_gpu_dist.py -q -m gpu 2>&1 | tail -2
