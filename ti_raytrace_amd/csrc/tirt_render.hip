@@ -481,7 +481,10 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
             }
 #endif
             // (keeps `prim` in a register of its own across the ancestor walk: without this the compiler (ROCm 7.2 hipcc, -O3) lets the
-            // walk's 16-byte row loads overwrite it and an accepted hit that went through the walk keeps the PREVIOUS hit's primitive id)
+            // walk's 16-byte row loads overwrite it and an accepted hit that went through the walk keeps the PREVIOUS hit's primitive id.
+            // Re-checked at the end of round 3, after the kernel's register allocation had changed completely (TR_COLD): still needed --
+            // without it test_quantised_nodes_on_grazing_rays fails and the next test faults.  That test is the tripwire; __graft_entry__.build()
+            // warns when the compiler is not the validated one.)
             asm volatile("" : "+v"(prim));
             if (cand) {
                 hit_t = t; hit_u = u; hit_v = v; hit_prim = prim; hit_leaf = leaf;
