@@ -1484,10 +1484,10 @@ __global__ void k_film(PathState ps, TileMap tm, int P, int F, uint32_t frame_be
 // the hero wavelength is not stored: Lambda = 360 + 100 * rand(pixel, frame, TM_DIM_SPEC_LAMBDA) is recomputed where it is needed.
 // Reference behaviours kept: the NEE sample is tinted with the colour of the surface that was HIT (`light_tint` of :213), not with
 // the light's emission; Disney.evaluate_pdf for the continuation is called with (N, V = next_dir, L = -direction) (:251).
-__global__ __launch_bounds__(SH_BLOCK, 4) void k_shade_spec(PathState ps, PathSoA in, PathSoA out, SceneView sc, SpecView sp, TileMap tm, int P,
+__global__ __launch_bounds__(SH_BLOCK, 4) void k_shade_spec(ShadeArgs paths_in_kernarg_segment, SceneView sc, SpecView sp, TileMap tm, int P,
                                                    uint32_t frame_begin, uint32_t seed, int bounce, int last_bounce,
                                                    const int *count_ptr, int count_fixed, unsigned long long *append_ctr,
-                                                   DevCounters *ctr, v3 eye, float *scw, float *fw)
+                                                   DevCounters *ctr, v3 eye)
 {
     __shared__ unsigned s_wcnt[2][SH_BLOCK / 64];
     __shared__ unsigned long long s_base[2];
@@ -1497,7 +1497,6 @@ __global__ __launch_bounds__(SH_BLOCK, 4) void k_shade_spec(PathState ps, PathSo
     const int total = gridDim.x * blockDim.x;
     const int rounds = (count + total - 1) / total;
     unsigned long long n_shaded = 0;
-    float *in_tw = in.brdf_pdf, *in_rw = (float *)in.flags, *out_tw = out.brdf_pdf, *out_rw = (float *)out.flags;
     for (int it = 0; it < rounds; it++) {
         const int q = it * total + blockIdx.x * blockDim.x + threadIdx.x;
         bool live = q < count, want_next = false, want_shadow = false;
@@ -1507,20 +1506,27 @@ __global__ __launch_bounds__(SH_BLOCK, 4) void k_shade_spec(PathState ps, PathSo
         float sh_dist = 0.0f; int sh_expect = -2;
         if (live) {
             const bool first = bounce == 0;
-            slot = first ? q : in.slot[q];
+            SH_COLD(ca);          // (the path-state pointers: read here, in one batch of scalar loads -- see k_shade)
+            const int *const c_slot = ca->in.slot; const float4 *const c_hit = ca->ps.hit;
+            const float *const c_ox = ca->in.ox, *const c_oy = ca->in.oy, *const c_oz = ca->in.oz, *const c_dx = ca->in.dx, *const c_dy = ca->in.dy, *const c_dz = ca->in.dz;
+            const float *const c_tr = ca->in.tr, *const c_tg = ca->in.tg, *const c_tb = ca->in.tb, *const c_rr = ca->in.rr, *const c_rg = ca->in.rg, *const c_rb = ca->in.rb;
+            const float *const c_tw = ca->in.brdf_pdf, *const c_rw = (const float *)ca->in.flags;
+            asm volatile("" :: "s"(c_slot), "s"(c_hit), "s"(c_ox), "s"(c_oy), "s"(c_oz), "s"(c_dx), "s"(c_dy), "s"(c_dz), "s"(c_tr), "s"(c_tg), "s"(c_tb),
+                         "s"(c_rr), "s"(c_rg), "s"(c_rb), "s"(c_tw), "s"(c_rw));
+            slot = first ? q : c_slot[q];
             const int f = slot / P, k = slot - f * P;
             const uint32_t pixel = (uint32_t)local_to_pixel(tm, k);
             const uint32_t frame = frame_begin + (uint32_t)f;
             const uint32_t dim0 = TM_DIM_BOUNCE0 + TM_DIMS_PER_BOUNCE * (uint32_t)bounce;
             const float Lambda = HERO_LAMBDA_MIN + HERO_LAMBDA_STEP * tm_rand(seed, pixel, frame, TM_DIM_SPEC_LAMBDA);     // PT_Spec.py:191
-            const v3 origin = first ? eye : V(in.ox[q], in.oy[q], in.oz[q]);
-            const v3 direction = V(in.dx[q], in.dy[q], in.dz[q]);
-            const float4 hrec = ps.hit[q];
+            const v3 origin = first ? eye : V(c_ox[q], c_oy[q], c_oz[q]);
+            const v3 direction = V(c_dx[q], c_dy[q], c_dz[q]);
+            const float4 hrec = c_hit[q];
             const float t = hrec.x;
             f4s throughout = f4_set(1.0f);
             if (!first) {
-                throughout.v[0] = in.tr[q]; throughout.v[1] = in.tg[q]; throughout.v[2] = in.tb[q]; throughout.v[3] = in_tw[q];
-                radiance.v[0] = in.rr[q]; radiance.v[1] = in.rg[q]; radiance.v[2] = in.rb[q]; radiance.v[3] = in_rw[q];
+                throughout.v[0] = c_tr[q]; throughout.v[1] = c_tg[q]; throughout.v[2] = c_tb[q]; throughout.v[3] = c_tw[q];
+                radiance.v[0] = c_rr[q]; radiance.v[1] = c_rg[q]; radiance.v[2] = c_rb[q]; radiance.v[3] = c_rw[q];
             }
             const f4s light_rad = hero_sample(sp.spd[0], Lambda);                                   // :212
             if (t < INF_VALUE) {
@@ -1623,20 +1629,34 @@ __global__ __launch_bounds__(SH_BLOCK, 4) void k_shade_spec(PathState ps, PathSo
         const int qn = (int)(unsigned)(bb & 0xffffffffull) + (int)pn + __popcll(nmask & lt_mask);
         const int qs = (int)(unsigned)(bb >> 32) + (int)psd + __popcll(smask & lt_mask);
         if (want_next) {
-            out.ox[qn] = next_o.x; out.oy[qn] = next_o.y; out.oz[qn] = next_o.z;
-            out.dx[qn] = next_d.x; out.dy[qn] = next_d.y; out.dz[qn] = next_d.z;
-            out.tr[qn] = next_thr.v[0]; out.tg[qn] = next_thr.v[1]; out.tb[qn] = next_thr.v[2]; out_tw[qn] = next_thr.v[3];
-            out.rr[qn] = radiance.v[0]; out.rg[qn] = radiance.v[1]; out.rb[qn] = radiance.v[2]; out_rw[qn] = radiance.v[3];
-            out.slot[qn] = slot;
+            SH_COLD(ca);
+            float *const o_ox = ca->out.ox, *const o_oy = ca->out.oy, *const o_oz = ca->out.oz, *const o_dx = ca->out.dx, *const o_dy = ca->out.dy, *const o_dz = ca->out.dz;
+            float *const o_tr = ca->out.tr, *const o_tg = ca->out.tg, *const o_tb = ca->out.tb, *const o_rr = ca->out.rr, *const o_rg = ca->out.rg, *const o_rb = ca->out.rb;
+            float *const o_tw = ca->out.brdf_pdf, *const o_rw = (float *)ca->out.flags; int *const o_slot = ca->out.slot;
+            asm volatile("" :: "s"(o_ox), "s"(o_oy), "s"(o_oz), "s"(o_dx), "s"(o_dy), "s"(o_dz), "s"(o_tr), "s"(o_tg), "s"(o_tb), "s"(o_rr), "s"(o_rg), "s"(o_rb),
+                         "s"(o_tw), "s"(o_rw), "s"(o_slot));
+            o_ox[qn] = next_o.x; o_oy[qn] = next_o.y; o_oz[qn] = next_o.z;
+            o_dx[qn] = next_d.x; o_dy[qn] = next_d.y; o_dz[qn] = next_d.z;
+            o_tr[qn] = next_thr.v[0]; o_tg[qn] = next_thr.v[1]; o_tb[qn] = next_thr.v[2]; o_tw[qn] = next_thr.v[3];
+            o_rr[qn] = radiance.v[0]; o_rg[qn] = radiance.v[1]; o_rb[qn] = radiance.v[2]; o_rw[qn] = radiance.v[3];
+            o_slot[qn] = slot;
         } else if (live) {
-            ps.fr[slot] = radiance.v[0]; ps.fg[slot] = radiance.v[1]; ps.fb[slot] = radiance.v[2]; fw[slot] = radiance.v[3];
+            SH_COLD(ca);
+            float *const f_r = ca->ps.fr, *const f_g = ca->ps.fg, *const f_b = ca->ps.fb, *const f_w = ca->ps.fw;
+            asm volatile("" :: "s"(f_r), "s"(f_g), "s"(f_b), "s"(f_w));
+            f_r[slot] = radiance.v[0]; f_g[slot] = radiance.v[1]; f_b[slot] = radiance.v[2]; f_w[slot] = radiance.v[3];
         }
         if (want_shadow) {
-            ps.sox[qs] = sh_o.x; ps.soy[qs] = sh_o.y; ps.soz[qs] = sh_o.z;
-            ps.sdx[qs] = sh_d.x; ps.sdy[qs] = sh_d.y; ps.sdz[qs] = sh_d.z;
-            ps.scr[qs] = sh_c.v[0]; ps.scg[qs] = sh_c.v[1]; ps.scb[qs] = sh_c.v[2]; scw[qs] = sh_c.v[3];
-            ps.sprim[qs] = sh_expect; ps.sdist[qs] = sh_dist;
-            ps.sdst[qs] = want_next ? qn : ~slot;
+            SH_COLD(ca);
+            float *const s_ox = ca->ps.sox, *const s_oy = ca->ps.soy, *const s_oz = ca->ps.soz, *const s_dx = ca->ps.sdx, *const s_dy = ca->ps.sdy, *const s_dz = ca->ps.sdz;
+            float *const s_cr = ca->ps.scr, *const s_cg = ca->ps.scg, *const s_cb = ca->ps.scb, *const s_cw = ca->ps.scw, *const s_dist = ca->ps.sdist;
+            int *const s_prim = ca->ps.sprim, *const s_dst = ca->ps.sdst;
+            asm volatile("" :: "s"(s_ox), "s"(s_oy), "s"(s_oz), "s"(s_dx), "s"(s_dy), "s"(s_dz), "s"(s_cr), "s"(s_cg), "s"(s_cb), "s"(s_cw), "s"(s_dist), "s"(s_prim), "s"(s_dst));
+            s_ox[qs] = sh_o.x; s_oy[qs] = sh_o.y; s_oz[qs] = sh_o.z;
+            s_dx[qs] = sh_d.x; s_dy[qs] = sh_d.y; s_dz[qs] = sh_d.z;
+            s_cr[qs] = sh_c.v[0]; s_cg[qs] = sh_c.v[1]; s_cb[qs] = sh_c.v[2]; s_cw[qs] = sh_c.v[3];
+            s_prim[qs] = sh_expect; s_dist[qs] = sh_dist;
+            s_dst[qs] = want_next ? qn : ~slot;
         }
     }
     __shared__ unsigned long long s_shaded;
@@ -1822,9 +1842,9 @@ int pt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed,
 
             stamp(evh, true);
             if (spec)
-                hipLaunchKernelGGL(k_shade_spec, dim3(grid_shade), dim3(SH_BLOCK), 0, st, L.ps, in, out, sv, *spec, tm, P, f0, seed, b,
+                hipLaunchKernelGGL(k_shade_spec, dim3(grid_shade), dim3(SH_BLOCK), 0, st, ShadeArgs{L.ps, in, out}, sv, *spec, tm, P, f0, seed, b,
                                    (b == max_depth - 1) ? 1 : 0, (b == 0) ? (const int *)nullptr : cnt_path(b), S,
-                                   append_ctr(b), ctr, eye_v, L.ps.scw, L.ps.fw);
+                                   append_ctr(b), ctr, eye_v);
             else
             hipLaunchKernelGGL(k_shade, dim3(grid_shade), dim3(SH_BLOCK), 0, st, ShadeArgs{L.ps, in, out}, sv, tm, P, f0, seed, b,
                                (b == max_depth - 1) ? 1 : 0, (b == 0) ? (const int *)nullptr : cnt_path(b), S,
