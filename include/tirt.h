@@ -158,6 +158,10 @@ int tirt_pt_rgb_render(tirt_ctx *ctx, uint32_t frame_begin, int frame_count, uin
  * connections up to MAX_DEPTH 5 with MIS, light-tracing splats; same film, camera and tiling as
  * PT_RGB (with tiles, every context accumulates splats into its full-size film: sum-reduce). */
 int tirt_bdpt_rgb_render(tirt_ctx *ctx, uint32_t frame_begin, int frame_count, uint32_t seed);
+/* BDPT.render x frame_count of integrator/BDPT_SPEC.py:660-691: the same bidirectional tracer carrying one wavelength per pixel sample
+ * (reflectances and emitters through the RGB -> spectrum table, dispersive glass, AddSplat through the CIE observer).  Needs
+ * tirt_spectral_upload.  The example that uses it: example/prism_rainbow.py (a laser through a prism). */
+int tirt_bdpt_spec_render(tirt_ctx *ctx, uint32_t frame_begin, int frame_count, uint32_t seed);
 
 /* ---- spectral path: integrator/PT_Spec.py (hero-wavelength path tracer) -----------------------------
  * tirt_spec_table_build: spectrum/JakobSpecTable.py:1-439 on the device -- the RGB -> sigmoid-spectrum coefficient table that

@@ -1988,12 +1988,47 @@ static v3 get_image_point(const orc_scene *s, const orc_bdpt *b, v3 p, int *u_o,
 
 /* shared tail of eye_path / light_path: BSDF sample at a surface vertex (BDPT_RGB.py:159-193, 255-289) */
 typedef struct { v3 next_dir; float f_or_b, brdf, pdfFwd; } bsample;
-static bsample bd_sample(const orc_scene *s, v3 dir, v3 normal, v3 fnormal, int mat_id, int mat_type,
+/* ---- BDPT_SPEC (integrator/BDPT_SPEC.py): the same bidirectional tracer carrying ONE wavelength per pixel sample.  `spc` == NULL is
+ * BDPT_RGB; otherwise the colours of BDPT_RGB become powers at spc->Lambda (replicated into the three components of the v3 the RGB code
+ * carries, so that every product below is the reference's scalar product), and the places where BDPT_SPEC.py differs from BDPT_RGB.py in
+ * more than that are marked "SPEC". */
+typedef struct { const orc_spec *sp; float Lambda; } bd_spec;
+#define BD_DIM_CONNECT_SPEC 256u          /* + 8 e: the seven numbers of sample_light() for the l == 1 connection at eye vertex e */
+#define BD_DIM_LAMBDA 2u                   /* the sample's wavelength (BDPT_SPEC.py:668); dims 0, 1 are the camera jitter */
+/* BDPT_SPEC.py:146-155 */
+static float bd_light_power(const bd_spec *spc, v3 emission)
+{
+    float ret = 0.0f;
+    const float scale = vnorm(emission);
+    if (scale > 0.0f) {
+        const v3 coff = r2s_fetch(spc->sp, vdivs(emission, scale));
+        ret = spd_sample(&spc->sp->spd[0], spc->Lambda) * r2s_eval(coff, spc->Lambda) * scale;
+    }
+    return ret;
+}
+/* BDPT_SPEC.py:134-144 */
+static float bd_reflect_power(const orc_scene *s, const bd_spec *spc, int mat_id)
+{
+    const float *m = s->material + (size_t)mat_id * MAT_VEC;
+    const v3 mat_color = V(m[2], m[3], m[4]);
+    if ((int)m[0] == MAT_LIGHT) return bd_light_power(spc, mat_color);
+    return r2s_eval(r2s_fetch(spc->sp, srgb_to_lrgb(mat_color)), spc->Lambda);
+}
+/* what BDPT_RGB multiplies a path's throughput with at a surface of material mat_id: its linear colour / its power at the wavelength */
+static v3 bd_reflect(const orc_scene *s, const bd_spec *spc, int mat_id)
+{
+    if (spc) { const float p = bd_reflect_power(s, spc, mat_id); return V(p, p, p); }
+    const float *m = s->material + (size_t)mat_id * MAT_VEC;
+    return srgb_to_lrgb(V(m[2], m[3], m[4]));
+}
+
+static bsample bd_sample(const orc_scene *s, const bd_spec *spc, v3 dir, v3 normal, v3 fnormal, int mat_id, int mat_type,
                          uint32_t seed, uint32_t pixel, uint32_t frame, uint32_t dim0, int32_t *delta)
 {
     bsample r; r.next_dir = dir; r.f_or_b = 1.0f; r.brdf = 0.0f; r.pdfFwd = 0.0f;
     if (mat_type == MAT_GLASS) {
-        r.next_dir = glass_sample(s, dir, normal, mat_id, tm_rand(seed, pixel, frame, dim0 + TM_SLOT_GLASS), &r.f_or_b);
+        if (spc) r.next_dir = glass_sample_lambda(dir, normal, spc->Lambda, tm_rand(seed, pixel, frame, dim0 + TM_SLOT_GLASS), &r.f_or_b);      /* SPEC: BDPT_SPEC.py:241, 335 */
+        else r.next_dir = glass_sample(s, dir, normal, mat_id, tm_rand(seed, pixel, frame, dim0 + TM_SLOT_GLASS), &r.f_or_b);
         r.brdf = 1.0f; r.pdfFwd = 1.0f;
         *delta = 1;
     } else {
@@ -2008,7 +2043,7 @@ static bsample bd_sample(const orc_scene *s, v3 dir, v3 normal, v3 fnormal, int 
 }
 
 /* BDPT_RGB.py:103-198 */
-static int bd_eye_path(const orc_scene *s, bpixel *P, int i, int j, int H, uint32_t frame, uint32_t seed,
+static int bd_eye_path(const orc_scene *s, const bd_spec *spc, bpixel *P, int i, int j, int H, uint32_t frame, uint32_t seed,
                        int32_t *stack, int stack_size, orc_stats *st)
 {
     uint32_t pixel = (uint32_t)(i * H + j);
@@ -2038,7 +2073,8 @@ static int bd_eye_path(const orc_scene *s, bpixel *P, int i, int j, int H, uint3
             e->pos = pos; e->normal = normal; e->snormal = fnormal; e->wo = dir; e->rpdf = 0.0f; e->prim = h.prim; e->mat = mat_id;
             e->fpdf = pdfFwd * fabs_(vdot(to, eye[pre_depth].normal)) * inv_dist2;
             if (mat_type == MAT_LIGHT) {
-                e->beta = vscale(vmul(beta, mat_color), fabs_(vdot(normal, dir)));
+                if (spc) e->beta = vmul(beta, bd_reflect(s, spc, mat_id));          /* SPEC: beta * reflect_power, no cosine (BDPT_SPEC.py:228) */
+                else e->beta = vscale(vmul(beta, mat_color), fabs_(vdot(normal, dir)));
                 e->type = VERTEX_LIGHT;
                 depth += 1;
                 break;
@@ -2046,8 +2082,8 @@ static int bd_eye_path(const orc_scene *s, bpixel *P, int i, int j, int H, uint3
                 e->beta = vscale(beta, fabs_(vdot(dir, normal)));
                 e->type = VERTEX_SURFACE;
             }
-            v3 reflect_color = srgb_to_lrgb(mat_color);
-            bsample bs = bd_sample(s, dir, normal, fnormal, mat_id, mat_type, seed, pixel, frame,
+            v3 reflect_color = bd_reflect(s, spc, mat_id);
+            bsample bs = bd_sample(s, spc, dir, normal, fnormal, mat_id, mat_type, seed, pixel, frame,
                                    BD_DIM_EYE + 8u * (uint32_t)depth, &e->delta);
             pdfFwd = bs.pdfFwd;
             if (pdfFwd > 0.0f) {
@@ -2059,7 +2095,7 @@ static int bd_eye_path(const orc_scene *s, bpixel *P, int i, int j, int H, uint3
                     pdfRev = disney_pdf(s, fnormal, bs.next_dir, vneg(dir), mat_id);
                 }
                 eye[pre_depth].rpdf = pdfRev * fabs_(vdot(to, e->normal)) * inv_dist2;
-                if (bs.f_or_b < 0.0f) {
+                if (!spc && bs.f_or_b < 0.0f) {            /* (SPEC has no extinction roulette) */
                     float R = m_exp(-h.t / m[6]);
                     if (tm_rand(seed, pixel, frame, BD_DIM_EYE + 8u * (uint32_t)depth + TM_SLOT_EXT) >= R) break;
                 }
@@ -2073,13 +2109,13 @@ static int bd_eye_path(const orc_scene *s, bpixel *P, int i, int j, int H, uint3
 }
 
 /* Scene.py:430-474 */
-static void bd_sample_light(const orc_scene *s, uint32_t seed, uint32_t pixel, uint32_t frame,
+static void bd_sample_light(const orc_scene *s, uint32_t seed, uint32_t pixel, uint32_t frame, uint32_t BD_DIM_LBASE,
                             v3 *pos, v3 *nor, v3 *dir, v3 *emission, int *prim, float *choice_pdf, float *dir_pdf)
 {
-    int lidx = (int)(tm_rand(seed, pixel, frame, BD_DIM_LSTART + 0) * (float)s->light_count);
+    int lidx = (int)(tm_rand(seed, pixel, frame, BD_DIM_LBASE + 0) * (float)s->light_count);
     if (lidx >= s->light_count) lidx = s->light_count - 1;
     int lp = s->light[lidx];
-    float a = tm_rand(seed, pixel, frame, BD_DIM_LSTART + 1), b = tm_rand(seed, pixel, frame, BD_DIM_LSTART + 2);
+    float a = tm_rand(seed, pixel, frame, BD_DIM_LBASE + 1), b = tm_rand(seed, pixel, frame, BD_DIM_LBASE + 2);
     v3 lpos, lnor;
     get_prim_random_point_normal(s, lp, a, b, &lpos, &lnor);
     int lmat = s->primitive[(size_t)lp * PRI_VEC + 2];
@@ -2087,7 +2123,7 @@ static void bd_sample_light(const orc_scene *s, uint32_t seed, uint32_t pixel, u
     float area = get_prim_area(s, lp);
     *choice_pdf = 1.0f / ((float)s->light_count * area);
     lnor = vnormalized(lnor);
-    v3 ld = cosine_sample_hemisphere(tm_rand(seed, pixel, frame, BD_DIM_LSTART + 3), tm_rand(seed, pixel, frame, BD_DIM_LSTART + 4));
+    v3 ld = cosine_sample_hemisphere(tm_rand(seed, pixel, frame, BD_DIM_LBASE + 3), tm_rand(seed, pixel, frame, BD_DIM_LBASE + 4));
     *dir_pdf = cosine_hemisphere_pdf(ld.z);
     *dir = inverse_transform(ld, lnor);
     *pos = lpos; *nor = lnor; *emission = V(lm[2], lm[3], lm[4]); *prim = lp;
@@ -2099,7 +2135,7 @@ static void bd_sample_light(const orc_scene *s, uint32_t seed, uint32_t pixel, u
             const float scale = sh[6];
             *dir_pdf = 1.0f;
             float r, phi;
-            map_to_disk(tm_rand(seed, pixel, frame, BD_DIM_LSTART + 5), tm_rand(seed, pixel, frame, BD_DIM_LSTART + 6), &r, &phi);
+            map_to_disk(tm_rand(seed, pixel, frame, BD_DIM_LBASE + 5), tm_rand(seed, pixel, frame, BD_DIM_LBASE + 6), &r, &phi);
             const float r1 = scale * m_tan(sh[4]), r2 = scale * m_tan(sh[5]);
             r *= r2;
             if (r > r1) *emission = vscale(*emission, 1.0f - (r - r1) / (r2 - r1));
@@ -2108,7 +2144,7 @@ static void bd_sample_light(const orc_scene *s, uint32_t seed, uint32_t pixel, u
         } else if (st == SHAPE_LASER) {
             *choice_pdf = 1.0f / (float)s->light_count;
             const float r = sh[4];
-            const float phi = tm_rand(seed, pixel, frame, BD_DIM_LSTART + 5) * M_PIf * 2.0f;
+            const float phi = tm_rand(seed, pixel, frame, BD_DIM_LBASE + 5) * M_PIf * 2.0f;
             v3 sp = V(r * m_cos(phi), r * m_sin(phi), 0.0f);
             sp = inverse_transform(sp, lnor);
             *dir = lnor;
@@ -2119,19 +2155,22 @@ static void bd_sample_light(const orc_scene *s, uint32_t seed, uint32_t pixel, u
 }
 
 /* BDPT_RGB.py:200-294 */
-static int bd_light_path(const orc_scene *s, bpixel *P, int i, int j, int H, uint32_t frame, uint32_t seed,
+static int bd_light_path(const orc_scene *s, const bd_spec *spc, bpixel *P, int i, int j, int H, uint32_t frame, uint32_t seed,
                          int32_t *stack, int stack_size, orc_stats *st)
 {
     uint32_t pixel = (uint32_t)(i * H + j);
     bvert *light = P->light;
     v3 lpos, lnor, ldir, emission; int lprim; float choice_pdf, dir_pdf;
-    bd_sample_light(s, seed, pixel, frame, &lpos, &lnor, &ldir, &emission, &lprim, &choice_pdf, &dir_pdf);
+    bd_sample_light(s, seed, pixel, frame, BD_DIM_LSTART, &lpos, &lnor, &ldir, &emission, &lprim, &choice_pdf, &dir_pdf);
     float light_pdf = choice_pdf;
-    light[0].pos = lpos; light[0].normal = lnor; light[0].beta = vdivs(emission, light_pdf);
+    if (spc) { const float pw = bd_light_power(spc, emission) / light_pdf; light[0].beta = V(pw, pw, pw); }      /* SPEC: BDPT_SPEC.py:284 */
+    else light[0].beta = vdivs(emission, light_pdf);
+    light[0].pos = lpos; light[0].normal = lnor;
     light[0].fpdf = light_pdf; light[0].rpdf = 0.0f; light[0].wo = ldir; light[0].type = VERTEX_LIGHT;
     int pre_depth = 0, depth = 1;
     float pdfFwd = dir_pdf, pdfRev = 0.0f;
-    v3 beta = vscale(vdivs(emission, light_pdf), fabs_(vdot(lnor, ldir)));
+    v3 beta = spc ? light[0].beta                                               /* SPEC: beta = power[0], no cosine (BDPT_SPEC.py:294) */
+                  : vscale(vdivs(emission, light_pdf), fabs_(vdot(lnor, ldir)));
     v3 origin = lpos, dir = ldir;
     while (depth < BD_LIGHT_MAX) {
         hit_t h = closet_hit(s, origin, dir, stack, stack_size, st);
@@ -2140,7 +2179,7 @@ static int bd_light_path(const orc_scene *s, bpixel *P, int i, int j, int H, uin
             v3 fnormal = vscale(normal, signf(vdot(vneg(dir), h.gnor)));
             int mat_id = s->primitive[(size_t)h.prim * PRI_VEC + 2];
             const float *m = s->material + (size_t)mat_id * MAT_VEC;
-            v3 mat_color = V(m[2], m[3], m[4]);
+            (void)m;
             int mat_type = (int)m[0];
             if (mat_type == MAT_LIGHT) break;
             bvert *L = &light[depth];
@@ -2151,8 +2190,8 @@ static int bd_light_path(const orc_scene *s, bpixel *P, int i, int j, int H, uin
             float inv_dist2 = 1.0f / (dist * dist);
             to = vdivs(to, dist);
             L->fpdf *= fabs_(vdot(to, light[pre_depth].normal)) * inv_dist2;
-            v3 reflect_color = srgb_to_lrgb(mat_color);
-            bsample bs = bd_sample(s, dir, normal, fnormal, mat_id, mat_type, seed, pixel, frame,
+            v3 reflect_color = bd_reflect(s, spc, mat_id);
+            bsample bs = bd_sample(s, spc, dir, normal, fnormal, mat_id, mat_type, seed, pixel, frame,
                                    BD_DIM_LIGHT + 8u * (uint32_t)depth, &L->delta);
             pdfFwd = bs.pdfFwd;
             if (pdfFwd > 0.0f) {
@@ -2164,7 +2203,7 @@ static int bd_light_path(const orc_scene *s, bpixel *P, int i, int j, int H, uin
                     pdfRev = disney_pdf(s, fnormal, bs.next_dir, vneg(dir), mat_id);
                 }
                 light[pre_depth].rpdf = pdfRev * fabs_(vdot(to, L->normal)) * inv_dist2;
-                if (bs.f_or_b < 0.0f) {
+                if (!spc && bs.f_or_b < 0.0f) {
                     float R = m_exp(-h.t / m[6]);
                     if (tm_rand(seed, pixel, frame, BD_DIM_LIGHT + 8u * (uint32_t)depth + TM_SLOT_EXT) >= R) break;
                 }
@@ -2295,7 +2334,7 @@ static float bd_mis_weight(const orc_scene *s, const orc_bdpt *B, bpixel *P, int
 }
 
 /* BDPT_RGB.py:481-592; returns radiance * misweight and the pixel it belongs to (-1: none) */
-static v3 bd_connect_path(const orc_scene *s, const orc_bdpt *B, bpixel *P, int i, int j, int e, int l, uint32_t frame,
+static v3 bd_connect_path(const orc_scene *s, const bd_spec *spc, const orc_bdpt *B, bpixel *P, int i, int j, int e, int l, uint32_t frame,
                           uint32_t seed, int32_t *stack, int stack_size, orc_stats *st, int *nu, int *nv)
 {
     bvert *eye = P->eye, *light = P->light;
@@ -2320,8 +2359,7 @@ static v3 bd_connect_path(const orc_scene *s, const orc_bdpt *B, bpixel *P, int 
                 float brdf = disney_evaluate_pdf(s, snormal, vneg(light[l - 1].wo), vneg(wi), mat_id, &pdf);
                 if (pdf > 0.0f) {
                     float G = fabs_(NdotL) / (t * t);
-                    const float *m = s->material + (size_t)mat_id * MAT_VEC;
-                    radiance = vdivs(vscale(vmul(vscale(light[l - 1].beta, G), srgb_to_lrgb(V(m[2], m[3], m[4]))), brdf), pdf);
+                    radiance = vdivs(vscale(vmul(vscale(light[l - 1].beta, G), bd_reflect(s, spc, mat_id)), brdf), pdf);
                     P->sample.pos = origin; P->sample.wo = wi; P->sample.type = VERTEX_LENS; P->sample.fpdf = 1.0f;
                 }
             }
@@ -2329,7 +2367,32 @@ static v3 bd_connect_path(const orc_scene *s, const orc_bdpt *B, bpixel *P, int 
     } else if (l == 1) {
         v3 surface = offset_ray(eye[e - 1].pos, eye[e - 1].snormal);
         int mat_id = eye[e - 1].mat;
-        if (eye[e - 1].delta != 1) {
+        if (spc && eye[e - 1].delta != 1) {
+            /* SPEC: BDPT_SPEC.py:605-630 -- sample_light() (Scene.py:430-474: its direction sample is drawn and dropped) instead of
+             * sample_li(surface); an emitter without a surface (spot, laser) can never be the shadow ray's hit, so it contributes
+             * through the light path only */
+            v3 light_pos, light_normal, light_dir_unused, light_emission; int light_prim; float light_choice_pdf, light_dir_pdf;
+            bd_sample_light(s, seed, pixel, frame, BD_DIM_CONNECT_SPEC + 8u * (uint32_t)e, &light_pos, &light_normal, &light_dir_unused,
+                            &light_emission, &light_prim, &light_choice_pdf, &light_dir_pdf);
+            const v3 wi = vnormalized(vsub(surface, light_pos));
+            const float NdotLl = vdot(wi, light_normal), NdotLe = vdot(wi, eye[e - 1].snormal);
+            int shadow_prim;
+            const float t = closet_hit_shadow(s, surface, vneg(wi), stack, stack_size, &shadow_prim, st);
+            if ((shadow_prim == light_prim) & (t > EPS_UF)) {
+                const float light_pdf = light_choice_pdf;
+                float pdf;
+                const float brdf = disney_evaluate_pdf(s, eye[e - 1].snormal, vneg(eye[e - 1].wo), vneg(wi), mat_id, &pdf);
+                if (pdf > 0.0f) {
+                    const float G = fabs_(NdotLe * NdotLl) / (t * t);
+                    v3 c = vdivs(vscale(vscale(eye[e - 1].beta, G), brdf), pdf);
+                    c = vmul(c, bd_reflect(s, spc, mat_id));
+                    c = vscale(c, bd_light_power(spc, light_emission));
+                    radiance = vdivs(c, light_pdf);
+                }
+                P->sample.pos = light_pos; P->sample.wo = wi; P->sample.type = VERTEX_LIGHT; P->sample.fpdf = light_pdf;
+                P->sample.prim = light_prim; P->sample.normal = light_normal; P->sample.snormal = light_normal;
+            }
+        } else if (eye[e - 1].delta != 1) {
             /* Scene.py:477-518 sample_li(surface) */
             uint32_t d0 = BD_DIM_CONNECT + 4u * (uint32_t)e;
             int lidx = (int)(tm_rand(seed, pixel, frame, d0) * (float)s->light_count);
@@ -2387,8 +2450,9 @@ static v3 bd_connect_path(const orc_scene *s, const orc_bdpt *B, bpixel *P, int 
                     v3 c = vmul(vscale(eye[e - 1].beta, G), light[l - 1].beta);
                     c = vdivs(vscale(c, brdfL), lpdf);
                     c = vdivs(vscale(c, brdfE), epdf);
-                    c = vmul(c, srgb_to_lrgb(V(mE[2], mE[3], mE[4])));
-                    radiance = vmul(c, srgb_to_lrgb(V(mL[2], mL[3], mL[4])));
+                    (void)mE; (void)mL;
+                    c = vmul(c, bd_reflect(s, spc, mat_idE));
+                    radiance = vmul(c, bd_reflect(s, spc, mat_idL));
                 }
             }
         }
@@ -2400,8 +2464,8 @@ static v3 bd_connect_path(const orc_scene *s, const orc_bdpt *B, bpixel *P, int 
 
 /* BDPT_RGB.py:595-642.  radiance: [W*H*3] scratch (cleared here); hdr: running mean.  Single thread:
  * light-tracing contributions land on other pixels (`radiance[eye_new_pos] += r_path`). */
-int orc_bdpt_render(const orc_scene *s, orc_bdpt *B, uint32_t frame_begin, int frame_count, uint32_t seed,
-                    int stack_size, float *radiance, float *hdr, orc_stats *stats)
+static int bdpt_render_common(const orc_scene *s, const orc_spec *spec, orc_bdpt *B, uint32_t frame_begin, int frame_count, uint32_t seed,
+                              int stack_size, float *radiance, float *hdr, orc_stats *stats)
 {
     int W = B->W, H = B->H;
     int32_t *stack = (int32_t *)malloc(sizeof(int32_t) * (size_t)(stack_size + 2));
@@ -2410,6 +2474,7 @@ int orc_bdpt_render(const orc_scene *s, orc_bdpt *B, uint32_t frame_begin, int f
      * ORC_BDPT_PIXEL = pixel whose connections are printed */
     const char *dbg_dump = getenv("ORC_BDPT_DUMP"), *dbg_pixel_s = getenv("ORC_BDPT_PIXEL");
     const long dbg_pixel = dbg_pixel_s ? atol(dbg_pixel_s) : -1;
+    const char *dbg_big_s = getenv("ORC_BDPT_BIG"); const double dbg_big = dbg_big_s ? atof(dbg_big_s) : 0.0;      /* print every connection above this value */
     for (int f = 0; f < frame_count; f++) {
         uint32_t frame = frame_begin + (uint32_t)f;
         memset(radiance, 0, sizeof(float) * (size_t)W * H * 3);
@@ -2422,8 +2487,12 @@ int orc_bdpt_render(const orc_scene *s, orc_bdpt *B, uint32_t frame_begin, int f
             int i = (int)(p / H), j = (int)(p % H);
             bpixel *P = &B->px[p];
             st.paths++;
-            int eye_depth = bd_eye_path(s, P, i, j, H, frame, seed, stack, stack_size, &st);
-            int light_depth = bd_light_path(s, P, i, j, H, frame, seed, stack, stack_size, &st);
+            /* SPEC: one wavelength per pixel sample, lambda_min + lambda_range * size * rand (BDPT_SPEC.py:668: up to one step beyond lambda_max,
+             * where the sensor reads zero) */
+            bd_spec spc_v; const bd_spec *spc = NULL;
+            if (spec) { spc_v.sp = spec; spc_v.Lambda = spec->s_min + (spec->s_range * (float)spec->n_sensor) * tm_rand(seed, (uint32_t)p, frame, BD_DIM_LAMBDA); spc = &spc_v; }
+            int eye_depth = bd_eye_path(s, spc, P, i, j, H, frame, seed, stack, stack_size, &st);
+            int light_depth = bd_light_path(s, spc, P, i, j, H, frame, seed, stack, stack_size, &st);
             const uint64_t shadow_before = st.rays_shadow;
             for (int e = 1; e <= eye_depth; e++) {
                 for (int l = 0; l <= light_depth; l++) {
@@ -2431,12 +2500,25 @@ int orc_bdpt_render(const orc_scene *s, orc_bdpt *B, uint32_t frame_begin, int f
                     if (((l == 1) & (e == 1)) | (depth < 0) | (depth > BD_MAX_DEPTH)) continue;
                     int nu, nv;
                     const uint64_t sh0__ = st.rays_shadow;
-                    v3 r = bd_connect_path(s, B, P, i, j, e, l, frame, seed, stack, stack_size, &st, &nu, &nv);
+                    v3 r = bd_connect_path(s, spc, B, P, i, j, e, l, frame, seed, stack, stack_size, &st, &nu, &nv);
+                    if (spc) {            /* SPEC: AddSplat (BDPT_SPEC.py:178-181): the sensor's response at the wavelength, as clamped sRGB, times the range */
+                        const v3 xyz = sensor_sample(spec, spc->Lambda);
+                        const float range = spec->s_max - spec->s_min;
+                        const float cr = ((float)3.240479 * xyz.x + (float)-1.537150 * xyz.y) + (float)-0.498535 * xyz.z;
+                        const float cg = ((float)-0.969256 * xyz.x + (float)1.875991 * xyz.y) + (float)0.041556 * xyz.z;
+                        const float cb = ((float)0.055648 * xyz.x + (float)-0.204043 * xyz.y) + (float)1.057311 * xyz.z;
+                        r = V((clampf(cr, 0.0f, 1000.0f) * range) * r.x, (clampf(cg, 0.0f, 1000.0f) * range) * r.x, (clampf(cb, 0.0f, 1000.0f) * range) * r.x);
+                    }
+                    if (dbg_big > 0.0 && (r.x > dbg_big || r.y > dbg_big || r.z > dbg_big)) {
+                        fprintf(stderr, "BIG pixel %ld frame %u e %d l %d r = %g %g %g eye_depth %d light_depth %d\n", p, frame, e, l, r.x, r.y, r.z, eye_depth, light_depth);
+                        for (int k = 0; k < eye_depth; k++) fprintf(stderr, "   eye[%d] type %d prim %d mat %d delta %d beta %g fpdf %g rpdf %g pos %g %g %g\n", k, P->eye[k].type, P->eye[k].prim, P->eye[k].mat, P->eye[k].delta, P->eye[k].beta.x, P->eye[k].fpdf, P->eye[k].rpdf, P->eye[k].pos.x, P->eye[k].pos.y, P->eye[k].pos.z);
+                        for (int k = 0; k < light_depth; k++) fprintf(stderr, "   light[%d] type %d prim %d mat %d delta %d beta %g fpdf %g rpdf %g pos %g %g %g\n", k, P->light[k].type, P->light[k].prim, P->light[k].mat, P->light[k].delta, P->light[k].beta.x, P->light[k].fpdf, P->light[k].rpdf, P->light[k].pos.x, P->light[k].pos.y, P->light[k].pos.z);
+                    }
                     if (dbg_pixel == p && f == frame_count - 1) {
                         fprintf(stderr, "pixel %ld frame %u e %d l %d: shadow rays %d, r = %g %g %g\n", p, frame, e, l, (int)(st.rays_shadow - sh0__), r.x, r.y, r.z);
-                        if (e == 1 && l == 0) {
+                        if ((e == 1 && l == 2) || (e == 2 && l == 0 && light_depth < 2)) {      /* (the first connection a pixel sample makes) */
                             for (int k = 0; k < BD_EYE_MAX; k++) fprintf(stderr, "   eye[%d] type %d prim %d mat %d delta %d beta %g %g %g fpdf %g rpdf %g pos %g %g %g\n", k, P->eye[k].type, P->eye[k].prim, P->eye[k].mat, P->eye[k].delta, P->eye[k].beta.x, P->eye[k].beta.y, P->eye[k].beta.z, P->eye[k].fpdf, P->eye[k].rpdf, P->eye[k].pos.x, P->eye[k].pos.y, P->eye[k].pos.z);
-                            for (int k = 0; k < BD_LIGHT_MAX; k++) fprintf(stderr, "   light[%d] type %d prim %d mat %d delta %d beta %g %g %g fpdf %g rpdf %g\n", k, P->light[k].type, P->light[k].prim, P->light[k].mat, P->light[k].delta, P->light[k].beta.x, P->light[k].beta.y, P->light[k].beta.z, P->light[k].fpdf, P->light[k].rpdf);
+                            for (int k = 0; k < BD_LIGHT_MAX; k++) fprintf(stderr, "   light[%d] type %d prim %d mat %d delta %d beta %g %g %g fpdf %g rpdf %g pos %g %g %g\n", k, P->light[k].type, P->light[k].prim, P->light[k].mat, P->light[k].delta, P->light[k].beta.x, P->light[k].beta.y, P->light[k].beta.z, P->light[k].fpdf, P->light[k].rpdf, P->light[k].pos.x, P->light[k].pos.y, P->light[k].pos.z);
                         }
                     }
                     long q = (e == 1) ? ((nu >= 0) ? (long)nu * H + nv : -1) : p;
@@ -2456,6 +2538,13 @@ int orc_bdpt_render(const orc_scene *s, orc_bdpt *B, uint32_t frame_begin, int f
     if (stats) *stats = st;
     return 0;
 }
+int orc_bdpt_render(const orc_scene *s, orc_bdpt *B, uint32_t frame_begin, int frame_count, uint32_t seed,
+                    int stack_size, float *radiance, float *hdr, orc_stats *stats)
+{ return bdpt_render_common(s, NULL, B, frame_begin, frame_count, seed, stack_size, radiance, hdr, stats); }
+/* integrator/BDPT_SPEC.py:660-691 */
+int orc_bdpt_spec_render(const orc_scene *s, const orc_spec *spec, orc_bdpt *B, uint32_t frame_begin, int frame_count, uint32_t seed,
+                         int stack_size, float *radiance, float *hdr, orc_stats *stats)
+{ return bdpt_render_common(s, spec, B, frame_begin, frame_count, seed, stack_size, radiance, hdr, stats); }
 
 /* ---- scalar KAT entry points (tests compare the HIP kernels' device functions) -------- */
 void orc_kat_disney(const float *mat10, const float *N, const float *Vv, const float *L, float *out2)

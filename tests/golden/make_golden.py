@@ -43,3 +43,9 @@ for name in ("glass", "metal", "non-metal"):
 # it can only be a structure pin
 img = np.asarray(Image.open(REF + "/image/spectral-cornellbox.png").convert("RGB")).astype(np.float32) / 255.0
 np.save("spectral_cornellbox_blocks.npy", img.reshape(32, 16, 32, 16, 3).mean(axis=(1, 3)).astype(np.float32))
+
+# image/rainbow.png: the gallery render of example/prism_rainbow.py (BDPT_SPEC: a laser through a glass prism, the spectrum on the far wall).
+# Taken with the close-up camera that the example keeps as comments (yaw 0.8, scale 20, target (-50, 2, -93): prism_rainbow.py:58-60), and
+# black outside the spectrum: tests/test_bdpt_spec.py renders the laser alone.  64 x 64 block means (8 x 8 pixels), sRGB in [0,1].
+img = np.asarray(Image.open(REF + "/image/rainbow.png").convert("RGB")).astype(np.float32) / 255.0
+np.save("rainbow_blocks.npy", img.reshape(64, 8, 64, 8, 3).mean(axis=(1, 3)).astype(np.float32))

@@ -81,6 +81,8 @@ def load(libm=False, native=False):
         L.orc_bdpt_destroy.argtypes = [_vp]
         L.orc_bdpt_render.restype = C.c_int
         L.orc_bdpt_render.argtypes = [_vp, _vp, C.c_uint32, C.c_int, C.c_uint32, C.c_int, _f32p, _f32p, C.POINTER(OrcStats)]
+        L.orc_bdpt_spec_render.restype = C.c_int
+        L.orc_bdpt_spec_render.argtypes = [_vp, _vp, _vp, C.c_uint32, C.c_int, C.c_uint32, C.c_int, _f32p, _f32p, C.POINTER(OrcStats)]
         L.orc_tone_map.argtypes = [C.c_float, _f32p, _f32p, C.c_long]
         L.orc_total_area.restype = C.c_float
         L.orc_total_area.argtypes = [_vp]
@@ -212,6 +214,17 @@ class OracleScene:
         rad = np.zeros((W, H, 3), np.float32)
         st = OrcStats()
         self.L.orc_bdpt_render(self.h, state, frame_begin, frame_count, seed, stack_size, rad.reshape(-1), hdr.reshape(-1), C.byref(st))
+        return hdr, st.as_dict(), state
+
+    def bdpt_spec_render(self, cam, W, H, frame_begin, frame_count, seed=1, stack_size=64, hdr=None, state=None):
+        """BDPT_SPEC.render x frame_count (set_spectral first).  Same conventions as bdpt_render."""
+        if hdr is None:
+            hdr = np.zeros((W, H, 3), np.float32)
+        if state is None:
+            state = self.L.orc_bdpt_create(W, H, np.ascontiguousarray(cam.view_np[0].reshape(-1), np.float32))
+        rad = np.zeros((W, H, 3), np.float32)
+        st = OrcStats()
+        self.L.orc_bdpt_spec_render(self.h, self.spec, state, frame_begin, frame_count, seed, stack_size, rad.reshape(-1), hdr.reshape(-1), C.byref(st))
         return hdr, st.as_dict(), state
 
     def set_spectral(self, t):

@@ -76,6 +76,7 @@ SIGNATURES = {
     "tirt_film_clear": (C.c_int, [_vp]),
     "tirt_pt_rgb_render": (C.c_int, [_vp, C.c_uint32, C.c_int, C.c_uint32, C.c_int, C.c_int, C.c_int]),
     "tirt_bdpt_rgb_render": (C.c_int, [_vp, C.c_uint32, C.c_int, C.c_uint32]),
+    "tirt_bdpt_spec_render": (C.c_int, [_vp, C.c_uint32, C.c_int, C.c_uint32]),
     "tirt_tone_map": (C.c_int, [_vp, C.c_float]),
     "tirt_film_download": (C.c_int, [_vp, _vp, _vp]),
     "tirt_film_export_device": (C.c_int, [_vp, _vp]),
@@ -253,6 +254,9 @@ class Context:
 
     def bdpt_rgb_render(self, frame_begin, frame_count, seed):
         check(lib().tirt_bdpt_rgb_render(self.handle, int(frame_begin), int(frame_count), int(seed)))
+
+    def bdpt_spec_render(self, frame_begin, frame_count, seed):
+        check(lib().tirt_bdpt_spec_render(self.handle, int(frame_begin), int(frame_count), int(seed)))
 
     def pt_spec_render(self, frame_begin, frame_count, seed, max_depth=10, stack_size=64, flags=0):
         check(lib().tirt_pt_spec_render(self.handle, int(frame_begin), int(frame_count), int(seed),

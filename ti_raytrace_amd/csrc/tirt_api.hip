@@ -318,7 +318,7 @@ void tirt_destroy(tirt_ctx *c)
         if (L.film_done) (void)hipEventDestroy(L.film_done);
         if (L.stream) (void)hipStreamDestroy(L.stream);
     }
-    c->spec_mem.release();
+    c->spec_mem.release(); c->spec_dev.release();
     if (c->spec_view) { delete (SpecView *)c->spec_view; c->spec_view = nullptr; }
     if (c->ev_main) (void)hipEventDestroy(c->ev_main);
     (void)hipEventDestroy(c->ev0); (void)hipEventDestroy(c->ev1);
@@ -636,6 +636,12 @@ int tirt_bdpt_rgb_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uin
 {
     CTX(c);
     return bdpt_render(c, frame_begin, frame_count, seed);
+}
+int tirt_bdpt_spec_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed)
+{
+    CTX(c);
+    TIRT_REQUIRE(c->spec_set && c->spec_dev.p, "tirt_bdpt_spec_render: spectral tables not uploaded (tirt_spectral_upload)");
+    return bdpt_render(c, frame_begin, frame_count, seed, true);
 }
 
 int tirt_tone_map(tirt_ctx *c, float exposure)

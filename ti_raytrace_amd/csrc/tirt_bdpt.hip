@@ -28,6 +28,7 @@
 // float atomics, so a frame is reproducible only up to the order of those additions (the parity test uses the north
 // star's 1e-3 relative-L2 tolerance; measured 1e-7).
 #include "tirt_internal.h"
+#include "tirt_spectral.h"
 
 namespace tirt {
 
@@ -97,12 +98,13 @@ TD v3 get_image_point(const CameraView &cam, const BdView &bv, v3 p, int &u, int
 
 struct bsample { v3 next_dir; float f_or_b, brdf, pdfFwd; };
 TD bsample bd_sample(const SceneView &s, v3 dir, v3 normal, v3 fnormal, int mat_id, int mat_type, uint32_t seed, uint32_t pixel,
-                     uint32_t frame, uint32_t dim0, int &delta)
+                     uint32_t frame, uint32_t dim0, int &delta, bool spectral = false, float Lambda = 0.0f)
 {
     bsample r; r.next_dir = dir; r.f_or_b = 1.0f; r.brdf = 0.0f; r.pdfFwd = 0.0f;
     const float *m = mat_row(s, mat_id);
     if (mat_type == MAT_GLASS) {
-        r.next_dir = glass_sample(m, dir, normal, tm_rand(seed, pixel, frame, dim0 + TM_SLOT_GLASS), r.f_or_b);
+        if (spectral) r.next_dir = glass_sample_lambda(dir, normal, Lambda, tm_rand(seed, pixel, frame, dim0 + TM_SLOT_GLASS), r.f_or_b);      // SPEC: BDPT_SPEC.py:241, 335
+        else r.next_dir = glass_sample(m, dir, normal, tm_rand(seed, pixel, frame, dim0 + TM_SLOT_GLASS), r.f_or_b);
         r.brdf = 1.0f; r.pdfFwd = 1.0f;
         delta = 1;
     } else {
@@ -115,7 +117,40 @@ TD bsample bd_sample(const SceneView &s, v3 dir, v3 normal, v3 fnormal, int mat_
     return r;
 }
 
-struct BdCtx { SceneView sc; CameraView cam; BdView bv; uint32_t seed; int bounded; };
+// `spec` != nullptr: BDPT_SPEC (integrator/BDPT_SPEC.py) -- the same tracer carrying ONE wavelength per pixel sample.  The colours of BDPT_RGB
+// become powers at that wavelength, replicated into the three components of the v3 the RGB code carries (so every product below is the
+// reference's scalar product); where BDPT_SPEC.py differs from BDPT_RGB.py in more than that, the code says "SPEC".  The SpecView lives in
+// device memory (tirt_spectral_upload) and is read through the pointer where it is needed.
+struct BdCtx { SceneView sc; CameraView cam; BdView bv; uint32_t seed; int bounded; const SpecView *spec; };
+constexpr uint32_t BD_DIM_LAMBDA = 2, BD_DIM_CONNECT_SPEC = 256;      // the sample's wavelength (dims 0, 1: camera jitter); + 8 e: sample_light() of the l == 1 connection
+// BDPT_SPEC.py:668: lambda_min + lambda_range * size * rand -- up to one step beyond lambda_max, where the sensor reads zero
+TD float bd_lambda(const BdCtx &c, uint32_t pixel, uint32_t frame)
+{ const SpecView &sp = *c.spec; return sp.s_min + (sp.s_range * (float)sp.n_sensor) * tm_rand(c.seed, pixel, frame, BD_DIM_LAMBDA); }
+TD float bd_light_power(const SpecView &sp, v3 emission, float Lambda)             // BDPT_SPEC.py:146-155
+{
+    float ret = 0.0f;
+    const float scale = norm(emission);
+    if (scale > 0.0f) {
+        const v3 coff = r2s_fetch(sp, emission / scale);
+        ret = spd_sample(sp.spd[0], Lambda) * r2s_eval(coff, Lambda) * scale;
+    }
+    return ret;
+}
+TD float bd_reflect_power(const SceneView &s, const SpecView &sp, int mat_id, float Lambda)      // BDPT_SPEC.py:134-144
+{
+    const float *m = s.material + (size_t)mat_id * MAT_VEC;
+    const v3 mat_color = V(m[2], m[3], m[4]);
+    if ((int)m[0] == MAT_LIGHT) return bd_light_power(sp, mat_color, Lambda);
+    return r2s_eval(r2s_fetch(sp, srgb_to_lrgb(mat_color)), Lambda);
+}
+// what BDPT_RGB multiplies a path's throughput with at a surface of material mat_id: its linear colour / its power at the wavelength
+template <bool SPEC>
+TD v3 bd_reflect(const BdCtx &c, int mat_id, float Lambda)
+{
+    if (SPEC) { const float p = bd_reflect_power(c.sc, *c.spec, mat_id, Lambda); return V(p, p, p); }
+    const float *m = c.sc.material + (size_t)mat_id * MAT_VEC;
+    return srgb_to_lrgb(V(m[2], m[3], m[4]));
+}
 
 
 // BDPT_RGB.py:300-479
@@ -245,7 +280,53 @@ TD float bd_mis_weight(const BdCtx &c, const bpixel *P, const bvert &sample, int
     return 1.0f / (1.0f + weight_sum);
 }
 
+// Scene.sample_light (Scene.py:430-474) with its random numbers at dimensions dim_base .. dim_base + 6
+TD void bd_sample_light(const BdCtx &c, uint32_t pixel, uint32_t frame, uint32_t dim_base, v3 &lpos_o, v3 &lnor_o, v3 &ldir_o, v3 &emission_o, int &lp_o,
+                        float &choice_pdf_o, float &dir_pdf_o)
+{
+    const SceneView &s = c.sc;
+    int lidx = (int)(tm_rand(c.seed, pixel, frame, dim_base + 0) * (float)s.light_count);
+    if (lidx >= s.light_count) lidx = s.light_count - 1;
+    const int lp = s.light[lidx];
+    v3 lpos, lnor;
+    get_prim_random_point_normal(s, lp, tm_rand(c.seed, pixel, frame, dim_base + 1), tm_rand(c.seed, pixel, frame, dim_base + 2), lpos, lnor);
+    const float *lm = mat_row(s, s.primitive[(size_t)lp * PRI_VEC + 2]);
+    v3 emission = V(lm[2], lm[3], lm[4]);
+    float choice_pdf = 1.0f / ((float)s.light_count * get_prim_area(s, lp));
+    lnor = normalized(lnor);
+    const v3 ld = cosine_sample_hemisphere(tm_rand(c.seed, pixel, frame, dim_base + 3), tm_rand(c.seed, pixel, frame, dim_base + 4));
+    float dir_pdf = cosine_hemisphere_pdf(ld.z);
+    v3 ldir = inverse_transform(ld, lnor);
+    const int *lpr = s.primitive + (size_t)lp * PRI_VEC;
+    if (lpr[0] != PRIMITIVE_TRI) {                                  // Scene.py:449-472: the two shape emitters without a surface
+        const float *sh = s.shape + (size_t)lpr[1] * SHA_VEC;
+        const int st = (int)sh[0];
+        if (st == SHAPE_SPOT) {
+            const float scale = sh[6];
+            dir_pdf = 1.0f;
+            float r, phi;
+            map_to_disk(tm_rand(c.seed, pixel, frame, dim_base + 5), tm_rand(c.seed, pixel, frame, dim_base + 6), r, phi);
+            const float r1 = scale * tm_tan(sh[4]), r2 = scale * tm_tan(sh[5]);
+            r *= r2;
+            if (r > r1) emission = emission * (1.0f - (r - r1) / (r2 - r1));
+            const v3 sp = V(r * tm_cos(phi), r * tm_sin(phi), tm_sqrt(maxf(0.0f, scale * scale - r * r)));
+            ldir = inverse_transform(sp, lnor);
+        } else if (st == SHAPE_LASER) {
+            choice_pdf = 1.0f / (float)s.light_count;
+            const float r = sh[4];
+            const float phi = tm_rand(c.seed, pixel, frame, dim_base + 5) * PI_UF * 2.0f;
+            v3 sp = V(r * tm_cos(phi), r * tm_sin(phi), 0.0f);
+            sp = inverse_transform(sp, lnor);
+            ldir = lnor;
+            dir_pdf = 1.0f;
+            lpos = lpos + sp;
+        }
+    }
+    lpos_o = lpos; lnor_o = lnor; ldir_o = ldir; emission_o = emission; lp_o = lp; choice_pdf_o = choice_pdf; dir_pdf_o = dir_pdf;
+}
+
 // BDPT_RGB.py:481-592
+template <bool SPEC>
 TD v3 bd_connect_path(const BdCtx &c, const bpixel *P, bvert &sample, int i, int j, int e, int l, uint32_t frame, int &nu, int &nv, Tracer &T)
 {
     const SceneView &s = c.sc;
@@ -253,6 +334,8 @@ TD v3 bd_connect_path(const BdCtx &c, const bpixel *P, bvert &sample, int i, int
     const bvert EV = P->eye[e - 1];
     const bvert LV = (l > 0) ? P->light[l - 1] : bvert();
     const uint32_t pixel = (uint32_t)(i * c.bv.H + j);
+    constexpr bool spectral = SPEC;
+    const float Lambda = spectral ? bd_lambda(c, pixel, frame) : 0.0f;
     v3 radiance = V(0.0f, 0.0f, 0.0f);
     nu = i; nv = j;
     if (l == 0) {
@@ -272,7 +355,7 @@ TD v3 bd_connect_path(const BdCtx &c, const bpixel *P, bvert &sample, int i, int
                 const float brdf = disney_evaluate_pdf(mat_row(s, mat_id), snormal, -LV.wo, -wi, pdf);
                 if (pdf > 0.0f) {
                     const float G = absf(NdotL) / (sh.t * sh.t);
-                    radiance = ((((LV.beta * G) * mat_lrgb(s, mat_id)) * brdf) / pdf);
+                    radiance = ((((LV.beta * G) * bd_reflect<SPEC>(c, mat_id, Lambda)) * brdf) / pdf);
                     sample.pos = origin; sample.wo = wi; sample.type = VERTEX_LENS; sample.fpdf = 1.0f;
                 }
             }
@@ -280,7 +363,30 @@ TD v3 bd_connect_path(const BdCtx &c, const bpixel *P, bvert &sample, int i, int
     } else if (l == 1) {
         const v3 surface = offset_ray(EV.pos, EV.snormal);
         const int mat_id = EV.mat;
-        if (EV.delta != 1) {
+        if (spectral && EV.delta != 1) {
+            // SPEC: BDPT_SPEC.py:605-630 -- sample_light() (its direction sample is drawn and dropped) instead of sample_li(surface); an emitter without
+            // a surface (spot, laser) can never be the shadow ray's hit, so it contributes through the light path only
+            v3 light_pos, light_normal, light_dir_unused, light_emission; int light_prim; float light_choice_pdf, light_dir_pdf;
+            bd_sample_light(c, pixel, frame, BD_DIM_CONNECT_SPEC + 8u * (uint32_t)e, light_pos, light_normal, light_dir_unused, light_emission, light_prim,
+                            light_choice_pdf, light_dir_pdf);
+            const v3 wi = normalized(surface - light_pos);
+            const float NdotLl = dot(wi, light_normal), NdotLe = dot(wi, EV.snormal);
+            const SimpleHit sh = bd_trace(T, surface, -wi, light_prim, c.bounded ? norm(surface - light_pos) : -1.0f);
+            if ((sh.prim == light_prim) & (sh.t > EPS_UF)) {
+                const float light_pdf = light_choice_pdf;
+                float pdf;
+                const float brdf = disney_evaluate_pdf(mat_row(s, mat_id), EV.snormal, -EV.wo, -wi, pdf);
+                if (pdf > 0.0f) {
+                    const float G = absf(NdotLe * NdotLl) / (sh.t * sh.t);
+                    v3 cc = ((EV.beta * G) * brdf) / pdf;
+                    cc = cc * bd_reflect<SPEC>(c, mat_id, Lambda);
+                    cc = cc * bd_light_power(*c.spec, light_emission, Lambda);
+                    radiance = cc / light_pdf;
+                }
+                sample.pos = light_pos; sample.wo = wi; sample.type = VERTEX_LIGHT; sample.fpdf = light_pdf;
+                sample.prim = light_prim; sample.normal = light_normal; sample.snormal = light_normal;
+            }
+        } else if (EV.delta != 1) {
             const uint32_t d0 = BD_DIM_CONNECT + 4u * (uint32_t)e;              // Scene.py:477-518 sample_li(surface)
             int lidx = (int)(tm_rand(c.seed, pixel, frame, d0) * (float)s.light_count);
             if (lidx >= s.light_count) lidx = s.light_count - 1;
@@ -331,8 +437,8 @@ TD v3 bd_connect_path(const BdCtx &c, const bpixel *P, bvert &sample, int i, int
                     v3 cc = (EV.beta * G) * LV.beta;
                     cc = (cc * brdfL) / lpdf;
                     cc = (cc * brdfE) / epdf;
-                    cc = cc * mat_lrgb(s, mat_idE);
-                    radiance = cc * mat_lrgb(s, mat_idL);
+                    cc = cc * bd_reflect<SPEC>(c, mat_idE, Lambda);
+                    radiance = cc * bd_reflect<SPEC>(c, mat_idL, Lambda);
                 }
             }
         }
@@ -356,6 +462,7 @@ TD void count_rays(unsigned long long *ctr, unsigned mine)
 }
 
 // BDPT_RGB.py:104-125 (lens vertex, camera ray) and :201-228 with Scene.sample_light (Scene.py:430-474)
+template <bool SPEC>
 __global__ void k_bd_init(BdCtx c, bpixel *items, BdStep *steps, BdRays rays, int *owner, int *alive_cnt, TileMap tm, int P, int N, uint32_t frame_begin, unsigned long long *paths)
 {
     const int it = blockIdx.x * blockDim.x + threadIdx.x;
@@ -379,49 +486,19 @@ __global__ void k_bd_init(BdCtx c, bpixel *items, BdStep *steps, BdRays rays, in
     }
     // light
     {
-        const SceneView &s = c.sc;
         bvert *light = B->light;
-        int lidx = (int)(tm_rand(c.seed, pixel, frame, BD_DIM_LSTART + 0) * (float)s.light_count);
-        if (lidx >= s.light_count) lidx = s.light_count - 1;
-        const int lp = s.light[lidx];
-        v3 lpos, lnor;
-        get_prim_random_point_normal(s, lp, tm_rand(c.seed, pixel, frame, BD_DIM_LSTART + 1), tm_rand(c.seed, pixel, frame, BD_DIM_LSTART + 2), lpos, lnor);
-        const float *lm = mat_row(s, s.primitive[(size_t)lp * PRI_VEC + 2]);
-        v3 emission = V(lm[2], lm[3], lm[4]);
-        float choice_pdf = 1.0f / ((float)s.light_count * get_prim_area(s, lp));
-        lnor = normalized(lnor);
-        const v3 ld = cosine_sample_hemisphere(tm_rand(c.seed, pixel, frame, BD_DIM_LSTART + 3), tm_rand(c.seed, pixel, frame, BD_DIM_LSTART + 4));
-        float dir_pdf = cosine_hemisphere_pdf(ld.z);
-        v3 ldir = inverse_transform(ld, lnor);
-        const int *lpr = s.primitive + (size_t)lp * PRI_VEC;
-        if (lpr[0] != PRIMITIVE_TRI) {                                  // Scene.py:449-472: the two shape emitters without a surface
-            const float *sh = s.shape + (size_t)lpr[1] * SHA_VEC;
-            const int st = (int)sh[0];
-            if (st == SHAPE_SPOT) {
-                const float scale = sh[6];
-                dir_pdf = 1.0f;
-                float r, phi;
-                map_to_disk(tm_rand(c.seed, pixel, frame, BD_DIM_LSTART + 5), tm_rand(c.seed, pixel, frame, BD_DIM_LSTART + 6), r, phi);
-                const float r1 = scale * tm_tan(sh[4]), r2 = scale * tm_tan(sh[5]);
-                r *= r2;
-                if (r > r1) emission = emission * (1.0f - (r - r1) / (r2 - r1));
-                const v3 sp = V(r * tm_cos(phi), r * tm_sin(phi), tm_sqrt(maxf(0.0f, scale * scale - r * r)));
-                ldir = inverse_transform(sp, lnor);
-            } else if (st == SHAPE_LASER) {
-                choice_pdf = 1.0f / (float)s.light_count;
-                const float r = sh[4];
-                const float phi = tm_rand(c.seed, pixel, frame, BD_DIM_LSTART + 5) * PI_UF * 2.0f;
-                v3 sp = V(r * tm_cos(phi), r * tm_sin(phi), 0.0f);
-                sp = inverse_transform(sp, lnor);
-                ldir = lnor;
-                dir_pdf = 1.0f;
-                lpos = lpos + sp;
-            }
-        }
+        v3 lpos, lnor, ldir, emission; int lp; float choice_pdf, dir_pdf;
+        bd_sample_light(c, pixel, frame, BD_DIM_LSTART, lpos, lnor, ldir, emission, lp, choice_pdf, dir_pdf);
+        (void)lp;
         const float light_pdf = choice_pdf;
-        light[0].pos = lpos; light[0].normal = lnor; light[0].beta = emission / light_pdf;
+        v3 beta0 = emission / light_pdf, beta1 = (emission / light_pdf) * absf(dot(lnor, ldir));
+        if (SPEC) {          // SPEC: power[0] = light power at the wavelength / pdf, and beta = power[0] without the cosine (BDPT_SPEC.py:284, 294)
+            const float pw = bd_light_power(*c.spec, emission, bd_lambda(c, pixel, frame)) / light_pdf;
+            beta0 = V(pw, pw, pw); beta1 = beta0;
+        }
+        light[0].pos = lpos; light[0].normal = lnor; light[0].beta = beta0;
         light[0].fpdf = light_pdf; light[0].rpdf = 0.0f; light[0].wo = ldir; light[0].type = VERTEX_LIGHT;
-        st.l_beta = (emission / light_pdf) * absf(dot(lnor, ldir)); st.l_pdfFwd = dir_pdf; st.l_alive = 1; st.light_depth = 1;
+        st.l_beta = beta1; st.l_pdfFwd = dir_pdf; st.l_alive = 1; st.light_depth = 1;
         put_ray(rays, (size_t)N + it, lpos, ldir); owner[N + it] = N + it;
     }
     steps[it] = st;
@@ -433,6 +510,7 @@ __global__ void k_bd_init(BdCtx c, bpixel *items, BdStep *steps, BdRays rays, in
 // The rays of a depth are a dense list (`rays`, `owner`: which sub-path -- t < N eye of item t, else light of item t - N); the
 // sub-paths that go on append their next ray to the list of the next depth (one atomic per wave), so the later depths launch
 // work only for what is still alive.
+template <bool SPEC>
 __global__ void k_bd_step(BdCtx c, bpixel *items, BdStep *steps, BdRays rays, const int *owner, BdRays rays_out, int *owner_out, int *alive_cnt,
                           const float4 *hits, TileMap tm, int P, int N, uint32_t frame_begin, int depth, unsigned long long *rays_closest)
 {
@@ -453,6 +531,8 @@ __global__ void k_bd_step(BdCtx c, bpixel *items, BdStep *steps, BdRays rays, co
             const uint32_t pixel = (uint32_t)local_to_pixel(tm, k), frame = frame_begin + (uint32_t)f;
             const SceneView &s = c.sc;
             bpixel *B = items + it;
+            constexpr bool spectral = SPEC;
+            const float Lambda = spectral ? bd_lambda(c, pixel, frame) : 0.0f;
             const v3 origin = V(rays.ox[qi], rays.oy[qi], rays.oz[qi]), dir = V(rays.dx[qi], rays.dy[qi], rays.dz[qi]);
             const float4 hr = hits[qi];
             SimpleHit sh; sh.t = hr.x; sh.u = hr.y; sh.v = hr.z; sh.prim = __float_as_int(hr.w);
@@ -479,15 +559,16 @@ __global__ void k_bd_step(BdCtx c, bpixel *items, BdStep *steps, BdRays rays, co
                     e->pos = pos; e->normal = normal; e->snormal = fnormal; e->wo = dir; e->rpdf = 0.0f; e->prim = sh.prim; e->mat = mat_id;
                     e->fpdf = pdfFwd * absf(dot(to, eye[pre_depth].normal)) * inv_dist2;
                     if (mat_type == MAT_LIGHT) {
-                        e->beta = (beta * mat_color) * absf(dot(normal, dir));
+                        if (spectral) e->beta = beta * bd_reflect<SPEC>(c, mat_id, Lambda);          // SPEC: beta * reflect_power, no cosine (BDPT_SPEC.py:228)
+                        else e->beta = (beta * mat_color) * absf(dot(normal, dir));
                         e->type = VERTEX_LIGHT;
                         final_depth = depth + 1;
                     } else {
                         e->beta = beta * absf(dot(dir, normal));
                         e->type = VERTEX_SURFACE;
-                        const v3 reflect_color = srgb_to_lrgb(mat_color);
+                        const v3 reflect_color = spectral ? bd_reflect<SPEC>(c, mat_id, Lambda) : srgb_to_lrgb(mat_color);
                         int delta = 0;
-                        const bsample bs = bd_sample(s, dir, normal, fnormal, mat_id, mat_type, c.seed, pixel, frame, BD_DIM_EYE + 8u * (uint32_t)depth, delta);
+                        const bsample bs = bd_sample(s, dir, normal, fnormal, mat_id, mat_type, c.seed, pixel, frame, BD_DIM_EYE + 8u * (uint32_t)depth, delta, spectral, Lambda);
                         e->delta = delta;
                         pdfFwd = bs.pdfFwd;
                         if (pdfFwd > 0.0f) {
@@ -500,7 +581,7 @@ __global__ void k_bd_step(BdCtx c, bpixel *items, BdStep *steps, BdRays rays, co
                             }
                             eye[pre_depth].rpdf = pdfRev * absf(dot(to, e->normal)) * inv_dist2;
                             bool killed = false;
-                            if (bs.f_or_b < 0.0f) {
+                            if (!spectral && bs.f_or_b < 0.0f) {          // (SPEC has no extinction roulette)
                                 const float R = tm_exp(-sh.t / m[6]);
                                 if (tm_rand(c.seed, pixel, frame, BD_DIM_EYE + 8u * (uint32_t)depth + TM_SLOT_EXT) >= R) killed = true;
                             }
@@ -536,9 +617,9 @@ __global__ void k_bd_step(BdCtx c, bpixel *items, BdStep *steps, BdRays rays, co
                         const float inv_dist2 = 1.0f / (dist * dist);
                         to = to / dist;
                         L->fpdf *= absf(dot(to, light[pre_depth].normal)) * inv_dist2;
-                        const v3 reflect_color = srgb_to_lrgb(mat_color);
+                        const v3 reflect_color = spectral ? bd_reflect<SPEC>(c, mat_id, Lambda) : srgb_to_lrgb(mat_color);
                         int delta = 0;
-                        const bsample bs = bd_sample(s, dir, normal, fnormal, mat_id, mat_type, c.seed, pixel, frame, BD_DIM_LIGHT + 8u * (uint32_t)depth, delta);
+                        const bsample bs = bd_sample(s, dir, normal, fnormal, mat_id, mat_type, c.seed, pixel, frame, BD_DIM_LIGHT + 8u * (uint32_t)depth, delta, spectral, Lambda);
                         L->delta = delta;
                         pdfFwd = bs.pdfFwd;
                         if (pdfFwd > 0.0f) {
@@ -551,7 +632,7 @@ __global__ void k_bd_step(BdCtx c, bpixel *items, BdStep *steps, BdRays rays, co
                             }
                             light[pre_depth].rpdf = pdfRev * absf(dot(to, L->normal)) * inv_dist2;
                             bool killed = false;
-                            if (bs.f_or_b < 0.0f) {
+                            if (!spectral && bs.f_or_b < 0.0f) {
                                 const float R = tm_exp(-sh.t / m[6]);
                                 if (tm_rand(c.seed, pixel, frame, BD_DIM_LIGHT + 8u * (uint32_t)depth + TM_SLOT_EXT) >= R) killed = true;
                             }
@@ -606,7 +687,7 @@ __global__ void k_bd_delta(bpixel *items, const BdStep *steps, TileMap tm, int P
 }
 
 // BDPT_RGB.py:615-637, the double loop over (e, l), in two passes around the batched connection queries.
-template <int PHASE>
+template <int PHASE, bool SPEC>
 __global__ void k_bd_connect(BdCtx c, bpixel *items, const BdStep *steps, TileMap tm, int P, int N, uint32_t frame_begin,
                              BdRays srays, int *sexpect, float *sbound, int *qidx, int *ibase, int *icount, int *scount, const float4 *shits,
                              float *radiance, long frame_stride, unsigned long long *rays_shadow)
@@ -642,7 +723,7 @@ __global__ void k_bd_connect(BdCtx c, bpixel *items, const BdStep *steps, TileMa
             }
             int nu = 0, nv = 0;
             v3 r = V(0.0f, 0.0f, 0.0f);
-            if (valid && !(PHASE == 0 && l == 0)) r = bd_connect_path(c, B, sample, i, j, e, l, frame, nu, nv, T);      // l == 0 needs no ray
+            if (valid && !(PHASE == 0 && l == 0)) r = bd_connect_path<SPEC>(c, B, sample, i, j, e, l, frame, nu, nv, T);      // l == 0 needs no ray
             if (PHASE == 0) {
                 // the item's j-th connection ray goes to staging slot [j][item] (k_bd_compact makes the queue dense: one atomic
                 // per wave at the end of this kernel instead of one per wave and pair -- same-address atomics retire at ~11 ns)
@@ -658,6 +739,15 @@ __global__ void k_bd_connect(BdCtx c, bpixel *items, const BdStep *steps, TileMa
                 }
             } else if (valid) {
                 const long q = (e == 1) ? ((nu >= 0) ? (long)nu * c.bv.H + nv : -1) : (long)p;
+                if (SPEC) {          // SPEC: AddSplat (BDPT_SPEC.py:178-181): the sensor's response at the wavelength, as clamped sRGB, times the range
+                    const SpecView &sp = *c.spec;
+                    const v3 xyz = sensor_sample(sp, bd_lambda(c, (uint32_t)p, frame));
+                    const float range = sp.s_max - sp.s_min;
+                    const float cr = (3.240479f * xyz.x + -1.537150f * xyz.y) + -0.498535f * xyz.z;
+                    const float cg = (-0.969256f * xyz.x + 1.875991f * xyz.y) + 0.041556f * xyz.z;
+                    const float cb = (0.055648f * xyz.x + -0.204043f * xyz.y) + 1.057311f * xyz.z;
+                    r = V((clampf(cr, 0.0f, 1000.0f) * range) * r.x, (clampf(cg, 0.0f, 1000.0f) * range) * r.x, (clampf(cb, 0.0f, 1000.0f) * range) * r.x);
+                }
                 if (q >= 0 && (r.x != 0.0f || r.y != 0.0f || r.z != 0.0f)) {
                     atomicAdd(&rad[3 * q], r.x); atomicAdd(&rad[3 * q + 1], r.y); atomicAdd(&rad[3 * q + 2], r.z);
                 }
@@ -711,7 +801,7 @@ __global__ void k_bdpt_film(const float *radiance, float *hdr, long nvals, float
     hdr[k] = radiance[k] * coff + hdr[k] * (1.0f - coff);
 }
 
-int bdpt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed)
+int bdpt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed, bool spectral)
 {
     TIRT_REQUIRE(c->built && c->cam_set && c->hdr.p, "tirt_bdpt_rgb_render: scene, camera and film must be set up");
     TIRT_REQUIRE(frame_count >= 0, "tirt_bdpt_rgb_render: bad frame_count");
@@ -759,6 +849,7 @@ int bdpt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t see
     }
     BdCtx bc;
     bc.sc = scene_view(c); bc.cam = c->cam; bc.seed = seed; bc.bounded = c->bdpt_bounded;
+    bc.spec = spectral ? c->spec_dev.as<SpecView>() : nullptr;
     for (int k = 0; k < 12; k++) bc.bv.view[k] = c->view[k];
     bc.bv.W = c->W; bc.bv.H = c->H;
     DevCounters *ctr = c->dev_counters.as<DevCounters>();
@@ -794,23 +885,29 @@ int bdpt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t see
         BdRays rset[2] = {sr, er};                                  // depth d reads rset[d & 1]
         int *oset[2] = {sexpect, gexpect};
         int *alive_cnt = scount + 4;
-        hipLaunchKernelGGL(k_bd_init, dim3((N + B - 1) / B), dim3(B), 0, st, bc, items, state, rset[1], oset[1], alive_cnt,
-                           tm, P, N, frame0, &ctr->paths);
+        if (spectral) hipLaunchKernelGGL(k_bd_init<true>, dim3((N + B - 1) / B), dim3(B), 0, st, bc, items, state, rset[1], oset[1], alive_cnt, tm, P, N, frame0, &ctr->paths);
+        else hipLaunchKernelGGL(k_bd_init<false>, dim3((N + B - 1) / B), dim3(B), 0, st, bc, items, state, rset[1], oset[1], alive_cnt, tm, P, N, frame0, &ctr->paths);
         // rays of the two sub-paths share the launches
         for (int d = 1; d < BD_EYE_MAX; d++) {
             const BdRays &ri = rset[d & 1], &ro = rset[(d + 1) & 1];
             if (int rc = trace_arrays(c, ri.ox, ri.oy, ri.oz, ri.dx, ri.dy, ri.dz, 2 * N, alive_cnt + d, ehits, nullptr, nullptr, false, lane)) return rc;
-            hipLaunchKernelGGL(k_bd_step, dim3((2 * N + B - 1) / B), dim3(B), 0, st, bc, items, state, ri, oset[d & 1], ro,
+            if (spectral) hipLaunchKernelGGL(k_bd_step<true>, dim3((2 * N + B - 1) / B), dim3(B), 0, st, bc, items, state, ri, oset[d & 1], ro,
+                               oset[(d + 1) & 1], alive_cnt, ehits, tm, P, N, frame0, d, &ctr->rays_closest);
+            else hipLaunchKernelGGL(k_bd_step<false>, dim3((2 * N + B - 1) / B), dim3(B), 0, st, bc, items, state, ri, oset[d & 1], ro,
                                oset[(d + 1) & 1], alive_cnt, ehits, tm, P, N, frame0, d, &ctr->rays_closest);
         }
         if (last_delta) TIRT_HIP(hipStreamWaitEvent(st, last_delta, 0));      // the per-pixel memory is replayed in frame order
         hipLaunchKernelGGL(k_bd_delta, dim3((P + B - 1) / B), dim3(B), 0, st, items, state, tm, P, F, c->bdpt_px.as<int>());
         if (NL > 1) { TIRT_HIP(hipEventRecord(bl.delta_done, st)); last_delta = bl.delta_done; }
-        hipLaunchKernelGGL(k_bd_connect<0>, dim3((N + B - 1) / B), dim3(B), 0, st, bc, items, state, tm, P, N, frame0,
+        if (spectral) hipLaunchKernelGGL((k_bd_connect<0, true>), dim3((N + B - 1) / B), dim3(B), 0, st, bc, items, state, tm, P, N, frame0,
+                           gr, gexpect, gbound, bl.qidx.as<int>(), ibase, icount, scount, shits, bl.rad.as<float>(), 3 * NP, &ctr->rays_shadow);
+        else hipLaunchKernelGGL((k_bd_connect<0, false>), dim3((N + B - 1) / B), dim3(B), 0, st, bc, items, state, tm, P, N, frame0,
                            gr, gexpect, gbound, bl.qidx.as<int>(), ibase, icount, scount, shits, bl.rad.as<float>(), 3 * NP, &ctr->rays_shadow);
         hipLaunchKernelGGL(k_bd_compact, dim3((N + B - 1) / B), dim3(B), 0, st, N, ibase, icount, gr, gexpect, gbound, sr, sexpect, sbound);
         if (int rc = trace_arrays(c, sr.ox, sr.oy, sr.oz, sr.dx, sr.dy, sr.dz, (int)(SCAP < (size_t)N * 27 ? SCAP : (size_t)N * 27), scount, shits, sexpect, sbound, false, lane)) return rc;
-        hipLaunchKernelGGL(k_bd_connect<1>, dim3((N + B - 1) / B), dim3(B), 0, st, bc, items, state, tm, P, N, frame0,
+        if (spectral) hipLaunchKernelGGL((k_bd_connect<1, true>), dim3((N + B - 1) / B), dim3(B), 0, st, bc, items, state, tm, P, N, frame0,
+                           sr, gexpect /* staged `expect` words: now the rays' places in the queue */, sbound, bl.qidx.as<int>(), ibase, icount, scount, shits, bl.rad.as<float>(), 3 * NP, &ctr->rays_shadow);
+        else hipLaunchKernelGGL((k_bd_connect<1, false>), dim3((N + B - 1) / B), dim3(B), 0, st, bc, items, state, tm, P, N, frame0,
                            sr, gexpect /* staged `expect` words: now the rays' places in the queue */, sbound, bl.qidx.as<int>(), ibase, icount, scount, shits, bl.rad.as<float>(), 3 * NP, &ctr->rays_shadow);
         if (last_film) TIRT_HIP(hipStreamWaitEvent(st, last_film, 0));        // the running mean applies the frames in order
         for (int f = 0; f < F; f++) {

@@ -262,6 +262,7 @@ struct tirt_ctx {
     int bdpt_bounded = 1;                          // option "bdpt_bounded": connection rays stop at their target distance
 
     // PT_Spec tables (tirt_spectral_upload): CIE observer, spectra, Rgb2Spec table, sky configuration -- one buffer, views in spec_host
+    tirt::DevBuf spec_dev;                      // the SpecView again, in device memory (BDPT_SPEC)
     tirt::DevBuf spec_mem; bool spec_set = false; void *spec_view = nullptr;      // spec_view: a heap tirt::SpecView (tirt_spectral.h) with device pointers
 
     // batch trace scratch
@@ -320,7 +321,7 @@ int launch_trace_batch(tirt_ctx *c, const float *rays, int nr, int stack_size, i
                        float *out_f, int32_t *out_prim, int32_t *counts);
 struct SpecView;
 int pt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed, int max_depth, int stack_size, int flags, const SpecView *spec = nullptr);   // spec != nullptr: PT_Spec
-int bdpt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed);
+int bdpt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed, bool spectral = false);      // spectral: BDPT_SPEC
 int trace_arrays(tirt_ctx *c, const float *ox, const float *oy, const float *oz, const float *dx, const float *dy, const float *dz,
                  int count, const int *count_ptr, float4 *hit, const int *expect, const float *bound, bool count_rays, int lane = -1);
 int ensure_counters(tirt_ctx *c);

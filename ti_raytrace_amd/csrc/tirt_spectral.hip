@@ -224,6 +224,9 @@ int tirt_spectral_upload(tirt_ctx *c, const tirt_spectral_t *t)
     v->sky_cfg = base + o_cfg; v->sky_rad = base + o_rad;
     for (int k = 0; k < 3; k++) v->sun_dir[k] = t->sun_dir[k];
     c->spec_view = v; c->spec_set = true;
+    // a copy of the view in device memory: the BDPT kernels read it through a pointer (BdCtx::spec, tirt_bdpt.hip)
+    if (c->spec_dev.ensure(sizeof(SpecView))) return TIRT_ERR_HIP;
+    TIRT_HIP(hipMemcpy(c->spec_dev.p, v, sizeof(SpecView), hipMemcpyHostToDevice));
     return TIRT_OK;
 }
 

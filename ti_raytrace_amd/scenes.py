@@ -7,7 +7,7 @@ import os
 
 import numpy as np
 
-from . import Example, PT_RGB, BDPT_RGB, PT_Spec
+from . import Example, PT_RGB, BDPT_RGB, PT_Spec, BDPT_SPEC
 from . import SceneData as SCD
 
 ASSETS = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "assets")
@@ -193,3 +193,34 @@ class synthetic(Example.example):
         Example.example.build_scene(self)
         self.scene.total_area()
         self.frame_camera(0.8)
+
+
+class prism_rainbow(Example.example):
+    """example/prism_rainbow.py:13-66: a glass prism (model/prism1.obj: glass, wall, ground) lit by a sphere light and by a LASER beam
+    (SceneData.SHPAE_LASER, radius 0.1, from (1, 0, 9) along -z) that the prism disperses into a spectrum, through BDPT_SPEC -- the light
+    sub-path is the only way light from an emitter without a surface reaches the film."""
+
+    def __init__(self, imgSizeX, imgSizeY, sample_count, device_id=None, laser_emission=500.0, sphere_emission=500.0, with_sphere_light=True, **kwargs):
+        Example.example.__init__(self, imgSizeX, imgSizeY, sample_count, device_id)
+        self.scene.add_obj(asset("model", "prism1.obj"))
+        # (with_sphere_light=False: the laser alone, which is what the reference's gallery image of this example shows -- everything but the
+        # spectrum on the wall is black there)
+        if with_sphere_light:
+            self.add_sphere_light(pos=(0.0, 20.0, 0.0), radius=5.0, emission=sphere_emission)
+        shape = SCD.Shape()
+        shape.type = SCD.SHPAE_LASER
+        shape.pos = [1.0, 0.0, 9.0]
+        shape.setRadius(0.1)
+        shape.setNormal([0.0, 0.0, -1.0])
+        mat = SCD.Material()
+        mat.type = SCD.MAT_LIGHT
+        mat.setColor([laser_emission, laser_emission, laser_emission])
+        self.scene.add_shape(shape, mat)
+        self.integrator = BDPT_SPEC.BDPT(imgSizeX, imgSizeY, self.cam, self.scene, 1024, **kwargs)
+
+    def build_scene(self):
+        Example.example.build_scene(self)
+        self.scene.total_area()
+        self.cam.scale = 10.0
+        self.cam.set_target(0.0, 0.0, 0.0)
+        self.cam.update()
