@@ -302,6 +302,23 @@ def run_config(name, device_id, seed=1):
         r["oracle_sample"] = "1024 pixels x 64 spp, bit for bit"
         r["reference_pin"] = "structure pin against image/spectral-cornellbox.png: tests/test_spectral.py (the gallery render is of an earlier scene set-up; no radiometric pin)"
         return r
+    if name == "prism_rainbow_bdpt_spec_512x512_64spp":       # SURVEY 8f rank 4, second half: example/prism_rainbow.py through BDPT_SPEC
+        W = H = 512; spp = 64
+        ex = scenes.prism_rainbow(W, H, spp, device_id=device_id, seed=seed); ex.build_scene()
+        hdr, r = timed(ex, spp, lambda: ex.integrator.render_frames(spp))
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_api
+        w = 48                                                    # splats land on any pixel: the oracle check is a whole (small) film, as for config 5
+        ex2 = scenes.prism_rainbow(w, w, 3, device_id=device_id, seed=seed); ex2.build_scene()
+        ex2.integrator.render_frames(3); got = ex2.integrator.hdr.to_numpy()
+        o = oracle_api.OracleScene(ex2.scene, ex2.cam); o.lbvh_build(); o.set_spectral(ex2.integrator.tables())
+        want, ost, _ = o.bdpt_spec_render(ex2.cam, w, w, 0, 3, seed=seed, stack_size=1024)
+        rel = float(np.sqrt(((got.astype(np.float64) - want) ** 2).sum() / max((want.astype(np.float64) ** 2).sum(), 1e-30)))
+        st2 = ex2.scene.ctx.stats()
+        r["oracle_sample_identical"] = bool(rel <= 1e-5 and st2["rays_closest"] >= ost["rays_closest"])
+        r["oracle_sample"] = "whole 48x48 film x 3 spp: rel-L2 %.2e (float-atomic splats)" % rel
+        r["reference_pin"] = "structure pin against image/rainbow.png: tests/test_bdpt_spec.py, tests/test_gpu_bdpt_spec.py"
+        return r
     raise SystemExit("unknown config " + name)
 
 
@@ -741,7 +758,8 @@ def main():
     # ---- the other BASELINE configs and the build at 1 M primitives, driver-observable (rank 0, N = 1, after the timed region) ----
     if rank == 0 and world == 1 and not args.no_configs:
         cfgs = {}
-        for name in ("config1_cornell_512x512_512spp", "config2_teapot_1024x1024_64spp", "config5_veach_bdpt_512x512_64spp", "spectral_cornell_512x512_64spp"):
+        for name in ("config1_cornell_512x512_512spp", "config2_teapot_1024x1024_64spp", "config5_veach_bdpt_512x512_64spp", "spectral_cornell_512x512_64spp",
+                     "prism_rainbow_bdpt_spec_512x512_64spp"):
             try:
                 cfgs[name] = run_config(name, local_rank, args.seed)
             except Exception as exc:        # noqa: BLE001 -- one failing config must not hide the headline line
