@@ -556,6 +556,7 @@ def main():
     ctx.stats_reset()
     t_begin = time.perf_counter()
     run_steps(args.steps)
+    t_submitted = time.perf_counter()             # the host has queued everything (the last, deferred batch goes out with the sync below)
     ctx.sync()
     t_reduce = time.perf_counter()
     film = tdist.reduce_film(ctx, W, H, dst=0, force=force_dist)   # one RCCL reduce of the framebuffer (world > 1)
@@ -582,6 +583,7 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": round(elapsed * 1e3 / max(args.steps, 1), 4),
+        "host_submit_ms": round((t_submitted - t_begin) * 1e3, 3),          # rank 0: time the host spent queueing the timed steps (inside the timed region)
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
