@@ -689,7 +689,7 @@ __global__ void k_bd_delta(bpixel *items, const BdStep *steps, TileMap tm, int P
 // BDPT_RGB.py:615-637, the double loop over (e, l), in two passes around the batched connection queries.
 template <int PHASE, bool SPEC>
 __global__ void k_bd_connect(BdCtx c, bpixel *items, const BdStep *steps, TileMap tm, int P, int N, uint32_t frame_begin,
-                             BdRays srays, int *sexpect, float *sbound, int *qidx, int *ibase, int *icount, int *scount, const float4 *shits,
+                             float4 *stage, int *qidx, int *ibase, int *icount, int *scount, const float4 *shits,
                              float *radiance, long frame_stride, unsigned long long *rays_shadow)
 {
     const int it = blockIdx.x * blockDim.x + threadIdx.x;
@@ -717,7 +717,7 @@ __global__ void k_bd_connect(BdCtx c, bpixel *items, const BdStep *steps, TileMa
             if (PHASE == 1 && valid) {
                 const int ql = qidx[(size_t)slot * (size_t)N + it];
                 if (ql >= 0) {                               // k_bd_compact left the ray's place in the dense queue where its `expect` was staged
-                    const float4 hr = shits[sexpect[(size_t)ql * (size_t)N + it]];
+                    const float4 hr = shits[__float_as_int(stage[2 * ((size_t)ql * (size_t)N + it) + 1].z)];
                     T.res.t = hr.x; T.res.u = hr.y; T.res.v = hr.z; T.res.prim = __float_as_int(hr.w);
                 }
             }
@@ -732,8 +732,10 @@ __global__ void k_bd_connect(BdCtx c, bpixel *items, const BdStep *steps, TileMa
                     if (T.want) {
                         local = (int)emitted++;
                         const size_t k = (size_t)local * (size_t)N + it;
-                        put_ray(srays, k, T.o, T.d);
-                        sexpect[k] = T.expect; sbound[k] = T.bound;
+                        // one 32-byte record per staged ray (two 16-byte stores): as six + two scattered words this kernel was bound by its
+                        // store REQUESTS (texture-address unit 0.89 busy, 34 write requests per item)
+                        stage[2 * k] = make_float4(T.o.x, T.o.y, T.o.z, T.d.x);
+                        stage[2 * k + 1] = make_float4(T.d.y, T.d.z, __int_as_float(T.expect), T.bound);
                     }
                     qidx[(size_t)slot * (size_t)N + it] = local;
                 }
@@ -770,7 +772,7 @@ __global__ void k_bd_connect(BdCtx c, bpixel *items, const BdStep *steps, TileMa
 // staging slots [j][item] -> dense connection-ray queue.  A wave moves the rays of its 64 items slot by slot: the j-th rays of the
 // items that have one are read from 64 consecutive staging words and written to consecutive queue words (per item, ray after ray,
 // the writes were 4-byte scatters: 5.0 -> 2.1 ms per 8 Mi items).  Where a ray went is left in its staged `expect` word for pass 1.
-__global__ void k_bd_compact(int N, const int *ibase, const int *icount, BdRays stage, int *sexpect_in, const float *sbound_in,
+__global__ void k_bd_compact(int N, const int *ibase, const int *icount, float4 *stage,
                              BdRays dense, int *sexpect, float *sbound)
 {
     const int it = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
@@ -784,10 +786,11 @@ __global__ void k_bd_compact(int N, const int *ibase, const int *icount, BdRays 
         if (m == 0ull) break;
         if (n > j) {
             const size_t k = (size_t)j * (size_t)N + it, q = (size_t)(off + __popcll(m & lt_mask));
-            dense.ox[q] = stage.ox[k]; dense.oy[q] = stage.oy[k]; dense.oz[q] = stage.oz[k];
-            dense.dx[q] = stage.dx[k]; dense.dy[q] = stage.dy[k]; dense.dz[q] = stage.dz[k];
-            sexpect[q] = sexpect_in[k]; sbound[q] = sbound_in[k];
-            sexpect_in[k] = (int)q;
+            const float4 s0 = stage[2 * k], s1 = stage[2 * k + 1];
+            dense.ox[q] = s0.x; dense.oy[q] = s0.y; dense.oz[q] = s0.z;
+            dense.dx[q] = s0.w; dense.dy[q] = s1.x; dense.dz[q] = s1.y;
+            sexpect[q] = __float_as_int(s1.z); sbound[q] = s1.w;
+            stage[2 * k + 1].z = __int_as_float((int)q);
         }
         off += __popcll(m);
     }
@@ -869,8 +872,8 @@ int bdpt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t see
         BdRays sr = {sf, sf + SCAP, sf + 2 * SCAP, sf + 3 * SCAP, sf + 4 * SCAP, sf + 5 * SCAP};
         int *sexpect = (int *)(sf + 6 * SCAP); float *sbound = sf + 7 * SCAP;
         float *gf = sf + 8 * SCAP;                                   // staging arrays, [slot j][item]
-        BdRays gr = {gf, gf + SCAP, gf + 2 * SCAP, gf + 3 * SCAP, gf + 4 * SCAP, gf + 5 * SCAP};
-        int *gexpect = (int *)(gf + 6 * SCAP); float *gbound = gf + 7 * SCAP;
+        float4 *stage = (float4 *)gf;                               // [slot j][item]: 32-byte records (o, d, expect, bound)
+        int *gexpect = (int *)gf;                                    // (the owner list of the sub-path phase: 2 N ints, before any record is staged)
         int *ibase = bl.qidx.as<int>() + NMAX * BD_PAIRS, *icount = ibase + NMAX;
         float4 *ehits = bl.hits.as<float4>(), *shits = ehits + 2 * NMAX;
         int *scount = bl.ctr.as<int>();
@@ -900,15 +903,15 @@ int bdpt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t see
         hipLaunchKernelGGL(k_bd_delta, dim3((P + B - 1) / B), dim3(B), 0, st, items, state, tm, P, F, c->bdpt_px.as<int>());
         if (NL > 1) { TIRT_HIP(hipEventRecord(bl.delta_done, st)); last_delta = bl.delta_done; }
         if (spectral) hipLaunchKernelGGL((k_bd_connect<0, true>), dim3((N + B - 1) / B), dim3(B), 0, st, bc, items, state, tm, P, N, frame0,
-                           gr, gexpect, gbound, bl.qidx.as<int>(), ibase, icount, scount, shits, bl.rad.as<float>(), 3 * NP, &ctr->rays_shadow);
+                           stage, bl.qidx.as<int>(), ibase, icount, scount, shits, bl.rad.as<float>(), 3 * NP, &ctr->rays_shadow);
         else hipLaunchKernelGGL((k_bd_connect<0, false>), dim3((N + B - 1) / B), dim3(B), 0, st, bc, items, state, tm, P, N, frame0,
-                           gr, gexpect, gbound, bl.qidx.as<int>(), ibase, icount, scount, shits, bl.rad.as<float>(), 3 * NP, &ctr->rays_shadow);
-        hipLaunchKernelGGL(k_bd_compact, dim3((N + B - 1) / B), dim3(B), 0, st, N, ibase, icount, gr, gexpect, gbound, sr, sexpect, sbound);
+                           stage, bl.qidx.as<int>(), ibase, icount, scount, shits, bl.rad.as<float>(), 3 * NP, &ctr->rays_shadow);
+        hipLaunchKernelGGL(k_bd_compact, dim3((N + B - 1) / B), dim3(B), 0, st, N, ibase, icount, stage, sr, sexpect, sbound);
         if (int rc = trace_arrays(c, sr.ox, sr.oy, sr.oz, sr.dx, sr.dy, sr.dz, (int)(SCAP < (size_t)N * 27 ? SCAP : (size_t)N * 27), scount, shits, sexpect, sbound, false, lane)) return rc;
         if (spectral) hipLaunchKernelGGL((k_bd_connect<1, true>), dim3((N + B - 1) / B), dim3(B), 0, st, bc, items, state, tm, P, N, frame0,
-                           sr, gexpect /* staged `expect` words: now the rays' places in the queue */, sbound, bl.qidx.as<int>(), ibase, icount, scount, shits, bl.rad.as<float>(), 3 * NP, &ctr->rays_shadow);
+                           stage /* the staged `expect` words are now the rays' places in the queue */, bl.qidx.as<int>(), ibase, icount, scount, shits, bl.rad.as<float>(), 3 * NP, &ctr->rays_shadow);
         else hipLaunchKernelGGL((k_bd_connect<1, false>), dim3((N + B - 1) / B), dim3(B), 0, st, bc, items, state, tm, P, N, frame0,
-                           sr, gexpect /* staged `expect` words: now the rays' places in the queue */, sbound, bl.qidx.as<int>(), ibase, icount, scount, shits, bl.rad.as<float>(), 3 * NP, &ctr->rays_shadow);
+                           stage /* the staged `expect` words are now the rays' places in the queue */, bl.qidx.as<int>(), ibase, icount, scount, shits, bl.rad.as<float>(), 3 * NP, &ctr->rays_shadow);
         if (last_film) TIRT_HIP(hipStreamWaitEvent(st, last_film, 0));        // the running mean applies the frames in order
         for (int f = 0; f < F; f++) {
             const float coff = 1.0f / ((float)(int)(frame0 + (uint32_t)f) + 1.0f);
