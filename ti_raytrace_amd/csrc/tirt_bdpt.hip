@@ -689,7 +689,7 @@ __global__ void k_bd_delta(bpixel *items, const BdStep *steps, TileMap tm, int P
 // BDPT_RGB.py:615-637, the double loop over (e, l), in two passes around the batched connection queries.
 template <int PHASE, bool SPEC>
 __global__ void k_bd_connect(BdCtx c, bpixel *items, const BdStep *steps, TileMap tm, int P, int N, uint32_t frame_begin,
-                             float4 *stage, int *qidx, int *ibase, int *icount, int *scount, const float4 *shits,
+                             float4 *stage, unsigned long long *qmask, int *ibase, int *icount, int *scount, const float4 *shits,
                              float *radiance, long frame_stride, unsigned long long *rays_shadow)
 {
     const int it = blockIdx.x * blockDim.x + threadIdx.x;
@@ -705,6 +705,10 @@ __global__ void k_bd_connect(BdCtx c, bpixel *items, const BdStep *steps, TileMa
     const uint32_t frame = frame_begin + (uint32_t)f;
     float *rad = radiance + (size_t)f * (size_t)frame_stride;
     unsigned emitted = 0;
+    // which (e, l) pairs of this item carry a connection ray: one bit per pair slot (49 of them).  The rays are staged in slot order, so a
+    // pair's ray is the (number of set bits below its slot)-th: one 8-byte word per item instead of 27 index words written and read back
+    unsigned long long pairs = 0ull;
+    if (PHASE == 1 && live) pairs = qmask[it];
     bvert sample = bvert();              // BDPT_RGB.py:60 `sample`: written by a connection, read by its MIS weight
     for (int e = 1; e <= BD_EYE_MAX; e++) {
         for (int l = 0; l <= BD_LIGHT_MAX; l++) {
@@ -715,7 +719,7 @@ __global__ void k_bd_connect(BdCtx c, bpixel *items, const BdStep *steps, TileMa
             Tracer T; T.phase = PHASE; T.want = false; T.res.t = INF_VALUE; T.res.u = 0.0f; T.res.v = 0.0f; T.res.prim = -1;
             T.o = V(0.0f, 0.0f, 0.0f); T.d = T.o; T.expect = -3; T.bound = -1.0f;
             if (PHASE == 1 && valid) {
-                const int ql = qidx[(size_t)slot * (size_t)N + it];
+                const int ql = ((pairs >> slot) & 1ull) ? __popcll(pairs & ((1ull << slot) - 1ull)) : -1;
                 if (ql >= 0) {                               // k_bd_compact left the ray's place in the dense queue where its `expect` was staged
                     const float4 hr = shits[__float_as_int(stage[2 * ((size_t)ql * (size_t)N + it) + 1].z)];
                     T.res.t = hr.x; T.res.u = hr.y; T.res.v = hr.z; T.res.prim = __float_as_int(hr.w);
@@ -728,16 +732,15 @@ __global__ void k_bd_connect(BdCtx c, bpixel *items, const BdStep *steps, TileMa
                 // the item's j-th connection ray goes to staging slot [j][item] (k_bd_compact makes the queue dense: one atomic
                 // per wave at the end of this kernel instead of one per wave and pair -- same-address atomics retire at ~11 ns)
                 if (valid) {
-                    int local = -1;
                     if (T.want) {
-                        local = (int)emitted++;
+                        const int local = (int)emitted++;
+                        pairs |= 1ull << slot;
                         const size_t k = (size_t)local * (size_t)N + it;
                         // one 32-byte record per staged ray (two 16-byte stores): as six + two scattered words this kernel was bound by its
                         // store REQUESTS (texture-address unit 0.89 busy, 34 write requests per item)
                         stage[2 * k] = make_float4(T.o.x, T.o.y, T.o.z, T.d.x);
                         stage[2 * k + 1] = make_float4(T.d.y, T.d.z, __int_as_float(T.expect), T.bound);
                     }
-                    qidx[(size_t)slot * (size_t)N + it] = local;
                 }
             } else if (valid) {
                 const long q = (e == 1) ? ((nu >= 0) ? (long)nu * c.bv.H + nv : -1) : (long)p;
@@ -765,7 +768,7 @@ __global__ void k_bd_connect(BdCtx c, bpixel *items, const BdStep *steps, TileMa
         int base = 0;
         if (lane == 63 && total) { base = atomicAdd(scount, total); atomicAdd(rays_shadow, (unsigned long long)total); }
         base = __shfl(base, 63, 64);
-        if (live) { ibase[it] = base; icount[it] = (int)emitted; }          // the wave's place in the dense queue; k_bd_compact orders it slot by slot
+        if (live) { ibase[it] = base; icount[it] = (int)emitted; qmask[it] = pairs; }          // the wave's place in the dense queue; k_bd_compact orders it slot by slot
     }
 }
 
@@ -845,7 +848,7 @@ int bdpt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t see
         auto &bl = c->bd[l];
         if (bl.items.ensure(sizeof(bpixel) * NMAX) || bl.state.ensure(sizeof(BdStep) * NMAX) ||
             bl.rays.ensure(sizeof(float) * (6 * 2 * NMAX + 16 * SCAP)) || bl.hits.ensure(sizeof(float4) * (2 * NMAX + SCAP)) ||
-            bl.qidx.ensure(sizeof(int) * NMAX * (BD_PAIRS + 2)) || bl.ctr.ensure(256) ||
+            bl.qidx.ensure(sizeof(int) * NMAX * 4) || bl.ctr.ensure(256) ||
             bl.rad.ensure(sizeof(float) * 3 * (size_t)NP * (size_t)FB_alloc)) return TIRT_ERR_HIP;
         if (!bl.delta_done) TIRT_HIP(hipEventCreateWithFlags(&bl.delta_done, hipEventDisableTiming));
         if (!bl.film_done) TIRT_HIP(hipEventCreateWithFlags(&bl.film_done, hipEventDisableTiming));
@@ -874,7 +877,8 @@ int bdpt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t see
         float *gf = sf + 8 * SCAP;                                   // staging arrays, [slot j][item]
         float4 *stage = (float4 *)gf;                               // [slot j][item]: 32-byte records (o, d, expect, bound)
         int *gexpect = (int *)gf;                                    // (the owner list of the sub-path phase: 2 N ints, before any record is staged)
-        int *ibase = bl.qidx.as<int>() + NMAX * BD_PAIRS, *icount = ibase + NMAX;
+        unsigned long long *qmask = bl.qidx.as<unsigned long long>();          // [item]: the pairs that have a connection ray
+        int *ibase = bl.qidx.as<int>() + NMAX * 2, *icount = ibase + NMAX;
         float4 *ehits = bl.hits.as<float4>(), *shits = ehits + 2 * NMAX;
         int *scount = bl.ctr.as<int>();
         bpixel *items = bl.items.as<bpixel>(); BdStep *state = bl.state.as<BdStep>();
@@ -903,15 +907,15 @@ int bdpt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t see
         hipLaunchKernelGGL(k_bd_delta, dim3((P + B - 1) / B), dim3(B), 0, st, items, state, tm, P, F, c->bdpt_px.as<int>());
         if (NL > 1) { TIRT_HIP(hipEventRecord(bl.delta_done, st)); last_delta = bl.delta_done; }
         if (spectral) hipLaunchKernelGGL((k_bd_connect<0, true>), dim3((N + B - 1) / B), dim3(B), 0, st, bc, items, state, tm, P, N, frame0,
-                           stage, bl.qidx.as<int>(), ibase, icount, scount, shits, bl.rad.as<float>(), 3 * NP, &ctr->rays_shadow);
+                           stage, qmask, ibase, icount, scount, shits, bl.rad.as<float>(), 3 * NP, &ctr->rays_shadow);
         else hipLaunchKernelGGL((k_bd_connect<0, false>), dim3((N + B - 1) / B), dim3(B), 0, st, bc, items, state, tm, P, N, frame0,
-                           stage, bl.qidx.as<int>(), ibase, icount, scount, shits, bl.rad.as<float>(), 3 * NP, &ctr->rays_shadow);
+                           stage, qmask, ibase, icount, scount, shits, bl.rad.as<float>(), 3 * NP, &ctr->rays_shadow);
         hipLaunchKernelGGL(k_bd_compact, dim3((N + B - 1) / B), dim3(B), 0, st, N, ibase, icount, stage, sr, sexpect, sbound);
         if (int rc = trace_arrays(c, sr.ox, sr.oy, sr.oz, sr.dx, sr.dy, sr.dz, (int)(SCAP < (size_t)N * 27 ? SCAP : (size_t)N * 27), scount, shits, sexpect, sbound, false, lane)) return rc;
         if (spectral) hipLaunchKernelGGL((k_bd_connect<1, true>), dim3((N + B - 1) / B), dim3(B), 0, st, bc, items, state, tm, P, N, frame0,
-                           stage /* the staged `expect` words are now the rays' places in the queue */, bl.qidx.as<int>(), ibase, icount, scount, shits, bl.rad.as<float>(), 3 * NP, &ctr->rays_shadow);
+                           stage /* the staged `expect` words are now the rays' places in the queue */, qmask, ibase, icount, scount, shits, bl.rad.as<float>(), 3 * NP, &ctr->rays_shadow);
         else hipLaunchKernelGGL((k_bd_connect<1, false>), dim3((N + B - 1) / B), dim3(B), 0, st, bc, items, state, tm, P, N, frame0,
-                           stage /* the staged `expect` words are now the rays' places in the queue */, bl.qidx.as<int>(), ibase, icount, scount, shits, bl.rad.as<float>(), 3 * NP, &ctr->rays_shadow);
+                           stage /* the staged `expect` words are now the rays' places in the queue */, qmask, ibase, icount, scount, shits, bl.rad.as<float>(), 3 * NP, &ctr->rays_shadow);
         if (last_film) TIRT_HIP(hipStreamWaitEvent(st, last_film, 0));        // the running mean applies the frames in order
         for (int f = 0; f < F; f++) {
             const float coff = 1.0f / ((float)(int)(frame0 + (uint32_t)f) + 1.0f);
