@@ -450,9 +450,9 @@ TD v3 bd_connect_path(const BdCtx &c, const bpixel *P, bvert &sample, int i, int
 
 // ---- wavefront state ------------------------------------------------------------------------------------------
 struct BdStep { v3 e_beta; float e_pdfFwd; v3 l_beta; float l_pdfFwd; int e_alive, l_alive, eye_depth, light_depth; };
-struct BdRays { float *ox, *oy, *oz, *dx, *dy, *dz; };            // struct-of-arrays ray list
+struct BdRays { float4 *r; };             // a ray list: 32-byte records (o.xyz, d.x), (d.y, d.z, bits expect, bound) -- TraceArgs::ray4: two memory instructions per ray and side
 constexpr int BD_PAIRS = BD_EYE_MAX * (BD_LIGHT_MAX + 1);          // (e - 1) * 7 + l
-TD void put_ray(const BdRays &r, size_t k, v3 o, v3 d) { r.ox[k] = o.x; r.oy[k] = o.y; r.oz[k] = o.z; r.dx[k] = d.x; r.dy[k] = d.y; r.dz[k] = d.z; }
+TD void put_ray(const BdRays &r, size_t k, v3 o, v3 d) { r.r[2 * k] = make_float4(o.x, o.y, o.z, d.x); r.r[2 * k + 1] = make_float4(d.y, d.z, 0.0f, 0.0f); }
 TD void count_rays(unsigned long long *ctr, unsigned mine)
 {
     unsigned long long v = mine;
@@ -533,7 +533,8 @@ __global__ void k_bd_step(BdCtx c, bpixel *items, BdStep *steps, BdRays rays, co
             bpixel *B = items + it;
             constexpr bool spectral = SPEC;
             const float Lambda = spectral ? bd_lambda(c, pixel, frame) : 0.0f;
-            const v3 origin = V(rays.ox[qi], rays.oy[qi], rays.oz[qi]), dir = V(rays.dx[qi], rays.dy[qi], rays.dz[qi]);
+            const float4 rq0 = rays.r[2 * (size_t)qi], rq1 = rays.r[2 * (size_t)qi + 1];
+            const v3 origin = V(rq0.x, rq0.y, rq0.z), dir = V(rq0.w, rq1.x, rq1.y);
             const float4 hr = hits[qi];
             SimpleHit sh; sh.t = hr.x; sh.u = hr.y; sh.v = hr.z; sh.prim = __float_as_int(hr.w);
             const int pre_depth = depth - 1;
@@ -775,8 +776,7 @@ __global__ void k_bd_connect(BdCtx c, bpixel *items, const BdStep *steps, TileMa
 // staging slots [j][item] -> dense connection-ray queue.  A wave moves the rays of its 64 items slot by slot: the j-th rays of the
 // items that have one are read from 64 consecutive staging words and written to consecutive queue words (per item, ray after ray,
 // the writes were 4-byte scatters: 5.0 -> 2.1 ms per 8 Mi items).  Where a ray went is left in its staged `expect` word for pass 1.
-__global__ void k_bd_compact(int N, const int *ibase, const int *icount, float4 *stage,
-                             BdRays dense, int *sexpect, float *sbound)
+__global__ void k_bd_compact(int N, const int *ibase, const int *icount, float4 *stage, BdRays dense)
 {
     const int it = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
@@ -790,9 +790,7 @@ __global__ void k_bd_compact(int N, const int *ibase, const int *icount, float4 
         if (n > j) {
             const size_t k = (size_t)j * (size_t)N + it, q = (size_t)(off + __popcll(m & lt_mask));
             const float4 s0 = stage[2 * k], s1 = stage[2 * k + 1];
-            dense.ox[q] = s0.x; dense.oy[q] = s0.y; dense.oz[q] = s0.z;
-            dense.dx[q] = s0.w; dense.dy[q] = s1.x; dense.dz[q] = s1.y;
-            sexpect[q] = __float_as_int(s1.z); sbound[q] = s1.w;
+            dense.r[2 * q] = s0; dense.r[2 * q + 1] = s1;                  // the record as it is: (o, d, expect, bound)
             stage[2 * k + 1].z = __int_as_float((int)q);
         }
         off += __popcll(m);
@@ -847,7 +845,7 @@ int bdpt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t see
     for (int l = 0; l < NL; l++) {
         auto &bl = c->bd[l];
         if (bl.items.ensure(sizeof(bpixel) * NMAX) || bl.state.ensure(sizeof(BdStep) * NMAX) ||
-            bl.rays.ensure(sizeof(float) * (6 * 2 * NMAX + 16 * SCAP)) || bl.hits.ensure(sizeof(float4) * (2 * NMAX + SCAP)) ||
+            bl.rays.ensure(sizeof(float) * (8 * 2 * NMAX + 16 * SCAP)) || bl.hits.ensure(sizeof(float4) * (2 * NMAX + SCAP)) ||
             bl.qidx.ensure(sizeof(int) * NMAX * 4) || bl.ctr.ensure(256) ||
             bl.rad.ensure(sizeof(float) * 3 * (size_t)NP * (size_t)FB_alloc)) return TIRT_ERR_HIP;
         if (!bl.delta_done) TIRT_HIP(hipEventCreateWithFlags(&bl.delta_done, hipEventDisableTiming));
@@ -870,10 +868,10 @@ int bdpt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t see
         auto &bl = c->bd[NL > 1 ? (batch & 1) : 0];
         hipStream_t st = lane < 0 ? c->stream : c->lanes[lane].stream;
         float *rf = bl.rays.as<float>();
-        BdRays er = {rf, rf + 2 * NMAX, rf + 4 * NMAX, rf + 6 * NMAX, rf + 8 * NMAX, rf + 10 * NMAX};
-        float *sf = rf + 12 * NMAX;
-        BdRays sr = {sf, sf + SCAP, sf + 2 * SCAP, sf + 3 * SCAP, sf + 4 * SCAP, sf + 5 * SCAP};
-        int *sexpect = (int *)(sf + 6 * SCAP); float *sbound = sf + 7 * SCAP;
+        BdRays er = {(float4 *)rf};                                  // 2 N records
+        float *sf = rf + 16 * NMAX;
+        BdRays sr = {(float4 *)sf};                                  // the dense connection-ray queue: SCAP records
+        int *sexpect = (int *)(sf + 16 * NMAX);                      // (the other owner list of the sub-path phase: behind the 2 N records that phase keeps in the queue's memory)
         float *gf = sf + 8 * SCAP;                                   // staging arrays, [slot j][item]
         float4 *stage = (float4 *)gf;                               // [slot j][item]: 32-byte records (o, d, expect, bound)
         int *gexpect = (int *)gf;                                    // (the owner list of the sub-path phase: 2 N ints, before any record is staged)
@@ -897,7 +895,7 @@ int bdpt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t see
         // rays of the two sub-paths share the launches
         for (int d = 1; d < BD_EYE_MAX; d++) {
             const BdRays &ri = rset[d & 1], &ro = rset[(d + 1) & 1];
-            if (int rc = trace_arrays(c, ri.ox, ri.oy, ri.oz, ri.dx, ri.dy, ri.dz, 2 * N, alive_cnt + d, ehits, nullptr, nullptr, false, lane)) return rc;
+            if (int rc = trace_arrays(c, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 2 * N, alive_cnt + d, ehits, nullptr, nullptr, false, lane, ri.r, false)) return rc;
             if (spectral) hipLaunchKernelGGL(k_bd_step<true>, dim3((2 * N + B - 1) / B), dim3(B), 0, st, bc, items, state, ri, oset[d & 1], ro,
                                oset[(d + 1) & 1], alive_cnt, ehits, tm, P, N, frame0, d, &ctr->rays_closest);
             else hipLaunchKernelGGL(k_bd_step<false>, dim3((2 * N + B - 1) / B), dim3(B), 0, st, bc, items, state, ri, oset[d & 1], ro,
@@ -910,8 +908,8 @@ int bdpt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t see
                            stage, qmask, ibase, icount, scount, shits, bl.rad.as<float>(), 3 * NP, &ctr->rays_shadow);
         else hipLaunchKernelGGL((k_bd_connect<0, false>), dim3((N + B - 1) / B), dim3(B), 0, st, bc, items, state, tm, P, N, frame0,
                            stage, qmask, ibase, icount, scount, shits, bl.rad.as<float>(), 3 * NP, &ctr->rays_shadow);
-        hipLaunchKernelGGL(k_bd_compact, dim3((N + B - 1) / B), dim3(B), 0, st, N, ibase, icount, stage, sr, sexpect, sbound);
-        if (int rc = trace_arrays(c, sr.ox, sr.oy, sr.oz, sr.dx, sr.dy, sr.dz, (int)(SCAP < (size_t)N * 27 ? SCAP : (size_t)N * 27), scount, shits, sexpect, sbound, false, lane)) return rc;
+        hipLaunchKernelGGL(k_bd_compact, dim3((N + B - 1) / B), dim3(B), 0, st, N, ibase, icount, stage, sr);
+        if (int rc = trace_arrays(c, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, (int)(SCAP < (size_t)N * 27 ? SCAP : (size_t)N * 27), scount, shits, nullptr, nullptr, false, lane, sr.r, true)) return rc;
         if (spectral) hipLaunchKernelGGL((k_bd_connect<1, true>), dim3((N + B - 1) / B), dim3(B), 0, st, bc, items, state, tm, P, N, frame0,
                            stage /* the staged `expect` words are now the rays' places in the queue */, qmask, ibase, icount, scount, shits, bl.rad.as<float>(), 3 * NP, &ctr->rays_shadow);
         else hipLaunchKernelGGL((k_bd_connect<1, false>), dim3((N + B - 1) / B), dim3(B), 0, st, bc, items, state, tm, P, N, frame0,
