@@ -19,6 +19,7 @@ def run_both(ex, W, H, frames):
     if ex.scene.vertex_index_np is not None and type(ex).__name__ == "veach_bdpt":
         o.process_normal(ex.scene.vertex_index_np)
     ctx = ex.scene.ctx
+    ctx.set_option("bdpt_state_fill", 2)          # vertex arrays poisoned with 0xFF before every batch: nothing may read an unwritten slot
     ctx.stats_reset()
     # frame by frame on the GPU, in one call on the oracle: the persistent per-pixel vertex state must carry over
     for _ in range(frames):
@@ -199,3 +200,28 @@ def test_bdpt_batching_and_lanes_change_nothing(gpu_ctx_ok):
     mm = m & np.isfinite(want).all(axis=2)
     assert mm.mean() > 0.95 and rel_l2(films[1][mm], want[mm]) <= 1e-3
     assert counts[1] == (ost["rays_closest"], ost["rays_shadow"])
+
+
+def test_vertex_arrays_need_no_clearing(gpu_ctx_ok):
+    """The per-item vertex arrays are not cleared between batches (the reference clears beta/type/fpdf/rpdf per frame,
+    BDPT_RGB.py:95-103; here no read reaches a slot its item has not written, and BdStep::e_tail tells k_bd_delta about
+    the one slot past the depth).  8 frames in batches of two on alternating lanes -- every batch after the first sees
+    the previous batch's vertices -- with the arrays left as they are, zero-filled and filled with 0xFF (NaN floats,
+    type/prim/mat/delta -1): same ray counts, same non-finite pixels, films within the float-atomic order of the splats."""
+    W = H = 64
+    films, counts = [], []
+    for fill in (1, 0, 2):
+        ex = scenes.veach_bdpt(W, H, 8, device_id=0)
+        ex.build_scene()
+        ctx = ex.scene.ctx
+        ctx.set_option("bdpt_batch_items", W * H * 2); ctx.set_option("bdpt_state_fill", fill)
+        ctx.stats_reset()
+        ctx.bdpt_rgb_render(0, 8, 1)
+        st = ctx.stats()
+        films.append(ctx.film_download(W, H)[0]); counts.append((st["rays_closest"], st["rays_shadow"]))
+    assert counts[0] == counts[1] == counts[2]
+    m = np.isfinite(films[0]).all(axis=2)
+    assert m.mean() > 0.95
+    for f in films[1:]:
+        assert (np.isfinite(f).all(axis=2) == m).all()
+        assert rel_l2(f[m], films[0][m]) <= 1e-6

@@ -22,6 +22,7 @@ def run_both(ex, W, H, frames, batch=False, frame_camera=False):
         o.process_normal(ex.scene.vertex_index_np)
     o.set_spectral(ex.integrator.tables())
     ctx = ex.scene.ctx
+    ctx.set_option("bdpt_state_fill", 2)          # vertex arrays poisoned with 0xFF before every batch: nothing may read an unwritten slot
     ctx.stats_reset()
     if batch:
         ex.integrator.render_frames(frames)

@@ -449,7 +449,8 @@ TD v3 bd_connect_path(const BdCtx &c, const bpixel *P, bvert &sample, int i, int
 }
 
 // ---- wavefront state ------------------------------------------------------------------------------------------
-struct BdStep { v3 e_beta; float e_pdfFwd; v3 l_beta; float l_pdfFwd; int e_alive, l_alive, eye_depth, light_depth; };
+// e_tail: slot eye[eye_depth] holds a SURFACE vertex of THIS item (its sampling ended the path, so the depth leaves it out) -- k_bd_delta
+struct BdStep { v3 e_beta; float e_pdfFwd; v3 l_beta; float l_pdfFwd; int e_tail, pad_, eye_depth, light_depth; };
 struct BdRays { float4 *r; };             // a ray list: 32-byte records (o.xyz, d.x), (d.y, d.z, bits expect, bound) -- TraceArgs::ray4: two memory instructions per ray and side
 constexpr int BD_PAIRS = BD_EYE_MAX * (BD_LIGHT_MAX + 1);          // (e - 1) * 7 + l
 TD void put_ray(const BdRays &r, size_t k, v3 o, v3 d) { r.r[2 * k] = make_float4(o.x, o.y, o.z, d.x); r.r[2 * k + 1] = make_float4(d.y, d.z, 0.0f, 0.0f); }
@@ -480,8 +481,10 @@ __global__ void k_bd_init(BdCtx c, bpixel *items, BdStep *steps, BdRays rays, in
         float jx = 0.0f, jy = 0.0f;
         if (frame != 0) { jx = tm_rand(c.seed, pixel, frame, TM_DIM_JX) - 0.5f; jy = tm_rand(c.seed, pixel, frame, TM_DIM_JY) - 0.5f; }
         const v3 dir = camera_ray_direction(c.cam, i, j, jx, jy);
-        eye[0].pos = origin; eye[0].normal = dir; eye[0].beta = V(1.0f, 1.0f, 1.0f); eye[0].fpdf = 1.0f; eye[0].type = VERTEX_LENS;
-        st.e_beta = V(1.0f, 1.0f, 1.0f); st.e_pdfFwd = 1.0f; st.e_alive = 1; st.eye_depth = 1;
+        bvert ev = bvert();                    // whole 96-byte stores: the fields the reference does not set are the zeros its field starts with
+        ev.pos = origin; ev.normal = dir; ev.beta = V(1.0f, 1.0f, 1.0f); ev.fpdf = 1.0f; ev.type = VERTEX_LENS;
+        eye[0] = ev;
+        st.e_beta = V(1.0f, 1.0f, 1.0f); st.e_pdfFwd = 1.0f; st.e_tail = 0; st.pad_ = 0; st.eye_depth = 1;
         put_ray(rays, (size_t)it, origin, dir); owner[it] = it;
     }
     // light
@@ -496,9 +499,11 @@ __global__ void k_bd_init(BdCtx c, bpixel *items, BdStep *steps, BdRays rays, in
             const float pw = bd_light_power(*c.spec, emission, bd_lambda(c, pixel, frame)) / light_pdf;
             beta0 = V(pw, pw, pw); beta1 = beta0;
         }
-        light[0].pos = lpos; light[0].normal = lnor; light[0].beta = beta0;
-        light[0].fpdf = light_pdf; light[0].rpdf = 0.0f; light[0].wo = ldir; light[0].type = VERTEX_LIGHT;
-        st.l_beta = beta1; st.l_pdfFwd = dir_pdf; st.l_alive = 1; st.light_depth = 1;
+        bvert lv = bvert();
+        lv.pos = lpos; lv.normal = lnor; lv.beta = beta0;
+        lv.fpdf = light_pdf; lv.rpdf = 0.0f; lv.wo = ldir; lv.type = VERTEX_LIGHT;
+        light[0] = lv;
+        st.l_beta = beta1; st.l_pdfFwd = dir_pdf; st.light_depth = 1;
         put_ray(rays, (size_t)N + it, lpos, ldir); owner[N + it] = N + it;
     }
     steps[it] = st;
@@ -544,6 +549,7 @@ __global__ void k_bd_step(BdCtx c, bpixel *items, BdStep *steps, BdRays rays, co
                 bvert *eye = B->eye;
                 float pdfFwd = st->e_pdfFwd, pdfRev = 0.0f;
                 v3 beta = st->e_beta;
+                bool stored_surface = false;
                 if (sh.t < INF_VALUE) {
                     int mat_id;
                     const HitAttr h = hit_attributes_rec(s.shade_rec, origin, dir, sh.prim, sh.t, sh.u, sh.v, mat_id);
@@ -566,7 +572,7 @@ __global__ void k_bd_step(BdCtx c, bpixel *items, BdStep *steps, BdRays rays, co
                         final_depth = depth + 1;
                     } else {
                         e->beta = beta * absf(dot(dir, normal));
-                        e->type = VERTEX_SURFACE;
+                        e->type = VERTEX_SURFACE; stored_surface = true;
                         const v3 reflect_color = spectral ? bd_reflect<SPEC>(c, mat_id, Lambda) : srgb_to_lrgb(mat_color);
                         int delta = 0;
                         const bsample bs = bd_sample(s, dir, normal, fnormal, mat_id, mat_type, c.seed, pixel, frame, BD_DIM_EYE + 8u * (uint32_t)depth, delta, spectral, Lambda);
@@ -596,7 +602,7 @@ __global__ void k_bd_step(BdCtx c, bpixel *items, BdStep *steps, BdRays rays, co
                     }
                     eye[depth] = ev;                      // one 96-byte store
                 }
-                st->e_beta = beta; st->e_pdfFwd = pdfFwd; st->eye_depth = final_depth; st->e_alive = go_on ? 1 : 0;
+                st->e_beta = beta; st->e_pdfFwd = pdfFwd; st->eye_depth = final_depth; st->e_tail = (stored_surface && final_depth == depth) ? 1 : 0;
             } else {
                 bvert *light = B->light;
                 float pdfFwd = st->l_pdfFwd, pdfRev = 0.0f;
@@ -647,7 +653,7 @@ __global__ void k_bd_step(BdCtx c, bpixel *items, BdStep *steps, BdRays rays, co
                         light[depth] = lv;
                     }
                 }
-                st->l_beta = beta; st->l_pdfFwd = pdfFwd; st->light_depth = final_depth; st->l_alive = go_on ? 1 : 0;
+                st->l_beta = beta; st->l_pdfFwd = pdfFwd; st->light_depth = final_depth;
             }
         }
     }
@@ -677,13 +683,14 @@ __global__ void k_bd_delta(bpixel *items, const BdStep *steps, TileMap tm, int P
         const size_t it = (size_t)f * P + k;
         bvert *eye = items[it].eye;
         const int ed = steps[it].eye_depth;
-        // v == ed: a surface vertex whose sampling ended the path (pdf 0, or the extinction roulette of a refraction) is not counted
-        // in the depth, but its delta has been stored (BDPT_RGB.py:160-187) -- the batch's vertex arrays start as zeros, so a
-        // SURFACE type there was written by this frame
-        for (int v = 1; v <= ed && v < BD_EYE_MAX; v++) {
+        for (int v = 1; v < ed; v++) {
             if (eye[v].type == VERTEX_SURFACE) mem[v] = eye[v].delta;
-            else if (v < ed && eye[v].type == VERTEX_LIGHT) eye[v].delta = mem[v];
+            else if (eye[v].type == VERTEX_LIGHT) eye[v].delta = mem[v];
         }
+        // v == ed: a surface vertex whose sampling ended the path (pdf 0, or the extinction roulette of a refraction) is not counted
+        // in the depth, but its delta has been stored (BDPT_RGB.py:160-187); BdStep::e_tail says that slot is this item's
+        // (the vertex arrays are not cleared between batches)
+        if (ed < BD_EYE_MAX && steps[it].e_tail) mem[ed] = eye[ed].delta;
     }
 }
 
@@ -884,7 +891,10 @@ int bdpt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t see
         const int N = F * P;
         const uint32_t frame0 = frame_begin + (uint32_t)f0;
         TIRT_HIP(hipMemsetAsync(bl.rad.p, 0, sizeof(float) * 3 * (size_t)NP * (size_t)F, st));
-        TIRT_HIP(hipMemsetAsync(bl.items.p, 0, sizeof(bpixel) * (size_t)N, st));
+        // No read of a vertex field goes to a slot this item has not written (header; k_bd_delta supplies the one exception), so the
+        // 1.2 KB per item need no clearing.  Option "bdpt_state_fill": 1 = zeros (the round-1..3 behaviour), 2 = 0xFF poison -- the
+        // parity tests render under poison and must not see a bit change.
+        if (c->bdpt_state_fill) TIRT_HIP(hipMemsetAsync(bl.items.p, c->bdpt_state_fill == 2 ? 0xFF : 0, sizeof(bpixel) * (size_t)N, st));
         TIRT_HIP(hipMemsetAsync(scount, 0, 64, st));                 // the connection-ray count and the alive counts of the depths
         // during the sub-path phase the dense connection-ray arrays and the two `expect` arrays are free: they hold the second ray list and the owners
         BdRays rset[2] = {sr, er};                                  // depth d reads rset[d & 1]
