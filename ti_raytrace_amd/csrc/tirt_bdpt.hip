@@ -694,11 +694,34 @@ __global__ void k_bd_delta(bpixel *items, const BdStep *steps, TileMap tm, int P
     }
 }
 
-// BDPT_RGB.py:615-637, the double loop over (e, l), in two passes around the batched connection queries.
-template <int PHASE, bool SPEC>
+// AddSplat (BDPT_RGB.py:594-613; SPEC: BDPT_SPEC.py:178-181): a contribution goes to the film pixel of its sample, or -- a light sub-path
+// vertex seen through the lens (e == 1) -- to the pixel it projects to, with float atomics.
+template <bool SPEC>
+TD void bd_splat(const BdCtx &c, float *rad, int e, int nu, int nv, int p, uint32_t frame, v3 r)
+{
+    const long q = (e == 1) ? ((nu >= 0) ? (long)nu * c.bv.H + nv : -1) : (long)p;
+    if (SPEC) {          // the sensor's response at the wavelength, as clamped sRGB, times the range
+        const SpecView &sp = *c.spec;
+        const v3 xyz = sensor_sample(sp, bd_lambda(c, (uint32_t)p, frame));
+        const float range = sp.s_max - sp.s_min;
+        const float cr = (3.240479f * xyz.x + -1.537150f * xyz.y) + -0.498535f * xyz.z;
+        const float cg = (-0.969256f * xyz.x + 1.875991f * xyz.y) + 0.041556f * xyz.z;
+        const float cb = (0.055648f * xyz.x + -0.204043f * xyz.y) + 1.057311f * xyz.z;
+        r = V((clampf(cr, 0.0f, 1000.0f) * range) * r.x, (clampf(cg, 0.0f, 1000.0f) * range) * r.x, (clampf(cb, 0.0f, 1000.0f) * range) * r.x);
+    }
+    if (q >= 0 && (r.x != 0.0f || r.y != 0.0f || r.z != 0.0f)) {
+        atomicAdd(&rad[3 * q], r.x); atomicAdd(&rad[3 * q + 1], r.y); atomicAdd(&rad[3 * q + 2], r.z);
+    }
+}
+
+constexpr int BD_OWNER_BITS = 26;                  // a queued connection's owner word: item | pair slot << 26 (49 slots; a batch holds < 2^26 items)
+
+// BDPT_RGB.py:615-637, the double loop over (e, l), per item: the geometry of every connection.  A pair that needs a visibility ray
+// stages it (k_bd_compact makes the queue dense, k_trace answers it, k_bd_resolve -- one thread per QUEUED CONNECTION -- adds the
+// contribution); the pairs that need none (l == 0: the eye sub-path ended on an emitter) are k_bd_emitted's.
+template <bool SPEC>
 __global__ void k_bd_connect(BdCtx c, bpixel *items, const BdStep *steps, TileMap tm, int P, int N, uint32_t frame_begin,
-                             float4 *stage, unsigned long long *qmask, int *ibase, int *icount, int *scount, const float4 *shits,
-                             float *radiance, long frame_stride, unsigned long long *rays_shadow)
+                             float4 *stage, unsigned long long *qmask, int *ibase, int *icount, int *scount, unsigned long long *rays_shadow)
 {
     const int it = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = it < N;
@@ -711,84 +734,103 @@ __global__ void k_bd_connect(BdCtx c, bpixel *items, const BdStep *steps, TileMa
         eye_depth = steps[it].eye_depth; light_depth = steps[it].light_depth;
     }
     const uint32_t frame = frame_begin + (uint32_t)f;
-    float *rad = radiance + (size_t)f * (size_t)frame_stride;
     unsigned emitted = 0;
-    // which (e, l) pairs of this item carry a connection ray: one bit per pair slot (49 of them).  The rays are staged in slot order, so a
-    // pair's ray is the (number of set bits below its slot)-th: one 8-byte word per item instead of 27 index words written and read back
+    // which (e, l) pairs of this item carry a connection ray: one bit per pair slot (49 of them).  The rays are staged in slot order, so
+    // k_bd_compact finds the slot of the item's j-th ray as the j-th set bit
     unsigned long long pairs = 0ull;
-    if (PHASE == 1 && live) pairs = qmask[it];
     bvert sample = bvert();              // BDPT_RGB.py:60 `sample`: written by a connection, read by its MIS weight
     for (int e = 1; e <= BD_EYE_MAX; e++) {
         for (int l = 0; l <= BD_LIGHT_MAX; l++) {
             const int depth = l + e - 2;
             if (((l == 1) & (e == 1)) | (depth < 0) | (depth > BD_MAX_DEPTH)) continue;       // wave-uniform
             const bool valid = live && e <= eye_depth && l <= light_depth;
+            if (!valid || l == 0) continue;
             const int slot = (e - 1) * (BD_LIGHT_MAX + 1) + l;
-            Tracer T; T.phase = PHASE; T.want = false; T.res.t = INF_VALUE; T.res.u = 0.0f; T.res.v = 0.0f; T.res.prim = -1;
+            Tracer T; T.phase = 0; T.want = false; T.res.t = INF_VALUE; T.res.u = 0.0f; T.res.v = 0.0f; T.res.prim = -1;
             T.o = V(0.0f, 0.0f, 0.0f); T.d = T.o; T.expect = -3; T.bound = -1.0f;
-            if (PHASE == 1 && valid) {
-                const int ql = ((pairs >> slot) & 1ull) ? __popcll(pairs & ((1ull << slot) - 1ull)) : -1;
-                if (ql >= 0) {                               // k_bd_compact left the ray's place in the dense queue where its `expect` was staged
-                    const float4 hr = shits[__float_as_int(stage[2 * ((size_t)ql * (size_t)N + it) + 1].z)];
-                    T.res.t = hr.x; T.res.u = hr.y; T.res.v = hr.z; T.res.prim = __float_as_int(hr.w);
-                }
-            }
             int nu = 0, nv = 0;
-            v3 r = V(0.0f, 0.0f, 0.0f);
-            if (valid && !(PHASE == 0 && l == 0)) r = bd_connect_path<SPEC>(c, B, sample, i, j, e, l, frame, nu, nv, T);      // l == 0 needs no ray
-            if (PHASE == 0) {
+            (void)bd_connect_path<SPEC>(c, B, sample, i, j, e, l, frame, nu, nv, T);       // pass 0: a traced pair sees a miss and returns zero
+            if (T.want) {
                 // the item's j-th connection ray goes to staging slot [j][item] (k_bd_compact makes the queue dense: one atomic
                 // per wave at the end of this kernel instead of one per wave and pair -- same-address atomics retire at ~11 ns)
-                if (valid) {
-                    if (T.want) {
-                        const int local = (int)emitted++;
-                        pairs |= 1ull << slot;
-                        const size_t k = (size_t)local * (size_t)N + it;
-                        // one 32-byte record per staged ray (two 16-byte stores): as six + two scattered words this kernel was bound by its
-                        // store REQUESTS (texture-address unit 0.89 busy, 34 write requests per item)
-                        stage[2 * k] = make_float4(T.o.x, T.o.y, T.o.z, T.d.x);
-                        stage[2 * k + 1] = make_float4(T.d.y, T.d.z, __int_as_float(T.expect), T.bound);
-                    }
-                }
-            } else if (valid) {
-                const long q = (e == 1) ? ((nu >= 0) ? (long)nu * c.bv.H + nv : -1) : (long)p;
-                if (SPEC) {          // SPEC: AddSplat (BDPT_SPEC.py:178-181): the sensor's response at the wavelength, as clamped sRGB, times the range
-                    const SpecView &sp = *c.spec;
-                    const v3 xyz = sensor_sample(sp, bd_lambda(c, (uint32_t)p, frame));
-                    const float range = sp.s_max - sp.s_min;
-                    const float cr = (3.240479f * xyz.x + -1.537150f * xyz.y) + -0.498535f * xyz.z;
-                    const float cg = (-0.969256f * xyz.x + 1.875991f * xyz.y) + 0.041556f * xyz.z;
-                    const float cb = (0.055648f * xyz.x + -0.204043f * xyz.y) + 1.057311f * xyz.z;
-                    r = V((clampf(cr, 0.0f, 1000.0f) * range) * r.x, (clampf(cg, 0.0f, 1000.0f) * range) * r.x, (clampf(cb, 0.0f, 1000.0f) * range) * r.x);
-                }
-                if (q >= 0 && (r.x != 0.0f || r.y != 0.0f || r.z != 0.0f)) {
-                    atomicAdd(&rad[3 * q], r.x); atomicAdd(&rad[3 * q + 1], r.y); atomicAdd(&rad[3 * q + 2], r.z);
-                }
+                const int local = (int)emitted++;
+                pairs |= 1ull << slot;
+                const size_t k = (size_t)local * (size_t)N + it;
+                // one 32-byte record per staged ray (two 16-byte stores): as six + two scattered words this kernel was bound by its
+                // store REQUESTS (texture-address unit 0.89 busy, 34 write requests per item)
+                stage[2 * k] = make_float4(T.o.x, T.o.y, T.o.z, T.d.x);
+                stage[2 * k + 1] = make_float4(T.d.y, T.d.z, __int_as_float(T.expect), T.bound);
             }
         }
     }
-    if (PHASE == 0) {
-        // dense queue positions of this wave's rays: [base, base + total), lane by lane
-        int incl = (int)emitted;
+    // dense queue positions of this wave's rays: [base, base + total), lane by lane
+    int incl = (int)emitted;
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
-        const int total = __shfl(incl, 63, 64);
-        int base = 0;
-        if (lane == 63 && total) { base = atomicAdd(scount, total); atomicAdd(rays_shadow, (unsigned long long)total); }
-        base = __shfl(base, 63, 64);
-        if (live) { ibase[it] = base; icount[it] = (int)emitted; qmask[it] = pairs; }          // the wave's place in the dense queue; k_bd_compact orders it slot by slot
+    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
+    const int total = __shfl(incl, 63, 64);
+    int base = 0;
+    if (lane == 63 && total) { base = atomicAdd(scount, total); atomicAdd(rays_shadow, (unsigned long long)total); }
+    base = __shfl(base, 63, 64);
+    if (live) { ibase[it] = base; icount[it] = (int)emitted; qmask[it] = pairs; }          // the wave's place in the dense queue; k_bd_compact orders it slot by slot
+}
+
+// The l == 0 pairs (BDPT_RGB.py:489-491): an eye vertex that lies on an emitter contributes its beta, MIS-weighted.  A sub-path ends on
+// the emitter it meets (:152-158), so per item only e = eye_depth can be one; the light sub-path's depth does not matter (l = 0 <= any).
+template <bool SPEC>
+__global__ void k_bd_emitted(BdCtx c, const bpixel *items, const BdStep *steps, TileMap tm, int P, int N, uint32_t frame_begin, float *radiance, long frame_stride)
+{
+    const int it = blockIdx.x * blockDim.x + threadIdx.x;
+    if (it >= N) return;
+    const int e = steps[it].eye_depth;
+    if (e < 2 || e > BD_EYE_MAX || e - 2 > BD_MAX_DEPTH || items[it].eye[e - 1].type != VERTEX_LIGHT) return;          // depth = e - 2 in 0..BD_MAX_DEPTH
+    const int f = it / P, k = it - f * P;
+    const int p = local_to_pixel(tm, k), i = p / c.bv.H, j = p - i * c.bv.H;
+    const uint32_t frame = frame_begin + (uint32_t)f;
+    Tracer T; T.phase = 1; T.want = false; T.res.t = INF_VALUE; T.res.u = 0.0f; T.res.v = 0.0f; T.res.prim = -1;
+    T.o = V(0.0f, 0.0f, 0.0f); T.d = T.o; T.expect = -3; T.bound = -1.0f;
+    bvert sample = bvert();
+    int nu = 0, nv = 0;
+    const v3 r = bd_connect_path<SPEC>(c, items + it, sample, i, j, e, 0, frame, nu, nv, T);
+    bd_splat<SPEC>(c, radiance + (size_t)f * (size_t)frame_stride, e, nu, nv, p, frame, r);
+}
+
+// Pass 1 of a connection, one thread per queued connection ray (per item, 27 pair slots of which ~7 carry a ray and ~4 of those are
+// unoccluded, the VALU ran at 19 % of its lanes): the traced answer, then -- only if the expected primitive is what the ray met --
+// contribution and MIS weight (BDPT_RGB.py:300-479), splatted with float atomics.
+template <bool SPEC>
+__global__ void k_bd_resolve(BdCtx c, const bpixel *items, TileMap tm, int P, uint32_t frame_begin, const unsigned *qown, const int *scount,
+                             const float4 *shits, const float4 *queue, float *radiance, long frame_stride)
+{
+    const int count = *scount;
+    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < count; q += (long)gridDim.x * blockDim.x) {
+        const float4 hr = shits[q];
+        // every branch of connect_path wants the ray's closest hit to be the expected primitive before anything else
+        if (__float_as_int(hr.w) != __float_as_int(queue[2 * q + 1].z)) continue;
+        const unsigned own = qown[q];
+        const int it = (int)(own & ((1u << BD_OWNER_BITS) - 1u)), slot = (int)(own >> BD_OWNER_BITS);
+        const int e = slot / (BD_LIGHT_MAX + 1) + 1, l = slot - (e - 1) * (BD_LIGHT_MAX + 1);
+        const int f = it / P, k = it - f * P;
+        const int p = local_to_pixel(tm, k), i = p / c.bv.H, j = p - i * c.bv.H;
+        const uint32_t frame = frame_begin + (uint32_t)f;
+        Tracer T; T.phase = 1; T.want = false; T.res.t = hr.x; T.res.u = hr.y; T.res.v = hr.z; T.res.prim = __float_as_int(hr.w);
+        T.o = V(0.0f, 0.0f, 0.0f); T.d = T.o; T.expect = -3; T.bound = -1.0f;
+        bvert sample = bvert();
+        int nu = 0, nv = 0;
+        const v3 r = bd_connect_path<SPEC>(c, items + it, sample, i, j, e, l, frame, nu, nv, T);
+        bd_splat<SPEC>(c, radiance + (size_t)f * (size_t)frame_stride, e, nu, nv, p, frame, r);
     }
 }
 
 // staging slots [j][item] -> dense connection-ray queue.  A wave moves the rays of its 64 items slot by slot: the j-th rays of the
 // items that have one are read from 64 consecutive staging words and written to consecutive queue words (per item, ray after ray,
-// the writes were 4-byte scatters: 5.0 -> 2.1 ms per 8 Mi items).  Where a ray went is left in its staged `expect` word for pass 1.
-__global__ void k_bd_compact(int N, const int *ibase, const int *icount, float4 *stage, BdRays dense)
+// the writes were 4-byte scatters: 5.0 -> 2.1 ms per 8 Mi items).  Whose ray it is (item, pair slot) goes to `qown` for k_bd_resolve.
+__global__ void k_bd_compact(int N, const int *ibase, const int *icount, const unsigned long long *qmask, const float4 *stage, BdRays dense, unsigned *qown)
 {
     const int it = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     const bool live = it < N;
     const int n = live ? icount[it] : 0;
+    unsigned long long rest = (n > 0) ? qmask[it] : 0ull;          // the pair slots of this item's rays, lowest first
     int off = live ? ibase[it] : 0;
     off = __shfl(off, 0, 64);                           // lane 0 of a wave is live whenever any lane is
     for (int j = 0; j < 27; j++) {
@@ -798,7 +840,8 @@ __global__ void k_bd_compact(int N, const int *ibase, const int *icount, float4 
             const size_t k = (size_t)j * (size_t)N + it, q = (size_t)(off + __popcll(m & lt_mask));
             const float4 s0 = stage[2 * k], s1 = stage[2 * k + 1];
             dense.r[2 * q] = s0; dense.r[2 * q + 1] = s1;                  // the record as it is: (o, d, expect, bound)
-            stage[2 * k + 1].z = __int_as_float((int)q);
+            qown[q] = (unsigned)it | ((unsigned)(__ffsll((long long)rest) - 1) << BD_OWNER_BITS);
+            rest &= rest - 1ull;
         }
         off += __popcll(m);
     }
@@ -847,13 +890,14 @@ int bdpt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t see
     // an example loop that renders one frame per call and never merges calls.
     const int FB_alloc = FB;
     const size_t NMAX = (size_t)FB_alloc * P;
+    TIRT_REQUIRE(NMAX < ((size_t)1 << BD_OWNER_BITS), "tirt_bdpt_rgb_render: bdpt_batch_items must stay below 2^26");
     TIRT_REQUIRE(NMAX * BD_PAIRS < ((size_t)1 << 31), "tirt_bdpt_rgb_render: film too large for one frame per batch");
     const size_t SCAP = NMAX * 27;                               // at most 27 (e, l) pairs per item carry a connection ray (staging: [27][N])
     for (int l = 0; l < NL; l++) {
         auto &bl = c->bd[l];
         if (bl.items.ensure(sizeof(bpixel) * NMAX) || bl.state.ensure(sizeof(BdStep) * NMAX) ||
             bl.rays.ensure(sizeof(float) * (8 * 2 * NMAX + 16 * SCAP)) || bl.hits.ensure(sizeof(float4) * (2 * NMAX + SCAP)) ||
-            bl.qidx.ensure(sizeof(int) * NMAX * 4) || bl.ctr.ensure(256) ||
+            bl.qidx.ensure(sizeof(int) * (NMAX * 4 + SCAP)) || bl.ctr.ensure(256) ||
             bl.rad.ensure(sizeof(float) * 3 * (size_t)NP * (size_t)FB_alloc)) return TIRT_ERR_HIP;
         if (!bl.delta_done) TIRT_HIP(hipEventCreateWithFlags(&bl.delta_done, hipEventDisableTiming));
         if (!bl.film_done) TIRT_HIP(hipEventCreateWithFlags(&bl.film_done, hipEventDisableTiming));
@@ -884,6 +928,7 @@ int bdpt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t see
         int *gexpect = (int *)gf;                                    // (the owner list of the sub-path phase: 2 N ints, before any record is staged)
         unsigned long long *qmask = bl.qidx.as<unsigned long long>();          // [item]: the pairs that have a connection ray
         int *ibase = bl.qidx.as<int>() + NMAX * 2, *icount = ibase + NMAX;
+        unsigned *qown = (unsigned *)(icount + NMAX);                // [queue place]: item | pair slot << 26
         float4 *ehits = bl.hits.as<float4>(), *shits = ehits + 2 * NMAX;
         int *scount = bl.ctr.as<int>();
         bpixel *items = bl.items.as<bpixel>(); BdStep *state = bl.state.as<BdStep>();
@@ -914,16 +959,20 @@ int bdpt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t see
         if (last_delta) TIRT_HIP(hipStreamWaitEvent(st, last_delta, 0));      // the per-pixel memory is replayed in frame order
         hipLaunchKernelGGL(k_bd_delta, dim3((P + B - 1) / B), dim3(B), 0, st, items, state, tm, P, F, c->bdpt_px.as<int>());
         if (NL > 1) { TIRT_HIP(hipEventRecord(bl.delta_done, st)); last_delta = bl.delta_done; }
-        if (spectral) hipLaunchKernelGGL((k_bd_connect<0, true>), dim3((N + B - 1) / B), dim3(B), 0, st, bc, items, state, tm, P, N, frame0,
-                           stage, qmask, ibase, icount, scount, shits, bl.rad.as<float>(), 3 * NP, &ctr->rays_shadow);
-        else hipLaunchKernelGGL((k_bd_connect<0, false>), dim3((N + B - 1) / B), dim3(B), 0, st, bc, items, state, tm, P, N, frame0,
-                           stage, qmask, ibase, icount, scount, shits, bl.rad.as<float>(), 3 * NP, &ctr->rays_shadow);
-        hipLaunchKernelGGL(k_bd_compact, dim3((N + B - 1) / B), dim3(B), 0, st, N, ibase, icount, stage, sr);
+        if (spectral) hipLaunchKernelGGL(k_bd_connect<true>, dim3((N + B - 1) / B), dim3(B), 0, st, bc, items, state, tm, P, N, frame0,
+                           stage, qmask, ibase, icount, scount, &ctr->rays_shadow);
+        else hipLaunchKernelGGL(k_bd_connect<false>, dim3((N + B - 1) / B), dim3(B), 0, st, bc, items, state, tm, P, N, frame0,
+                           stage, qmask, ibase, icount, scount, &ctr->rays_shadow);
+        hipLaunchKernelGGL(k_bd_compact, dim3((N + B - 1) / B), dim3(B), 0, st, N, ibase, icount, qmask, stage, sr, qown);
         if (int rc = trace_arrays(c, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, (int)(SCAP < (size_t)N * 27 ? SCAP : (size_t)N * 27), scount, shits, nullptr, nullptr, false, lane, sr.r, true)) return rc;
-        if (spectral) hipLaunchKernelGGL((k_bd_connect<1, true>), dim3((N + B - 1) / B), dim3(B), 0, st, bc, items, state, tm, P, N, frame0,
-                           stage /* the staged `expect` words are now the rays' places in the queue */, qmask, ibase, icount, scount, shits, bl.rad.as<float>(), 3 * NP, &ctr->rays_shadow);
-        else hipLaunchKernelGGL((k_bd_connect<1, false>), dim3((N + B - 1) / B), dim3(B), 0, st, bc, items, state, tm, P, N, frame0,
-                           stage /* the staged `expect` words are now the rays' places in the queue */, qmask, ibase, icount, scount, shits, bl.rad.as<float>(), 3 * NP, &ctr->rays_shadow);
+        if (spectral) hipLaunchKernelGGL(k_bd_emitted<true>, dim3((N + B - 1) / B), dim3(B), 0, st, bc, items, state, tm, P, N, frame0, bl.rad.as<float>(), 3 * NP);
+        else hipLaunchKernelGGL(k_bd_emitted<false>, dim3((N + B - 1) / B), dim3(B), 0, st, bc, items, state, tm, P, N, frame0, bl.rad.as<float>(), 3 * NP);
+        {
+            size_t rg = ((size_t)N * 8 + B - 1) / B;                 // grid-stride over the queue (its length is on the device): ~7 rays per item
+            if (rg > 8192) rg = 8192;
+            if (spectral) hipLaunchKernelGGL(k_bd_resolve<true>, dim3((unsigned)rg), dim3(B), 0, st, bc, items, tm, P, frame0, qown, scount, shits, sr.r, bl.rad.as<float>(), 3 * NP);
+            else hipLaunchKernelGGL(k_bd_resolve<false>, dim3((unsigned)rg), dim3(B), 0, st, bc, items, tm, P, frame0, qown, scount, shits, sr.r, bl.rad.as<float>(), 3 * NP);
+        }
         if (last_film) TIRT_HIP(hipStreamWaitEvent(st, last_film, 0));        // the running mean applies the frames in order
         for (int f = 0; f < F; f++) {
             const float coff = 1.0f / ((float)(int)(frame0 + (uint32_t)f) + 1.0f);
