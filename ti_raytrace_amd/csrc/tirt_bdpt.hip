@@ -327,11 +327,11 @@ TD void bd_sample_light(const BdCtx &c, uint32_t pixel, uint32_t frame, uint32_t
 
 // BDPT_RGB.py:481-592
 template <bool SPEC>
-TD v3 bd_connect_path(const BdCtx &c, const bpixel *P, bvert &sample, int i, int j, int e, int l, uint32_t frame, int &nu, int &nv, Tracer &T)
+TD v3 bd_connect_path(const BdCtx &c, const bpixel *P, const bvert &EV, bvert &sample, int i, int j, int e, int l, uint32_t frame, int &nu, int &nv, Tracer &T)
 {
     const SceneView &s = c.sc;
-    // private copies of the two vertices being connected (one wide load each; nothing is written to the arrays)
-    const bvert EV = P->eye[e - 1];
+    // private copies of the two vertices being connected (one wide load each; nothing is written to the arrays): EV = eye[e - 1] is the
+    // caller's (the per-item loop keeps it across the l loop), LV is loaded here
     const bvert LV = (l > 0) ? P->light[l - 1] : bvert();
     const uint32_t pixel = (uint32_t)(i * c.bv.H + j);
     constexpr bool spectral = SPEC;
@@ -740,6 +740,9 @@ __global__ void k_bd_connect(BdCtx c, bpixel *items, const BdStep *steps, TileMa
     unsigned long long pairs = 0ull;
     bvert sample = bvert();              // BDPT_RGB.py:60 `sample`: written by a connection, read by its MIS weight
     for (int e = 1; e <= BD_EYE_MAX; e++) {
+        if (__ballot(live && e <= eye_depth) == 0ull) break;
+        bvert EV = bvert();
+        if (live && e <= eye_depth) EV = B->eye[e - 1];                 // once per e, not once per pair (the kernel is bound by its vector-memory instructions)
         for (int l = 0; l <= BD_LIGHT_MAX; l++) {
             const int depth = l + e - 2;
             if (((l == 1) & (e == 1)) | (depth < 0) | (depth > BD_MAX_DEPTH)) continue;       // wave-uniform
@@ -749,7 +752,7 @@ __global__ void k_bd_connect(BdCtx c, bpixel *items, const BdStep *steps, TileMa
             Tracer T; T.phase = 0; T.want = false; T.res.t = INF_VALUE; T.res.u = 0.0f; T.res.v = 0.0f; T.res.prim = -1;
             T.o = V(0.0f, 0.0f, 0.0f); T.d = T.o; T.expect = -3; T.bound = -1.0f;
             int nu = 0, nv = 0;
-            (void)bd_connect_path<SPEC>(c, B, sample, i, j, e, l, frame, nu, nv, T);       // pass 0: a traced pair sees a miss and returns zero
+            (void)bd_connect_path<SPEC>(c, B, EV, sample, i, j, e, l, frame, nu, nv, T);       // pass 0: a traced pair sees a miss and returns zero
             if (T.want) {
                 // the item's j-th connection ray goes to staging slot [j][item] (k_bd_compact makes the queue dense: one atomic
                 // per wave at the end of this kernel instead of one per wave and pair -- same-address atomics retire at ~11 ns)
@@ -790,34 +793,60 @@ __global__ void k_bd_emitted(BdCtx c, const bpixel *items, const BdStep *steps, 
     T.o = V(0.0f, 0.0f, 0.0f); T.d = T.o; T.expect = -3; T.bound = -1.0f;
     bvert sample = bvert();
     int nu = 0, nv = 0;
-    const v3 r = bd_connect_path<SPEC>(c, items + it, sample, i, j, e, 0, frame, nu, nv, T);
+    const bvert EV = items[it].eye[e - 1];
+    const v3 r = bd_connect_path<SPEC>(c, items + it, EV, sample, i, j, e, 0, frame, nu, nv, T);
     bd_splat<SPEC>(c, radiance + (size_t)f * (size_t)frame_stride, e, nu, nv, p, frame, r);
 }
 
 // Pass 1 of a connection, one thread per queued connection ray (per item, 27 pair slots of which ~7 carry a ray and ~4 of those are
 // unoccluded, the VALU ran at 19 % of its lanes): the traced answer, then -- only if the expected primitive is what the ray met --
 // contribution and MIS weight (BDPT_RGB.py:300-479), splatted with float atomics.
+constexpr int BD_RESOLVE_CHUNK = 2048;            // queue entries a block filters at a time
 template <bool SPEC>
 __global__ void k_bd_resolve(BdCtx c, const bpixel *items, TileMap tm, int P, uint32_t frame_begin, const unsigned *qown, const int *scount,
                              const float4 *shits, const float4 *queue, float *radiance, long frame_stride)
 {
-    const int count = *scount;
-    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < count; q += (long)gridDim.x * blockDim.x) {
-        const float4 hr = shits[q];
-        // every branch of connect_path wants the ray's closest hit to be the expected primitive before anything else
-        if (__float_as_int(hr.w) != __float_as_int(queue[2 * q + 1].z)) continue;
-        const unsigned own = qown[q];
-        const int it = (int)(own & ((1u << BD_OWNER_BITS) - 1u)), slot = (int)(own >> BD_OWNER_BITS);
-        const int e = slot / (BD_LIGHT_MAX + 1) + 1, l = slot - (e - 1) * (BD_LIGHT_MAX + 1);
-        const int f = it / P, k = it - f * P;
-        const int p = local_to_pixel(tm, k), i = p / c.bv.H, j = p - i * c.bv.H;
-        const uint32_t frame = frame_begin + (uint32_t)f;
-        Tracer T; T.phase = 1; T.want = false; T.res.t = hr.x; T.res.u = hr.y; T.res.v = hr.z; T.res.prim = __float_as_int(hr.w);
-        T.o = V(0.0f, 0.0f, 0.0f); T.d = T.o; T.expect = -3; T.bound = -1.0f;
-        bvert sample = bvert();
-        int nu = 0, nv = 0;
-        const v3 r = bd_connect_path<SPEC>(c, items + it, sample, i, j, e, l, frame, nu, nv, T);
-        bd_splat<SPEC>(c, radiance + (size_t)f * (size_t)frame_stride, e, nu, nv, p, frame, r);
+    // every branch of connect_path wants the ray's closest hit to be the expected primitive before anything else (and about half of the
+    // connections are occluded): a block first filters a chunk of the queue into a list of those in LDS, then works through the list
+    // with all its lanes
+    __shared__ int s_list[BD_RESOLVE_CHUNK];
+    __shared__ int s_n;
+    const int count = *scount, lane = threadIdx.x & 63;
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    for (long c0 = (long)blockIdx.x * BD_RESOLVE_CHUNK; c0 < count; c0 += (long)gridDim.x * BD_RESOLVE_CHUNK) {
+        if (threadIdx.x == 0) s_n = 0;
+        __syncthreads();
+        for (int r = 0; r < BD_RESOLVE_CHUNK; r += (int)blockDim.x) {
+            const long q = c0 + r + threadIdx.x;
+            const bool m = q < count && __float_as_int(shits[q].w) == __float_as_int(queue[2 * q + 1].z);
+            const unsigned long long bm = __ballot(m);
+            if (bm == 0ull) continue;
+            const int leader = __ffsll((long long)bm) - 1;
+            int base = 0;
+            if (lane == leader) base = atomicAdd(&s_n, __popcll(bm));
+            base = __shfl(base, leader, 64);
+            if (m) s_list[base + __popcll(bm & lt)] = (int)(q - c0);
+        }
+        __syncthreads();
+        const int n = s_n;
+        for (int k = threadIdx.x; k < n; k += (int)blockDim.x) {
+            const long q = c0 + s_list[k];
+            const float4 hr = shits[q];
+            const unsigned own = qown[q];
+            const int it = (int)(own & ((1u << BD_OWNER_BITS) - 1u)), slot = (int)(own >> BD_OWNER_BITS);
+            const int e = slot / (BD_LIGHT_MAX + 1) + 1, l = slot - (e - 1) * (BD_LIGHT_MAX + 1);
+            const int f = it / P, kk = it - f * P;
+            const int p = local_to_pixel(tm, kk), i = p / c.bv.H, j = p - i * c.bv.H;
+            const uint32_t frame = frame_begin + (uint32_t)f;
+            Tracer T; T.phase = 1; T.want = false; T.res.t = hr.x; T.res.u = hr.y; T.res.v = hr.z; T.res.prim = __float_as_int(hr.w);
+            T.o = V(0.0f, 0.0f, 0.0f); T.d = T.o; T.expect = -3; T.bound = -1.0f;
+            bvert sample = bvert();
+            int nu = 0, nv = 0;
+            const bvert EV = items[it].eye[e - 1];
+            const v3 r = bd_connect_path<SPEC>(c, items + it, EV, sample, i, j, e, l, frame, nu, nv, T);
+            bd_splat<SPEC>(c, radiance + (size_t)f * (size_t)frame_stride, e, nu, nv, p, frame, r);
+        }
+        __syncthreads();
     }
 }
 
