@@ -14,7 +14,7 @@
 //   k_bd_connect<1>    contribution + MIS weight (BDPT_RGB.py:300-479), splats with float atomics
 //   k_bdpt_film        running mean, frames in order                                   BDPT_RGB.py:639-642
 //
-// An item is one (frame, pixel) pair with its own vertex arrays (`bpixel`, 1.5 KB); a batch holds up to
+// An item is one (frame, pixel) pair with its own vertex arrays (`bpixel`, 1.0 KB); a batch holds up to
 // `bdpt_batch_items` of them (frames x owned pixels), so many frames are in flight at once.  The reference keeps ONE
 // set of vertex arrays per pixel and clears only beta/type/fpdf/rpdf between frames; walking through every read of a
 // field that the current frame has not written shows a single one that matters: the `delta` flag of an eye vertex
@@ -38,8 +38,10 @@ constexpr int VERTEX_NONE = 0, VERTEX_LIGHT = 1, VERTEX_LENS = 2, VERTEX_SURFACE
 constexpr uint32_t BD_DIM_EYE = 16, BD_DIM_LSTART = 80, BD_DIM_LIGHT = 96, BD_DIM_CONNECT = 176;
 constexpr float EPS_UF = 0.00001f;                 // UtilsFunc.py:36
 
-// BDPT_Vertex.py:10-21; padded to 96 bytes and 16-byte aligned: a vertex moves as six dwordx4 accesses instead of 21 scalar ones
-struct alignas(16) bvert { v3 pos, normal, snormal, beta, wo; float fpdf, rpdf; int type, prim, mat, delta; int pad_[3]; };
+// BDPT_Vertex.py:10-21 in 80 bytes, 16-byte aligned, every vector with a scalar that is read with it: a vertex moves as five dwordx4
+// accesses instead of 21 scalar ones, and a connection's geometry pass reads (pos, prim), (snormal, mat) and the type/delta word.
+struct alignas(16) bvert { v3 pos; int prim; v3 snormal; int mat; v3 normal; float fpdf; v3 beta; float rpdf; v3 wo; short type, delta; };
+static_assert(sizeof(bvert) == 80, "bvert is five quads");
 struct bpixel { bvert eye[BD_EYE_MAX], light[BD_LIGHT_MAX]; };       // the reference's sample / temp vertices (BDPT_RGB.py:60-64) are locals of the connection code
 
 struct BdView { float view[12]; int W, H; };
@@ -481,7 +483,7 @@ __global__ void k_bd_init(BdCtx c, bpixel *items, BdStep *steps, BdRays rays, in
         float jx = 0.0f, jy = 0.0f;
         if (frame != 0) { jx = tm_rand(c.seed, pixel, frame, TM_DIM_JX) - 0.5f; jy = tm_rand(c.seed, pixel, frame, TM_DIM_JY) - 0.5f; }
         const v3 dir = camera_ray_direction(c.cam, i, j, jx, jy);
-        bvert ev = bvert();                    // whole 96-byte stores: the fields the reference does not set are the zeros its field starts with
+        bvert ev = bvert();                    // whole 80-byte stores: the fields the reference does not set are the zeros its field starts with
         ev.pos = origin; ev.normal = dir; ev.beta = V(1.0f, 1.0f, 1.0f); ev.fpdf = 1.0f; ev.type = VERTEX_LENS;
         eye[0] = ev;
         st.e_beta = V(1.0f, 1.0f, 1.0f); st.e_pdfFwd = 1.0f; st.e_tail = 0; st.pad_ = 0; st.eye_depth = 1;
@@ -600,7 +602,7 @@ __global__ void k_bd_step(BdCtx c, bpixel *items, BdStep *steps, BdRays rays, co
                             }
                         }
                     }
-                    eye[depth] = ev;                      // one 96-byte store
+                    eye[depth] = ev;                      // one 80-byte store
                 }
                 st->e_beta = beta; st->e_pdfFwd = pdfFwd; st->eye_depth = final_depth; st->e_tail = (stored_surface && final_depth == depth) ? 1 : 0;
             } else {
@@ -966,7 +968,7 @@ int bdpt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t see
         const uint32_t frame0 = frame_begin + (uint32_t)f0;
         TIRT_HIP(hipMemsetAsync(bl.rad.p, 0, sizeof(float) * 3 * (size_t)NP * (size_t)F, st));
         // No read of a vertex field goes to a slot this item has not written (header; k_bd_delta supplies the one exception), so the
-        // 1.2 KB per item need no clearing.  Option "bdpt_state_fill": 1 = zeros (the round-1..3 behaviour), 2 = 0xFF poison -- the
+        // 1.0 KB per item need no clearing.  Option "bdpt_state_fill": 1 = zeros (the round-1..3 behaviour), 2 = 0xFF poison -- the
         // parity tests render under poison and must not see a bit change.
         if (c->bdpt_state_fill) TIRT_HIP(hipMemsetAsync(bl.items.p, c->bdpt_state_fill == 2 ? 0xFF : 0, sizeof(bpixel) * (size_t)N, st));
         TIRT_HIP(hipMemsetAsync(scount, 0, 64, st));                 // the connection-ray count and the alive counts of the depths
