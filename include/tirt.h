@@ -95,8 +95,8 @@ int tirt_sync(tirt_ctx *ctx);
  *            gets depends on the visiting order (none in any render); takes effect at the next tirt_lbvh_build
  *          "wide_collapse" (0/1, default 0) -- how the binary tree is grouped into 4-wide nodes: 0 = greedily by surface area, 1 = the
  *            grouping of least total node area (dynamic programme); same results, 1-9 % fewer node visits, no measurable gain
- *          "bdpt_batch_items" -- (frame, pixel) items per BDPT wavefront batch (default 8 Mi, ~3.5 KB of HBM each: 29 GB), shared by the two batches in flight on render lanes 0 and 1
- *            (config 5 on one lane: 1 Mi 1 649, 2 Mi 1 799, 4 Mi 1 887, 8 Mi 1 937 Mrays/s; two lanes of 4 Mi: 2 230)
+ *          "bdpt_batch_items" -- (frame, pixel) items per BDPT wavefront batch (default 16 Mi, ~3.5 KB of HBM each: 58 GB), shared by the two batches in flight on render lanes 0 and 1
+ *            (config 5, round 3: 4 Mi 2 890, 8 Mi 2 900, 16 Mi 2 995, 32 Mi 2 980 Mrays/s; 256 frames: 8 Mi 2 912, 16 Mi 2 923, 32 Mi 3 032)
  *          "bdpt_state_fill" (diagnostic) -- what a BDPT batch does to its per-item vertex arrays first: 0 = nothing (default: no read reaches a slot
  *            its item has not written), 1 = zeros (rounds 1-3: +3.5 % time on config 5), 2 = 0xFF poison (the parity tests run under it)
  *          (trace_lds_depth is checked against the LDS a block can have on the device) */

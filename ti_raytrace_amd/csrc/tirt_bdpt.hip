@@ -9,9 +9,11 @@
 //   6 x { trace the live rays ; k_bd_step(d) }   vertex d of the eye and of the light sub-path; the rays of a depth are a
 //                      dense list, survivors append to the next depth's list               BDPT_RGB.py:126-198, 229-294
 //   k_bd_delta         the one field that survives from frame to frame (see below)
-//   k_bd_connect<0>    geometry of every (e, l) connection, connection rays to a dense queue   BDPT_RGB.py:481-592
+//   k_bd_connect       per item: geometry of every (e, l) connection, connection rays staged   BDPT_RGB.py:481-592
+//   k_bd_compact       staged rays -> dense queue, with an owner word (item, pair slot) each
 //   trace queries      "is the expected primitive the closest hit?"  (k_trace<KIND_QUERY>, bounded)
-//   k_bd_connect<1>    contribution + MIS weight (BDPT_RGB.py:300-479), splats with float atomics
+//   k_bd_emitted       the l == 0 pairs (eye sub-path ended on an emitter): no ray
+//   k_bd_resolve       per QUEUED CONNECTION: contribution + MIS weight (BDPT_RGB.py:300-479), splats with float atomics
 //   k_bdpt_film        running mean, frames in order                                   BDPT_RGB.py:639-642
 //
 // An item is one (frame, pixel) pair with its own vertex arrays (`bpixel`, 1.0 KB); a batch holds up to

@@ -258,7 +258,7 @@ struct tirt_ctx {
     // launches of one batch (VALU-bound) run next to the vertex / connection kernels of the other (HBM-bound)
     struct BdLane { tirt::DevBuf items, state, rays, hits, qidx, ctr, rad; hipEvent_t delta_done = nullptr, film_done = nullptr; } bd[2];
     int bdpt_state_fill = 0;                       // option "bdpt_state_fill" (diagnostic): 0 = vertex arrays not cleared per batch, 1 = zeros, 2 = 0xFF poison
-    size_t bdpt_batch_items = (size_t)8 << 20;   // option "bdpt_batch_items": (frame, pixel) items per wavefront batch
+    size_t bdpt_batch_items = (size_t)16 << 20;   // option "bdpt_batch_items": (frame, pixel) items per wavefront batch
     int bdpt_stack = 64;                           // option "bdpt_stack_size": traversal stack entries of BDPT's rays (BDPT.__init__'s stack_size; LDS part + paged spill)
     int bdpt_bounded = 1;                          // option "bdpt_bounded": connection rays stop at their target distance
 
