@@ -457,6 +457,11 @@ TD v3 bd_connect_path(const BdCtx &c, const bpixel *P, const bvert &EV, bvert &s
 struct BdStep { v3 e_beta; float e_pdfFwd; v3 l_beta; float l_pdfFwd; int e_tail, pad_, eye_depth, light_depth; };
 struct BdRays { float4 *r; };             // a ray list: 32-byte records (o.xyz, d.x), (d.y, d.z, bits expect, bound) -- TraceArgs::ray4: two memory instructions per ray and side
 constexpr int BD_PAIRS = BD_EYE_MAX * (BD_LIGHT_MAX + 1);          // (e - 1) * 7 + l
+// The pairs that can carry a connection ray: l >= 1, (e, l) != (1, 1), 0 <= e + l - 2 <= BD_MAX_DEPTH -- for e = 1..6: 5, 5, 4, 3, 2, 1
+// (the seven l == 0 pairs never do).  The staging area, the dense queue and its hit records are sized by it.
+constexpr int BD_RAY_PAIRS = 20;
+constexpr int bd_count_ray_pairs() { int n = 0; for (int e = 1; e <= BD_EYE_MAX; e++) for (int l = 1; l <= BD_LIGHT_MAX; l++) if (!(l == 1 && e == 1) && l + e - 2 >= 0 && l + e - 2 <= BD_MAX_DEPTH) n++; return n; }
+static_assert(bd_count_ray_pairs() == BD_RAY_PAIRS, "BD_RAY_PAIRS");
 TD void put_ray(const BdRays &r, size_t k, v3 o, v3 d) { r.r[2 * k] = make_float4(o.x, o.y, o.z, d.x); r.r[2 * k + 1] = make_float4(d.y, d.z, 0.0f, 0.0f); }
 TD void count_rays(unsigned long long *ctr, unsigned mine)
 {
@@ -802,7 +807,7 @@ __global__ void k_bd_emitted(BdCtx c, const bpixel *items, const BdStep *steps, 
     bd_splat<SPEC>(c, radiance + (size_t)f * (size_t)frame_stride, e, nu, nv, p, frame, r);
 }
 
-// Pass 1 of a connection, one thread per queued connection ray (per item, 27 pair slots of which ~7 carry a ray and ~4 of those are
+// Pass 1 of a connection, one thread per queued connection ray (per item, 27 pair slots of which at most 20 and on average ~7 carry a ray and ~4 of those are
 // unoccluded, the VALU ran at 19 % of its lanes): the traced answer, then -- only if the expected primitive is what the ray met --
 // contribution and MIS weight (BDPT_RGB.py:300-479), splatted with float atomics.
 constexpr int BD_RESOLVE_CHUNK = 2048;            // queue entries a block filters at a time
@@ -866,7 +871,7 @@ __global__ void k_bd_compact(int N, const int *ibase, const int *icount, const u
     unsigned long long rest = (n > 0) ? qmask[it] : 0ull;          // the pair slots of this item's rays, lowest first
     int off = live ? ibase[it] : 0;
     off = __shfl(off, 0, 64);                           // lane 0 of a wave is live whenever any lane is
-    for (int j = 0; j < 27; j++) {
+    for (int j = 0; j < BD_RAY_PAIRS; j++) {
         const unsigned long long m = __ballot(n > j);
         if (m == 0ull) break;
         if (n > j) {
@@ -925,7 +930,7 @@ int bdpt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t see
     const size_t NMAX = (size_t)FB_alloc * P;
     TIRT_REQUIRE(NMAX < ((size_t)1 << BD_OWNER_BITS), "tirt_bdpt_rgb_render: bdpt_batch_items must stay below 2^26");
     TIRT_REQUIRE(NMAX * BD_PAIRS < ((size_t)1 << 31), "tirt_bdpt_rgb_render: film too large for one frame per batch");
-    const size_t SCAP = NMAX * 27;                               // at most 27 (e, l) pairs per item carry a connection ray (staging: [27][N])
+    const size_t SCAP = NMAX * BD_RAY_PAIRS;                     // at most 20 (e, l) pairs per item carry a connection ray (staging: [20][N])
     for (int l = 0; l < NL; l++) {
         auto &bl = c->bd[l];
         if (bl.items.ensure(sizeof(bpixel) * NMAX) || bl.state.ensure(sizeof(BdStep) * NMAX) ||
@@ -997,7 +1002,7 @@ int bdpt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t see
         else hipLaunchKernelGGL(k_bd_connect<false>, dim3((N + B - 1) / B), dim3(B), 0, st, bc, items, state, tm, P, N, frame0,
                            stage, qmask, ibase, icount, scount, &ctr->rays_shadow);
         hipLaunchKernelGGL(k_bd_compact, dim3((N + B - 1) / B), dim3(B), 0, st, N, ibase, icount, qmask, stage, sr, qown);
-        if (int rc = trace_arrays(c, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, (int)(SCAP < (size_t)N * 27 ? SCAP : (size_t)N * 27), scount, shits, nullptr, nullptr, false, lane, sr.r, true)) return rc;
+        if (int rc = trace_arrays(c, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, (int)(SCAP < (size_t)N * BD_RAY_PAIRS ? SCAP : (size_t)N * BD_RAY_PAIRS), scount, shits, nullptr, nullptr, false, lane, sr.r, true)) return rc;
         if (spectral) hipLaunchKernelGGL(k_bd_emitted<true>, dim3((N + B - 1) / B), dim3(B), 0, st, bc, items, state, tm, P, N, frame0, bl.rad.as<float>(), 3 * NP);
         else hipLaunchKernelGGL(k_bd_emitted<false>, dim3((N + B - 1) / B), dim3(B), 0, st, bc, items, state, tm, P, N, frame0, bl.rad.as<float>(), 3 * NP);
         {
