@@ -115,6 +115,8 @@ def rocprof_passes(child, groups, timeout_s=240):
             cmd = ["timeout", "-k", "5", str(timeout_s), exe, "--kernel-trace", "--pmc"] + list(counters) + ["--output-format", "csv", "-d", d, "--"] + child
             pr = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout_s + 60)
             fs = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            out["__child_tail"] = {"launches": 0, "dur_ns": 0.0, "rc": pr.returncode,
+                                   "text": " | ".join(l for l in pr.stdout.decode("utf-8", "replace").splitlines() if "rocprofv3" not in l and "output_stream" not in l)[-700:]}
             if not fs:
                 raise RuntimeError("%s pass produced no counter file (rc %d)" % (counters[0], pr.returncode))
             seen = set()
@@ -342,7 +344,7 @@ def bdpt_roofline(device_id):
                    "hbm_frac": round(by / v["dur_ns"] / HBM_PEAK_GBS, 4)}
     bd = {n: r for n, r in rows.items() if n.startswith("k_bd")}
     if not bd:
-        return {"error": "no k_bd_* dispatch in the profiler passes"}
+        return {"error": "no k_bd_* dispatch in the profiler passes", "child": k.get("__child_tail")}
     dom = max(bd, key=lambda n: bd[n]["time_share"])
     return {"bound": "hbm", "kernel": dom, "achieved": rows[dom]["hbm_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": rows[dom]["hbm_frac"],
             "traffic": rows[dom]["hbm_bytes_per_launch"], "kernels": rows,
