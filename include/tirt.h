@@ -73,8 +73,6 @@ int tirt_sync(tirt_ctx *ctx);
  *          "overlap_lanes" (1..8, default 4) -- wavefront batches in flight on separate streams
  *          "trace_lds_depth" / "trace_refill_min" / "trace_node_min" / "trace_grid" / "trace_grid_alone" / "trace_slices" /
  *          "shade_grid" -- kernel tuning
- *          "trace_queue" (0/1, default 0) -- 1 runs the ordered traversal with a per-wave leaf queue (k_trace_q: primitive tests of a wave's
- *            rays are queued in LDS and run 64 at a time by whichever lanes; same results, measured 4 % slower: an experiment kept for A/B)
  *          "bdpt_bounded" (0/1, default 1) -- BDPT connection rays are cut off at their target distance (same
  *            visibility answers as the full closest-hit query; 0 = reference-style full query, for cross-checks)
  *          "merge_paths" -- consecutive tirt_pt_rgb_render calls over contiguous frames are merged

@@ -255,7 +255,7 @@ def test_measurement_helpers(gpu_ctx_ok):
     ex.build_scene()
     info = ex.scene.ctx.bvh_info()
     assert info["prim_bytes"] == 48 * 5001 and 1200 < info["nodes"] < 5001 and info["node_bytes"] == 64 * info["nodes"]
-    assert info["nodes_in_lds"] == min(info["nodes"], 224)          # TR_TOP_SLOTS (tirt_internal.h; 176 with option trace_queue = 1)
+    assert info["nodes_in_lds"] == min(info["nodes"], 224)          # TR_TOP_SLOTS (tirt_internal.h)
     rate = ex.scene.ctx.micro_gather_rate(1 << 20, 200)
     assert 500.0 < rate < 40000.0                      # GB/s: a sane number, not a benchmark
 

@@ -370,7 +370,6 @@ int tirt_set_option(tirt_ctx *c, const char *name, double value)
         c->tr_lds_depth = (int)value; return TIRT_OK;
     }
     if (!strcmp(name, "bdpt_stack_size")) { TIRT_REQUIRE(value >= 16 && value <= 4096, "bdpt_stack_size: 16..4096"); c->bdpt_stack = (int)value; return TIRT_OK; }
-    if (!strcmp(name, "trace_queue")) { c->tr_queue = value != 0.0 ? 1 : 0; return TIRT_OK; }
     if (!strcmp(name, "trace_timeline")) { c->timeline_arm = (int)value; c->timeline_waves = 0; return TIRT_OK; }
     if (!strcmp(name, "trace_refill_min")) { TIRT_REQUIRE(value >= 1 && value <= 64, "trace_refill_min: 1..64"); c->tr_refill_min = (int)value; return TIRT_OK; }
     if (!strcmp(name, "trace_node_min")) { TIRT_REQUIRE(value >= 1 && value <= 64, "trace_node_min: 1..64"); c->tr_node_min = (int)value; return TIRT_OK; }
@@ -709,7 +708,7 @@ int tirt_bvh_info(tirt_ctx *c, uint64_t out[4])
     TIRT_REQUIRE(out && c->built, "tirt_bvh_info: LBVH not built");
     const int nq = c->wide_nodes;
     out[0] = (uint64_t)nq * 64u; out[1] = (uint64_t)c->n * sizeof(float4) * TRI_STRIDE; out[2] = (uint64_t)nq;
-    const int top = c->tr_queue ? TRQ_TOP_SLOTS : TR_TOP_SLOTS;
+    const int top = TR_TOP_SLOTS;
     out[3] = (uint64_t)(nq < top ? nq : top);
     return TIRT_OK;
 }

@@ -76,10 +76,6 @@ constexpr int TR_TOP_LEVELS = TR_TOP_LEVELS_N;           // levels of 4-wide nod
 #endif
 constexpr int TR_TOP_FULL = ((1 << (2 * TR_TOP_LEVELS)) - 1) / 3;
 constexpr int TR_TOP_SLOTS = TR_TOP_FULL < TR_TOP_CAP ? TR_TOP_FULL : TR_TOP_CAP;   // the first 224 nodes in breadth-first order: four levels and the start of the fifth
-#ifndef TRQ_TOP_N
-#define TRQ_TOP_N 176
-#endif
-constexpr int TRQ_TOP_SLOTS = TRQ_TOP_N;            // k_trace_q (leaf queue per wave, tirt_render.hip): tree-top records in LDS -- 32 KB of stacks + 11 KB + 10 KB of queues = 53 KB, three blocks per CU
 // cnode: the 4-wide nodes again, 64 bytes each, box planes quantised on ONE grid over the root box (k_cnodes):
 //   plane = grid_min + h * cell with h an fp16 number of cells measured from the CENTRE of the root box (|h| <= 30000:
 //   the spacing of fp16 there is 16 cells = 2.7e-4 of the extent, finer towards the centre), min planes rounded down
@@ -246,7 +242,6 @@ struct tirt_ctx {
     // traversal tunables (options "trace_lds_depth", "trace_refill_min", "trace_node_min", "trace_grid",
     // "trace_slices" = number of ray-fetch cursors, "shade_grid" = persistent blocks of k_shade)
     int tr_lds_depth = 16, tr_refill_min = 18, tr_node_min = 38, tr_grid = 1280, tr_slice_log2 = 5, sh_grid = 1024;
-    int tr_queue = 0;                              // option "trace_queue": 1 = the ordered traversal runs k_trace_q (per-wave leaf queue, tirt_render.hip: an experiment, 4 % slower); 0 = k_trace
     int tr_grid_alone = 1280;                     // "trace_grid_alone" / "trace_grid": persistent k_trace blocks of a batch submitted to an idle / a busy GPU. Both five per CU
                                                   // (tirt_create scales them by the device's CU count): blocks of the next batch's launch move in as this one's drain
     tirt::DevBuf counters_mem, spill;            // used by the batch trace entry points (main stream)

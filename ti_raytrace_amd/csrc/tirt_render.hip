@@ -569,482 +569,6 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------------
-// k_trace_q: the ordered traversal with a LEAF QUEUE per wave -- an experiment of round 3, kept as option "trace_queue" = 1 (default 0:
-// k_trace above).  Results are bit-identical (tests/test_gpu_trace.py and test_gpu_render.py pass with it on).
-//
-// In k_trace a lane that reaches a leaf waits (after one stashed leaf) until the wave leaves its inner-node loop and runs the
-// primitive tests for whichever lanes hold one: the node loop runs at 0.71 lane utilisation, the primitive tests at 0.50 -- and
-// the kernel is bound by VALU issue, so idle lanes are lost throughput.  Here a leaf is not tested by the lane that found it: the
-// lane appends (its lane number, the leaf) to a ring of 128 entries in LDS and goes on walking at once.  Whenever 64 entries have
-// gathered (or the wave has little node work left) the whole wave tests 64 of them, one per lane, whoever they belong to: the
-// testing lane reads the owner's ray out of the owner's registers (ds_bpermute), runs the same Moller-Trumbore / sphere test and
-// the same verification of the reference's visiting condition, and reports through LDS -- a 64-bit atomic min per owner on
-// (t bits, ~leaf), which is the reference's order: smaller t first, on equal t the larger compact-node index (file header) --; the
-// owner then takes u, v and the primitive id out of the winning lane's registers.  A ray is finished when its stack is empty AND
-// all of its queued tests have come back.
-// Measured (MI355X, headline scene, profiles/r03q_*): lane utilisation of the node loop 0.71 -> 0.77, of the primitive tests
-// 0.50 -> 0.67, VALU wave-instructions per launch -2 % -- the queue bookkeeping (13 cross-lane pulls, three LDS round trips, the
-// owner's update: ~450 instructions per phase instead of ~330) eats most of what the fuller waves save.  One lane: 21.4 ms of
-// traversal per 32 Mi-path batch instead of 22.0 with 128 VGPRs and two blocks per CU, 23.5 ms with 96 VGPRs; whole job 3 910 /
-// 4 000 Mrays/s against k_trace's 4 180 (the fatter kernel overlaps worse with the other batch's shading).  Not a win: off.
-#ifndef TRQ_MIN_WAVES
-#define TRQ_MIN_WAVES 5        // 96 VGPRs (at 80 the leaf phase spills ~100 bytes per lane to scratch and the kernel turns memory-bound: 39 ms per batch instead of 23.5)
-#endif
-constexpr int TRQ_RING = 128;                 // leaf-queue entries per wave (a node step appends at most 64, a phase is run from 64 on)
-constexpr unsigned TRQ_WAVE_BYTES = TRQ_RING * 4u + 64u * 8u + 64u * 4u;      // ring | per-owner key | per-owner (tests done, winner lane)
-inline size_t traceq_lds_bytes(int depth) { return sizeof(int) * (size_t)depth * TR_BLOCK + (size_t)TRQ_TOP_SLOTS * 64 + (size_t)(TR_BLOCK / 64) * TRQ_WAVE_BYTES; }
-template <bool COUNT, int KIND>
-__global__ __launch_bounds__(TR_BLOCK, TRQ_MIN_WAVES) void k_trace_q(TraceArgs a)
-{
-    constexpr int MODE = TIRT_TRAVERSE_ORDERED;
-    extern __shared__ __attribute__((aligned(16))) int lds_stack[];      // [lds_depth][TR_BLOCK]
-    const int TR_LDS_DEPTH = a.lds_depth;
-    constexpr bool MAY_SHADOW = (KIND != KIND_CLOSEST);
-    constexpr bool BOUNDED = MAY_SHADOW && (MODE != TIRT_TRAVERSE_EXHAUSTIVE);
-    const int count_c = (KIND == KIND_SHADOW_ACC || KIND == KIND_QUERY) ? 0 : (a.count_ptr ? *a.count_ptr : a.count_fixed);
-    const int count_s = (KIND == KIND_CLOSEST) ? 0 : (KIND == KIND_MIXED ? *a.scount_ptr : (a.count_ptr ? *a.count_ptr : a.count_fixed));
-    const int count = count_c + count_s;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const size_t gstride = (size_t)gridDim.x * TR_BLOCK, gtid = (size_t)blockIdx.x * TR_BLOCK + tid;
-    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    const BvhView &b = a.bvh;
-
-    // per-lane ray state
-    bool have = false, par = false, is_sh = (KIND == KIND_SHADOW_ACC || KIND == KIND_QUERY);
-    int q = 0, cur = TR_SENT, hit_prim = -1, hit_leaf = -1, expect = -3;
-    int pend = 0;                               // primitive tests of this ray that sit in the leaf queue
-    unsigned n_overflow = 0;
-    float hit_t = INF_VALUE, hit_u = 0.0f, hit_v = 0.0f, cull_far = 3.0e38f, settle = -1.0f;
-    float lim = INF_VALUE;                      // ordered mode: min(hit_t * 1.0001, cull_far, INF_VALUE), entry distances beyond it are skipped
-    // (ordered mode: a NEGATIVE cull_far marks a ray whose origin is more than TR_FAR_RHO root-box extents away -- no distance culling for it, see the set-up code)
-    unsigned nbox = 0, nleaf = 0;
-    RayCtx r = {};
-    // ordered mode: the ray in the grid of the quantised nodes.  Plane h (fp16, in cells) of axis a is crossed at
-    // t = h * gA + gB (gA = cell / d, gB = (grid_min - o) / d); gBn / gBf are gB moved outward by a margin of
-    // 0.25 cells + 0.25 cells per root-box extent of distance between the origin and the grid (see the set-up code
-    // for what it covers); grot = 16 where gA < 0 rotates a (min | max << 16) plane
-    // pair so that the low half is always the near plane.  Axis-parallel components (|d| < 1e-6, where the
-    // reference tests the origin against the slab instead, UtilsFunc.py:500-503) do the same in grid units through
-    // the same two FMAs: gA = 1e30, gBn / gBf = (-(origin cell) -+ margin) * 1e30, so that the "near distance" is hugely
-    // negative or positive and the "far distance" hugely positive or negative according to the side of the planes
-    // the origin lies on.  (Ignoring such an axis would be conservative too, but a ray that ignores an axis walks a
-    // whole slice of the scene: a few of them per million rays set the duration of every launch.)
-    float gAx = 0.0f, gAy = 0.0f, gAz = 0.0f, gBnx = 0.0f, gBny = 0.0f, gBnz = 0.0f, gBfx = 0.0f, gBfy = 0.0f, gBfz = 0.0f;
-    int grotx = 0, groty = 0, grotz = 0;
-    bool exhausted = false;
-    const int S_LOG = a.slice_log2, S_MASK = (1 << S_LOG) - 1;
-    int home = (int)((blockIdx.x * (TR_BLOCK / 64) + (tid >> 6)) & S_MASK), tried = 0;      // wave-uniform
-    const int full_chunks = count >> 6;
-    unsigned long long sum_box = 0, sum_leaf = 0, sum_box_s = 0, sum_leaf_s = 0, n_over = 0;
-    unsigned long long d_it_node = 0, d_lanes_node = 0, d_it_leaf = 0, d_lanes_leaf = 0, d_refills = 0, d_outer = 0;
-
-    // Traversal stack.  `sa` is the LDS address of the TOP entry; entry e of a lane lives at
-    // lds_stack + e * TR_BLOCK * 4 + tid * 4.  Entry 0 is a sentinel (TR_SENT, written once), so a pop
-    // needs no emptiness test; entries 1 .. TR_LDS_DEPTH-1 hold the stack.  A lane whose LDS part is
-    // full pages its oldest TR_PAGE entries out to the global spill buffer ([entry][global thread])
-    // and pages them back in when it pops the sentinel -- both on wave-uniform cold paths outside the
-    // inner-node loop (which leaves as soon as some lane's LDS part is full), so the hot loop only
-    // ever touches LDS.  Addresses are compared as signed ints: after popping the sentinel `sa` is one
-    // entry below the bottom.
-    constexpr unsigned ENTRY = TR_BLOCK * 4u;
-    const unsigned sa_bottom = (unsigned)(size_t)(lds_int *)lds_stack + (unsigned)tid * 4u;
-    const unsigned sa_hi = (unsigned)(TR_LDS_DEPTH - 3) * ENTRY + sa_bottom;     // a step pushes up to three entries: page out at this fill level
-    unsigned sa = sa_bottom;
-    int paged = 0;                              // pages of this lane's stack that live in the spill buffer
-#define LDS_AT(addr) (*(lds_int *)(size_t)(addr))
-    LDS_AT(sa_bottom) = TR_SENT;
-    // the top TR_TOP_LEVELS levels of the 4-wide tree (7 x 16 bytes per record) sit behind the stacks: a
-    // visit there costs LDS bandwidth instead of the texture-address path this kernel is bound by
-    const unsigned top_base = (unsigned)(size_t)(lds_int *)lds_stack + (unsigned)TR_LDS_DEPTH * ENTRY;
-    typedef unsigned u4v __attribute__((ext_vector_type(4)));
-    typedef __attribute__((address_space(3))) u4v lds_u4;
-    const int top_n = b.top_count < TRQ_TOP_SLOTS ? b.top_count : TRQ_TOP_SLOTS;
-    // leaf queue of this wave, behind the tree top
-    const unsigned wq_base = top_base + (unsigned)TRQ_TOP_SLOTS * 64u + (unsigned)(tid >> 6) * TRQ_WAVE_BYTES;
-    const unsigned key_base = wq_base + (unsigned)TRQ_RING * 4u, done_base = key_base + 64u * 8u;
-    typedef __attribute__((address_space(3))) unsigned long long lds_u64;
-#define LDS_K(addr) (*(lds_u64 *)(size_t)(addr))
-    LDS_K(key_base + (unsigned)lane * 8u) = ~0ull;
-    LDS_AT(done_base + (unsigned)lane * 4u) = 0;
-    int q_head = 0, q_n = 0;                    // wave-uniform: ring entries [q_head, q_head + q_n) mod TRQ_RING are waiting
-    {
-        for (int k = tid; k < top_n * 4; k += TR_BLOCK)
-        { const uint4 g = b.cnode[k]; *(lds_u4 *)(size_t)(top_base + (unsigned)k * 16u) = u4v{g.x, g.y, g.z, g.w}; }
-        __syncthreads();
-    }
-#define TR_PAGE_OUT()                                                                                \
-    do {                                                                                             \
-        if ((paged + 1) * TR_PAGE <= a.spill_depth) {                                                \
-            for (int k__ = 0; k__ < TR_PAGE; k__++)                                                  \
-                a.spill[(size_t)(paged * TR_PAGE + k__) * gstride + gtid] = LDS_AT(sa_bottom + (unsigned)(k__ + 1) * ENTRY); \
-            for (unsigned e__ = sa_bottom + (TR_PAGE + 1) * ENTRY; e__ <= sa; e__ += ENTRY)          \
-                LDS_AT(e__ - TR_PAGE * ENTRY) = LDS_AT(e__);                                         \
-            sa -= TR_PAGE * ENTRY; paged++;                                                          \
-        } else { n_overflow++; sa -= ENTRY; }      /* out of room: the entry on top is lost (counted) */ \
-    } while (0)
-#define TR_PAGE_IN()                                                                                 \
-    do {                                                                                             \
-        paged--;                                                                                     \
-        for (int k__ = 0; k__ < TR_PAGE; k__++)                                                      \
-            LDS_AT(sa_bottom + (unsigned)(k__ + 1) * ENTRY) = a.spill[(size_t)(paged * TR_PAGE + k__) * gstride + gtid]; \
-        sa = sa_bottom + TR_PAGE * ENTRY;                                                            \
-    } while (0)
-#define TR_POP(dst) do { dst = LDS_AT(sa); sa -= ENTRY; } while (0)
-
-    for (;;) {
-        // ---- refill idle lanes -------------------------------------------------------------
-        const unsigned long long idle = ballot64(!have);
-        if (idle != 0ull && !exhausted && (__popcll(idle) >= a.refill_min || idle == ~0ull)) {
-            const int n_idle = __popcll(idle);
-            if (COUNT) d_refills++;
-            const int leader = __ffsll((long long)idle) - 1;
-            // rays of slice `home`: its 64-ray chunks are the global chunks home, home + S, home + 2S, ...
-            const int len = (((full_chunks >> S_LOG) + (home < (full_chunks & S_MASK) ? 1 : 0)) << 6) +
-                            (home == (full_chunks & S_MASK) ? (count & 63) : 0);
-            int base = 0;
-            if (lane == leader) base = atomicAdd(a.fetch + home * TR_FETCH_STRIDE, n_idle);
-            base = __shfl(base, leader, 64);
-            const int v = base + __popcll(idle & lt_mask);                // index within the slice
-            const int my = v < len ? (((((v >> 6) << S_LOG) + home) << 6) | (v & 63)) : count;
-            if (base + n_idle >= len) {                                    // slice drained: move on
-                home = (home + 1) & S_MASK;
-                if (++tried > S_MASK) exhausted = true;
-            }
-            if (!have && my < count) {
-                q = my;
-                if (KIND == KIND_MIXED) { is_sh = my >= count_c; if (is_sh) q = my - count_c; }
-                const bool mixed_sh = (KIND == KIND_MIXED) && is_sh;
-                const v3 o = mixed_sh ? V(a.sox[q], a.soy[q], a.soz[q])
-                                      : ((KIND == KIND_CLOSEST && a.ox == nullptr) ? V(a.eye[0], a.eye[1], a.eye[2]) : V(a.ox[q], a.oy[q], a.oz[q]));
-                const v3 d = mixed_sh ? V(a.sdx[q], a.sdy[q], a.sdz[q]) : V(a.dx[q], a.dy[q], a.dz[q]);
-                r = make_ray(o, d);
-                par = ray_has_parallel_axis(r);
-                hit_t = INF_VALUE; hit_u = 0.0f; hit_v = 0.0f; hit_prim = -1; hit_leaf = -1;
-                nbox = 1; nleaf = 0; sa = sa_bottom; paged = 0; n_overflow = 0; pend = 0;
-                cull_far = 3.0e38f; settle = -1.0f; expect = -3;
-                float t_bound = -1.0f;
-                if (MAY_SHADOW && is_sh) {
-                    expect = a.sprim[q];
-                    if (BOUNDED) t_bound = a.sdist[q];
-                }
-                if (MODE != TIRT_TRAVERSE_EXHAUSTIVE) {
-                    // margin in cells, the same on all axes: 0.25 + 0.25 per root-box extent between the origin and the
-                    // grid (largest axis).  It has to cover (i) the rounding of q * gA + gB (<= 0.016 cells per extent of
-                    // distance) and (ii) what the reference's primitive tests accept outside a leaf box: Moller-Trumbore
-                    // works on o - v0 and is off by ~5e-7 of the origin's distance IN EVERY DIRECTION (0.03 cells per extent)
-                    const float relx__ = b.grid_min[0] - o.x, rely__ = b.grid_min[1] - o.y, relz__ = b.grid_min[2] - o.z;
-                    const float rho__ = maxf(maxf(absf(relx__) * b.inv_extent[0], absf(rely__) * b.inv_extent[1]), absf(relz__) * b.inv_extent[2]);
-                    const float mc__ = 0.25f + 0.25f * rho__;
-                    // From far away the reference's Moller-Trumbore returns distances that are rounding noise (its o - v0 carries
-                    // |o - v0| * 2^-24, divided by a determinant of the order of the triangle's area): a small or edge-on triangle
-                    // seen from hundreds of extents away can "hit" tens of units in FRONT of the surface the ray really meets first,
-                    // and the reference, which never culls by distance, takes it.  A ray that starts more than TR_FAR_RHO extents
-                    // from the grid therefore does not cull by distance either (no hit-distance cull, no target-distance bound):
-                    // it visits every leaf whose boxes it passes, as the reference does, and so finds the same candidates.
-                    if (rho__ > TR_FAR_RHO) cull_far = -3.0e38f;
-#define TR_GRID_AXIS(rel, dd, idd, k, gA, gBn, gBf, grot)                                            \
-                    do {                                                                             \
-                        if (absf(dd) < 0.000001f) {      /* the reference's parallel case: origin inside the slab or no hit */ \
-                            const float og__ = -(rel) * b.inv_cell[k];                               \
-                            gA = 1.0e30f; gBn = (-og__ - (mc__ + 1.0f)) * 1.0e30f; gBf = (-og__ + (mc__ + 1.0f)) * 1.0e30f; grot = 0; \
-                        } else {                                                                     \
-                            gA = b.cell[k] * (idd);                                                  \
-                            const float gB__ = (rel) * (idd);                                        \
-                            const float m__ = mc__ * absf(gA);                                       \
-                            gBn = gB__ - m__; gBf = gB__ + m__; grot = gA < 0.0f ? 16 : 0;           \
-                        }                                                                            \
-                    } while (0)
-                    TR_GRID_AXIS(relx__, d.x, r.idx, 0, gAx, gBnx, gBfx, grotx);
-                    TR_GRID_AXIS(rely__, d.y, r.idy, 1, gAy, gBny, gBfy, groty);
-                    TR_GRID_AXIS(relz__, d.z, r.idz, 2, gAz, gBnz, gBfz, grotz);
-                }
-                if (BOUNDED && t_bound > 0.0f && cull_far > 0.0f) { cull_far = t_bound * 1.01f; settle = t_bound * 0.99f; }
-                lim = __builtin_fminf(__builtin_fminf(hit_t * 1.0001f, __builtin_fabsf(cull_far)), INF_VALUE);      // (v_min: a canonical value, so the node loop does not re-canonicalise it every step)
-                // (a far-origin ray cannot trust the padded boxes of the analytic spheres: it starts at a chain node that holds the root and
-                // those spheres with whole-grid boxes, BvhView::far_qcode, and so tests them whatever their boxes say -- as the reference does)
-                cur = (MODE == TIRT_TRAVERSE_EXHAUSTIVE) ? b.root_code : (cull_far < 0.0f ? b.far_qcode : b.root_qcode);
-                if (cur >= 0) {
-                    float tn;
-                    if (!slabs(r, b.root_min[0], b.root_min[1], b.root_min[2], b.root_max[0], b.root_max[1], b.root_max[2], tn)) cur = TR_SENT;
-                }
-                // A ray with a NaN component passes every `slabs` test (all comparisons are false)
-                // and fails every primitive test, in the reference as well: it walks the whole tree
-                // and misses.  Same result, without the walk (ordered mode; the exhaustive mode keeps the walk).  (NaN shading normals come from
-                // process_normal's acos of a dot product just above 1, Scene.py:377.)
-                if (MODE != TIRT_TRAVERSE_EXHAUSTIVE &&
-                    !((o.x == o.x) & (o.y == o.y) & (o.z == o.z) & (d.x == d.x) & (d.y == d.y) & (d.z == d.z))) cur = TR_SENT;
-                have = true;
-            }
-        }
-        if (ballot64(have) == 0ull) { if (exhausted) break; continue; }
-
-        // ---- inner nodes.  Lanes that reached a leaf (or finished) wait here; the loop goes on
-        // while at least node_min lanes still have inner-node work, or nobody is waiting at all.
-        // (idle lanes keep cur == TR_SENT, so `cur >= 0` alone means "has inner-node work".)
-        // Written to keep the VALU and SALU instruction counts down (59 VALU per step, was 82): the
-        // t-cull folded into the far distance, selects on lane masks, stack push/pop without index
-        // arithmetic or emptiness tests, no cold code inside the loop.
-        // A lane that reaches a leaf does not stop there: the leaf goes into a one-entry stash (`pend`) and the walk
-        // goes on with the next stack entry; only a second leaf makes the lane wait.  The primitive tests then run for
-        // all stashed leaves of the wave together (lane utilisation of the node loop 0.61 -> 0.73, of the leaf phase 0.38 -> 0.45), at the
-        // price of a few node visits the earlier hit would have culled (+2 %).
-        const int lim_i = __float_as_int(lim);                  // > 0 always
-        for (;;) {
-            // lanes standing on a leaf append it to the wave's queue and go on with their next stack entry
-            // (idle lanes keep cur == TR_SENT, which is negative too)
-            const bool on_leaf = (cur < 0) & (cur != TR_SENT);
-            const unsigned long long lm = ballot64(on_leaf);
-            if (lm != 0ull) {
-                if (on_leaf) {
-                    const unsigned pos = (unsigned)(q_head + q_n + __popcll(lm & lt_mask)) & (unsigned)(TRQ_RING - 1);
-                    const unsigned code = (unsigned)~cur;                   // prim slot | shape << 30
-                    LDS_AT(wq_base + pos * 4u) = (int)(((unsigned)lane << 26) | ((code >> 5) & 0x2000000u) | (code & 0x1ffffffu));
-                    pend++;
-                    if (COUNT) nleaf += 1;
-                    TR_POP(cur);
-                }
-                q_n += __popcll(lm);
-            }
-            if (q_n >= 64) break;                                  // a full wave of primitive tests is waiting
-            const bool act = cur >= 0;
-            const unsigned long long am = ballot64(act);
-            if (am == 0ull) break;
-            const int n_act = __popcll(am);
-            if (n_act < a.node_min && q_n > 0) break;              // little node work left: the tests that are queued may be what the others wait for
-            if (wave_any((int)sa >= (int)sa_hi)) break;        // a lane's LDS stack is full: page out below (cold)
-            if (COUNT) { d_it_node++; d_lanes_node += (unsigned long long)n_act; }
-            if (act) {
-                if (MODE == TIRT_TRAVERSE_EXHAUSTIVE) {
-                    // reference order on the two-child nodes: both children of every box that passes
-                    // `slabs`, leaves without a box test, right child first (left is pushed)
-                    const float4 *w = (const float4 *)((const char *)b.wnode + ((unsigned)cur << 6));
-                    const float4 q0 = w[0], q1 = w[1], q2 = w[2], q3 = w[3];
-                    const int cl = __float_as_int(q3.x), cr = __float_as_int(q3.y);
-                    if (COUNT) nbox += 2;
-                    float tl, tr;
-                    int pl, pr;
-                    if (!par) {
-                        pl = slabs_fast(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tl);
-                        pr = slabs_fast(r, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tr);
-                    } else {
-                        pl = slabs(r, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, tl);
-                        pr = slabs(r, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, tr);
-                    }
-                    const bool hl = (pl != 0) || (cl < 0), hr = (pr != 0) || (cr < 0);
-                    if (hl && hr) { sa += ENTRY; LDS_AT(sa) = cr; }
-                    int next = hl ? cl : cr;
-                    if (!(hl || hr)) TR_POP(next);
-                    cur = next;
-                } else {
-                    // ordered mode on the quantised 4-wide nodes: four box tests, children visited near to far
-                    uint4 q0, q1, q2, q3;
-                    if (cur < top_n) {               // breadth-first numbering: the first nodes are the top of the tree, resident in LDS
-                        const lds_u4 *t = (const lds_u4 *)(size_t)(top_base + (unsigned)cur * 64u);
-                        const u4v t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3];
-#define TR_U4(v) make_uint4((v).x, (v).y, (v).z, (v).w)
-                        q0 = TR_U4(t0); q1 = TR_U4(t1); q2 = TR_U4(t2); q3 = TR_U4(t3);
-                        if (COUNT) d_outer++;
-                    } else {
-                        const uint4 *w = (const uint4 *)((const char *)b.cnode + ((unsigned)cur << 6));
-                        q0 = w[0]; q1 = w[1]; q2 = w[2]; q3 = w[3];
-                    }
-                    int c0 = (int)q3.x, c1 = (int)q3.y, c2 = (int)q3.z, c3 = (int)q3.w;
-                    if (COUNT) nbox += 4;
-                    constexpr float MISS = 3.0e38f;
-                    float d0, d1, d2, d3;                // entry distance of a hit box, MISS otherwise
-                    // near/far crossing of each axis: one rotate, two v_fma_mix_f32 (fp16 plane x f32 + f32); then
-                    // box hit and entry not beyond the cull distance: tn <= min(tf, lim)
-#define TR_CBOX(X, Y, Z, dist)                                                                       \
-                    do {                                                                             \
-                        const unsigned ux__ = __builtin_amdgcn_alignbit((X), (X), grotx);            \
-                        const unsigned uy__ = __builtin_amdgcn_alignbit((Y), (Y), groty);            \
-                        const unsigned uz__ = __builtin_amdgcn_alignbit((Z), (Z), grotz);            \
-                        const h2v hx__ = __builtin_bit_cast(h2v, ux__), hy__ = __builtin_bit_cast(h2v, uy__), hz__ = __builtin_bit_cast(h2v, uz__); \
-                        const float nx__ = __builtin_fmaf((float)hx__.x, gAx, gBnx), fx__ = __builtin_fmaf((float)hx__.y, gAx, gBfx); \
-                        const float ny__ = __builtin_fmaf((float)hy__.x, gAy, gBny), fy__ = __builtin_fmaf((float)hy__.y, gAy, gBfy); \
-                        const float nz__ = __builtin_fmaf((float)hz__.x, gAz, gBnz), fz__ = __builtin_fmaf((float)hz__.y, gAz, gBfz); \
-                        const float tn__ = __builtin_fmaxf(__builtin_fmaxf(nx__, ny__), __builtin_fmaxf(nz__, 0.0f)); \
-                        /* the far distance in the INTEGER domain (v_min_i32 / v_min3_i32: no canonicalisation of `lim` per step):   \
-                           exact for non-negative floats, and a negative operand (box behind the ray) gives a negative result */      \
-                        const int tfi__ = min(min(__float_as_int(fx__), __float_as_int(fy__)), min(__float_as_int(fz__), lim_i));     \
-                        const float tf__ = __int_as_float(tfi__);                                    \
-                        dist = (tn__ <= tf__) ? tn__ : MISS;                                         \
-                    } while (0)
-                    TR_CBOX(q0.x, q0.y, q0.z, d0);
-                    TR_CBOX(q0.w, q1.x, q1.y, d1);
-                    TR_CBOX(q1.z, q1.w, q2.x, d2);
-                    TR_CBOX(q2.y, q2.z, q2.w, d3);
-                    // sort the four (distance, child) pairs: misses end up last
-#define TR_CE(da, ca, db, cb)                                                                        \
-                    do {                                                                             \
-                        const bool s__ = (db) < (da);                                                \
-                        const float lo__ = s__ ? (db) : (da), hi__ = s__ ? (da) : (db);              \
-                        const int clo__ = s__ ? (cb) : (ca), chi__ = s__ ? (ca) : (cb);              \
-                        da = lo__; db = hi__; ca = clo__; cb = chi__;                                \
-                    } while (0)
-                    // (nearest-only selection, 3 exchanges instead of 5, measured 5 % slower: more nodes visited)
-                    TR_CE(d0, c0, d1, c1); TR_CE(d2, c2, d3, c3); TR_CE(d0, c0, d2, c2); TR_CE(d1, c1, d3, c3); TR_CE(d1, c1, d2, c2);
-                    if (d3 < MISS) { sa += ENTRY; LDS_AT(sa) = c3; }
-                    if (d2 < MISS) { sa += ENTRY; LDS_AT(sa) = c2; }
-                    if (d1 < MISS) { sa += ENTRY; LDS_AT(sa) = c1; }
-                    int next = c0;
-                    if (!(d0 < MISS)) TR_POP(next);
-                    cur = next;
-                }
-            }
-        }
-
-        // ---- cold: lanes whose LDS stack is full move their oldest entries to the spill buffer ------
-        if (wave_any(have && (int)sa >= (int)sa_hi)) {
-            if (have && (int)sa >= (int)sa_hi) TR_PAGE_OUT();
-        }
-
-        // ---- primitive tests: up to 64 queue entries, one per lane, whoever they belong to ------------------------
-        if (q_n > 0) {
-            const int cnt = q_n < 64 ? q_n : 64;
-            const bool mine = lane < cnt;
-            const unsigned item = mine ? (unsigned)LDS_AT(wq_base + ((unsigned)(q_head + lane) & (unsigned)(TRQ_RING - 1)) * 4u) : 0u;
-            const int oa = (int)((item >> 26) << 2);                     // the owner's lane, as a ds_bpermute address
-            // the owner's ray and its current hit, out of the owner's registers (every lane executes these: a lane only answers while it is active)
-#define TR_PULL_F(x) __int_as_float(__builtin_amdgcn_ds_bpermute(oa, __float_as_int(x)))
-            RayCtx rv;
-            rv.ox = TR_PULL_F(r.ox); rv.oy = TR_PULL_F(r.oy); rv.oz = TR_PULL_F(r.oz);
-            rv.dx = TR_PULL_F(r.dx); rv.dy = TR_PULL_F(r.dy); rv.dz = TR_PULL_F(r.dz);
-            rv.idx = TR_PULL_F(r.idx); rv.idy = TR_PULL_F(r.idy); rv.idz = TR_PULL_F(r.idz);
-            const float o_hit_t = TR_PULL_F(hit_t);
-            const int o_hit_leaf = __builtin_amdgcn_ds_bpermute(oa, hit_leaf);
-            const bool o_par = __builtin_amdgcn_ds_bpermute(oa, par ? 1 : 0) != 0;
-            if (COUNT) { d_it_leaf++; d_lanes_leaf += (unsigned long long)cnt; }
-            float t_u = 0.0f, t_v = 0.0f; int t_prim = -1;
-            unsigned long long key = ~0ull;
-            bool cand = false;
-            if (mine) {
-                const float4 *tp = b.tri + (size_t)(item & 0x1ffffffu) * TRI_STRIDE;          // records in the traversal tree's leaf order
-                const float4 ta = tp[0], tb = tp[1], tc = tp[2];
-                int prim = __float_as_int(tc.w);                                              // the primitive id rides in the last word
-                const v3 o = V(rv.ox, rv.oy, rv.oz), d = V(rv.dx, rv.dy, rv.dz);
-                const bool is_tri = (item & 0x2000000u) == 0u;
-                const v3 pa = V(ta.x, ta.y, ta.z), pb = V(tb.x, tb.y, tb.z), pc = V(tc.x, tc.y, tc.z);
-                float t, u, v;
-                if (is_tri) {
-                    t = intersect_tri_packed(o, d, pa, pb - pa, pc - pa, u, v);          // E1 = v2 - v1, E2 = v3 - v1 (Scene.py:608-609)
-                } else {
-                    float cc; u = 0.0f; v = 0.0f; t = INF_VALUE;
-                    if ((int)tb.y == SHAPE_SPHERE) { const v3 oc = pa - o; if (dot(d, oc) > 0.0f) t = intersect_sphere(o, d, pa, tb.x, cc); }      // (see k_trace)
-                }
-                const int leaf = __float_as_int(ta.w);
-                // reference: accept iff 0 < t < hit_t (so never t >= INF_VALUE); equal-t candidates: see header
-                cand = (t > 0.0f) & ((t < o_hit_t) | ((t == o_hit_t) & (o_hit_leaf >= 0) & (leaf > o_hit_leaf)));
-#ifndef TR_NO_VERIFY
-                if (cand) {
-                    // The quantised boxes that led here contain the reference's: would the reference have visited this leaf
-                    // (Scene.py:702-744: every proper ancestor's box passes `slabs`)?  The leaf's own exact box passing implies
-                    // it (the outer of two nested boxes passes whenever the inner one does: `slabs` is monotone in the planes);
-                    // that box is the min / max of the three positions just loaded (accel/LBvh.py:397-426; spheres: centre -+ r).
-                    // Otherwise -- a hit within rounding distance of the leaf box's boundary -- the ancestors are asked one by one.
-                    v3 bmn, bmx;
-                    if (is_tri) {
-                        bmn = V(TR_MIN3(pa.x, pb.x, pc.x), TR_MIN3(pa.y, pb.y, pc.y), TR_MIN3(pa.z, pb.z, pc.z));
-                        bmx = V(TR_MAX3(pa.x, pb.x, pc.x), TR_MAX3(pa.y, pb.y, pc.y), TR_MAX3(pa.z, pb.z, pc.z));
-                    } else {
-                        bmn = V(pa.x - tb.x, pa.y - tb.x, pa.z - tb.x); bmx = V(pa.x + tb.x, pa.y + tb.x, pa.z + tb.x);
-                    }
-                    float tn_;
-                    const int inside = o_par ? slabs(rv, bmn.x, bmn.y, bmn.z, bmx.x, bmx.y, bmx.z, tn_) : slabs_fast(rv, bmn.x, bmn.y, bmn.z, bmx.x, bmx.y, bmx.z, tn_);
-                    if (!inside) {
-                        for (int an = b.cparent[leaf]; an >= 0; an = b.cparent[an]) {
-                            const float *ab = b.compact + (size_t)an * CPN_VEC + 2;
-                            if (!slabs(rv, ab[0], ab[1], ab[2], ab[3], ab[4], ab[5], tn_)) { cand = false; break; }
-                        }
-                    }
-                }
-#endif
-                // (keeps `prim` in a register of its own across the ancestor walk: see k_trace)
-                asm volatile("" : "+v"(prim));
-                if (cand) {
-                    // smaller t first; on equal t the larger compact-node index: the reference's winner (file header)
-                    key = ((unsigned long long)(unsigned)__float_as_int(t) << 32) | (unsigned long long)(0xffffffffu - (unsigned)leaf);
-                    __hip_atomic_fetch_min(&LDS_K(key_base + (unsigned)(oa << 1)), key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                    t_u = u; t_v = v; t_prim = prim;
-                }
-                __hip_atomic_fetch_add(&LDS_AT(done_base + (unsigned)oa), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            // the winner of every owner says which lane it is (one winner per owner: keys differ in the leaf)
-            if (cand && LDS_K(key_base + (unsigned)(oa << 1)) == key)
-                __hip_atomic_fetch_or(&LDS_AT(done_base + (unsigned)oa), (int)(0x8000u | ((unsigned)lane << 8)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            // owners take their results
-            const unsigned w = (unsigned)LDS_AT(done_base + (unsigned)lane * 4u);
-            const int wl = (int)(((w >> 8) & 63u) << 2);
-            const float w_u = __int_as_float(__builtin_amdgcn_ds_bpermute(wl, __float_as_int(t_u)));
-            const float w_v = __int_as_float(__builtin_amdgcn_ds_bpermute(wl, __float_as_int(t_v)));
-            const int w_prim = __builtin_amdgcn_ds_bpermute(wl, t_prim);
-            if (w != 0u) {
-                pend -= (int)(w & 0xffu);
-                LDS_AT(done_base + (unsigned)lane * 4u) = 0;
-                if (w & 0x8000u) {
-                    const unsigned long long kk = LDS_K(key_base + (unsigned)lane * 8u);
-                    LDS_K(key_base + (unsigned)lane * 8u) = ~0ull;
-                    hit_t = __int_as_float((int)(unsigned)(kk >> 32)); hit_leaf = (int)(0xffffffffu - (unsigned)kk);
-                    hit_u = w_u; hit_v = w_v; hit_prim = w_prim;
-                    lim = __builtin_fminf(__builtin_fminf(cull_far < 0.0f ? INF_VALUE : hit_t * 1.0001f, __builtin_fabsf(cull_far)), INF_VALUE);
-                    if (BOUNDED && hit_prim != expect && hit_t < settle) { cur = TR_SENT; sa = sa_bottom; paged = 0; }      // answer settled: "occluded"
-                }
-            }
-            q_head = (q_head + cnt) & (TRQ_RING - 1); q_n -= cnt;
-        }
-
-        // ---- a lane that popped the sentinel but has paged-out entries gets them back (cold) ---------
-        if (ballot64(have && cur == TR_SENT && paged > 0) != 0ull) {
-            if (have && cur == TR_SENT && paged > 0) { TR_PAGE_IN(); TR_POP(cur); }
-        }
-
-        // ---- finished rays write back and free their lane ---------------------------------------
-        if (have && cur == TR_SENT && pend == 0) {
-            if (!(MAY_SHADOW && is_sh) || KIND == KIND_QUERY) {
-                a.hit[q] = make_float4(hit_t, hit_u, hit_v, __int_as_float(hit_prim));
-            } else if (hit_prim == expect) {                 // integrator/PT_RGB.py:105-109
-                const int dst = a.sdst[q];
-                float *pr = dst >= 0 ? a.rr + dst : a.fr + ~dst;
-                float *pg = dst >= 0 ? a.rg + dst : a.fg + ~dst;
-                float *pb = dst >= 0 ? a.rb + dst : a.fb + ~dst;
-                *pr = *pr + a.scr[q]; *pg = *pg + a.scg[q]; *pb = *pb + a.scb[q];
-                if (a.scw) { float *pw = dst >= 0 ? a.rw + dst : a.fw + ~dst; *pw = *pw + a.scw[q]; }
-            }
-            if (COUNT) {
-                if (MAY_SHADOW && is_sh) { sum_box_s += nbox; sum_leaf_s += nleaf; }
-                else { sum_box += nbox; sum_leaf += nleaf; }
-                if (a.per_ray_counts) a.per_ray_counts[q] = make_int2((int)nbox, (int)nleaf);
-            }
-            if (n_overflow) n_over++;
-            have = false; sa = sa_bottom;
-        }
-    }
-    if (a.ctr) {
-        if (COUNT) {
-            sum_box = wave_sum(sum_box); sum_leaf = wave_sum(sum_leaf);
-            sum_box_s = wave_sum(sum_box_s); sum_leaf_s = wave_sum(sum_leaf_s);
-            if (lane == 0 && (sum_box | sum_leaf)) { atomicAdd(&a.ctr->box_closest, sum_box); atomicAdd(&a.ctr->leaf_closest, sum_leaf); }
-            if (lane == 0 && (sum_box_s | sum_leaf_s)) { atomicAdd(&a.ctr->box_shadow, sum_box_s); atomicAdd(&a.ctr->leaf_shadow, sum_leaf_s); }
-        }
-        if (COUNT) { d_outer = wave_sum(d_outer); if (lane == 0) atomicAdd(&a.ctr->it_outer, d_outer); }   // lane-visits of LDS-resident (top) nodes
-        if (COUNT && lane == 0) {
-            atomicAdd(&a.ctr->it_node, d_it_node); atomicAdd(&a.ctr->lanes_node, d_lanes_node);
-            atomicAdd(&a.ctr->it_leaf, d_it_leaf); atomicAdd(&a.ctr->lanes_leaf, d_lanes_leaf);
-            atomicAdd(&a.ctr->refills, d_refills);
-        }
-        if (n_over) atomicAdd(&a.ctr->stack_overflow, n_over);
-        if (gtid == 0 && !a.no_ray_count) {
-            if (count_c) atomicAdd(&a.ctr->rays_closest, (unsigned long long)count_c);
-            if (count_s) atomicAdd(&a.ctr->rays_shadow, (unsigned long long)count_s);
-        }
-    }
-}
-
 // diagnostics: option "trace_timeline" = k >= 0 arms the k-th counting launch from now on; it writes [start, queue empty, end, hw id] per wave
 static unsigned long long *timeline_for(tirt_ctx *c, int flags, int grid)
 {
@@ -1071,28 +595,11 @@ static int launch_trace_as(tirt_ctx *c, hipStream_t stream, const TraceArgs &a, 
     hipLaunchKernelGGL((k_trace<MODE, COUNT, KIND>), g, b, lds, stream, a);
     return TIRT_OK;
 }
-template <bool COUNT, int KIND>
-static int launch_traceq_as(tirt_ctx *c, hipStream_t stream, const TraceArgs &a, dim3 g, dim3 b, size_t lds)
-{
-    static size_t allowed[TIRT_MAX_DEVICES] = {};
-    TIRT_REQUIRE(lds <= c->lds_optin, "k_trace_q: trace_lds_depth needs more LDS than the device has per block");
-    const int dev = (c->device >= 0 && c->device < TIRT_MAX_DEVICES) ? c->device : 0;
-    if (lds > allowed[dev] || c->device >= TIRT_MAX_DEVICES) {
-        TIRT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trace_q<COUNT, KIND>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        allowed[dev] = lds;
-    }
-    hipLaunchKernelGGL((k_trace_q<COUNT, KIND>), g, b, lds, stream, a);
-    return TIRT_OK;
-}
 template <int KIND>
 static int launch_trace(tirt_ctx *c, hipStream_t stream, const TraceArgs &a, int flags, int grid)
 {
     const bool exh = (flags & TIRT_TRAVERSE_EXHAUSTIVE) != 0, cnt = (flags & TIRT_COUNT_NODES) != 0;
     dim3 g(grid), b(TR_BLOCK);
-    if (!exh && c->tr_queue) {                 // ordered traversal with the per-wave leaf queue (option "trace_queue", default on)
-        const size_t ldsq = traceq_lds_bytes(a.lds_depth);
-        return cnt ? launch_traceq_as<true, KIND>(c, stream, a, g, b, ldsq) : launch_traceq_as<false, KIND>(c, stream, a, g, b, ldsq);
-    }
     const size_t lds = trace_lds_bytes(a.lds_depth);
     if (exh && cnt) return launch_trace_as<TIRT_TRAVERSE_EXHAUSTIVE, true, KIND>(c, stream, a, g, b, lds);
     if (exh) return launch_trace_as<TIRT_TRAVERSE_EXHAUSTIVE, false, KIND>(c, stream, a, g, b, lds);
