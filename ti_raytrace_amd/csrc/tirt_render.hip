@@ -1288,7 +1288,7 @@ int pt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed,
         if (want > cap) cap = want;
     }
     for (int k = 0; k < n_lanes; k++) {
-        // very large films (196 B per path and lane): use fewer lanes rather than run out of HBM
+        // very large films (204 B per path and lane): use fewer lanes rather than run out of HBM
         if (k > 0 && cap > c->lanes[k].path_capacity) {
             size_t free_b = 0, total_b = 0;
             if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b < path_state_bytes(cap) + ((size_t)2 << 30)) { n_lanes = k; break; }
