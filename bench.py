@@ -49,6 +49,7 @@ Extra objects:
                 reference's own ti.cpu path cannot run: Taichi is not installable here).
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -768,6 +769,7 @@ def main():
                 cfgs[name] = run_config(name, local_rank, args.seed)
             except Exception as exc:        # noqa: BLE001 -- one failing config must not hide the headline line
                 cfgs[name] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+            gc.collect()                    # the config's contexts (tens of GB of wavefront state each) go now, not when the collector gets round to their cycles
         cfgs["config3_headline"] = "this line's `value` (%d steps x %d frames of the 100k scene)" % (args.steps, fps)
         if not args.no_traffic:
             cfgs["config5_veach_bdpt_512x512_64spp"]["roofline"] = bdpt_roofline(local_rank)
