@@ -922,6 +922,18 @@ int bdpt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t see
         if (FB > half) FB = half;                                   // the two lanes share the batch budget
         if (FB > (frame_count + 1) / 2) FB = (frame_count + 1) / 2;
     }
+    {
+        // not more than the device has free right now (plus what this context's BDPT buffers hold already: growing them frees them first), less
+        // 2 GB: a batch half the size is a few per cent slower, a failed hipMalloc ends the render (bench.py's profiler child, next to the
+        // contexts of the other configs, ran into exactly that with 16 Mi-item batches)
+        const size_t per_item = sizeof(bpixel) + sizeof(BdStep) + sizeof(float) * (16 + 16 * BD_RAY_PAIRS) + sizeof(float4) * (2 + BD_RAY_PAIRS) + sizeof(int) * (4 + BD_RAY_PAIRS);
+        size_t free_b = 0, total_b = 0, held = 0;
+        for (int l = 0; l < 2; l++) held += c->bd[l].items.bytes + c->bd[l].state.bytes + c->bd[l].rays.bytes + c->bd[l].hits.bytes + c->bd[l].qidx.bytes + c->bd[l].rad.bytes;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            const size_t avail = free_b + held > ((size_t)2 << 30) ? free_b + held - ((size_t)2 << 30) : 0;
+            while (FB > 1 && (size_t)NL * (size_t)FB * ((size_t)P * per_item + sizeof(float) * 3 * (size_t)NP) > avail) FB = (FB + 1) / 2;
+        } else (void)hipGetLastError();
+    }
     { const int nb = (frame_count + FB - 1) / FB; FB = (frame_count + nb - 1) / nb; }       // batches of equal size
     // buffers for the batches of THIS call (a frame-at-a-time caller gets one-frame buffers; DevBuf::ensure only ever grows, so a caller
     // whose calls grow re-allocates a few times at most).  Round 2 reserved for the whole job from the "job_frames" hint -- 31 GB for
