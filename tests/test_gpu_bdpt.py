@@ -232,7 +232,8 @@ def test_bdpt_batches_shrink_to_the_free_memory(gpu_ctx_ok):
     but ~6 GB of the HBM taken by somebody else, 64 frames of 256^2 (4 Mi items: 12 GB of wavefront state as one pair of batches) still render --
     in smaller batches, with the same ray counts and the same film up to the float-atomic order of the splats."""
     import ctypes
-    hip = ctypes.CDLL("/opt/rocm/lib/libamdhip64.so")          # the runtime libtirt itself runs on (the hog must live in the same process)
+    ex0 = scenes.veach_bdpt(8, 8, 1, device_id=0); ex0.build_scene()          # (libtirt and its HIP runtime are loaded now)
+    hip = ctypes.CDLL("libamdhip64.so.7")                     # by SONAME: the runtime already in the process, whichever copy that is (_native._prefer_torch_hip_runtime)
     hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
     hip.hipMemGetInfo.argtypes = [ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]
     hip.hipFree.argtypes = [ctypes.c_void_p]

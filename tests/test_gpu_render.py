@@ -428,3 +428,20 @@ def test_blocked_tile_order_changes_no_bit(gpu_ctx_ok):
         ex.integrator.render_frames(3)
         total += ex.integrator.hdr.to_numpy()
     assert np.array_equal(total.view(np.uint32), films[0].view(np.uint32))
+
+
+def test_torch_cuda_still_comes_up_after_this_library(gpu_ctx_ok):
+    """PyTorch-ROCm bundles a HIP runtime with the system one's SONAME: the copy loaded first serves the process, and torch.cuda does not come
+    up on the system copy.  `_native.lib()` therefore loads torch's first (ti_raytrace_amd/_native.py) -- in a fresh interpreter, rendering
+    with this package and THEN asking torch for the device must work (the multi-GPU path of bench.py needs both)."""
+    import subprocess, sys, os
+    code = ("from ti_raytrace_amd import scenes\n"
+            "ex = scenes.cornell(32, 32, 2, device_id=0) if hasattr(scenes, 'cornell') else scenes.veach_bdpt(32, 32, 2, device_id=0)\n"
+            "ex.build_scene(); ex.integrator.render_frames(2)\n"
+            "import torch\n"
+            "assert torch.cuda.is_available(), 'torch.cuda lost the device'\n"
+            "print(float(torch.ones(8, device='cuda:0').sum()))\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ); env.pop("TIRT_SYSTEM_HIP", None)
+    pr = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert pr.returncode == 0 and pr.stdout.decode().strip().endswith("8.0"), pr.stdout.decode()[-800:]

@@ -118,6 +118,25 @@ SIGNATURES.update({
 _lib = None
 
 
+def _prefer_torch_hip_runtime():
+    """PyTorch-ROCm ships its own HIP runtime under the SONAME of the system one (libamdhip64.so.7); whichever is loaded first serves the
+    whole process, and torch.cuda does not come up on the system one ("No HIP GPUs are available" after this library initialised HIP).
+    So torch's copy is loaded first -- without importing torch -- when there is one: libtirt.so runs on it as it does when the
+    application imported torch before this package (bench.py, the multi-GPU path).  TIRT_SYSTEM_HIP=1 keeps the system runtime."""
+    if os.environ.get("TIRT_SYSTEM_HIP", "0") not in ("", "0"):
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.origin:
+            return
+        path = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.exists(path):
+            C.CDLL(path, mode=C.RTLD_GLOBAL)
+    except (OSError, ImportError, ValueError):
+        pass                                   # no torch, or a torch without a bundled runtime: the system one
+
+
 def lib():
     """Load libtirt.so once.  Raises TirtError (never falls back) when it is not built."""
     global _lib
@@ -127,6 +146,7 @@ def lib():
                 "HIP extension %s is missing -- build it with `python -c 'import "
                 "__graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950). "
                 "There is no CPU fallback." % LIB_PATH)
+        _prefer_torch_hip_runtime()
         try:
             handle = C.CDLL(LIB_PATH)
         except OSError as exc:
