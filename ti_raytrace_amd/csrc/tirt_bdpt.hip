@@ -10,7 +10,7 @@
 //                      dense list, survivors append to the next depth's list               BDPT_RGB.py:126-198, 229-294
 //   k_bd_delta         the one field that survives from frame to frame (see below)
 //   k_bd_connect       per item: geometry of every (e, l) connection, connection rays staged   BDPT_RGB.py:481-592
-//   k_bd_compact       staged rays -> dense queue, with an owner word (item, pair slot) each
+//   k_bd_compact       the dense queue: per place, where the ray is staged and whose it is (item, pair slot) -- the rays are not copied
 //   trace queries      "is the expected primitive the closest hit?"  (k_trace<KIND_QUERY>, bounded)
 //   k_bd_emitted       the l == 0 pairs (eye sub-path ended on an emitter): no ray
 //   k_bd_resolve       per QUEUED CONNECTION: contribution + MIS weight (BDPT_RGB.py:300-479), splats with float atomics
@@ -813,7 +813,7 @@ __global__ void k_bd_emitted(BdCtx c, const bpixel *items, const BdStep *steps, 
 constexpr int BD_RESOLVE_CHUNK = 2048;            // queue entries a block filters at a time
 template <bool SPEC>
 __global__ void k_bd_resolve(BdCtx c, const bpixel *items, TileMap tm, int P, uint32_t frame_begin, const unsigned *qown, const int *scount,
-                             const float4 *shits, const float4 *queue, float *radiance, long frame_stride)
+                             const float4 *shits, const float4 *stage, const int *qlist, float *radiance, long frame_stride)
 {
     // every branch of connect_path wants the ray's closest hit to be the expected primitive before anything else (and about half of the
     // connections are occluded): a block first filters a chunk of the queue into a list of those in LDS, then works through the list
@@ -827,7 +827,7 @@ __global__ void k_bd_resolve(BdCtx c, const bpixel *items, TileMap tm, int P, ui
         __syncthreads();
         for (int r = 0; r < BD_RESOLVE_CHUNK; r += (int)blockDim.x) {
             const long q = c0 + r + threadIdx.x;
-            const bool m = q < count && __float_as_int(shits[q].w) == __float_as_int(queue[2 * q + 1].z);
+            const bool m = q < count && __float_as_int(shits[q].w) == __float_as_int(stage[2 * (size_t)qlist[q] + 1].z);
             const unsigned long long bm = __ballot(m);
             if (bm == 0ull) continue;
             const int leader = __ffsll((long long)bm) - 1;
@@ -859,10 +859,11 @@ __global__ void k_bd_resolve(BdCtx c, const bpixel *items, TileMap tm, int P, ui
     }
 }
 
-// staging slots [j][item] -> dense connection-ray queue.  A wave moves the rays of its 64 items slot by slot: the j-th rays of the
-// items that have one are read from 64 consecutive staging words and written to consecutive queue words (per item, ray after ray,
-// the writes were 4-byte scatters: 5.0 -> 2.1 ms per 8 Mi items).  Whose ray it is (item, pair slot) goes to `qown` for k_bd_resolve.
-__global__ void k_bd_compact(int N, const int *ibase, const int *icount, const unsigned long long *qmask, const float4 *stage, BdRays dense, unsigned *qown)
+// staging slots [j][item] -> dense connection-ray queue.  The queue is a list of PLACES: a wave numbers the rays of its 64 items slot by slot
+// (the j-th rays of the items that have one take consecutive queue places, so that k_trace's lanes read neighbouring staging records), and
+// writes per place where the ray is staged (`qlist`, read by k_trace through TraceArgs::ray_index and by k_bd_resolve) and whose it is
+// (`qown`: item, pair slot).  The rays themselves stay where they are (rounds 2-3a copied them: 128 B of traffic and 32 B of state per ray).
+__global__ void k_bd_compact(int N, const int *ibase, const int *icount, const unsigned long long *qmask, int *qlist, unsigned *qown)
 {
     const int it = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
@@ -876,8 +877,7 @@ __global__ void k_bd_compact(int N, const int *ibase, const int *icount, const u
         if (m == 0ull) break;
         if (n > j) {
             const size_t k = (size_t)j * (size_t)N + it, q = (size_t)(off + __popcll(m & lt_mask));
-            const float4 s0 = stage[2 * k], s1 = stage[2 * k + 1];
-            dense.r[2 * q] = s0; dense.r[2 * q + 1] = s1;                  // the record as it is: (o, d, expect, bound)
+            qlist[q] = (int)k;                                             // the ray stays where it was staged: the queue is a list of places (k_trace reads through it)
             qown[q] = (unsigned)it | ((unsigned)(__ffsll((long long)rest) - 1) << BD_OWNER_BITS);
             rest &= rest - 1ull;
         }
@@ -946,8 +946,8 @@ int bdpt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t see
     for (int l = 0; l < NL; l++) {
         auto &bl = c->bd[l];
         if (bl.items.ensure(sizeof(bpixel) * NMAX) || bl.state.ensure(sizeof(BdStep) * NMAX) ||
-            bl.rays.ensure(sizeof(float) * (8 * 2 * NMAX + 16 * SCAP)) || bl.hits.ensure(sizeof(float4) * (2 * NMAX + SCAP)) ||
-            bl.qidx.ensure(sizeof(int) * (NMAX * 4 + SCAP)) || bl.ctr.ensure(256) ||
+            bl.rays.ensure(sizeof(float) * (8 * 2 * NMAX + 8 * SCAP)) || bl.hits.ensure(sizeof(float4) * (2 * NMAX + SCAP)) ||
+            bl.qidx.ensure(sizeof(int) * (NMAX * 4 + 2 * SCAP)) || bl.ctr.ensure(256) ||
             bl.rad.ensure(sizeof(float) * 3 * (size_t)NP * (size_t)FB_alloc)) return TIRT_ERR_HIP;
         if (!bl.delta_done) TIRT_HIP(hipEventCreateWithFlags(&bl.delta_done, hipEventDisableTiming));
         if (!bl.film_done) TIRT_HIP(hipEventCreateWithFlags(&bl.film_done, hipEventDisableTiming));
@@ -970,15 +970,15 @@ int bdpt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t see
         hipStream_t st = lane < 0 ? c->stream : c->lanes[lane].stream;
         float *rf = bl.rays.as<float>();
         BdRays er = {(float4 *)rf};                                  // 2 N records
-        float *sf = rf + 16 * NMAX;
-        BdRays sr = {(float4 *)sf};                                  // the dense connection-ray queue: SCAP records
-        int *sexpect = (int *)(sf + 16 * NMAX);                      // (the other owner list of the sub-path phase: behind the 2 N records that phase keeps in the queue's memory)
-        float *gf = sf + 8 * SCAP;                                   // staging arrays, [slot j][item]
-        float4 *stage = (float4 *)gf;                               // [slot j][item]: 32-byte records (o, d, expect, bound)
-        int *gexpect = (int *)gf;                                    // (the owner list of the sub-path phase: 2 N ints, before any record is staged)
+        float *gf = rf + 16 * NMAX;                                  // staging area, [slot j][item]: 8 SCAP = 160 NMAX words
+        float4 *stage = (float4 *)gf;                               // [slot j][item]: 32-byte records (o, d, expect, bound); k_trace reads them where they lie
+        // during the sub-path phase nothing is staged yet: the area holds the second ray list (2 N records) and the two owner lists (2 N ints each)
+        BdRays sr = {(float4 *)gf};
+        int *sexpect = (int *)(gf + 16 * NMAX), *gexpect = (int *)(gf + 18 * NMAX);
         unsigned long long *qmask = bl.qidx.as<unsigned long long>();          // [item]: the pairs that have a connection ray
         int *ibase = bl.qidx.as<int>() + NMAX * 2, *icount = ibase + NMAX;
         unsigned *qown = (unsigned *)(icount + NMAX);                // [queue place]: item | pair slot << 26
+        int *qlist = (int *)(qown + SCAP);                            // [queue place]: where the ray is staged (j * N + item)
         float4 *ehits = bl.hits.as<float4>(), *shits = ehits + 2 * NMAX;
         int *scount = bl.ctr.as<int>();
         bpixel *items = bl.items.as<bpixel>(); BdStep *state = bl.state.as<BdStep>();
@@ -1013,15 +1013,15 @@ int bdpt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t see
                            stage, qmask, ibase, icount, scount, &ctr->rays_shadow);
         else hipLaunchKernelGGL(k_bd_connect<false>, dim3((N + B - 1) / B), dim3(B), 0, st, bc, items, state, tm, P, N, frame0,
                            stage, qmask, ibase, icount, scount, &ctr->rays_shadow);
-        hipLaunchKernelGGL(k_bd_compact, dim3((N + B - 1) / B), dim3(B), 0, st, N, ibase, icount, qmask, stage, sr, qown);
-        if (int rc = trace_arrays(c, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, (int)(SCAP < (size_t)N * BD_RAY_PAIRS ? SCAP : (size_t)N * BD_RAY_PAIRS), scount, shits, nullptr, nullptr, false, lane, sr.r, true)) return rc;
+        hipLaunchKernelGGL(k_bd_compact, dim3((N + B - 1) / B), dim3(B), 0, st, N, ibase, icount, qmask, qlist, qown);
+        if (int rc = trace_arrays(c, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, (int)(SCAP < (size_t)N * BD_RAY_PAIRS ? SCAP : (size_t)N * BD_RAY_PAIRS), scount, shits, nullptr, nullptr, false, lane, stage, true, qlist)) return rc;
         if (spectral) hipLaunchKernelGGL(k_bd_emitted<true>, dim3((N + B - 1) / B), dim3(B), 0, st, bc, items, state, tm, P, N, frame0, bl.rad.as<float>(), 3 * NP);
         else hipLaunchKernelGGL(k_bd_emitted<false>, dim3((N + B - 1) / B), dim3(B), 0, st, bc, items, state, tm, P, N, frame0, bl.rad.as<float>(), 3 * NP);
         {
             size_t rg = ((size_t)N * 8 + B - 1) / B;                 // grid-stride over the queue (its length is on the device): ~7 rays per item
             if (rg > 8192) rg = 8192;
-            if (spectral) hipLaunchKernelGGL(k_bd_resolve<true>, dim3((unsigned)rg), dim3(B), 0, st, bc, items, tm, P, frame0, qown, scount, shits, sr.r, bl.rad.as<float>(), 3 * NP);
-            else hipLaunchKernelGGL(k_bd_resolve<false>, dim3((unsigned)rg), dim3(B), 0, st, bc, items, tm, P, frame0, qown, scount, shits, sr.r, bl.rad.as<float>(), 3 * NP);
+            if (spectral) hipLaunchKernelGGL(k_bd_resolve<true>, dim3((unsigned)rg), dim3(B), 0, st, bc, items, tm, P, frame0, qown, scount, shits, stage, qlist, bl.rad.as<float>(), 3 * NP);
+            else hipLaunchKernelGGL(k_bd_resolve<false>, dim3((unsigned)rg), dim3(B), 0, st, bc, items, tm, P, frame0, qown, scount, shits, stage, qlist, bl.rad.as<float>(), 3 * NP);
         }
         if (last_film) TIRT_HIP(hipStreamWaitEvent(st, last_film, 0));        // the running mean applies the frames in order
         for (int f = 0; f < F; f++) {

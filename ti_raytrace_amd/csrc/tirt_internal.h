@@ -320,7 +320,7 @@ int pt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed,
 int bdpt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed, bool spectral = false);      // spectral: BDPT_SPEC
 int trace_arrays(tirt_ctx *c, const float *ox, const float *oy, const float *oz, const float *dx, const float *dy, const float *dz,
                  int count, const int *count_ptr, float4 *hit, const int *expect, const float *bound, bool count_rays, int lane = -1,
-                 const float4 *ray4 = nullptr, bool query = false);      // ray4: the rays as 32-byte records (TraceArgs::ray4); query: bounded queries whose expect / bound ride in the records
+                 const float4 *ray4 = nullptr, bool query = false, const int *ray_index = nullptr);      // (ray_index: TraceArgs) ray4: the rays as 32-byte records (TraceArgs::ray4); query: bounded queries whose expect / bound ride in the records
 int ensure_counters(tirt_ctx *c);
 int ensure_shade_records(tirt_ctx *c);
 int sync_all(tirt_ctx *c);

@@ -67,6 +67,7 @@ struct TraceArgs {
     // KIND_CLOSEST / KIND_QUERY: the rays as 32-byte records instead of six arrays -- (o.xyz, d.x), (d.y, d.z, bits expect, bound): two 16-byte
     // loads per ray where the arrays take six to eight (the BDPT ray lists: their kernels are bound by the number of memory instructions)
     const float4 *ray4;
+    const int *ray_index;                        // KIND_QUERY: ray q is record ray_index[q] of ray4 (BDPT: the connection rays stay where they were staged; the queue is a list of places)
 };
 
 // Persistent waves with ray re-fetch ("while-while" traversal): every wave keeps pulling rays
@@ -214,6 +215,7 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
             const float *const c_sdx = MAY_SHADOW ? ca->sdx : nullptr, *const c_sdy = MAY_SHADOW ? ca->sdy : nullptr, *const c_sdz = MAY_SHADOW ? ca->sdz : nullptr;
             const int *const c_sprim = MAY_SHADOW ? ca->sprim : nullptr; const float *const c_sdist = MAY_SHADOW ? ca->sdist : nullptr;
             const float4 *const c_ray4 = (KIND == KIND_CLOSEST || KIND == KIND_QUERY) ? ca->ray4 : nullptr;
+            const int *const c_rindex = (KIND == KIND_QUERY) ? ca->ray_index : nullptr;
             const float c_gm0 = ca->bvh.grid_min[0], c_gm1 = ca->bvh.grid_min[1], c_gm2 = ca->bvh.grid_min[2];
             const float c_ie0 = ca->bvh.inv_extent[0], c_ie1 = ca->bvh.inv_extent[1], c_ie2 = ca->bvh.inv_extent[2];
             const float c_ic0 = ca->bvh.inv_cell[0], c_ic1 = ca->bvh.inv_cell[1], c_ic2 = ca->bvh.inv_cell[2];
@@ -224,7 +226,7 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
             asm volatile("" :: "s"(c_fetch), "s"(c_ox), "s"(c_oy), "s"(c_oz), "s"(c_dx), "s"(c_dy), "s"(c_dz), "s"(c_gm0), "s"(c_gm1), "s"(c_gm2), "s"(c_ie0), "s"(c_ie1), "s"(c_ie2),
                          "s"(c_ic0), "s"(c_ic1), "s"(c_ic2), "s"(c_ce0), "s"(c_ce1), "s"(c_ce2), "s"(c_rn0), "s"(c_rn1), "s"(c_rn2), "s"(c_rx0), "s"(c_rx1), "s"(c_rx2));
             if (MAY_SHADOW) asm volatile("" :: "s"(c_sox), "s"(c_soy), "s"(c_soz), "s"(c_sdx), "s"(c_sdy), "s"(c_sdz), "s"(c_sprim), "s"(c_sdist));
-            if (KIND == KIND_CLOSEST || KIND == KIND_QUERY) asm volatile("" :: "s"(c_ray4));
+            if (KIND == KIND_CLOSEST || KIND == KIND_QUERY) asm volatile("" :: "s"(c_ray4), "s"(c_rindex));
             const int n_idle = __popcll(idle);
             if (COUNT) d_refills++;
             const int leader = __ffsll((long long)idle) - 1;
@@ -247,7 +249,8 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
                 v3 o, d; int rec_expect = -3; float rec_bound = -1.0f;
                 const bool from_rec = (KIND == KIND_CLOSEST || KIND == KIND_QUERY) && c_ray4 != nullptr;          // wave-uniform
                 if (from_rec) {
-                    const float4 r0 = c_ray4[2 * (size_t)q], r1 = c_ray4[2 * (size_t)q + 1];
+                    const size_t ri = (KIND == KIND_QUERY && c_rindex) ? (size_t)c_rindex[q] : (size_t)q;
+                    const float4 r0 = c_ray4[2 * ri], r1 = c_ray4[2 * ri + 1];
                     o = V(r0.x, r0.y, r0.z); d = V(r0.w, r1.x, r1.y); rec_expect = __float_as_int(r1.z); rec_bound = r1.w;
                 } else {
                     o = mixed_sh ? V(c_sox[q], c_soy[q], c_soz[q])
@@ -698,7 +701,7 @@ int launch_trace_batch(tirt_ctx *c, const float *rays, int nr, int stack_size, i
 // the stream of a render lane with that lane's ray-fetch cursors and spill buffer (two BDPT batches in flight).
 int trace_arrays(tirt_ctx *c, const float *ox, const float *oy, const float *oz, const float *dx, const float *dy, const float *dz,
                  int count, const int *count_ptr, float4 *hit, const int *expect, const float *bound, bool count_rays, int lane,
-                 const float4 *ray4, bool query)
+                 const float4 *ray4, bool query, const int *ray_index)
 {
     if (count <= 0) return TIRT_OK;
     hipStream_t st = lane < 0 ? c->stream : c->lanes[lane].stream;
@@ -711,7 +714,7 @@ int trace_arrays(tirt_ctx *c, const float *ox, const float *oy, const float *oz,
     TIRT_HIP(hipMemsetAsync(fetch.p, 0, sizeof(int) * TR_FETCH_STRIDE * TR_SLICES_MAX, st));
     TraceArgs a = {};
     a.bvh = bvh_view(c);
-    a.ox = ox; a.oy = oy; a.oz = oz; a.dx = dx; a.dy = dy; a.dz = dz; a.ray4 = ray4;
+    a.ox = ox; a.oy = oy; a.oz = oz; a.dx = dx; a.dy = dy; a.dz = dz; a.ray4 = ray4; a.ray_index = ray_index;
     a.count_ptr = count_ptr; a.count_fixed = count; a.hit = hit;      // count: the capacity when count_ptr is given (sizes the grid)
     a.sprim = expect; a.sdist = bound;
     a.spill = spill.as<int>(); a.spill_depth = spill_depth;
