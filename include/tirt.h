@@ -242,6 +242,14 @@ int tirt_kat_math(tirt_ctx *ctx, int fn, const float *x, const float *y, float *
  *       1 Disney.sample        in: mat10,dir3,N3,rnd3    out: dir3
  *       2 Glass.sample         in: mat10,dir3,N3,prob    out: dir3, f_or_b
  *       3 UF.offset_ray        in: p3,n3                 out: p3
+ *       4 UF.CosineSampleHemisphere in: u1,u2  out: dir3     5 UF.mapToDisk in: u1,u2 out: r,phi      6 UF.powerHeuristic in: a,b out: w
+ *       7 UF.inverse_transform in: dir3,N3 out: dir3         8 UF.srgb_to_lrgb / 9 UF.lrgb_to_srgb / 10 UF.tone_ACES in: c3 out: c3
+ *       11 UF.refract in: I3,N3,eta out: R3,suc              12 UF.schlick in: cos,ior    13 UF.GTR2 in: NDotH,a    14 UF.smithG_GGX in: NDotv,alphaG
+ *       15 UF.SchlickFresnel in: u                           16 Glass.sample_lambda in: dir3,N3,lambda,prob out: dir3,f_or_b
+ *       17 Camera.get_ray_direction in: view_inv16,fx,fy,cx,cy,i,j,jx,jy out: dir3
+ *       18 UF.slabs in: o3,d3,min3,max3 out: hit (0/1), hit by the branch-free form of the traversal kernel
+ *       (4..18: the helpers behind 0..3 one by one, for tests/test_gpu_kat.py against tests/golden/refkat.npz -- values computed by the
+ *       reference's own source text)
  * in: [n*in_stride] out: [n*out_stride] */
 int tirt_kat_brdf(tirt_ctx *ctx, int which, const float *in, int in_stride, float *out, int out_stride, int n);
 

@@ -2592,6 +2592,33 @@ void orc_kat_math(int fn, const float *x, const float *y, float *out, int n)
         }
     }
 }
+/* Further per-function entry points for tests/test_refkat.py: the values the REFERENCE'S OWN SOURCE TEXT computes (executed through the
+ * stand-in of tools/refkat, build container only) are compared with these.  `in` / `out` are plain float rows, see the test for the layouts. */
+void orc_kat_util(int which, const float *in, float *out)
+{
+    switch (which) {
+        case 0: { v3 r = cosine_sample_hemisphere(in[0], in[1]); out[0] = r.x; out[1] = r.y; out[2] = r.z; break; }
+        case 1: map_to_disk(in[0], in[1], &out[0], &out[1]); break;
+        case 2: out[0] = power_heuristic(in[0], in[1]); break;
+        case 3: { v3 r = inverse_transform(V(in[0], in[1], in[2]), V(in[3], in[4], in[5])); out[0] = r.x; out[1] = r.y; out[2] = r.z; break; }
+        case 4: { v3 r = srgb_to_lrgb(V(in[0], in[1], in[2])); out[0] = r.x; out[1] = r.y; out[2] = r.z; break; }
+        case 5: { v3 r = lrgb_to_srgb(V(in[0], in[1], in[2])); out[0] = r.x; out[1] = r.y; out[2] = r.z; break; }
+        case 6: out[0] = tone_aces1(in[0]); out[1] = tone_aces1(in[1]); out[2] = tone_aces1(in[2]); break;
+        case 7: { float suc; v3 r = refract_(V(in[0], in[1], in[2]), V(in[3], in[4], in[5]), in[6], &suc); out[0] = r.x; out[1] = r.y; out[2] = r.z; out[3] = suc; break; }
+        case 8: out[0] = schlick(in[0], in[1]); break;
+        case 9: out[0] = gtr2(in[0], in[1]); break;
+        case 10: out[0] = smithg_ggx(in[0], in[1]); break;
+        case 11: out[0] = schlick_fresnel(in[0]); break;
+        case 12: { orc_scene s; memset(&s, 0, sizeof(s)); s.material = (float *)in;
+                   out[0] = disney_pdf(&s, V(in[10], in[11], in[12]), V(in[13], in[14], in[15]), V(in[16], in[17], in[18]), 0); break; }
+        case 13: { float fb; v3 r = glass_sample_lambda(V(in[0], in[1], in[2]), V(in[3], in[4], in[5]), in[6], in[7], &fb);
+                   out[0] = r.x; out[1] = r.y; out[2] = r.z; out[3] = fb; break; }
+        case 14: { int32_t a, b; memcpy(&a, in, 4); memcpy(&b, in + 1, 4); out[0] = (float)common_upper_bits(a, b); break; }
+        case 15: { orc_scene s; memset(&s, 0, sizeof(s)); memcpy(s.view_inv, in, sizeof(float) * 16); s.fx = in[16]; s.fy = in[17]; s.cx = in[18]; s.cy = in[19];
+                   v3 r = camera_dir(&s, (int)in[20], (int)in[21], in[22], in[23]); out[0] = r.x; out[1] = r.y; out[2] = r.z; break; }
+        default: break;
+    }
+}
 int orc_uses_libm(void)
 {
 #ifdef ORACLE_LIBM

@@ -115,3 +115,63 @@ def test_hand_made_rays_on_two_triangles(gpu_ctx_ok):
         if gcnt is not None:
             assert np.array_equal(gcnt, wcnt)
     assert wprim[0] in (0, 2) and wprim[7] == -1 and wprim[4] == 3
+
+
+# ---- the device functions against values computed by the reference's OWN SOURCE TEXT -------------------------------------------
+# tests/golden/refkat.npz: tools/refkat/make_refkat.py imports /root/reference/{UtilsFunc,Camera}.py, brdf/{Disney,Glass}.py through
+# a stand-in for the taichi package (build container only) and calls their functions.  tests/test_refkat.py holds the oracle to the
+# same numbers; see its header for what the tolerances mean (a transcription check: discrete outputs exact, values to ~1e-6 of
+# the result's magnitude because sin / cos / pow come from different math libraries).
+import os                                                                              # noqa: E402
+from test_refkat import close, worst                                                   # noqa: E402
+
+RG = np.load(os.path.join(os.path.dirname(__file__), "golden", "refkat.npz"))
+
+
+def test_reference_text_disney_and_glass(ctx):                                          # brdf/Disney.py:17-108, brdf/Glass.py:9-59
+    got = ctx.kat_brdf(0, RG["disney_in"], 2); want = RG["disney_evaluate_pdf"]
+    assert np.array_equal(want[:, 1] < 0, got[:, 1] < 0)
+    assert close(got[:, :1], want[:, :1], 2e-6), worst(got[:, :1], want[:, :1])
+    assert close(got[:, 1:], want[:, 1:], 2e-6), worst(got[:, 1:], want[:, 1:])
+    got = ctx.kat_brdf(1, RG["disney_sample_in"], 3); want = RG["disney_sample"]
+    assert close(got, want[:, :3], 4e-6), worst(got, want[:, :3])
+    got = ctx.kat_brdf(2, RG["glass_sample_in"], 4); want = RG["glass_sample"]
+    assert np.array_equal(got[:, 3], want[:, 3])                                        # reflect / refract: the same decision for every sample
+    assert close(got[:, :3], want[:, :3], 2e-6), worst(got[:, :3], want[:, :3])
+    x = RG["glass_sample_in"]
+    rows = np.concatenate([x[:, 10:16], RG["glass_lambda"][:, None], x[:, 16:17]], 1)
+    got = ctx.kat_brdf(16, rows, 4); want = RG["glass_sample_lambda"]
+    assert np.array_equal(got[:, 3], want[:, 3])
+    assert close(got[:, :3], want[:, :3], 2e-6), worst(got[:, :3], want[:, :3])
+
+
+def test_reference_text_utils(ctx):                                                     # UtilsFunc.py:305-523
+    got = ctx.kat_brdf(3, RG["offset_ray_in"], 3)
+    assert same_bits(got, RG["offset_ray"])
+    got = ctx.kat_brdf(18, RG["slabs_in"], 2)
+    assert np.array_equal(got[:, 0].astype(np.int32), RG["slabs"])
+    assert np.array_equal(got[:, 1].astype(np.int32), RG["slabs"])                      # slabs_fast where k_trace uses it
+    u = RG["u2"]; col = RG["colour_in"]; eta = RG["refract_in"][:, 6]
+    assert close(ctx.kat_brdf(4, u, 3), RG["CosineSampleHemisphere"], 2e-6)
+    assert close(ctx.kat_brdf(5, u, 2), RG["mapToDisk"], 2e-6)
+    assert close(ctx.kat_brdf(6, u * np.float32([7.0, 3.0]), 1), RG["powerHeuristic"][:, None], 1e-6)
+    x = RG["inverse_transform_in"].copy()
+    x[:, 3:6] *= (np.float32(1.0) + np.float32(0.5) * (np.arange(len(x)) % 3).astype(np.float32))[:, None]
+    assert close(ctx.kat_brdf(7, x, 3), RG["inverse_transform"], 2e-6)
+    assert close(ctx.kat_brdf(8, col, 3), RG["srgb_to_lrgb"], 2e-6)
+    assert close(ctx.kat_brdf(9, col * np.float32(1.5), 3), RG["lrgb_to_srgb"], 2e-6)
+    assert close(ctx.kat_brdf(10, col * np.float32(4.0), 3), RG["tone_ACES"], 2e-6)
+    assert close(ctx.kat_brdf(11, RG["refract_in"], 4), RG["refract"], 2e-6)
+    assert close(ctx.kat_brdf(12, np.stack([u[:, 0], np.float32(1.0) / eta], 1), 1), RG["schlick"][:, None], 2e-6)
+    assert close(ctx.kat_brdf(13, np.stack([u[:, 0], np.maximum(np.float32(0.001), u[:, 1])], 1), 1), RG["GTR2"][:, None], 2e-6)
+    assert close(ctx.kat_brdf(14, u, 1), RG["smithG_GGX"][:, None], 2e-6)
+    assert close(ctx.kat_brdf(15, u[:, :1] * np.float32(1.2) - np.float32(0.1), 1), RG["SchlickFresnel"][:, None], 2e-6)
+
+
+def test_reference_text_camera(ctx):                                                    # Camera.py:122-142
+    vi = RG["camera_view_inv"].reshape(-1); k = RG["camera_fx_fy_cx_cy"]; uv = RG["camera_uv"]; jit = RG["camera_jitter"]
+    n = len(uv)
+    rows = np.concatenate([np.tile(vi, (n, 1)), np.tile(k, (n, 1)), uv.astype(np.float32), np.zeros((n, 2), np.float32)], 1)
+    assert close(ctx.kat_brdf(17, rows, 3), RG["camera_dir_frame0"], 2e-6)
+    rows[:, 22:24] = jit - np.float32(0.5)
+    assert close(ctx.kat_brdf(17, rows, 3), RG["camera_dir_jittered"], 2e-6)

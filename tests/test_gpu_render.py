@@ -445,3 +445,17 @@ def test_torch_cuda_still_comes_up_after_this_library(gpu_ctx_ok):
     env = dict(os.environ); env.pop("TIRT_SYSTEM_HIP", None)
     pr = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     assert pr.returncode == 0 and pr.stdout.decode().strip().endswith("8.0"), pr.stdout.decode()[-800:]
+
+
+@pytest.mark.parametrize("name", ["cornell", "sphere"])
+def test_device_film_equals_the_reference_text_film(gpu_ctx_ok, name):
+    """tests/golden/refkat_render.npz: the film integrator/PT_RGB.py's own source text produces (executed as plain Python through the
+    taichi stand-in of tools/refkat, build container only; tests/test_refkat.py has the details and holds the oracle to it)."""
+    from test_refkat import GR, reference_text_scene, film_close
+    ex, W, H, frames, seed = reference_text_scene(name, device_id=0)
+    ex.integrator.seed = seed
+    ex.build_scene()
+    ex.integrator.render_frames(frames)
+    got = ex.integrator.hdr.to_numpy()
+    rel, per = film_close(got, GR["render_%s_film" % name])
+    assert rel <= 1e-5 and per <= 1e-4, (rel, per)

@@ -211,6 +211,41 @@ __global__ void k_kat_brdf(int which, const float *in, int in_stride, float *out
     } else if (which == 3) {
         v3 r = offset_ray(V(a[0], a[1], a[2]), V(a[3], a[4], a[5]));
         o[0] = r.x; o[1] = r.y; o[2] = r.z;
+    } else if (which == 4) {
+        v3 r = cosine_sample_hemisphere(a[0], a[1]); o[0] = r.x; o[1] = r.y; o[2] = r.z;
+    } else if (which == 5) {
+        map_to_disk(a[0], a[1], o[0], o[1]);
+    } else if (which == 6) {
+        o[0] = power_heuristic(a[0], a[1]);
+    } else if (which == 7) {
+        v3 r = inverse_transform(V(a[0], a[1], a[2]), V(a[3], a[4], a[5])); o[0] = r.x; o[1] = r.y; o[2] = r.z;
+    } else if (which == 8) {
+        v3 r = srgb_to_lrgb(V(a[0], a[1], a[2])); o[0] = r.x; o[1] = r.y; o[2] = r.z;
+    } else if (which == 9) {
+        o[0] = lrgb_to_srgb1(a[0]); o[1] = lrgb_to_srgb1(a[1]); o[2] = lrgb_to_srgb1(a[2]);
+    } else if (which == 10) {
+        o[0] = tone_aces1(a[0]); o[1] = tone_aces1(a[1]); o[2] = tone_aces1(a[2]);
+    } else if (which == 11) {
+        float suc; v3 r = refract_(V(a[0], a[1], a[2]), V(a[3], a[4], a[5]), a[6], suc); o[0] = r.x; o[1] = r.y; o[2] = r.z; o[3] = suc;
+    } else if (which == 12) {
+        o[0] = schlick(a[0], a[1]);
+    } else if (which == 13) {
+        o[0] = gtr2(a[0], a[1]);
+    } else if (which == 14) {
+        o[0] = smithg_ggx(a[0], a[1]);
+    } else if (which == 15) {
+        o[0] = schlick_fresnel(a[0]);
+    } else if (which == 16) {
+        float fb; v3 r = glass_sample_lambda(V(a[0], a[1], a[2]), V(a[3], a[4], a[5]), a[6], a[7], fb); o[0] = r.x; o[1] = r.y; o[2] = r.z; o[3] = fb;
+    } else if (which == 17) {
+        CameraView cv; for (int k = 0; k < 12; k++) cv.view_inv[k] = a[k];
+        cv.eye[0] = cv.eye[1] = cv.eye[2] = 0.0f; cv.fx = a[16]; cv.fy = a[17]; cv.cx = a[18]; cv.cy = a[19];
+        v3 r = camera_ray_direction(cv, (int)a[20], (int)a[21], a[22], a[23]); o[0] = r.x; o[1] = r.y; o[2] = r.z;
+    } else if (which == 18) {
+        const RayCtx r = make_ray(V(a[0], a[1], a[2]), V(a[3], a[4], a[5])); float tn;
+        const int full = slabs(r, a[6], a[7], a[8], a[9], a[10], a[11], tn);
+        o[0] = (float)full;
+        o[1] = ray_has_parallel_axis(r) ? (float)full : (float)slabs_fast(r, a[6], a[7], a[8], a[9], a[10], a[11], tn);     // the branch-free form k_trace uses where it may
     }
 }
 
@@ -815,8 +850,8 @@ int tirt_kat_math(tirt_ctx *c, int fn, const float *x, const float *y, float *ou
 int tirt_kat_brdf(tirt_ctx *c, int which, const float *in, int in_stride, float *out, int out_stride, int n)
 {
     CTX(c);
-    TIRT_REQUIRE(in && out && n >= 0 && which >= 0 && which <= 3, "tirt_kat_brdf: bad args");
-    const int need_in[4] = {19, 19, 17, 6}, need_out[4] = {2, 3, 4, 3};
+    TIRT_REQUIRE(in && out && n >= 0 && which >= 0 && which <= 18, "tirt_kat_brdf: bad args");
+    const int need_in[19] = {19, 19, 17, 6, 2, 2, 2, 6, 3, 3, 3, 7, 2, 2, 2, 1, 8, 24, 12}, need_out[19] = {2, 3, 4, 3, 3, 2, 1, 3, 3, 3, 3, 4, 1, 1, 1, 1, 4, 3, 2};
     TIRT_REQUIRE(in_stride >= need_in[which] && out_stride >= need_out[which], "tirt_kat_brdf: stride too small");
     if (n == 0) return TIRT_OK;
     DevBuf din, dout;
