@@ -228,7 +228,9 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
             if (MAY_SHADOW) asm volatile("" :: "s"(c_sox), "s"(c_soy), "s"(c_soz), "s"(c_sdx), "s"(c_sdy), "s"(c_sdz), "s"(c_sprim), "s"(c_sdist));
             if (KIND == KIND_CLOSEST || KIND == KIND_QUERY) asm volatile("" :: "s"(c_ray4), "s"(c_rindex));
             const int n_idle = __popcll(idle);
+#ifndef TR_DRAIN_DIAG
             if (COUNT) d_refills++;
+#endif
             const int leader = __ffsll((long long)idle) - 1;
             // rays of slice `home`: its 64-ray chunks are the global chunks home, home + S, home + 2S, ...
             const int len = (((full_chunks >> S_LOG) + (home < (full_chunks & S_MASK) ? 1 : 0)) << 6) +
@@ -321,6 +323,15 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
             }
         }
         if (ballot64(have) == 0ull) { if (exhausted) break; continue; }
+#ifdef TR_DRAIN_DIAG
+        // diagnostic build (tools/timeline.py, counting launches): what a wave holds once the queue is empty -- outer iterations, busy lanes, and how
+        // many of them have at least one / two / four entries above the sentinel of their stack (work another lane could take over)
+        if (COUNT && exhausted) {
+            const int dep__ = (int)(sa - sa_bottom) >> 10;
+            d_refills++; d_outer += (unsigned long long)(have ? 1 : 0);
+            sum_box_s += (have && dep__ >= 1) ? 1 : 0; sum_leaf_s += (have && dep__ >= 2) ? 1 : 0; sum_leaf += (have && dep__ >= 4) ? 1 : 0;
+        }
+#endif
 
         // ---- inner nodes.  Lanes that reached a leaf (or finished) wait here; the loop goes on
         // while at least node_min lanes still have inner-node work, or nobody is waiting at all.
@@ -334,12 +345,20 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
         // price of a few node visits the earlier hit would have culled (+2 %).
         if (STASH) { if (have && cur < 0 && cur != TR_SENT && pend == 0) { pend = cur; TR_POP(cur); } }
         const int lim_i = __float_as_int(lim);                  // > 0 always
+        // The node loop is left once fewer than node_min lanes have node work and some lane waits at a leaf -- at most: a wave that holds few
+        // rays (the end of a launch, no refill any more) would leave it for every single leaf, so the threshold is also bounded by 3/4 of
+        // the lanes that hold a ray at all (1/2 and 5/8: no gain, 7/8: half of it; a lone batch -- one rank's share of an 8-GPU job --
+        // 3.13 -> 3.06 ms per step, four overlapped batches unchanged: profiles/r04g_node_threshold_ab.log)
+#ifndef TR_NODE_FRAC
+#define TR_NODE_FRAC 6
+#endif
+        int node_min_w = (__popcll(ballot64(have)) * TR_NODE_FRAC) >> 3; node_min_w = node_min_w < a.node_min ? node_min_w : a.node_min;
         for (;;) {
             const bool act = cur >= 0;
             const unsigned long long am = ballot64(act);
             if (am == 0ull) break;
             const int n_act = __popcll(am);
-            if (n_act < a.node_min && ballot64(have && cur < 0) != 0ull) break;
+            if (n_act < node_min_w && ballot64(have && cur < 0) != 0ull) break;
             if (wave_any((int)sa >= (int)sa_hi)) break;        // a lane's LDS stack is full: page out below (cold)
             if (COUNT) { d_it_node++; d_lanes_node += (unsigned long long)n_act; }
             if (act) {
@@ -372,7 +391,9 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
                         const u4v t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3];
 #define TR_U4(v) make_uint4((v).x, (v).y, (v).z, (v).w)
                         q0 = TR_U4(t0); q1 = TR_U4(t1); q2 = TR_U4(t2); q3 = TR_U4(t3);
+#ifndef TR_DRAIN_DIAG
                         if (COUNT) d_outer++;
+#endif
                     } else {
                         const uint4 *w = (const uint4 *)((const char *)b.cnode + ((unsigned)cur << 6));
                         q0 = w[0]; q1 = w[1]; q2 = w[2]; q3 = w[3];
@@ -534,8 +555,10 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
                 if (c_scw) { float *pw = dst >= 0 ? ca->rw + dst : ca->fw + ~dst; *pw = *pw + c_scw[q]; }
             }
             if (COUNT) {
+#ifndef TR_DRAIN_DIAG
                 if (MAY_SHADOW && is_sh) { sum_box_s += nbox; sum_leaf_s += nleaf; }
                 else { sum_box += nbox; sum_leaf += nleaf; }
+#endif
                 if (ca->per_ray_counts) ca->per_ray_counts[q] = make_int2((int)nbox, (int)nleaf);
             }
             if (n_overflow) n_over++;
