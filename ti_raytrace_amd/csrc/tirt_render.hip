@@ -513,6 +513,14 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
                         const float *ab = b.compact + (size_t)an * CPN_VEC + 2;
                         if (!slabs(rv, ab[0], ab[1], ab[2], ab[3], ab[4], ab[5], tn_)) { cand = false; break; }
                     }
+#ifndef TR_NO_PRIM_RELOAD
+                    // the primitive id again, from the leaf's reference row (UtilsFunc.py:get_compact_node_prim): the same number that came with the
+                    // primitive record -- read here so that NOTHING of that record has to survive the walk above.  ROCm 7.2's register allocator lets
+                    // the walk's row loads (global_load_dwordx4 v[8:11]) land on the register that holds the record's last word while it is still
+                    // needed below (tools/dbg/prim_clobber.sh shows the ISA; 156 of 15 000 box-grazing rays on the Cornell box then kept the PREVIOUS
+                    // hit's primitive id, tests/test_gpu_trace.py::test_quantised_nodes_on_grazing_rays).  Round 3 pinned the value with an empty asm.
+                    prim = (int)b.compact[(size_t)leaf * CPN_VEC + 1];
+#endif
                 }
             }
 #endif
@@ -521,7 +529,9 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
             // Re-checked at the end of round 3, after the kernel's register allocation had changed completely (TR_COLD): still needed --
             // without it test_quantised_nodes_on_grazing_rays fails and the next test faults.  That test is the tripwire; __graft_entry__.build()
             // warns when the compiler is not the validated one.)
+#ifdef TR_PRIM_PIN
             asm volatile("" : "+v"(prim));
+#endif
             if (cand) {
                 hit_t = t; hit_u = u; hit_v = v; hit_prim = prim; hit_leaf = leaf;
                 lim = __builtin_fminf(__builtin_fminf(cull_far < 0.0f ? INF_VALUE : hit_t * 1.0001f, __builtin_fabsf(cull_far)), INF_VALUE);      // (v_min: a canonical value, so the node loop does not re-canonicalise it every step)
