@@ -10,6 +10,14 @@
  * owns all device memory.  One host thread drives one tirt_ctx (one HIP device, one
  * stream).  Every function returns 0 on success, <0 on error (tirt_last_error() gives
  * the message); nothing throws across the boundary.
+ *
+ * Embedding.  The library itself touches no process state: no environment variable is read or written, no signal handler or
+ * thread is installed (librccl is dlopen()ed by tirt_comm_init only).  A context runs up to `overlap_lanes` (default 4) HIP
+ * streams side by side; the ROCm runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), so an embedder that
+ * wants each lane on a queue of its own sets GPU_MAX_HW_QUEUES >= 5 before the HIP runtime initialises.  The Python package
+ * ti_raytrace_amd does exactly that at import (setdefault to 8) and pre-loads PyTorch's bundled libamdhip64.so when torch is
+ * installed, so that libtirt.so and torch share one runtime; TIRT_NO_ENV_TUNING=1 switches both off, TIRT_SYSTEM_HIP=1 only the
+ * preload (ti_raytrace_amd/__init__.py, _native.py).  libtirt.so's DT_NEEDED entry is libamdhip64.so.7 by SONAME.
  */
 #ifndef TIRT_H
 #define TIRT_H
@@ -83,7 +91,7 @@ int tirt_sync(tirt_ctx *ctx);
  *            lane count beyond four; lane buffers are sized for that and only as many lanes get one (a 512^2 x 8 spp job does
  *            not allocate 32 Mi-path lanes).  Set it before the first render call of the job
  *          "batch_paths" -- pixel-samples kept in flight per wavefront batch (default 32 Mi, or planned from "job_frames";
- *            196 B of HBM each, lanes hold 1.5 x that)
+ *            204 B of HBM each, lanes hold 1.5 x that)
  *          "split_lone_batch" (0 = off, or the number of parts 2..8; default 0 since round 3) -- a context that owns 1/6 or less of the film
  *            (tile_count >= 6) and whose whole job is one batch runs it as that many smaller batches on as many lanes
  *          "traversal_tree" (0/1, default 1) -- the tree tirt_lbvh_build collapses into the 4-wide traversal nodes: 1 = a binned-SAH
@@ -93,6 +101,7 @@ int tirt_sync(tirt_ctx *ctx);
  *            gets depends on the visiting order (none in any render); takes effect at the next tirt_lbvh_build
  *          "wide_collapse" (0/1, default 0) -- how the binary tree is grouped into 4-wide nodes: 0 = greedily by surface area, 1 = the
  *            grouping of least total node area (dynamic programme); same results, 1-9 % fewer node visits, no measurable gain
+ *          "bdpt_mem_budget" -- bytes a BDPT call may take for its batch state even when more is free (0 = off; tests)
  *          "bdpt_batch_items" -- (frame, pixel) items per BDPT wavefront batch (default 16 Mi, ~2.3 KB of HBM each: 39 GB; 5 Mi = 12 GB runs config 5 at 2 900 Mrays/s), shared by the two batches in flight on render lanes 0 and 1
  *            (config 5, round 3: 4 Mi 2 890, 8 Mi 2 900, 16 Mi 2 995, 32 Mi 2 980 Mrays/s; 256 frames: 8 Mi 2 912, 16 Mi 2 923, 32 Mi 3 032)
  *            A call never sizes its batches beyond what hipMemGetInfo reports free (less 2 GB): next to other users of the device it renders in smaller batches.

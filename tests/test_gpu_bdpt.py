@@ -228,26 +228,18 @@ def test_vertex_arrays_need_no_clearing(gpu_ctx_ok):
 
 
 def test_bdpt_batches_shrink_to_the_free_memory(gpu_ctx_ok):
-    """A BDPT call sizes its batches by `bdpt_batch_items` AND by what the device has free (tirt_bdpt.hip: hipMemGetInfo less 2 GB): with all
-    but ~6 GB of the HBM taken by somebody else, 64 frames of 256^2 (4 Mi items: 12 GB of wavefront state as one pair of batches) still render --
-    in smaller batches, with the same ray counts and the same film up to the float-atomic order of the splats."""
-    import ctypes
-    ex0 = scenes.veach_bdpt(8, 8, 1, device_id=0); ex0.build_scene()          # (libtirt and its HIP runtime are loaded now)
-    hip = ctypes.CDLL("libamdhip64.so.7")                     # by SONAME: the runtime already in the process, whichever copy that is (_native._prefer_torch_hip_runtime)
-    hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
-    hip.hipMemGetInfo.argtypes = [ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]
-    hip.hipFree.argtypes = [ctypes.c_void_p]
+    """A BDPT call sizes its batches by `bdpt_batch_items` AND by what the device has free (tirt_bdpt.hip: hipMemGetInfo less 2 GB): with only
+    6 GB to take -- option "bdpt_mem_budget", which caps what the call believes is free; nothing is allocated to squeeze it, other jobs on the
+    device are left alone -- 64 frames of 256^2 (4 Mi items: 12 GB of wavefront state as one pair of batches) still render, in smaller
+    batches, with the same ray counts and the same film up to the float-atomic order of the splats."""
     W = H = 256
     out = []
     for squeeze in (False, True):
         ex = scenes.veach_bdpt(W, H, 64, device_id=0)
         ex.build_scene()
         ctx = ex.scene.ctx
-        hog = ctypes.c_void_p()
         if squeeze:
-            free_b, total_b = ctypes.c_size_t(), ctypes.c_size_t()
-            assert hip.hipMemGetInfo(ctypes.byref(free_b), ctypes.byref(total_b)) == 0
-            assert hip.hipMalloc(ctypes.byref(hog), max(free_b.value - (6 << 30), 1 << 20)) == 0
+            ctx.set_option("bdpt_mem_budget", float(6 << 30))
         try:
             ctx.stats_reset()
             ctx.bdpt_rgb_render(0, 64, 1)
@@ -255,7 +247,6 @@ def test_bdpt_batches_shrink_to_the_free_memory(gpu_ctx_ok):
             out.append((ctx.film_download(W, H)[0], st["rays_closest"], st["rays_shadow"]))
         finally:
             ctx.close()
-            if hog: hip.hipFree(hog)
     assert out[0][1:] == out[1][1:]
     m = np.isfinite(out[0][0]).all(axis=2)
     assert (np.isfinite(out[1][0]).all(axis=2) == m).all() and m.mean() > 0.95

@@ -436,7 +436,7 @@ def test_torch_cuda_still_comes_up_after_this_library(gpu_ctx_ok):
     with this package and THEN asking torch for the device must work (the multi-GPU path of bench.py needs both)."""
     import subprocess, sys, os
     code = ("from ti_raytrace_amd import scenes\n"
-            "ex = scenes.cornell(32, 32, 2, device_id=0) if hasattr(scenes, 'cornell') else scenes.veach_bdpt(32, 32, 2, device_id=0)\n"
+            "ex = scenes.cornell_box(32, 32, 2, device_id=0)\n"
             "ex.build_scene(); ex.integrator.render_frames(2)\n"
             "import torch\n"
             "assert torch.cuda.is_available(), 'torch.cuda lost the device'\n"

@@ -5,7 +5,7 @@ one-bit radix passes with Blelloch scans, Karras kernel, ~depth refit launches w
 sync each, and a recursive *Python* flatten; accel/LBvh.py:192-226) with one call into
 ``tirt_lbvh_build``: a handful of HIP kernels, no host round trips.  The products are the
 reference's own: ``morton_code_s`` (sorted pairs), ``bvh_node`` (11 f32) and ``compact_node``
-(9 f32, DFS order) -- bit-identical to the CPU oracle (tests/test_lbvh_gpu.py).
+(9 f32, DFS order) -- bit-identical to the CPU oracle (tests/test_gpu_lbvh.py).
 """
 import numpy as np
 

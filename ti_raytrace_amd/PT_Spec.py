@@ -19,7 +19,8 @@ from .Scene import DeviceField
 
 MAX_DEPTH = 10           # integrator/PT_Spec.py:26
 _SPECTRUM_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "assets", "spectrum")
-_TABLE_CACHE = {}        # (res) -> (scale, data): the optimiser's output does not depend on the scene
+_TABLE_CACHE = {}        # (res, who built it) -> (scale, data): the optimiser's output does not depend on the scene, but a table the
+                         # tests made with the oracle's generator must not stand in for the device-built one (or the reverse) in one process
 
 
 class PathTrace:
@@ -104,13 +105,18 @@ class PathTrace:
         build_table(res, cie_xyz[471,3], d65[471]) -> (scale, data): the device's tirt_spec_table_build in the product, the
         oracle's generator in the CPU tests."""
         self.sky.setup_data_gpu()
-        self._d65_raw = self.d65.data_np.copy()
+        first = not hasattr(self, "_d65_raw")
+        if first:
+            self._d65_raw = self.d65.data_np.copy()          # D65 as read, before normalize_spec scales it (a second call must not take the scaled one)
         if self.rgb2spec.table_data_np is None:
-            if 64 not in _TABLE_CACHE:
-                _TABLE_CACHE[64] = build_table(64, self.data_np, self.d65_from_360())
+            who = getattr(build_table, "__self__", None)
+            key = (64, type(who).__name__ if who is not None else getattr(build_table, "__qualname__", repr(build_table)))
+            if key not in _TABLE_CACHE:
+                _TABLE_CACHE[key] = build_table(64, self.data_np, self.d65_from_360())
             self.rgb2spec.table_res, self.rgb2spec.table_size = 64, 64 * 64 * 64 * 9
-            self.rgb2spec.table_scale_np, self.rgb2spec.table_data_np = _TABLE_CACHE[64]
-        self.normalize_spec(self.d65)
+            self.rgb2spec.table_scale_np, self.rgb2spec.table_data_np = _TABLE_CACHE[key]
+        if first:
+            self.normalize_spec(self.d65)
 
     def setup_data_gpu(self):
         ctx = self.scene.ctx

@@ -123,7 +123,7 @@ def _prefer_torch_hip_runtime():
     whole process, and torch.cuda does not come up on the system one ("No HIP GPUs are available" after this library initialised HIP).
     So torch's copy is loaded first -- without importing torch -- when there is one: libtirt.so runs on it as it does when the
     application imported torch before this package (bench.py, the multi-GPU path).  TIRT_SYSTEM_HIP=1 keeps the system runtime."""
-    if os.environ.get("TIRT_SYSTEM_HIP", "0") not in ("", "0"):
+    if os.environ.get("TIRT_SYSTEM_HIP", "0") not in ("", "0") or os.environ.get("TIRT_NO_ENV_TUNING", "0") not in ("", "0"):
         return
     try:
         import importlib.util
@@ -135,6 +135,21 @@ def _prefer_torch_hip_runtime():
             C.CDLL(path, mode=C.RTLD_GLOBAL)
     except (OSError, ImportError, ValueError):
         pass                                   # no torch, or a torch without a bundled runtime: the system one
+
+
+def _check_one_hip_runtime():
+    """libtirt.so needs `libamdhip64.so.7` (DT_NEEDED, by SONAME).  The preload above only satisfies that when torch's bundled runtime carries
+    the same SONAME; a wheel with another (or a hashed) name leaves the loader to pull in the system runtime as well -- two HIP runtimes in one
+    process, each with its own devices, streams and allocations.  Say so instead of failing later in some unrelated call."""
+    try:
+        with open("/proc/self/maps") as f:
+            libs = sorted({line.split()[-1] for line in f if "libamdhip64" in line})
+    except OSError:
+        return
+    if len({os.path.realpath(p) for p in libs}) > 1:
+        import warnings
+        warnings.warn("two HIP runtimes are mapped into this process (%s): libtirt.so and PyTorch will not see each other's device memory; "
+                      "set TIRT_SYSTEM_HIP=1 (and import torch after this package), or make the SONAMEs agree" % ", ".join(libs), RuntimeWarning)
 
 
 def lib():
@@ -151,6 +166,7 @@ def lib():
             handle = C.CDLL(LIB_PATH)
         except OSError as exc:
             raise TirtError("cannot load %s: %s" % (LIB_PATH, exc))
+        _check_one_hip_runtime()
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)
             fn.restype = res

@@ -922,6 +922,9 @@ int bdpt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t see
         if (FB > half) FB = half;                                   // the two lanes share the batch budget
         if (FB > (frame_count + 1) / 2) FB = (frame_count + 1) / 2;
     }
+    // the traversal's own buffers first (stack spill: ~2 GB per lane at bdpt_stack_size 1024), so that the measurement below sees them and a
+    // failed allocation leaves the film untouched (they used to be allocated inside the batch loop, after the guard)
+    for (int l = 0; l < NL; l++) if (int rc = trace_arrays_prepare(c, NL > 1 ? l : -1)) return rc;
     {
         // not more than the device has free right now (plus what this context's BDPT buffers hold already: growing them frees them first), less
         // 2 GB: a batch half the size is a few per cent slower, a failed hipMalloc ends the render (bench.py's profiler child, next to the
@@ -930,7 +933,8 @@ int bdpt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t see
         size_t free_b = 0, total_b = 0, held = 0;
         for (int l = 0; l < 2; l++) held += c->bd[l].items.bytes + c->bd[l].state.bytes + c->bd[l].rays.bytes + c->bd[l].hits.bytes + c->bd[l].qidx.bytes + c->bd[l].rad.bytes;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-            const size_t avail = free_b + held > ((size_t)2 << 30) ? free_b + held - ((size_t)2 << 30) : 0;
+            size_t avail = free_b + held > ((size_t)2 << 30) ? free_b + held - ((size_t)2 << 30) : 0;
+            if (c->bdpt_mem_budget && avail > c->bdpt_mem_budget) avail = c->bdpt_mem_budget;      // option "bdpt_mem_budget": pretend the device has only this much left
             while (FB > 1 && (size_t)NL * (size_t)FB * ((size_t)P * per_item + sizeof(float) * 3 * (size_t)NP) > avail) FB = (FB + 1) / 2;
         } else (void)hipGetLastError();
     }

@@ -254,6 +254,7 @@ struct tirt_ctx {
     struct BdLane { tirt::DevBuf items, state, rays, hits, qidx, ctr, rad; hipEvent_t delta_done = nullptr, film_done = nullptr; } bd[2];
     int bdpt_state_fill = 0;                       // option "bdpt_state_fill" (diagnostic): 0 = vertex arrays not cleared per batch, 1 = zeros, 2 = 0xFF poison
     size_t bdpt_batch_items = (size_t)16 << 20;   // option "bdpt_batch_items": (frame, pixel) items per wavefront batch
+    size_t bdpt_mem_budget = 0;                    // option "bdpt_mem_budget" (bytes, 0 = off): upper bound on what a BDPT call may take for its batch state, as if the device had only that much free (tests)
     int bdpt_stack = 64;                           // option "bdpt_stack_size": traversal stack entries of BDPT's rays (BDPT.__init__'s stack_size; LDS part + paged spill)
     int bdpt_bounded = 1;                          // option "bdpt_bounded": connection rays stop at their target distance
 
@@ -321,6 +322,7 @@ int bdpt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t see
 int trace_arrays(tirt_ctx *c, const float *ox, const float *oy, const float *oz, const float *dx, const float *dy, const float *dz,
                  int count, const int *count_ptr, float4 *hit, const int *expect, const float *bound, bool count_rays, int lane = -1,
                  const float4 *ray4 = nullptr, bool query = false, const int *ray_index = nullptr);      // (ray_index: TraceArgs) ray4: the rays as 32-byte records (TraceArgs::ray4); query: bounded queries whose expect / bound ride in the records
+int trace_arrays_prepare(tirt_ctx *c, int lane);      // allocates what trace_arrays needs on that lane (stack spill, fetch cursors)
 int ensure_counters(tirt_ctx *c);
 int ensure_shade_records(tirt_ctx *c);
 int sync_all(tirt_ctx *c);

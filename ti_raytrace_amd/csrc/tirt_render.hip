@@ -729,6 +729,19 @@ int launch_trace_batch(tirt_ctx *c, const float *rays, int nr, int stack_size, i
     return TIRT_OK;
 }
 
+// The buffers trace_arrays needs on a lane (lane < 0: the main stream) -- the paged tail of the traversal stacks, sized by the integrator's
+// stack size (2 GB per lane at bdpt_stack_size 1024), and the ray-fetch cursors -- allocated up front: a caller that sizes its batches to the free
+// memory (bdpt_render) calls this BEFORE it measures, and a failed allocation ends the call before anything has been blended into the film.
+int trace_arrays_prepare(tirt_ctx *c, int lane)
+{
+    DevBuf &spill = lane < 0 ? c->spill : c->lanes[lane].spill;
+    DevBuf &fetch = lane < 0 ? c->counters_mem : c->lanes[lane].counters_mem;
+    int spill_depth;
+    if (ensure_spill(c, spill, c->bdpt_stack, spill_depth)) return TIRT_ERR_HIP;
+    if (fetch.ensure(sizeof(int) * TR_FETCH_STRIDE * TR_SLICES_MAX)) return TIRT_ERR_HIP;
+    return TIRT_OK;
+}
+
 // Closest hits (expect == nullptr) or bounded connection queries of `count` rays held in device arrays, hit records to
 // `hit` -- the traversal service of the BDPT wavefront (tirt_bdpt.hip).  Ordered traversal, on the main stream (lane < 0) or on
 // the stream of a render lane with that lane's ray-fetch cursors and spill buffer (two BDPT batches in flight).

@@ -197,7 +197,15 @@ int tirt_spectral_upload(tirt_ctx *c, const tirt_spectral_t *t)
     if (int rc = flush_pending(c)) return rc;
     if (sync_all(c)) return TIRT_ERR_HIP;
     size_t n_spd = 0;
-    for (int k = 0; k < 4; k++) { TIRT_REQUIRE(t->spd_n[k] >= 2, "tirt_spectral_upload: a spectrum needs two samples"); n_spd += (size_t)t->spd_n[k]; }
+    // the samplers index with (int)((lambda - min) / range) and clamp only the upper neighbour (Spectrum.py:sample): a table shorter than its
+    // declared wavelength span would be read past its end
+    auto spans = [](float lo, float hi, float step, int n) { return step > 0.0f && hi >= lo && (double)(hi - lo) / (double)step <= (double)(n - 1) + 1.0e-3; };
+    TIRT_REQUIRE(spans(t->s_min, t->s_max, t->s_range, t->n_sensor), "tirt_spectral_upload: the sensor table is shorter than (s_max - s_min) / s_range + 1");
+    for (int k = 0; k < 4; k++) {
+        TIRT_REQUIRE(t->spd_n[k] >= 2, "tirt_spectral_upload: a spectrum needs two samples");
+        TIRT_REQUIRE(spans(t->spd_min[k], t->spd_max[k], t->spd_range[k], t->spd_n[k]), "tirt_spectral_upload: a spectrum is shorter than (max - min) / range + 1");
+        n_spd += (size_t)t->spd_n[k];
+    }
     const size_t n_tbl = (size_t)9 * t->tbl_res * t->tbl_res * t->tbl_res;
     // one buffer: sensor | spectra | table scale | table data | sky configs | sky radiances (all f32, 16-byte aligned pieces)
     auto al = [](size_t n) { return (n + 3) & ~(size_t)3; };
