@@ -139,6 +139,27 @@ L2_PEAK_GBS = 34500.0          # aggregate L2 bandwidth
 VALU_PEAK_GINSTR = 1024 * 2.4 / 2.0    # wave64 VALU instructions per ns: 1024 SIMD-32s x 2.4 GHz, 2 cycles per instruction at best (the 157.3 TFLOP/s FP32 vector peak)
 
 
+def shade_ceilings(sh):
+    """The three ceilings of MI355X_MICROARCH.md for k_shade, from its share of the same profiler passes (durations: the profiled ones)."""
+    if not sh or not sh.get("avg_launch_ms_profiled"):
+        return None
+    dur = sh["avg_launch_ms_profiled"] * 1e-3
+    o = {"avg_launch_ms_profiled": sh["avg_launch_ms_profiled"], "launches": sh["launches"],
+         "hbm": {"bytes_per_launch": sh["bytes_per_launch"], "GBps": round(sh["bytes_per_launch"] / dur / 1e9, 1), "frac": round(sh["bytes_per_launch"] / dur / 1e9 / HBM_PEAK_GBS, 4)}}
+    if sh.get("l2_read_bytes_per_launch"):
+        o["l2"] = {"read_bytes_per_launch": sh["l2_read_bytes_per_launch"], "GBps": round(sh["l2_read_bytes_per_launch"] / dur / 1e9, 1),
+                   "frac": round(sh["l2_read_bytes_per_launch"] / dur / 1e9 / L2_PEAK_GBS, 4), "hit_rate": sh.get("l2_hit_rate")}
+    if sh.get("valu_busy") is not None:
+        o["valu"] = {"issue_busy": sh["valu_busy"], "lane_util": sh["valu_lane_util"], "frac": round(sh["valu_busy"] * sh["valu_lane_util"], 4),
+                     "cycles_per_inst": sh["valu_cycles_per_inst"], "wave_insts_per_launch": sh["valu_wave_insts_per_launch"], "ta_busy": sh.get("ta_busy")}
+    fr = {kk: (vv["issue_busy"] if kk == "valu" else vv["frac"]) for kk, vv in o.items() if isinstance(vv, dict)}
+    o["bound"] = max(fr, key=fr.get) if fr else None
+    o["note"] = ("measured alone on one lane; in the timed region it runs beside the traversal kernels of other batches, whose VALU issue it shares. "
+                 "About 45 % of its VALU instructions are the correctly rounded sqrt / division sequences and the f64 sin / cos polynomials that make "
+                 "the film bit-identical to the CPU oracle (DESIGN.md section 4)")
+    return o
+
+
 def measure_trace_counters(args):
     """What the traversal kernel does to the memory system and to the VALUs, measured now on a child run of this script
     (1 warm-up + 1 step, one render lane: one wavefront batch, launches do not overlap).  Four rocprofv3 passes:
@@ -160,42 +181,57 @@ def measure_trace_counters(args):
                                     "GRBM_GUI_ACTIVE", "TA_TA_BUSY_sum")])
     except Exception as exc:            # noqa: BLE001 -- a failed profiler pass must not fail the bench line
         return {"error": "%s: %s" % (type(exc).__name__, exc)}
-    tr = [v for n, v in k.items() if n.startswith("k_trace")]
-    if not tr:
+    def digest(match):
+        sel = [v for n, v in k.items() if match(n)]
+        if not sel:
+            return None, None
+        tot = {}
+        for v in sel:
+            for c, x in v.items():
+                tot[c] = tot.get(c, 0.0) + x
+        n = max(int(tot["launches"]), 1)
+        out = {"launches": n, "avg_launch_ms_profiled": round(tot["dur_ns"] / n / 1e6, 5),
+               "FETCH_SIZE_KB_per_launch": round(tot.get("FETCH_SIZE", 0.0) / n, 1), "WRITE_SIZE_KB_per_launch": round(tot.get("WRITE_SIZE", 0.0) / n, 1)}
+        out["bytes_per_launch"] = round((2.0 * out["FETCH_SIZE_KB_per_launch"] + out["WRITE_SIZE_KB_per_launch"]) * 1024.0)
+        cyc = tot.get("GRBM_GUI_ACTIVE", 0.0) / 8.0           # summed over the 8 XCDs
+        if cyc > 0 and tot.get("SQ_INSTS_VALU", 0) > 0:
+            out["valu_busy"] = round(tot["SQ_ACTIVE_INST_VALU"] * 4.0 / (cyc * 1024.0), 4)        # quad-cycles per SIMD -> share of the kernel's cycles
+            out["ta_busy"] = round(tot["TA_TA_BUSY_sum"] / (cyc * 256.0), 4)
+            out["valu_lane_util"] = round(tot["SQ_THREAD_CYCLES_VALU"] / (tot["SQ_ACTIVE_INST_VALU"] * 64.0), 4)
+            out["valu_cycles_per_inst"] = round(tot["SQ_ACTIVE_INST_VALU"] * 4.0 / tot["SQ_INSTS_VALU"], 3)
+            out["valu_wave_insts_per_launch"] = round(tot["SQ_INSTS_VALU"] / n)
+            out["clock_GHz_profiled"] = round(cyc / tot["dur_ns"], 3)
+            out["lds_bank_conflict_frac_of_lds_cycles"] = round(tot.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(tot.get("SQ_LDS_IDX_ACTIVE", 0.0), 1.0), 4)
+            out["lds_bank_conflict_cycles_frac_of_kernel"] = round(tot.get("SQ_LDS_BANK_CONFLICT", 0.0) / (cyc * 256.0), 4)   # LDS is per CU
+        return out, tot
+
+    out, tot = digest(lambda name: name.startswith("k_trace"))
+    if out is None:
         return {"error": "no k_trace dispatch in the profiler passes"}
-    tot = {}
-    for v in tr:
-        for c, x in v.items():
-            tot[c] = tot.get(c, 0.0) + x
-    n = max(int(tot["launches"]), 1)
-    out = {"launches": n, "avg_launch_ms_profiled": round(tot["dur_ns"] / n / 1e6, 5),
-           "FETCH_SIZE_KB_per_launch": round(tot.get("FETCH_SIZE", 0.0) / n, 1), "WRITE_SIZE_KB_per_launch": round(tot.get("WRITE_SIZE", 0.0) / n, 1)}
-    out["bytes_per_launch"] = round((2.0 * out["FETCH_SIZE_KB_per_launch"] + out["WRITE_SIZE_KB_per_launch"]) * 1024.0)
-    cyc = tot.get("GRBM_GUI_ACTIVE", 0.0) / 8.0           # summed over the 8 XCDs
-    if cyc > 0 and tot.get("SQ_INSTS_VALU", 0) > 0:
-        out["valu_busy"] = round(tot["SQ_ACTIVE_INST_VALU"] * 4.0 / (cyc * 1024.0), 4)        # quad-cycles per SIMD -> share of the kernel's cycles
-        out["ta_busy"] = round(tot["TA_TA_BUSY_sum"] / (cyc * 256.0), 4)
-        out["valu_lane_util"] = round(tot["SQ_THREAD_CYCLES_VALU"] / (tot["SQ_ACTIVE_INST_VALU"] * 64.0), 4)
-        out["valu_cycles_per_inst"] = round(tot["SQ_ACTIVE_INST_VALU"] * 4.0 / tot["SQ_INSTS_VALU"], 3)
-        out["valu_wave_insts_per_launch"] = round(tot["SQ_INSTS_VALU"] / n)
-        out["clock_GHz_profiled"] = round(cyc / tot["dur_ns"], 3)
-        out["lds_bank_conflict_frac_of_lds_cycles"] = round(tot.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(tot.get("SQ_LDS_IDX_ACTIVE", 0.0), 1.0), 4)
-        out["lds_bank_conflict_cycles_frac_of_kernel"] = round(tot.get("SQ_LDS_BANK_CONFLICT", 0.0) / (cyc * 256.0), 4)   # LDS is per CU
+    n = out["launches"]
+    if "valu_busy" in out:
         # every kernel of the wavefront loop, both profiled steps: what one step asks of the VALUs (for `whole_job` in the roofline object)
         per = {}
         for name, v in k.items():
             if name.startswith(("k_trace", "k_shade", "k_generate", "k_film")) and v.get("SQ_INSTS_VALU", 0) > 0:
                 per[name] = round(v["SQ_INSTS_VALU"] / 2.0)
         out["valu_wave_insts_per_step_by_kernel"] = per
+    bytes_per_req = 64.0
     if tot.get("TCP_TCC_READ_REQ_sum", 0) > 0:
         out["l2_hit_rate"] = round(tot["TCC_HIT_sum"] / max(tot["TCC_HIT_sum"] + tot["TCC_MISS_sum"], 1.0), 4)
         film = k.get("k_film")
-        bytes_per_req = 64.0
         if film and film.get("TCP_TCC_READ_REQ_sum", 0) > 0 and film["launches"] > 0:
             known = film["launches"] * (12.0 * fps * P + 12.0 * P)                  # fr, fg, fb of every path + the film itself
             bytes_per_req = known / film["TCP_TCC_READ_REQ_sum"]
             out["l2_bytes_per_request_calibrated_on_k_film"] = round(bytes_per_req, 2)
         out["l2_read_bytes_per_launch"] = round(tot["TCP_TCC_READ_REQ_sum"] * bytes_per_req / n)
+    # the shading kernel, same passes, same definitions (17 % of a step's VALU instructions: on the critical path of a VALU-bound job)
+    sh, sh_tot = digest(lambda name: name == "k_shade")
+    if sh is not None:
+        if sh_tot.get("TCP_TCC_READ_REQ_sum", 0) > 0:
+            sh["l2_read_bytes_per_launch"] = round(sh_tot["TCP_TCC_READ_REQ_sum"] * bytes_per_req / sh["launches"])
+            sh["l2_hit_rate"] = round(sh_tot["TCC_HIT_sum"] / max(sh_tot["TCC_HIT_sum"] + sh_tot["TCC_MISS_sum"], 1.0), 4)
+        out["k_shade"] = sh
     out["source"] = ("rocprofv3 --kernel-trace --pmc passes (FETCH_SIZE | WRITE_SIZE | TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum | SQ_INSTS_VALU "
                      "SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE TA_TA_BUSY_sum) run by bench.py on a "
                      "child process; FETCH_SIZE x 2 (gfx950)")
@@ -700,9 +736,14 @@ def main():
         known = {k: v for k, v in fr.items() if v is not None}
         bound = max(known, key=known.get) if known else "valu"
         if bound == "valu" and valu:
-            top = {"achieved": valu["Ginstr_per_s"], "peak": round(valu["Ginstr_per_s"] / max(valu["issue_busy"], 1e-9), 1),
-                   "unit": "Ginstr/s (wave64 VALU instructions; peak = the rate at which this instruction mix saturates VALU issue: 1024 SIMDs x clock / measured cycles per instruction)",
-                   "frac": valu["issue_busy"]}
+            # VALU issue is the bound; an issue slot whose lanes are masked off is not work, so what is counted is LANE-instructions: the wave
+            # instructions the kernel issues x the share of their 64 lanes that are active, against the rate at which this instruction mix would
+            # leave the VALUs with every lane active and no idle cycle.  frac = issue_busy x lane_util.
+            peak_w = valu["Ginstr_per_s"] / max(valu["issue_busy"], 1e-9)
+            top = {"achieved": round(valu["Ginstr_per_s"] * 64.0 * valu["lane_util"], 1), "peak": round(peak_w * 64.0, 1),
+                   "unit": "G lane-instructions/s (wave64 VALU instructions x active lanes; peak = 64 lanes x the rate at which this instruction mix saturates "
+                           "VALU issue: 1024 SIMDs x clock / measured cycles per instruction)",
+                   "frac": round(valu["issue_busy"] * valu["lane_util"], 4)}
         elif bound == "l2" and l2:
             top = {"achieved": l2["GBps"], "peak": L2_PEAK_GBS, "unit": "GB/s", "frac": l2["frac"]}
         elif hbm:
@@ -715,6 +756,14 @@ def main():
             "achieved": top["achieved"], "peak": top["peak"], "unit": top["unit"], "frac": top["frac"],
             "traffic": tr_bytes,
             "fractions": fr, "hbm": hbm, "l2": l2, "valu": valu,
+            "frac_def": "issue_busy x lane_util of the dominant kernel when VALU issue is the bound (`fractions.valu` is issue_busy alone: that picks the bound)",
+            # the same against the guide's issue peak (a wave64 VALU instruction every 2 cycles: MI355X_MICROARCH.md's 157.3 TFLOP/s FP32); this mix
+            # (v_fma_mix, v_min3 / v_max3, v_cndmask, v_alignbit) issues at ~4
+            "frac_vs_guide_issue_peak": round(valu["rate_frac_of_fp32_peak"] * valu["lane_util"], 4) if valu else None,
+            "why_not_hbm": ("north_star's >= 40 % of the HBM roofline does not apply to this kernel at this scene size: what it walks (2.7 MB of nodes + 4.8 MB of "
+                            "primitive records) stays in L2 / LDS (hit rate in `l2`), so its HBM-side traffic is the ray and hit streams only -- counter traffic / "
+                            "gathered bytes = `hbm_over_gathered` -- and no re-read is wasted; the ceiling it does sit at is VALU issue" ),
+            "hbm_over_gathered": round(tr_bytes / max(gather_bytes / n_launch, 1.0), 4) if tr_bytes else None,
             "hbm_GBps": hbm["GBps"] if hbm else None, "hbm_frac": fr["hbm"], "l2_frac": fr["l2"], "valu_frac": fr["valu"],
             # the records the launch gathers from global memory against the two ceilings of that access pattern measured in THIS run
             # (random 64-byte records, 4 x dwordx4 per lane: from an array of the traversal data's size, and from 2 MB = L2-resident);
@@ -725,6 +774,7 @@ def main():
                        "working_set_bytes": int(working_set),
                        "def": "64 B x 4-wide node visits not served from LDS + 48 B x primitive tests + 40 B x rays (ordered-traversal device counters of the "
                               "same frames) / mean k_trace launch duration (HIP events); peaks: tirt_micro_gather_rate"},
+            "k_shade": shade_ceilings(pmc.get("k_shade") if ok else None),
             "traffic_detail": pmc, "bvh": info,
             "avg_launch_ms": round(avg_ms, 5), "launches": int(n_launch),
             "node_visits_per_ray": round(node_visits / max(rays_o, 1), 2),
@@ -747,12 +797,15 @@ def main():
             # fraction of any roofline of this kernel
             "alg_reference_semantics": {
                 "bytes_per_launch": round(alg_trace / n_launch, 1),
-                "GBps_equivalent": round((alg_trace / n_launch) / (avg_ms * 1e-3) / 1e9, 1) if avg_ms > 0 else None,
+                # NOT a bandwidth of this kernel: the bytes the REFERENCE'S algorithm would have moved for these rays, divided by the time this
+                # kernel takes for them (it visits ~11 times fewer nodes and is L2-resident)
+                "reference_bytes_per_second_of_this_kernel_GBps__not_a_bandwidth": round((alg_trace / n_launch) / (avg_ms * 1e-3) / 1e9, 1) if avg_ms > 0 else None,
+                "times_fewer_bytes_gathered_than_the_reference_semantics": round(alg_trace / max(gather_bytes, 1.0), 1),
                 "bytes_per_closest_ray": round(alg_closest / max(c["rays_closest"], 1), 1),
                 "bytes_per_shadow_ray": round(alg_shadow / max(c["rays_shadow"], 1), 1),
                 "n_box_per_closest_ray": round(c["box_closest"] / max(c["rays_closest"], 1), 2),
                 "n_leaf_per_closest_ray": round(c["leaf_closest"] / max(c["rays_closest"], 1), 2),
-                "whole_job_GBps_equivalent": round((alg_closest + alg_shadow + 260.0 * c["shaded"] + 24.0 * c["paths"]) /
+                "whole_job_reference_bytes_per_second_GBps__not_a_bandwidth": round((alg_closest + alg_shadow + 260.0 * c["shaded"] + 24.0 * c["paths"]) /
                                                    max(t["ms_render"], 1e-9) / 1e6, 2)},
         }
 
