@@ -71,6 +71,23 @@ def spot_laser_scene(W, H, kinds=("spot", "laser"), device_id=None, integrator="
     return ex
 
 
+def cornell_glass_wall(W, H, device_id=None, integrator="pt"):
+    """The Cornell box with its red wall turned into a sheet of glass (ior 1.5, extinction 500 scene units): Disney surfaces, the quad
+    light AND Glass.sample / the delta flags / the extinction roulette in one small scene (tools/refkat/make_refkat.py renders it through
+    the reference's own source text; tests/test_refkat.py and the GPU tests render it through the oracle and the device)."""
+    from ti_raytrace_amd import BDPT_RGB
+    ex = scenes.cornell_box(W, H, 4, device_id=device_id)
+    for m in ex.scene.material_cpu:
+        if m.type == SCD.MAT_DISNEY and tuple(np.round(m.color[:3], 3)) == (1.0, 0.0, 0.0):
+            m.type = SCD.MAT_GLASS; m.setIor(1.5); m.setExtinciton(500.0)
+            break
+    else:
+        raise AssertionError("no red material in cornell_box.obj")
+    if integrator == "bdpt":
+        ex.integrator = BDPT_RGB.BDPT(W, H, ex.cam, ex.scene, 64)
+    return ex
+
+
 def rel_l2(a, b):
     return float(np.sqrt(((a.astype(np.float64) - b) ** 2).sum() / max((b.astype(np.float64) ** 2).sum(), 1e-30)))
 

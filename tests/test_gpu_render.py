@@ -447,7 +447,7 @@ def test_torch_cuda_still_comes_up_after_this_library(gpu_ctx_ok):
     assert pr.returncode == 0 and pr.stdout.decode().strip().endswith("8.0"), pr.stdout.decode()[-800:]
 
 
-@pytest.mark.parametrize("name", ["cornell", "sphere"])
+@pytest.mark.parametrize("name", ["cornell", "sphere", "cornell_glass"])
 def test_device_film_equals_the_reference_text_film(gpu_ctx_ok, name):
     """tests/golden/refkat_render.npz: the film integrator/PT_RGB.py's own source text produces (executed as plain Python through the
     taichi stand-in of tools/refkat, build container only; tests/test_refkat.py has the details and holds the oracle to it)."""

@@ -226,15 +226,18 @@ def render_reference_text(out, W, H, frames, seed, scene_name):
         return f
     ti.set_math({"sin": m1(0), "cos": m1(1), "exp": m1(2), "log": m1(3), "pow": m2(4), "atan2": m2(5), "acos": m1(6)})
 
+    from common import cornell_glass_wall
     if scene_name == "cornell":
         ex = scenes.cornell_box(W, H, 4, device_id=None)
+    elif scene_name == "cornell_glass":
+        ex = cornell_glass_wall(W, H)
     else:                                                          # glass + disney + sphere light + env map + smooth normals
         ex = scenes.single_model(W, H, 4, model="sphere.obj", device_id=None)
     host_only(ex, 0.8)
     sc = ex.scene
     orc = oa.OracleScene(sc, ex.cam)
     orc.lbvh_build()
-    if scene_name != "cornell":
+    if scene_name == "sphere":
         vi = np.ascontiguousarray(sc.vertex_index_np, np.int32)
         orc.L.orc_process_normal(orc.h, vi)                        # smooth normals (Scene.process_normal), pinned elsewhere
         sc.vertex_np[...] = orc.vertex()
@@ -299,21 +302,144 @@ def render_reference_text(out, W, H, frames, seed, scene_name):
     ti.set_math({k: None for k in ()}); ti._math_impl.clear()
 
 
+# ---- integrator/BDPT_RGB.py (BASELINE config 5's integrator), executed from its source text the same way -------------------------------
+# render(): eye_path, light_path (Scene.sample_light), connect_path for every (e, l) with its Scene.closet_hit_shadow, mis_weight with its
+# save / modify / restore of vertices through the temp arrays, the light-tracing splats through Camera.get_image_point -- and the
+# reference's one-set-of-vertex-arrays-per-pixel that persists from frame to frame (the `delta` memory the device replays in k_bd_delta).
+# ti.random() by call site again: which function draws (walking up to eye_path / light_path / connect_path for the depth or the eye
+# vertex), the how-many-th draw of that function in bytecode order -> the oracle's BD_DIM_* schedule (oracle.c:1914-1917).
+def _random_call_offsets(code):
+    """bytecode offsets of the `ti.random()` calls of a function, in source order"""
+    import dis
+    offs, pending = [], False
+    for ins in dis.get_instructions(code):
+        if ins.opname in ("LOAD_METHOD", "LOAD_ATTR") and ins.argval == "random":
+            pending = True
+        elif pending and ins.opname.startswith("CALL"):
+            offs.append(ins.offset); pending = False
+        elif ins.opname in ("LOAD_GLOBAL", "LOAD_FAST") and pending and ins.argval != "ti":
+            pending = False
+    return offs
+
+
+def render_bdpt_reference_text(out, W, H, frames, seed, scene_name):
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+    import oracle_api as oa
+    from common import host_only
+    from ti_raytrace_amd import scenes
+    import Scene as RScene, BDPT_RGB as RBD, SceneData as RSCD
+    for _m in (RScene, RBD):
+        _m.pow = ti.pow_
+    L = oa.load()
+
+    def m1(fn):
+        def f(x):
+            o = np.zeros(1, np.float32); L.orc_kat_math(fn, np.array([x], np.float32), np.zeros(1, np.float32), o, 1); return o[0]
+        return f
+
+    def m2(fn):
+        def f(x, y):
+            o = np.zeros(1, np.float32); L.orc_kat_math(fn, np.array([x], np.float32), np.array([y], np.float32), o, 1); return o[0]
+        return f
+    ti.set_math({"sin": m1(0), "cos": m1(1), "exp": m1(2), "log": m1(3), "pow": m2(4), "atan2": m2(5), "acos": m1(6)})
+    from common import cornell_glass_wall
+    ex = scenes.cornell_box(W, H, 4, device_id=None) if scene_name == "cornell" else cornell_glass_wall(W, H, integrator="bdpt")
+    host_only(ex, 0.8)
+    sc = ex.scene
+    orc = oa.OracleScene(sc, ex.cam)
+    orc.lbvh_build()
+    _, _, compact = orc.lbvh_get()
+    rcam = Camera.Camera(W, H, 4)
+    rcam.view.from_numpy(ex.cam.view_np); rcam.view_inv.from_numpy(ex.cam.view_inv_np); rcam.eye.from_numpy(ex.cam.eye_np)
+    rs = RScene.Scene()
+    rs.material.from_numpy(sc.material_np); rs.vertex.from_numpy(sc.vertex_np); rs.primitive.from_numpy(sc.primitive_np)
+    rs.shape.from_numpy(sc.shape_np); rs.light.from_numpy(sc.light_np.astype(np.int32))
+    rs.light_count = sc.light_count; rs.primitive_count = sc.primitive_count; rs.env_power = np.float32(sc.env_power)
+    rs.env.np_img = sc.env.np_img; rs.env.wid, rs.env.hgt = sc.env.np_img.shape; rs.env.buf.from_numpy(sc.env.np_img)
+
+    class _B:
+        pass
+    rs.bvh = _B(); rs.bvh.compact_node = ti.Vector.field(RSCD.CPNOD_VEC_SIZE, dtype=ti.f32); rs.bvh.compact_node.from_numpy(compact)
+    bd = RBD.BDPT(W, H, rcam, rs, 64)
+    bd.setup_data_cpu()
+
+    offsets = {}
+    used = set()
+    EYE, LSTART, LIGHT, CONNECT = 16, 80, 96, 176             # oracle.c: BD_DIM_EYE / LSTART / LIGHT / CONNECT
+
+    def rnd():
+        f = sys._getframe(2)
+        if f.f_code not in offsets:
+            offsets[f.f_code] = _random_call_offsets(f.f_code)
+        k = offsets[f.f_code].index(f.f_lasti)
+        name = f.f_code.co_name
+        chain = []
+        g = f
+        while g is not None and g.f_code.co_name != "render":
+            chain.append(g); g = g.f_back
+        names = [c.f_code.co_name for c in chain]
+        i, j = g.f_locals["i"], g.f_locals["j"]
+
+        def local(fn, var):
+            return next(c for c in chain if c.f_code.co_name == fn).f_locals[var]
+        if name == "get_ray_direction":
+            dim = k
+        elif name in ("eye_path", "light_path"):                 # the extinction roulette of that sub-path's vertex
+            dim = (EYE if name == "eye_path" else LIGHT) + 8 * int(f.f_locals["depth"]) + 6
+        elif name == "sample" and ("eye_path" in names or "light_path" in names):       # Glass.sample: slot 0; Disney.sample: slots 3, 4, 5
+            base = (EYE + 8 * int(local("eye_path", "depth"))) if "eye_path" in names else (LIGHT + 8 * int(local("light_path", "depth")))
+            dim = base + (0 if f.f_globals["__name__"] == "Glass" else 3 + k)
+        elif "sample_light" in names:                                  # Scene.sample_light for the light sub-path's first vertex
+            dim = LSTART + {"get_random_light_prim_index": 0, "get_prim_random_point_normal": 1 + k, "sample_light": 3 + k}[name]
+        elif "sample_li" in names and "connect_path" in names:         # the l == 1 connection at eye vertex e
+            dim = CONNECT + 4 * int(local("connect_path", "e")) + {"get_random_light_prim_index": 0, "get_prim_random_point_normal": 1 + k}[name]
+        else:
+            raise RuntimeError("ti.random() from an unexpected place: %s" % names)
+        used.add((name, k))
+        return L.orc_kat_rand(seed, int(i) * H + int(j), int(rcam.frame_gpu[0]), dim)
+    ti.set_random(rnd)
+
+    import io, contextlib
+    for fr in range(frames):
+        rcam.frame_gpu[0] = fr
+        with contextlib.redirect_stdout(io.StringIO()):
+            bd.render()
+    film = bd.hdr.to_numpy().astype(np.float32)
+    want, st, _ = orc.bdpt_render(ex.cam, W, H, 0, frames, seed=seed)
+    rel = float(np.sqrt(((film.astype(np.float64) - want) ** 2).sum() / max((want.astype(np.float64) ** 2).sum(), 1e-30)))
+    per = np.abs(film.astype(np.float64) - want) / np.maximum(np.abs(want), 1e-3)
+    print("BDPT %s %dx%d x %d frames: reference text vs oracle: rel-L2 %.3e, worst value %.3e, draw sites used %d, film mean %.4f"
+          % (scene_name, W, H, frames, rel, per.max(), len(used), float(film.mean())))
+    out["bdpt_%s_film" % scene_name] = film
+    out["bdpt_%s_cfg" % scene_name] = np.array([W, H, frames, seed], np.int64)
+    ti._math_impl.clear()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden", "refkat.npz"))
     ap.add_argument("--render", action="store_true", help="also run integrator/PT_RGB.py's render from its source text (minutes)")
     ap.add_argument("--render-only", action="store_true")
+    ap.add_argument("--bdpt-only", action="store_true", help="integrator/BDPT_RGB.py's render from its source text (minutes)")
     a = ap.parse_args()
-    if not a.render_only:
+    if not (a.render_only or a.bdpt_only):
         out = {}
         kat_functions(out)
         np.savez_compressed(a.out, **out)
         print("wrote", a.out, "(%d arrays, %.1f KB)" % (len(out), os.path.getsize(a.out) / 1024))
+    if a.bdpt_only:
+        out = {}
+        render_bdpt_reference_text(out, 16, 16, 4, 7, "cornell")
+        render_bdpt_reference_text(out, 16, 16, 4, 7, "cornell_glass")
+        path = a.out.replace("refkat.npz", "refkat_bdpt.npz")
+        np.savez_compressed(path, **out)
+        print("wrote", path)
+        return
     if a.render or a.render_only:
         out = {}
         render_reference_text(out, 16, 16, 4, 7, "cornell")
         render_reference_text(out, 16, 16, 4, 7, "sphere")
+        render_reference_text(out, 16, 16, 4, 7, "cornell_glass")
         path = a.out.replace("refkat.npz", "refkat_render.npz")
         np.savez_compressed(path, **out)
         print("wrote", path)

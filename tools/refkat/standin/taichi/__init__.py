@@ -245,8 +245,18 @@ class _Root:
 root = _Root()
 
 
+def _pot(n):
+    p = 1
+    while p < n:
+        p <<= 1
+    return p
+
+
 class Field:
-    """ti.field / ti.Vector.field / ti.Matrix.field backed by a numpy array; element access returns python-side Vector / Matrix copies."""
+    """ti.field / ti.Vector.field / ti.Matrix.field backed by a numpy array; element access returns python-side Vector / Matrix copies.
+    As in Taichi's dense SNodes, every axis is padded to a power of two and an index is taken modulo that size (bit extraction): the
+    reference writes to index -1 in places (BDPT_RGB.py:472-477 restores `light[l-1]` / `eye[e-2]` with l = 0 / e = 1), which in Taichi
+    lands in the padding behind a depth axis of 6 or 7 -- not, as a Python index would, on the last real element."""
     def __init__(self, dtype, shape=None, inner=None):
         self.dtype = np.int32 if dtype in (i32, int) else (np.uint32 if dtype is u32 else np.float32)
         self.inner = inner
@@ -256,20 +266,28 @@ class Field:
 
     def _alloc(self, shape):
         inner = () if self.inner is None else ((self.inner,) if isinstance(self.inner, int) else tuple(self.inner))
-        self.a = np.zeros(tuple(shape) + inner, self.dtype)
-        self.shape = tuple(shape)
+        self.shape = tuple(int(x) for x in shape)
+        self.pot = tuple(_pot(x) for x in self.shape)
+        self.a = np.zeros(self.pot + inner, self.dtype)
+
+    def _logical(self):
+        return self.a[tuple(slice(0, n) for n in self.shape)]
 
     def from_numpy(self, arr):
         arr = np.asarray(arr)
-        if self.a is None or self.a.shape != arr.shape:
-            self.a = np.zeros(arr.shape, self.dtype)
-            nin = 0 if self.inner is None else (1 if isinstance(self.inner, int) else 2)
-            self.shape = arr.shape[: arr.ndim - nin]
-        self.a[...] = arr.astype(self.dtype)
+        nin = 0 if self.inner is None else (1 if isinstance(self.inner, int) else 2)
+        shape = arr.shape[: arr.ndim - nin]
+        if self.a is None or self.shape != tuple(shape):
+            self._alloc(shape)
+        self._logical()[...] = arr.astype(self.dtype)
 
-    def to_numpy(self): return self.a.copy()
+    def to_numpy(self): return self._logical().copy()
 
-    def _idx(self, k): return k if isinstance(k, tuple) else (k,)
+    def _idx(self, k):
+        if isinstance(k, Vector):                    # field[ti.Vector([u, v])]
+            k = tuple(k.e)
+        k = k if isinstance(k, tuple) else (k,)
+        return tuple(int(x) & (p - 1) for x, p in zip(k, self.pot))
 
     def __getitem__(self, k):
         v = self.a[self._idx(k)]
