@@ -88,6 +88,16 @@ def cornell_glass_wall(W, H, device_id=None, integrator="pt"):
     return ex
 
 
+def refkat_lbvh_scene(which, device_id=None):
+    """The two scenes tools/refkat/make_refkat.py --lbvh-only builds through the reference's accel/LBvh.py (tests/golden/refkat_lbvh.npz)"""
+    if which == "duplicates":
+        ex = duplicate_code_scene(16, 16, device_id=device_id)
+        ex.add_sphere_light(pos=(0.3, 0.2, -0.4), radius=0.2, emission=10.0)
+    else:
+        ex = tiny_scene(700, seed=11, W=16, H=16, spread=0.2, device_id=device_id)
+    return ex
+
+
 def rel_l2(a, b):
     return float(np.sqrt(((a.astype(np.float64) - b) ** 2).sum() / max((b.astype(np.float64) ** 2).sum(), 1e-30)))
 

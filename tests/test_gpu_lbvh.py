@@ -88,3 +88,18 @@ def test_headline_100k(gpu_ctx_ok):
     assert_same_lbvh(ex, o)
     st = ex.scene.ctx.stats()
     print("GPU LBVH build: %.3f ms for %d primitives" % (st["ms_build"], ex.scene.primitive_count))
+
+
+@pytest.mark.parametrize("which", ["duplicates", "random700"])
+def test_device_lbvh_equals_the_reference_text_lbvh(gpu_ctx_ok, which):
+    """tests/golden/refkat_lbvh.npz: what accel/LBvh.py's own source text builds (executed as plain Python through the taichi stand-in of
+    tools/refkat, build container only; tests/test_refkat.py has the details and holds the oracle to it)."""
+    from common import refkat_lbvh_scene
+    from test_refkat import GL
+    ex = refkat_lbvh_scene(which, device_id=0)
+    ex.build_scene()
+    n = ex.scene.primitive_count
+    gm, gb, gc = ex.scene.ctx.lbvh_download(n)
+    assert np.array_equal(gm, GL["lbvh_%s_morton" % which])
+    assert np.array_equal(gb.view(np.uint32), GL["lbvh_%s_bvh_node" % which].view(np.uint32))
+    assert np.array_equal(gc.view(np.uint32), GL["lbvh_%s_compact_node" % which].view(np.uint32))

@@ -218,3 +218,26 @@ def test_oracle_bdpt_film_equals_the_reference_text_film(name):
     assert np.isfinite(want).all() and want.mean() > 0.05
     rel, per = film_close(got, want)
     assert rel <= 1e-5 and per <= 1e-4, (rel, per)
+
+
+# ---- accel/LBvh.py from its source text (tests/golden/refkat_lbvh.npz) -----------------------------------------------------------------
+# build_morton_3d, the 30 one-bit radix passes with their Blelloch scans, build_lbvh with determineRange / findSplit, gen_aabb to its fixed point and
+# the recursive flatten, executed as plain Python (the stand-in's decorators give `a = b` Taichi's copy semantics: LBvh.py:404-411 assigns one
+# vertex to min_v3 AND max_v3 and then edits both) on two scenes nodelist.txt does not reach: 154 primitives with 111 adjacent EQUAL Morton codes
+# (the duplicate rule of determineRange, accel/LBvh.py:240-251) plus two analytic spheres, and 701 random primitives.  Bit for bit.
+GL = np.load(os.path.join(os.path.dirname(__file__), "golden", "refkat_lbvh.npz"))
+
+
+@pytest.mark.parametrize("which", ["duplicates", "random700"])
+def test_oracle_lbvh_equals_the_reference_text_lbvh(which):
+    from common import host_only, refkat_lbvh_scene
+    ex = refkat_lbvh_scene(which); host_only(ex, 0.8)
+    orc = oa.OracleScene(ex.scene, ex.cam)
+    orc.lbvh_build()
+    m, b, c = orc.lbvh_get()
+    assert int(GL["lbvh_%s_n" % which][0]) == ex.scene.primitive_count
+    if which == "duplicates":
+        assert int(GL["lbvh_%s_n" % which][1]) > 50                # adjacent equal codes: the rule is exercised
+    assert np.array_equal(m, GL["lbvh_%s_morton" % which])
+    assert np.array_equal(b.view(np.uint32), GL["lbvh_%s_bvh_node" % which].view(np.uint32))
+    assert np.array_equal(c.view(np.uint32), GL["lbvh_%s_compact_node" % which].view(np.uint32))

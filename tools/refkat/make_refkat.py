@@ -415,18 +415,70 @@ def render_bdpt_reference_text(out, W, H, frames, seed, scene_name):
     ti._math_impl.clear()
 
 
+# ---- accel/LBvh.py: the reference's LBVH build executed from its source text ------------------------------------------------------------
+# build_morton_3d, the 30 one-bit radix passes with their Blelloch scans (radix_sort_predicate / blelloch_scan_reduce / _downsweep /
+# radix_sort_fill), build_lbvh with determineRange / findSplit (the duplicate-code rule included), gen_aabb until done, the recursive Python
+# flatten -- on scenes nodelist.txt (35 primitives, no equal codes) does not reach: 154 primitives with runs of IDENTICAL Morton codes and two
+# analytic spheres; 701 random primitives.  Struct-for loops run in index order here, in parallel in Taichi: every loop of this file is order-independent
+# (scan steps touch disjoint pairs; gen_aabb is iterated to a fixed point).
+def lbvh_reference_text(out, which):
+    import tempfile
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+    import oracle_api as oa
+    from common import duplicate_code_scene, host_only
+    import LBvh as RL, SceneData as RSCD
+    RL.min, RL.max = ti.vmin, ti.vmax
+    from common import refkat_lbvh_scene
+    ex = refkat_lbvh_scene(which)
+    host_only(ex, 0.8)
+    sc = ex.scene
+    n = sc.primitive_count
+    vertex = ti.Vector.field(RSCD.VER_VEC_SIZE, dtype=ti.f32); vertex.from_numpy(sc.vertex_np)
+    shape = ti.Vector.field(RSCD.SHA_VEC_SIZE, dtype=ti.f32); shape.from_numpy(sc.shape_np)
+    prim = ti.Vector.field(RSCD.PRI_VEC_SIZE, dtype=ti.i32); prim.from_numpy(sc.primitive_np)
+    bvh = RL.Bvh(n, sc.minboundarynp, sc.maxboundarynp)
+    cwd = os.getcwd()
+    import io, contextlib
+    with tempfile.TemporaryDirectory() as tmp:                     # (the reference writes nodelist.txt into the working directory)
+        os.chdir(tmp)
+        try:
+            with contextlib.redirect_stdout(io.StringIO()):
+                bvh.setup_data_cpu()
+                bvh.setup_data_gpu(vertex, shape, prim)
+        finally:
+            os.chdir(cwd)
+    morton = bvh.morton_code_s.to_numpy().astype(np.int32)
+    node = bvh.bvh_node.to_numpy().astype(np.float32)
+    compact = bvh.compact_node.to_numpy().astype(np.float32)
+    orc = oa.OracleScene(sc, ex.cam); orc.lbvh_build()
+    om, ob, oc = orc.lbvh_get()
+    dup = int((np.diff(morton[:, 0]) == 0).sum())
+    print("LBVH %d primitives (%d adjacent equal Morton codes): reference text vs oracle: morton %s, bvh_node %s, compact_node %s"
+          % (n, dup, np.array_equal(morton, om), np.array_equal(node.view(np.uint32), ob.view(np.uint32)), np.array_equal(compact.view(np.uint32), oc.view(np.uint32))))
+    out.update({"lbvh_%s_morton" % which: morton, "lbvh_%s_bvh_node" % which: node, "lbvh_%s_compact_node" % which: compact, "lbvh_%s_n" % which: np.array([n, dup], np.int64)})
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden", "refkat.npz"))
     ap.add_argument("--render", action="store_true", help="also run integrator/PT_RGB.py's render from its source text (minutes)")
     ap.add_argument("--render-only", action="store_true")
+    ap.add_argument("--lbvh-only", action="store_true", help="accel/LBvh.py's build from its source text")
     ap.add_argument("--bdpt-only", action="store_true", help="integrator/BDPT_RGB.py's render from its source text (minutes)")
     a = ap.parse_args()
-    if not (a.render_only or a.bdpt_only):
+    if not (a.render_only or a.bdpt_only or a.lbvh_only):
         out = {}
         kat_functions(out)
         np.savez_compressed(a.out, **out)
         print("wrote", a.out, "(%d arrays, %.1f KB)" % (len(out), os.path.getsize(a.out) / 1024))
+    if a.lbvh_only:
+        out = {}
+        lbvh_reference_text(out, "duplicates")
+        lbvh_reference_text(out, "random700")
+        path = a.out.replace("refkat.npz", "refkat_lbvh.npz")
+        np.savez_compressed(path, **out)
+        print("wrote", path)
+        return
     if a.bdpt_only:
         out = {}
         render_bdpt_reference_text(out, 16, 16, 4, 7, "cornell")

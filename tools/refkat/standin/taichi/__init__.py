@@ -31,8 +31,41 @@ def init(*a, **kw):
     pass
 
 
-def func(f): return f
-def kernel(f): return f
+def _copy(x):
+    return x.copy() if isinstance(x, (Vector, Matrix)) else x
+
+
+def _taichi_scope(f):
+    """What the decorators do here: in Taichi scope `a = b` COPIES a vector (min_v3 = v1; max_v3 = v1; min_v3[k] = ... in accel/LBvh.py:404-411
+    must not touch max_v3), in Python it makes a second name for one object.  The function is recompiled from its source with every plain
+    `name = name` assignment turned into `name = copy(name)`; nothing else changes (same file name and line numbers, same globals)."""
+    import ast, inspect, textwrap
+    try:
+        src = textwrap.dedent(inspect.getsource(f))
+    except (OSError, TypeError):
+        return f
+    tree = ast.parse(src)
+    fd = tree.body[0]
+    fd.decorator_list = []
+
+    class T(ast.NodeTransformer):
+        def visit_Assign(self, node):
+            self.generic_visit(node)
+            if isinstance(node.value, ast.Name) and all(isinstance(t, ast.Name) for t in node.targets):
+                node.value = ast.Call(func=ast.Name(id="__ti_copy__", ctx=ast.Load()), args=[node.value], keywords=[])
+            return node
+    T().visit(tree)
+    ast.increment_lineno(tree, f.__code__.co_firstlineno - 1)          # line k of the snippet is line co_firstlineno + k - 1 of the file
+    ast.fix_missing_locations(tree)
+    g = f.__globals__
+    g["__ti_copy__"] = _copy
+    ns = {}
+    exec(compile(tree, inspect.getsourcefile(f) or "<taichi-scope>", "exec"), g, ns)
+    return ns[f.__name__]
+
+
+def func(f): return _taichi_scope(f)
+def kernel(f): return _taichi_scope(f)
 def pyfunc(f): return f
 def data_oriented(c): return c
 def static(x): return x
@@ -122,8 +155,32 @@ def bit_cast(x, dtype):
     raise TypeError(dtype)
 
 
+class _IntRef(int):
+    """an element of a scalar integer field: an int that remembers where it lives, so that ti.atomic_add(field[i], v) can write"""
+    def __new__(cls, v, arr, idx):
+        o = int.__new__(cls, v); o._arr, o._idx = arr, idx
+        return o
+
+
 def atomic_add(a, b):
-    raise NotImplementedError("field += is done through Field.__setitem__")
+    old = int(a)
+    a._arr[a._idx] = old + int(b)
+    return old
+
+
+def vmin(a, b):
+    """what `min(a, b)` means inside a ti.func (elementwise on vectors); make_refkat.py binds the reference modules' `min` / `max` to these"""
+    if isinstance(a, Vector) or isinstance(b, Vector):
+        n = len(a) if isinstance(a, Vector) else len(b)
+        return Vector([vmin(a[k] if isinstance(a, Vector) else a, b[k] if isinstance(b, Vector) else b) for k in range(n)])
+    return b if b < a else a
+
+
+def vmax(a, b):
+    if isinstance(a, Vector) or isinstance(b, Vector):
+        n = len(a) if isinstance(a, Vector) else len(b)
+        return Vector([vmax(a[k] if isinstance(a, Vector) else a, b[k] if isinstance(b, Vector) else b) for k in range(n)])
+    return b if b > a else a
 
 
 # ---- vectors and matrices -----------------------------------------------------------------------------
@@ -228,6 +285,9 @@ class Matrix:
     def transpose(self):
         return Matrix([list(c) for c in zip(*self.m)])
 
+    def copy(self):
+        return Matrix([list(r) for r in self.m])
+
 
 # ---- fields --------------------------------------------------------------------------------------------
 class _Place:
@@ -292,7 +352,7 @@ class Field:
     def __getitem__(self, k):
         v = self.a[self._idx(k)]
         if self.inner is None:
-            return int(v) if self.dtype != np.float32 else np.float32(v)
+            return _IntRef(int(v), self.a, self._idx(k)) if self.dtype != np.float32 else np.float32(v)
         if isinstance(self.inner, int):
             return _Row(self.a, self._idx(k))
         return Matrix(v.tolist())
@@ -306,6 +366,8 @@ class Field:
             self.a[self._idx(k)] = v
 
     def __iter__(self):
+        if len(self.shape) == 1:                     # `for i in field` of a 1-D field: scalar indices
+            return iter(range(self.shape[0]))
         return iter(np.ndindex(*self.shape))
 
 
