@@ -103,3 +103,13 @@ def test_device_lbvh_equals_the_reference_text_lbvh(gpu_ctx_ok, which):
     assert np.array_equal(gm, GL["lbvh_%s_morton" % which])
     assert np.array_equal(gb.view(np.uint32), GL["lbvh_%s_bvh_node" % which].view(np.uint32))
     assert np.array_equal(gc.view(np.uint32), GL["lbvh_%s_compact_node" % which].view(np.uint32))
+
+
+def test_device_smooth_normals_equal_the_reference_text(gpu_ctx_ok):
+    """Scene.process_normal / total_area from the reference's source text (tests/golden/refkat_lbvh.npz, tests/test_refkat.py) vs k_smooth_normal / k_total_area."""
+    from test_refkat import GL
+    ex = scenes.single_model(16, 16, 4, model="sphere.obj", device_id=0)
+    ex.build_scene()                      # (single_model.build_scene runs process_normal and total_area on the device)
+    got = ex.scene.ctx.vertex_download(ex.scene.vertex_count)
+    assert np.array_equal(got.view(np.uint32), GL["normals_vertex_after"].view(np.uint32))
+    assert float(ex.scene.light_area.to_numpy()[0]) == float(GL["normals_total_area"][0])

@@ -241,3 +241,18 @@ def test_oracle_lbvh_equals_the_reference_text_lbvh(which):
     assert np.array_equal(m, GL["lbvh_%s_morton" % which])
     assert np.array_equal(b.view(np.uint32), GL["lbvh_%s_bvh_node" % which].view(np.uint32))
     assert np.array_equal(c.view(np.uint32), GL["lbvh_%s_compact_node" % which].view(np.uint32))
+
+
+def test_oracle_smooth_normals_equal_the_reference_text():
+    """Scene.process_normal (Scene.py:754-798) and Scene.total_area (:747-750) from their source text on single_model.py's sphere.obj (6 840
+    vertices): the per-vertex LBVH walk, the angle x area weights in the reference's visiting order, the final normalisation.  Bit for bit."""
+    from common import host_only
+    from ti_raytrace_amd import scenes
+    ex = scenes.single_model(16, 16, 4, model="sphere.obj", device_id=None); host_only(ex, 0.8)
+    assert np.array_equal(ex.scene.vertex_np.astype(np.float32).view(np.uint32), GL["normals_vertex_before"].view(np.uint32))      # the same input
+    orc = oa.OracleScene(ex.scene, ex.cam); orc.lbvh_build()
+    orc.L.orc_process_normal(orc.h, np.ascontiguousarray(ex.scene.vertex_index_np, np.int32))
+    got, want = orc.vertex(), GL["normals_vertex_after"]
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert not np.array_equal(want[:, 3:6], GL["normals_vertex_before"][:, 3:6])          # the pass did smooth something
+    assert float(orc.L.orc_total_area(orc.h)) == float(GL["normals_total_area"][0])

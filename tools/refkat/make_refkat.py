@@ -458,6 +458,54 @@ def lbvh_reference_text(out, which):
     out.update({"lbvh_%s_morton" % which: morton, "lbvh_%s_bvh_node" % which: node, "lbvh_%s_compact_node" % which: compact, "lbvh_%s_n" % which: np.array([n, dup], np.int64)})
 
 
+# ---- Scene.process_normal (Scene.py:754-798) and Scene.total_area (:747-750) from their source text ---------------------------------------
+# The smooth-normal pass walks the LBVH per vertex (point-in-box, the reference's push order), adds angle x area weighted neighbour normals in
+# that order, normalises -- including the NaNs it makes where acos gets a dot product just above 1 (Scene.py:377).  sphere.obj of single_model.py.
+def normals_reference_text(out):
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+    import oracle_api as oa
+    from common import host_only
+    from ti_raytrace_amd import scenes
+    import Scene as RScene, SceneData as RSCD
+    RScene.pow = ti.pow_
+    L = oa.load()
+
+    def m1(fn):
+        def f(x):
+            o = np.zeros(1, np.float32); L.orc_kat_math(fn, np.array([x], np.float32), np.zeros(1, np.float32), o, 1); return o[0]
+        return f
+    ti.set_math({"acos": m1(6)})
+    ex = scenes.single_model(16, 16, 4, model="sphere.obj", device_id=None)
+    host_only(ex, 0.8)
+    sc = ex.scene
+    orc = oa.OracleScene(sc, ex.cam); orc.lbvh_build()
+    _, _, compact = orc.lbvh_get()
+    rs = RScene.Scene()
+    rs.material.from_numpy(sc.material_np); rs.vertex.from_numpy(sc.vertex_np); rs.primitive.from_numpy(sc.primitive_np)
+    rs.shape.from_numpy(sc.shape_np); rs.light.from_numpy(sc.light_np.astype(np.int32)); rs.light_count = sc.light_count
+    rs.vertex_index.from_numpy(np.ascontiguousarray(sc.vertex_index_np, np.int32))
+    rs.smooth_normal.from_numpy(np.zeros((sc.vertex_count, 3), np.float32))
+    rs.stack.from_numpy(np.zeros((sc.vertex_count, RScene.MAX_STACK_SIZE), np.int32))
+    rs.light_area.from_numpy(np.zeros(1, np.float32))
+
+    class _B:
+        pass
+    rs.bvh = _B(); rs.bvh.compact_node = ti.Vector.field(RSCD.CPNOD_VEC_SIZE, dtype=ti.f32); rs.bvh.compact_node.from_numpy(compact)
+    before = sc.vertex_np.copy()
+    rs.process_normal()
+    rs.total_area()
+    got = rs.vertex.to_numpy().astype(np.float32)
+    orc.L.orc_process_normal(orc.h, np.ascontiguousarray(sc.vertex_index_np, np.int32))
+    want = orc.vertex()
+    nan_same = np.array_equal(np.isnan(got), np.isnan(want))
+    fin = np.isfinite(want)
+    print("process_normal %d vertices: reference text vs oracle: NaN pattern equal %s (%d NaN components), bit-identical rows %d / %d, max abs diff %.3e; total_area %r vs %r"
+          % (len(got), nan_same, int(np.isnan(want).sum()), int(((got.view(np.uint32) == want.view(np.uint32)) | ~fin).all(axis=1).sum()), len(got),
+             float(np.abs(np.where(fin, got - want, 0)).max()), float(rs.light_area[0]), float(orc.L.orc_total_area(orc.h))))
+    out.update(normals_vertex_before=before.astype(np.float32), normals_vertex_after=got, normals_total_area=np.array([rs.light_area[0]], np.float32))
+    ti._math_impl.clear()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden", "refkat.npz"))
@@ -475,6 +523,7 @@ def main():
         out = {}
         lbvh_reference_text(out, "duplicates")
         lbvh_reference_text(out, "random700")
+        normals_reference_text(out)
         path = a.out.replace("refkat.npz", "refkat_lbvh.npz")
         np.savez_compressed(path, **out)
         print("wrote", path)
