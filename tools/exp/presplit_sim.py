@@ -76,6 +76,17 @@ def run(label, boxes, owner):
                  rays.ctypes.data_as(C.c_void_p), len(rays), out.ctypes.data_as(C.c_void_p), tt.ctypes.data_as(C.c_void_p))
     print("%-28s refs %7d (x%.2f)  internal visits %.2f  triangle tests %.2f  hit rate %.3f" % (label, m, m / n, out[0], out[1], out[2]))
     if m == n:
+        for rel in (1e-3, 1e-2):
+            o3 = np.zeros(3, np.float64)
+            sim.simulate_plane_pretest(compact.ctypes.data_as(C.c_void_p), owner.ctypes.data_as(C.c_void_p), np.ascontiguousarray(T.reshape(-1, 9)).ctypes.data_as(C.c_void_p),
+                                       rays.ctypes.data_as(C.c_void_p), len(rays), C.c_float(rel), o3.ctypes.data_as(C.c_void_p))
+            print("   plane pre-test (crossing inside the leaf box's interval, widened by %g): triangle tests %.2f -> %.2f" % (rel, o3[0], o3[1]))
+        for mode, name in ((0, "bounding sphere"), (1, "AABB")):
+            for rel in (1e-3, 2e-2):
+                o4 = np.zeros(3, np.float64)
+                sim.simulate_point_pretest(compact.ctypes.data_as(C.c_void_p), owner.ctypes.data_as(C.c_void_p), np.ascontiguousarray(T.reshape(-1, 9)).ctypes.data_as(C.c_void_p),
+                                           rays.ctypes.data_as(C.c_void_p), len(rays), C.c_float(rel), mode, o4.ctypes.data_as(C.c_void_p))
+                print("   plane crossing in (0, best] and inside the %s (widened by %g): triangle tests %.2f -> %.2f, wrongly rejected hits %d" % (name, rel, o4[0], o4[1], int(o4[2])))
         for pk in (2, 3, 4):
             o2 = np.zeros(3, np.float64)
             sim.simulate_packets(compact.ctypes.data_as(C.c_void_p), csize.ctypes.data_as(C.c_void_p), pk, owner.ctypes.data_as(C.c_void_p),
