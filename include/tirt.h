@@ -65,6 +65,7 @@ typedef struct {
     /* timeline of the traversal waves (TIRT_COUNT_NODES only), 100 MHz ticks: their lifetimes summed, the part of a lifetime after the wave
      * found the ray queue empty (it only finishes the rays it holds), and how many waves ran */
     uint64_t diag_wave_ticks, diag_drain_ticks, diag_waves;
+    uint64_t launches_tail;   /* PT_RGB batches whose last bounces ran as one persistent launch (option "tail_paths") */
 } tirt_stats_t;
 
 const char *tirt_last_error(void);

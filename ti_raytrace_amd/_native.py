@@ -40,7 +40,7 @@ class Stats(C.Structure):
                                   "ms_trace_shadow", "ms_shade")] + [
         (n, C.c_uint64) for n in ("launches_trace_closest", "launches_trace_shadow",
                                   "launches_shade", "diag_it_node", "diag_lanes_node", "diag_it_leaf",
-                                  "diag_lanes_leaf", "diag_refills", "diag_it_outer", "diag_wave_ticks", "diag_drain_ticks", "diag_waves")]
+                                  "diag_lanes_leaf", "diag_refills", "diag_it_outer", "diag_wave_ticks", "diag_drain_ticks", "diag_waves", "launches_tail")]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

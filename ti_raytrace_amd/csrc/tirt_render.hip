@@ -36,9 +36,21 @@ namespace tirt {
 
 constexpr int TR_GRID_MAX = 2048;      // upper bound on persistent blocks (sizes the spill buffer)
 
-enum { KIND_CLOSEST = 0, KIND_SHADOW_ACC = 1, KIND_MIXED = 2, KIND_QUERY = 3 };
+enum { KIND_CLOSEST = 0, KIND_SHADOW_ACC = 1, KIND_MIXED = 2, KIND_QUERY = 3, KIND_TAIL = 4 };
 // MIXED: closest rays of bounce b + shadow rays of bounce b-1 in one launch.  QUERY: connection rays of BDPT -- "is sprim[q] the closest
 // hit, about sdist[q] away?" walked like a shadow ray (bounded), answered with the hit record (t, u, v, prim) instead of an accumulation.
+// TAIL: the rest of a PT_RGB batch in ONE launch, once few paths are left (see TailArgs): a lane keeps a PATH -- shades its hit (shade_path,
+// the same code as k_shade), walks its NEE shadow ray, then its next ray, bounce after bounce -- and fetches another path when this one ends.
+
+// KIND_TAIL.  The queue holds `*count_ptr` PATHS whose closest hit of bounce `bounce0` is in `hit` (an ordinary launch traced it, together with
+// the shadow rays of the bounce before).  State of path q in place at index q of the arrays the launch was given: ray (ox .. dz), throughput,
+// radiance (rr, rg, rb), brdf pdf, flags, slot; its pending shadow ray at index q of (sox .. sdz, scr .. scb, sprim, sdist).  Every path adds
+// exactly what the per-bounce launches add, in the same order (emission, then the NEE sample of that bounce once its ray has arrived), so the
+// film is the same bit for bit; random numbers are a function of (pixel, frame, bounce), not of who asks when.
+struct TailArgs {
+    SceneView sc; TileMap tm; int P; uint32_t frame_begin, seed; int bounce0, max_depth;
+    float *tr, *tg, *tb, *brdf_pdf; uint32_t *flags; const int *slot;
+};
 
 struct TraceArgs {
     BvhView bvh;
@@ -68,7 +80,133 @@ struct TraceArgs {
     // loads per ray where the arrays take six to eight (the BDPT ray lists: their kernels are bound by the number of memory instructions)
     const float4 *ray4;
     const int *ray_index;                        // KIND_QUERY: ray q is record ray_index[q] of ray4 (BDPT: the connection rays stay where they were staged; the queue is a list of places)
+    TailArgs tail;                               // KIND_TAIL
 };
+
+// One path at one bounce: what integrator/PT_RGB.py:66-132 does between the closest hit and the next one -- emission (with MIS), the glass / disney
+// branch, the NEE sample (its shadow ray and the contribution it adds IF the ray arrives), the next ray and the throughput, the environment
+// for a miss.  Shared by k_shade (one launch per bounce) and by the persistent tail kernel (k_trace<KIND_TAIL>), so that both apply the
+// same instructions to a path.  `radiance`, `throughout`, `brdf_pdf`, `perfect_spec` are the path's state coming in; `radiance` is updated in place.
+struct ShadeStep {
+    bool want_next = false, want_shadow = false, shaded = false;
+    v3 next_o = V(0.0f, 0.0f, 0.0f), next_d = next_o, next_thr = next_o, sh_o = next_o, sh_d = next_o, sh_c = next_o;
+    float next_pdf = 0.0f, sh_dist = 0.0f; int next_spec = 0, sh_expect = -2;
+};
+TD void shade_path(const SceneView &sc, const TileMap &tm, int P, uint32_t frame_begin, uint32_t seed, int bounce, int last_bounce, int slot,
+                   const v3 origin, const v3 direction, const float4 hrec, v3 throughout, v3 &radiance, float brdf_pdf, int perfect_spec, ShadeStep &s)
+{
+    const int f = slot / P, k = slot - f * P;
+    const uint32_t pixel = (uint32_t)local_to_pixel(tm, k);
+    const uint32_t frame = frame_begin + (uint32_t)f;
+    const uint32_t dim0 = TM_DIM_BOUNCE0 + TM_DIMS_PER_BOUNCE * (uint32_t)bounce;
+    const float t = hrec.x;
+    if (t < INF_VALUE) {
+        const int prim_id = __float_as_int(hrec.w);
+        int mat_id;
+        const HitAttr h = hit_attributes_rec(sc.shade_rec, origin, direction, prim_id, t, hrec.y, hrec.z, mat_id);
+        const v3 normal = h.nor;
+        const v3 fnormal = normal * signf(dot(-direction, h.gnor));            // UtilsFunc.py:465-467
+        const float *m = sc.material + (size_t)mat_id * MAT_VEC;
+        const v3 mat_color = V(m[2], m[3], m[4]);
+        const int mat_type = (int)m[0];
+        if (mat_type == MAT_LIGHT) {                                           // PT_RGB.py:72-81
+            const float fCosTheta = absf(dot(direction, h.gnor));
+            if (perfect_spec == 1) {
+                radiance = radiance + throughout * mat_color;
+            } else {
+                const float area = get_prim_area(sc, prim_id) * (float)sc.light_count;
+                const float light_pdf = (t * t) / (area * fCosTheta);
+                radiance = radiance + (throughout * power_heuristic(brdf_pdf, light_pdf)) * mat_color;
+            }
+        } else {
+            s.shaded = true;
+            // UF.srgb_to_lrgb(material colour) (PT_RGB.py:86): per-material table filled by the same device function
+            const v3 reflect_color = V(sc.mat_lrgb[mat_id * 3], sc.mat_lrgb[mat_id * 3 + 1], sc.mat_lrgb[mat_id * 3 + 2]);
+            v3 next_dir; float f_or_b = 1.0f, brdf = 1.0f;
+            if (mat_type == MAT_GLASS) {                                       // PT_RGB.py:89-92
+                perfect_spec = 1;
+                next_dir = glass_sample(m, direction, normal, tm_rand(seed, pixel, frame, dim0 + TM_SLOT_GLASS), f_or_b);
+                brdf = 1.0f; brdf_pdf = 1.0f;
+            } else {
+                perfect_spec = 0;
+                // Scene.py:477-518 sample_li.  No emitters (env-lit scene): the reference would index light[-1]
+                // (Scene.py:423-428, undefined) -- defined here, as in the oracle, as "no NEE sample"
+                if (sc.light_count > 0) {
+                int lidx = (int)(tm_rand(seed, pixel, frame, dim0 + TM_SLOT_LIGHT) * (float)sc.light_count);
+                if (lidx >= sc.light_count) lidx = sc.light_count - 1;
+                const int light_prim = sc.light[lidx];
+                const float ra = tm_rand(seed, pixel, frame, dim0 + TM_SLOT_LA);
+                const float rb = tm_rand(seed, pixel, frame, dim0 + TM_SLOT_LB);
+                v3 light_pos, light_normal;
+                get_prim_random_point_normal(sc, light_prim, ra, rb, light_pos, light_normal);
+                const int lmat = sc.primitive[(size_t)light_prim * PRI_VEC + 2];
+                const float *lm = sc.material + (size_t)lmat * MAT_VEC;
+                const v3 light_emission0 = V(lm[2], lm[3], lm[4]);
+                const float light_area = get_prim_area(sc, light_prim);
+                float light_choice_pdf = 1.0f / ((float)sc.light_count * light_area);
+                light_normal = normalized(light_normal);
+                v3 light_dir = h.pos - light_pos;
+                const float light_dist = norm(light_dir);
+                light_dir = light_dir / light_dist;
+                const v3 light_emission = light_emission0 * light_shape_visible(sc, light_prim, light_dir, light_normal, light_dist, light_choice_pdf);   // spot / laser (Scene.py:491-516)
+                const float NdotL_surface = dot(fnormal, light_dir);            // PT_RGB.py:101-109
+                const float NdotL_light = dot(light_normal, light_dir);
+                if ((NdotL_surface < 0.0f) & (NdotL_light > 0.0f)) {
+                    s.want_shadow = true;
+                    float e_pdf;
+                    const float e_brdf = disney_evaluate_pdf(m, fnormal, -direction, -light_dir, e_pdf);
+                    const float light_pdf = light_dist * light_dist * light_choice_pdf / NdotL_light;
+                    v3 c = V(0.0f, 0.0f, 0.0f);
+                    int expect = -2;                       // never equals a primitive id
+                    if (e_pdf > 0.0f) {
+                        const float w = power_heuristic(light_pdf, e_pdf) / maxf(0.0001f, light_pdf);
+                        c = light_emission * w;
+                        c = c * throughout;
+                        c = c * reflect_color;
+                        c = c * e_brdf;
+                        c = c * absf(NdotL_surface);
+                        expect = prim_id;
+                    }
+                    s.sh_o = light_pos; s.sh_d = light_dir; s.sh_c = c; s.sh_expect = expect; s.sh_dist = light_dist;
+                }
+                }   // light_count > 0
+                next_dir = disney_sample(m, direction, fnormal, tm_rand(seed, pixel, frame, dim0 + TM_SLOT_LOBE),
+                                         tm_rand(seed, pixel, frame, dim0 + TM_SLOT_R1),
+                                         tm_rand(seed, pixel, frame, dim0 + TM_SLOT_R2));
+                f_or_b = 1.0f;
+                brdf = disney_evaluate_pdf(m, fnormal, -direction, next_dir, brdf_pdf);
+                brdf *= absf(dot(normal, next_dir));
+            }
+            const v3 next_origin = offset_ray(h.pos, fnormal * signf(f_or_b));   // PT_RGB.py:115
+            if (brdf_pdf > 0.0f) {
+                bool alive = true;
+                if (f_or_b < 0.0f) {                                             // PT_RGB.py:118-122
+                    const float extinction = m[6];
+                    const float R = tm_exp(-t / extinction);
+                    if (tm_rand(seed, pixel, frame, dim0 + TM_SLOT_EXT) >= R) alive = false;
+                }
+                if (alive) {
+                    throughout = throughout * (reflect_color * (brdf / brdf_pdf));
+                    s.want_next = !last_bounce;      // depth reaches MAX_DEPTH after the last bounce: the loop ends
+                    s.next_o = next_origin; s.next_d = next_dir; s.next_thr = throughout;
+                    s.next_pdf = brdf_pdf; s.next_spec = perfect_spec;
+                }
+            }
+        }
+    } else if (sc.env_power == 0.0f && (direction.x - direction.x == 0.0f) && (direction.y - direction.y == 0.0f) &&
+               (direction.z - direction.z == 0.0f)) {
+        // black environment (PT_RGB.py:127-132 with env_power == 0): for a finite direction the lookup returns a
+        // finite e >= 0, so (e * throughput) * 0 is +-0 with throughput's sign, or NaN where throughput is not
+        // finite -- exactly throughput * env_power, without the two atan2, four texel fetches and three pow
+        radiance = radiance + throughout * sc.env_power;
+    } else {                                                                     // PT_RGB.py:127-132
+        const float dis = tm_sqrt(direction.x * direction.x + direction.z * direction.z);
+        const float tx = (tm_atan2(direction.z, direction.x) + PI_SCENE) / PI_SCENE / 2.0f;
+        const float ty = tm_atan2(direction.y, dis) / PI_SCENE + 0.5f;
+        const v3 e = srgb_to_lrgb(texture2d(sc, tx, ty));
+        radiance = radiance + (e * throughout) * sc.env_power;
+    }
+}
 
 // Persistent waves with ray re-fetch ("while-while" traversal): every wave keeps pulling rays
 // from the queue through one wave-aggregated atomic whenever at least TR_REFILL_MIN of its 64
@@ -105,8 +243,11 @@ TD unsigned long long wave_sum(unsigned long long v)
 typedef const __attribute__((address_space(4))) TraceArgs *cold_args_t;
 #define TR_COLD(ca) cold_args_t ca = (cold_args_t)__builtin_amdgcn_kernarg_segment_ptr(); asm volatile("" : "+s"(ca))
 
+#ifndef TR_TAIL_WAVES
+#define TR_TAIL_WAVES 3       // the tail kernel carries the shading code: 168 VGPRs, three 256-thread blocks per CU
+#endif
 template <int MODE, bool COUNT, int KIND>
-__global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
+__global__ __launch_bounds__(TR_BLOCK, KIND == KIND_TAIL ? TR_TAIL_WAVES : TR_MIN_WAVES) void k_trace(TraceArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) int lds_stack[];      // [lds_depth][TR_BLOCK]
     const int TR_LDS_DEPTH = a.lds_depth;
@@ -118,7 +259,7 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
 #endif
     constexpr bool BOUNDED = MAY_SHADOW && (MODE != TIRT_TRAVERSE_EXHAUSTIVE);
     const int count_c = (KIND == KIND_SHADOW_ACC || KIND == KIND_QUERY) ? 0 : (a.count_ptr ? *a.count_ptr : a.count_fixed);
-    const int count_s = (KIND == KIND_CLOSEST) ? 0 : (KIND == KIND_MIXED ? *a.scount_ptr : (a.count_ptr ? *a.count_ptr : a.count_fixed));
+    const int count_s = (KIND == KIND_CLOSEST || KIND == KIND_TAIL) ? 0 : (KIND == KIND_MIXED ? *a.scount_ptr : (a.count_ptr ? *a.count_ptr : a.count_fixed));
     const int count = count_c + count_s;
     const int tid = threadIdx.x, lane = tid & 63;
     const size_t gstride = (size_t)gridDim.x * TR_BLOCK, gtid = (size_t)blockIdx.x * TR_BLOCK + tid;
@@ -134,6 +275,10 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
     float lim = INF_VALUE;                      // ordered mode: min(hit_t * 1.0001, cull_far, INF_VALUE), entry distances beyond it are skipped
     // (ordered mode: a NEGATIVE cull_far marks a ray whose origin is more than TR_FAR_RHO root-box extents away -- no distance culling for it, see the set-up code)
     unsigned nbox = 0, nleaf = 0;
+    // KIND_TAIL: what the lane's path waits for.  0 no path; 1 closest-hit ray under way; 2 hit found (hit_t .. hit_prim), to be shaded;
+    // 3 / 6 shadow ray under way (3: a next ray follows, 6: the path ends with it); 4 next ray to be set up; 5 / 7 shadow ray to be set up (-> 3 / 6)
+    int st = 0, bounce_l = 0;
+    unsigned n_rc = 0, n_rs = 0, n_sh = 0;
     RayCtx r = {};
     // ordered mode: the ray in the grid of the quantised nodes.  Plane h (fp16, in cells) of axis a is crossed at
     // t = h * gA + gB (gA = cell / d, gB = (grid_min - o) / d); gBn / gBf are gB moved outward by a margin of
@@ -205,7 +350,8 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
     for (;;) {
         // ---- refill idle lanes -------------------------------------------------------------
         const unsigned long long idle = ballot64(!have);
-        if (idle != 0ull && !exhausted && (__popcll(idle) >= a.refill_min || idle == ~0ull)) {
+        const bool tail_waiting = (KIND == KIND_TAIL) && wave_any(!have && st != 0);
+        if (idle != 0ull && (!exhausted || tail_waiting) && (__popcll(idle) >= a.refill_min || idle == ~0ull)) {
             TR_COLD(ca);
             // (all of them read here, in one batch of scalar loads with one wait: left to itself the compiler loads each where it is used,
             // a chain of a dozen dependent round trips per refill)
@@ -227,27 +373,78 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
                          "s"(c_ic0), "s"(c_ic1), "s"(c_ic2), "s"(c_ce0), "s"(c_ce1), "s"(c_ce2), "s"(c_rn0), "s"(c_rn1), "s"(c_rn2), "s"(c_rx0), "s"(c_rx1), "s"(c_rx2));
             if (MAY_SHADOW) asm volatile("" :: "s"(c_sox), "s"(c_soy), "s"(c_soz), "s"(c_sdx), "s"(c_sdy), "s"(c_sdz), "s"(c_sprim), "s"(c_sdist));
             if (KIND == KIND_CLOSEST || KIND == KIND_QUERY) asm volatile("" :: "s"(c_ray4), "s"(c_rindex));
-            const int n_idle = __popcll(idle);
+            // (KIND_TAIL: only lanes without a path fetch one)
+            const unsigned long long fm = (KIND == KIND_TAIL) ? ballot64(!have && st == 0) : idle;
+            int my = count;
+            if (fm != 0ull && !exhausted) {
+            const int n_idle = __popcll(fm);
 #ifndef TR_DRAIN_DIAG
             if (COUNT) d_refills++;
 #endif
-            const int leader = __ffsll((long long)idle) - 1;
+            const int leader = __ffsll((long long)fm) - 1;
             // rays of slice `home`: its 64-ray chunks are the global chunks home, home + S, home + 2S, ...
             const int len = (((full_chunks >> S_LOG) + (home < (full_chunks & S_MASK) ? 1 : 0)) << 6) +
                             (home == (full_chunks & S_MASK) ? (count & 63) : 0);
             int base = 0;
             if (lane == leader) base = atomicAdd(c_fetch + home * TR_FETCH_STRIDE, n_idle);
             base = __shfl(base, leader, 64);
-            const int v = base + __popcll(idle & lt_mask);                // index within the slice
-            const int my = v < len ? (((((v >> 6) << S_LOG) + home) << 6) | (v & 63)) : count;
+            const int v = base + __popcll(fm & lt_mask);                  // index within the slice
+            my = v < len ? (((((v >> 6) << S_LOG) + home) << 6) | (v & 63)) : count;
             if (base + n_idle >= len) {                                    // slice drained: move on
                 home = (home + 1) & S_MASK;
                 if (++tried > S_MASK) { exhausted = true; if (COUNT) tk_exh = wall_clock64(); }
             }
-            if (!have && my < count) {
-                q = my;
+            }
+            if (KIND == KIND_TAIL) {
+                // a new path arrives with the closest hit of bounce `bounce0` found
+                if (!have && st == 0 && my < count) {
+                    q = my; bounce_l = ca->tail.bounce0; st = 2;
+                    const float4 h0 = ca->hit[q];
+                    hit_t = h0.x; hit_u = h0.y; hit_v = h0.z; hit_prim = __float_as_int(h0.w);
+                }
+                const bool sh_now = !have && st == 2;
+                if (wave_any(sh_now)) {
+                    if (sh_now) {
+                        float *const w_ox = (float *)c_ox, *const w_oy = (float *)c_oy, *const w_oz = (float *)c_oz, *const w_dx = (float *)c_dx, *const w_dy = (float *)c_dy, *const w_dz = (float *)c_dz;
+                        float *const c_tr = ca->tail.tr, *const c_tg = ca->tail.tg, *const c_tb = ca->tail.tb, *const c_pdf = ca->tail.brdf_pdf;
+                        float *const c_rr = ca->rr, *const c_rg = ca->rg, *const c_rb = ca->rb;
+                        uint32_t *const c_flags = ca->tail.flags; const int *const c_slot = ca->tail.slot;
+                        asm volatile("" :: "s"(c_tr), "s"(c_tg), "s"(c_tb), "s"(c_pdf), "s"(c_rr), "s"(c_rg), "s"(c_rb), "s"(c_flags), "s"(c_slot));
+                        const int slot = c_slot[q];
+                        const v3 p_o = V(w_ox[q], w_oy[q], w_oz[q]), p_d = V(w_dx[q], w_dy[q], w_dz[q]);
+                        const v3 p_thr = V(c_tr[q], c_tg[q], c_tb[q]);
+                        v3 p_rad = V(c_rr[q], c_rg[q], c_rb[q]);
+                        const float p_pdf = c_pdf[q]; const int p_spec = (int)(c_flags[q] & 1u);
+                        ShadeStep ss;
+                        shade_path(a.tail.sc, a.tail.tm, a.tail.P, a.tail.frame_begin, a.tail.seed, bounce_l, bounce_l == a.tail.max_depth - 1 ? 1 : 0, slot,
+                                   p_o, p_d, make_float4(hit_t, hit_u, hit_v, __int_as_float(hit_prim)), p_thr, p_rad, p_pdf, p_spec, ss);
+                        if (ss.shaded) n_sh++;
+                        if (ss.want_next) {
+                            w_ox[q] = ss.next_o.x; w_oy[q] = ss.next_o.y; w_oz[q] = ss.next_o.z; w_dx[q] = ss.next_d.x; w_dy[q] = ss.next_d.y; w_dz[q] = ss.next_d.z;
+                            c_tr[q] = ss.next_thr.x; c_tg[q] = ss.next_thr.y; c_tb[q] = ss.next_thr.z; c_pdf[q] = ss.next_pdf; c_flags[q] = (uint32_t)ss.next_spec;
+                            c_rr[q] = p_rad.x; c_rg[q] = p_rad.y; c_rb[q] = p_rad.z;
+                        } else {
+                            float *const f_r = ca->fr, *const f_g = ca->fg, *const f_b = ca->fb;
+                            f_r[slot] = p_rad.x; f_g[slot] = p_rad.y; f_b[slot] = p_rad.z;
+                        }
+                        if (ss.want_shadow) {
+                            float *const s_ox = (float *)c_sox, *const s_oy = (float *)c_soy, *const s_oz = (float *)c_soz, *const s_dx = (float *)c_sdx, *const s_dy = (float *)c_sdy, *const s_dz = (float *)c_sdz;
+                            float *const s_cr = (float *)ca->scr, *const s_cg = (float *)ca->scg, *const s_cb = (float *)ca->scb, *const s_dist = (float *)c_sdist; int *const s_prim = (int *)c_sprim;
+                            s_ox[q] = ss.sh_o.x; s_oy[q] = ss.sh_o.y; s_oz[q] = ss.sh_o.z; s_dx[q] = ss.sh_d.x; s_dy[q] = ss.sh_d.y; s_dz[q] = ss.sh_d.z;
+                            s_cr[q] = ss.sh_c.x; s_cg[q] = ss.sh_c.y; s_cb[q] = ss.sh_c.z; s_prim[q] = ss.sh_expect; s_dist[q] = ss.sh_dist;
+                        }
+                        st = ss.want_shadow ? (ss.want_next ? 5 : 7) : (ss.want_next ? 4 : 0);
+                    }
+                }
+            }
+            const bool setup_now = (KIND == KIND_TAIL) ? (!have && st >= 4) : (!have && my < count);
+            if (setup_now) {
+                if (KIND == KIND_TAIL) {
+                    is_sh = st != 4;
+                    if (is_sh) { n_rs++; st = (st == 5) ? 3 : 6; } else { n_rc++; st = 1; bounce_l++; }
+                } else q = my;
                 if (KIND == KIND_MIXED) { is_sh = my >= count_c; if (is_sh) q = my - count_c; }
-                const bool mixed_sh = (KIND == KIND_MIXED) && is_sh;
+                const bool mixed_sh = (KIND == KIND_MIXED || KIND == KIND_TAIL) && is_sh;
                 v3 o, d; int rec_expect = -3; float rec_bound = -1.0f;
                 const bool from_rec = (KIND == KIND_CLOSEST || KIND == KIND_QUERY) && c_ray4 != nullptr;          // wave-uniform
                 if (from_rec) {
@@ -322,7 +519,7 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
                 have = true;
             }
         }
-        if (ballot64(have) == 0ull) { if (exhausted) break; continue; }
+        if (ballot64(have) == 0ull) { if (exhausted && !(KIND == KIND_TAIL && wave_any(st != 0))) break; continue; }
 #ifdef TR_DRAIN_DIAG
         // diagnostic build (tools/timeline.py, counting launches): what a wave holds once the queue is empty -- outer iterations, busy lanes, and how
         // many of them have at least one / two / four entries above the sentinel of their stack (work another lane could take over)
@@ -545,6 +742,23 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
         }
 
         // ---- finished rays write back and free their lane ---------------------------------------
+        if (KIND == KIND_TAIL) {
+            if (have && cur == TR_SENT && pend == 0) {
+                if (is_sh) {
+                    if (hit_prim == expect) {                     // integrator/PT_RGB.py:105-109: the sample arrives
+                        TR_COLD(ca);
+                        const bool to_film = st == 6;
+                        const int dst = to_film ? ca->tail.slot[q] : q;
+                        float *pr = (to_film ? ca->fr : ca->rr) + dst, *pg = (to_film ? ca->fg : ca->rg) + dst, *pb = (to_film ? ca->fb : ca->rb) + dst;
+                        *pr = *pr + ca->scr[q]; *pg = *pg + ca->scg[q]; *pb = *pb + ca->scb[q];
+                    }
+                    st = (st == 3) ? 4 : 0;
+                } else st = 2;
+                if (COUNT) { if (is_sh) { sum_box_s += nbox; sum_leaf_s += nleaf; } else { sum_box += nbox; sum_leaf += nleaf; } }
+                if (n_overflow) n_over++;
+                have = false; sa = sa_bottom;
+            }
+        } else
         if (have && cur == TR_SENT && pend == 0) {
             TR_COLD(ca);
             float4 *const c_hit = ca->hit;
@@ -598,6 +812,14 @@ __global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
             }
         }
         if (n_over) atomicAdd(&ca->ctr->stack_overflow, n_over);
+        if (KIND == KIND_TAIL) {
+            const unsigned long long t_rc = wave_sum((unsigned long long)n_rc), t_rs = wave_sum((unsigned long long)n_rs), t_sh = wave_sum((unsigned long long)n_sh);
+            if (lane == 0) {
+                if (t_rc) atomicAdd(&ca->ctr->rays_closest, t_rc);
+                if (t_rs) atomicAdd(&ca->ctr->rays_shadow, t_rs);
+                if (t_sh) atomicAdd(&ca->ctr->shaded, t_sh);
+            }
+        } else
         if (gtid == 0 && !ca->no_ray_count) {
             if (count_c) atomicAdd(&ca->ctr->rays_closest, (unsigned long long)count_c);
             if (count_s) atomicAdd(&ca->ctr->rays_shadow, (unsigned long long)count_s);
@@ -641,6 +863,57 @@ static int launch_trace(tirt_ctx *c, hipStream_t stream, const TraceArgs &a, int
     if (exh) return launch_trace_as<TIRT_TRAVERSE_EXHAUSTIVE, false, KIND>(c, stream, a, g, b, lds);
     if (cnt) return launch_trace_as<TIRT_TRAVERSE_ORDERED, true, KIND>(c, stream, a, g, b, lds);
     return launch_trace_as<TIRT_TRAVERSE_ORDERED, false, KIND>(c, stream, a, g, b, lds);
+}
+
+// KIND_TAIL: ordered traversal only; as many persistent blocks as are resident at once (a block that had to wait for another to end would start when the work is gone)
+static int launch_tail(tirt_ctx *c, hipStream_t stream, const TraceArgs &a, int flags, int grid_cap)
+{
+    const bool cnt = (flags & TIRT_COUNT_NODES) != 0;
+    const size_t lds = trace_lds_bytes(a.lds_depth);
+    static int per_cu[TIRT_MAX_DEVICES][2] = {};
+    const int dev = (c->device >= 0 && c->device < TIRT_MAX_DEVICES) ? c->device : 0;
+    if (per_cu[dev][cnt] == 0) {
+        int nb = 0;
+        const void *fn = cnt ? reinterpret_cast<const void *>(&k_trace<TIRT_TRAVERSE_ORDERED, true, KIND_TAIL>) : reinterpret_cast<const void *>(&k_trace<TIRT_TRAVERSE_ORDERED, false, KIND_TAIL>);
+        TIRT_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        TIRT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, TR_BLOCK, lds));
+        per_cu[dev][cnt] = nb > 0 ? nb : 1;
+    }
+    int grid = per_cu[dev][cnt] * c->cu_count; if (grid > grid_cap) grid = grid_cap; if (grid < 1) grid = 1;
+    dim3 g(grid), b(TR_BLOCK);
+    if (cnt) return launch_trace_as<TIRT_TRAVERSE_ORDERED, true, KIND_TAIL>(c, stream, a, g, b, lds);
+    return launch_trace_as<TIRT_TRAVERSE_ORDERED, false, KIND_TAIL>(c, stream, a, g, b, lds);
+}
+
+// The bounce from which a batch of S paths runs as one tail launch (-1: no tail).  Chosen from what earlier batches of this scene did: the first
+// bounce that no more than tail_paths paths are expected to enter.
+static int choose_tail_bounce(const tirt_ctx *c, size_t S, int max_depth, int flags, bool spectral)
+{
+    if (spectral || (flags & TIRT_TRAVERSE_EXHAUSTIVE) || c->time_kernels || max_depth < 2) return -1;
+    if (c->tail_bounce == 0) return -1;
+    if (c->tail_bounce > 0) return c->tail_bounce < max_depth ? c->tail_bounce : -1;
+    if (c->tail_paths <= 0 || c->live_frac.size() < 2) return -1;
+    const double want = (double)c->tail_paths / (double)S;
+    const int known = (int)c->live_frac.size() - 1;              // live_frac[0 .. known]
+    for (int b = 1; b <= known && b < max_depth; b++) if (c->live_frac[b] <= want) return b;
+    // beyond what was seen: the last survival ratio carries on
+    double f = c->live_frac[known], r = known >= 1 && c->live_frac[known - 1] > 0.0f ? f / c->live_frac[known - 1] : 0.7;
+    if (r > 0.95) r = 0.95;
+    for (int b = known + 1; b < max_depth; b++) { f *= r; if (f <= want) return b; }
+    return -1;
+}
+static void collect_live_counts(tirt_ctx *c)
+{
+    for (int k = 0; k < c->n_lanes; k++) {
+        Lane &L = c->lanes[k];
+        if (!L.counts_pending || hipEventQuery(L.counts_done) != hipSuccess) continue;
+        L.counts_pending = false;
+        if (L.counts_S <= 0 || L.counts_known < 1) continue;
+        c->live_frac.assign((size_t)L.counts_known + 1, 0.0f);
+        c->live_frac[0] = 1.0f;
+        for (int b = 1; b <= L.counts_known; b++) c->live_frac[b] = (float)((double)(unsigned)(L.host_counts[b - 1] & 0xffffffffull) / (double)L.counts_S);
+    }
+    (void)hipGetLastError();           // hipEventQuery's hipErrorNotReady is not an error
 }
 
 static int ensure_spill(tirt_ctx *c, DevBuf &spill, int stack_size, int &spill_depth)
@@ -846,124 +1119,18 @@ __global__ __launch_bounds__(SH_BLOCK, SH_MIN_WAVES) void k_shade(ShadeArgs path
             asm volatile("" :: "s"(c_slot), "s"(c_flags), "s"(c_hit), "s"(c_ox), "s"(c_oy), "s"(c_oz), "s"(c_dx), "s"(c_dy), "s"(c_dz), "s"(c_tr), "s"(c_tg), "s"(c_tb),
                          "s"(c_rr), "s"(c_rg), "s"(c_rb), "s"(c_pdf));
             slot = first ? q : c_slot[q];
-            const int f = slot / P, k = slot - f * P;
-            const uint32_t pixel = (uint32_t)local_to_pixel(tm, k);
-            const uint32_t frame = frame_begin + (uint32_t)f;
-            const uint32_t dim0 = TM_DIM_BOUNCE0 + TM_DIMS_PER_BOUNCE * (uint32_t)bounce;
             const v3 origin = first ? eye : V(c_ox[q], c_oy[q], c_oz[q]);
             const v3 direction = V(c_dx[q], c_dy[q], c_dz[q]);
             const float4 hrec = c_hit[q];
-            const float t = hrec.x;
             v3 throughout = first ? V(1.0f, 1.0f, 1.0f) : V(c_tr[q], c_tg[q], c_tb[q]);
             radiance = first ? V(0.0f, 0.0f, 0.0f) : V(c_rr[q], c_rg[q], c_rb[q]);
             float brdf_pdf = first ? 1.0f : c_pdf[q];
             int perfect_spec = first ? 1 : (int)(c_flags[q] & 1u);
-            if (t < INF_VALUE) {
-                const int prim_id = __float_as_int(hrec.w);
-                int mat_id;
-                const HitAttr h = hit_attributes_rec(sc.shade_rec, origin, direction, prim_id, t, hrec.y, hrec.z, mat_id);
-                const v3 normal = h.nor;
-                const v3 fnormal = normal * signf(dot(-direction, h.gnor));            // UtilsFunc.py:465-467
-                const float *m = sc.material + (size_t)mat_id * MAT_VEC;
-                const v3 mat_color = V(m[2], m[3], m[4]);
-                const int mat_type = (int)m[0];
-                if (mat_type == MAT_LIGHT) {                                           // PT_RGB.py:72-81
-                    const float fCosTheta = absf(dot(direction, h.gnor));
-                    if (perfect_spec == 1) {
-                        radiance = radiance + throughout * mat_color;
-                    } else {
-                        const float area = get_prim_area(sc, prim_id) * (float)sc.light_count;
-                        const float light_pdf = (t * t) / (area * fCosTheta);
-                        radiance = radiance + (throughout * power_heuristic(brdf_pdf, light_pdf)) * mat_color;
-                    }
-                } else {
-                    n_shaded++;
-                    // UF.srgb_to_lrgb(material colour) (PT_RGB.py:86): per-material table filled by the same device function
-                    const v3 reflect_color = V(sc.mat_lrgb[mat_id * 3], sc.mat_lrgb[mat_id * 3 + 1], sc.mat_lrgb[mat_id * 3 + 2]);
-                    v3 next_dir; float f_or_b = 1.0f, brdf = 1.0f;
-                    if (mat_type == MAT_GLASS) {                                       // PT_RGB.py:89-92
-                        perfect_spec = 1;
-                        next_dir = glass_sample(m, direction, normal, tm_rand(seed, pixel, frame, dim0 + TM_SLOT_GLASS), f_or_b);
-                        brdf = 1.0f; brdf_pdf = 1.0f;
-                    } else {
-                        perfect_spec = 0;
-                        // Scene.py:477-518 sample_li.  No emitters (env-lit scene): the reference would index light[-1]
-                        // (Scene.py:423-428, undefined) -- defined here, as in the oracle, as "no NEE sample"
-                        if (sc.light_count > 0) {
-                        int lidx = (int)(tm_rand(seed, pixel, frame, dim0 + TM_SLOT_LIGHT) * (float)sc.light_count);
-                        if (lidx >= sc.light_count) lidx = sc.light_count - 1;
-                        const int light_prim = sc.light[lidx];
-                        const float ra = tm_rand(seed, pixel, frame, dim0 + TM_SLOT_LA);
-                        const float rb = tm_rand(seed, pixel, frame, dim0 + TM_SLOT_LB);
-                        v3 light_pos, light_normal;
-                        get_prim_random_point_normal(sc, light_prim, ra, rb, light_pos, light_normal);
-                        const int lmat = sc.primitive[(size_t)light_prim * PRI_VEC + 2];
-                        const float *lm = sc.material + (size_t)lmat * MAT_VEC;
-                        const v3 light_emission0 = V(lm[2], lm[3], lm[4]);
-                        const float light_area = get_prim_area(sc, light_prim);
-                        float light_choice_pdf = 1.0f / ((float)sc.light_count * light_area);
-                        light_normal = normalized(light_normal);
-                        v3 light_dir = h.pos - light_pos;
-                        const float light_dist = norm(light_dir);
-                        light_dir = light_dir / light_dist;
-                        const v3 light_emission = light_emission0 * light_shape_visible(sc, light_prim, light_dir, light_normal, light_dist, light_choice_pdf);   // spot / laser (Scene.py:491-516)
-                        const float NdotL_surface = dot(fnormal, light_dir);            // PT_RGB.py:101-109
-                        const float NdotL_light = dot(light_normal, light_dir);
-                        if ((NdotL_surface < 0.0f) & (NdotL_light > 0.0f)) {
-                            want_shadow = true;
-                            float e_pdf;
-                            const float e_brdf = disney_evaluate_pdf(m, fnormal, -direction, -light_dir, e_pdf);
-                            const float light_pdf = light_dist * light_dist * light_choice_pdf / NdotL_light;
-                            v3 c = V(0.0f, 0.0f, 0.0f);
-                            int expect = -2;                       // never equals a primitive id
-                            if (e_pdf > 0.0f) {
-                                const float w = power_heuristic(light_pdf, e_pdf) / maxf(0.0001f, light_pdf);
-                                c = light_emission * w;
-                                c = c * throughout;
-                                c = c * reflect_color;
-                                c = c * e_brdf;
-                                c = c * absf(NdotL_surface);
-                                expect = prim_id;
-                            }
-                            sh_o = light_pos; sh_d = light_dir; sh_c = c; sh_expect = expect; sh_dist = light_dist;
-                        }
-                        }   // light_count > 0
-                        next_dir = disney_sample(m, direction, fnormal, tm_rand(seed, pixel, frame, dim0 + TM_SLOT_LOBE),
-                                                 tm_rand(seed, pixel, frame, dim0 + TM_SLOT_R1),
-                                                 tm_rand(seed, pixel, frame, dim0 + TM_SLOT_R2));
-                        f_or_b = 1.0f;
-                        brdf = disney_evaluate_pdf(m, fnormal, -direction, next_dir, brdf_pdf);
-                        brdf *= absf(dot(normal, next_dir));
-                    }
-                    const v3 next_origin = offset_ray(h.pos, fnormal * signf(f_or_b));   // PT_RGB.py:115
-                    if (brdf_pdf > 0.0f) {
-                        bool alive = true;
-                        if (f_or_b < 0.0f) {                                             // PT_RGB.py:118-122
-                            const float extinction = m[6];
-                            const float R = tm_exp(-t / extinction);
-                            if (tm_rand(seed, pixel, frame, dim0 + TM_SLOT_EXT) >= R) alive = false;
-                        }
-                        if (alive) {
-                            throughout = throughout * (reflect_color * (brdf / brdf_pdf));
-                            want_next = !last_bounce;      // depth reaches MAX_DEPTH after the last bounce: the loop ends
-                            next_o = next_origin; next_d = next_dir; next_thr = throughout;
-                            next_pdf = brdf_pdf; next_spec = perfect_spec;
-                        }
-                    }
-                }
-            } else if (sc.env_power == 0.0f && (direction.x - direction.x == 0.0f) && (direction.y - direction.y == 0.0f) &&
-                       (direction.z - direction.z == 0.0f)) {
-                // black environment (PT_RGB.py:127-132 with env_power == 0): for a finite direction the lookup returns a
-                // finite e >= 0, so (e * throughput) * 0 is +-0 with throughput's sign, or NaN where throughput is not
-                // finite -- exactly throughput * env_power, without the two atan2, four texel fetches and three pow
-                radiance = radiance + throughout * sc.env_power;
-            } else {                                                                     // PT_RGB.py:127-132
-                const float dis = tm_sqrt(direction.x * direction.x + direction.z * direction.z);
-                const float tx = (tm_atan2(direction.z, direction.x) + PI_SCENE) / PI_SCENE / 2.0f;
-                const float ty = tm_atan2(direction.y, dis) / PI_SCENE + 0.5f;
-                const v3 e = srgb_to_lrgb(texture2d(sc, tx, ty));
-                radiance = radiance + (e * throughout) * sc.env_power;
-            }
+            ShadeStep ss;
+            shade_path(sc, tm, P, frame_begin, seed, bounce, last_bounce, slot, origin, direction, hrec, throughout, radiance, brdf_pdf, perfect_spec, ss);
+            want_next = ss.want_next; want_shadow = ss.want_shadow; if (ss.shaded) n_shaded++;
+            next_o = ss.next_o; next_d = ss.next_d; next_thr = ss.next_thr; next_pdf = ss.next_pdf; next_spec = ss.next_spec;
+            sh_o = ss.sh_o; sh_d = ss.sh_d; sh_c = ss.sh_c; sh_expect = ss.sh_expect; sh_dist = ss.sh_dist;
         }
         // dense compaction: survivors go to consecutive indices of the other PathSoA, finished
         // paths deposit their radiance in the per-path final array, shadow rays get their own
@@ -1319,6 +1486,7 @@ int pt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed,
     const TileMap tm = {c->tile_rank, c->tile_count, c->tile_size, c->H, c->tile_blocked};
     DevCounters *ctr = c->dev_counters.as<DevCounters>();
     const int B = 256;
+    collect_live_counts(c);
     // everything queued on the main stream (uploads, film clear, tone map) precedes the lanes' work
     TIRT_HIP(hipEventRecord(c->ev_main, c->stream));
     int n_lanes = c->time_kernels ? 1 : c->n_lanes;
@@ -1385,6 +1553,8 @@ int pt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed,
         const int sh_cap = two_big ? 2 * c->sh_grid : c->sh_grid;
         int grid_shade = (S + SH_BLOCK - 1) / SH_BLOCK; if (grid_shade > sh_cap) grid_shade = sh_cap;
         v3 eye_v; eye_v.x = c->cam.eye[0]; eye_v.y = c->cam.eye[1]; eye_v.z = c->cam.eye[2];
+        const int tail_b = choose_tail_bounce(c, (size_t)S, max_depth, flags, spec != nullptr);
+        int counts_known = 0;
         for (int b = 0; b < max_depth; b++) {
             const PathSoA &in = L.ps.st[b & 1], &out = L.ps.st[(b + 1) & 1];
             // closest hits of bounce b, together with the NEE shadow rays of bounce b-1 (they add into
@@ -1408,6 +1578,20 @@ int pt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed,
             if (int rc = (b == 0) ? launch_trace<KIND_CLOSEST>(c, st, a, flags, grid_full) : launch_trace<KIND_MIXED>(c, st, a, flags, grid_full)) return rc;
             stamp(evc, false);
             c->launches_trace_closest++;
+            counts_known = b;              // append_ctr(b - 1), the paths that entered bounce b, has been written by now
+
+            if (b == tail_b) {
+                // everything that is left of the batch in one launch: the paths' state stays where it is (`in`), their shadow rays go to index q of the shadow arrays
+                TraceArgs t = a;
+                t.count_ptr = cnt_path(b); t.count_fixed = 0; t.scount_ptr = nullptr;
+                t.fetch = fetch(b + 1);    // (the cursors of a launch this batch no longer makes)
+                t.timeline = nullptr; t.no_ray_count = 1;
+                t.tail.sc = sv; t.tail.tm = tm; t.tail.P = P; t.tail.frame_begin = f0; t.tail.seed = seed; t.tail.bounce0 = b; t.tail.max_depth = max_depth;
+                t.tail.tr = in.tr; t.tail.tg = in.tg; t.tail.tb = in.tb; t.tail.brdf_pdf = in.brdf_pdf; t.tail.flags = in.flags; t.tail.slot = in.slot;
+                if (int rc = launch_tail(c, st, t, flags, grid_full)) return rc;
+                c->launches_tail++;
+                break;
+            }
 
             stamp(evh, true);
             if (spec)
@@ -1444,6 +1628,18 @@ int pt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed,
         else hipLaunchKernelGGL(k_film, dim3((P + B - 1) / B), dim3(B), 0, st, L.ps, tm, P, F, f0, c->hdr.as<float>());
         TIRT_HIP(hipEventRecord(L.film_done, st));
         L.film_recorded = true;
+        if (!spec && c->tail_bounce < 0 && c->tail_paths > 0 && counts_known >= 1) {      // the batch's per-bounce path counts, for the batches to come (never waited for)
+            if (L.host_counts_cap < max_depth) {
+                if (L.host_counts) (void)hipHostFree(L.host_counts);
+                L.host_counts = nullptr; L.host_counts_cap = 0;
+                TIRT_HIP(hipHostMalloc((void **)&L.host_counts, sizeof(unsigned long long) * (size_t)max_depth, hipHostMallocDefault));
+                L.host_counts_cap = max_depth;
+            }
+            if (!L.counts_done) TIRT_HIP(hipEventCreateWithFlags(&L.counts_done, hipEventDisableTiming));
+            TIRT_HIP(hipMemcpy2DAsync(L.host_counts, sizeof(unsigned long long), L.counters_mem.p, LINE, sizeof(unsigned long long), (size_t)counts_known, hipMemcpyDeviceToHost, st));
+            TIRT_HIP(hipEventRecord(L.counts_done, st));
+            L.counts_pending = true; L.counts_S = S; L.counts_known = counts_known;
+        }
         c->last_film = L.film_done;
         TIRT_HIP(hipEventRecord(r1, st));
         if (c->time_kernels) {
