@@ -95,6 +95,10 @@ int tirt_sync(tirt_ctx *ctx);
  *            204 B of HBM each, lanes hold 1.5 x that)
  *          "split_lone_batch" (0 = off, or the number of parts 2..8; default 0 since round 3) -- a context that owns 1/6 or less of the film
  *            (tile_count >= 6) and whose whole job is one batch runs it as that many smaller batches on as many lanes
+ *          "tail_paths" (default 0 = off) / "tail_bounce" (-1 = chosen, 0 = never, k = from bounce k) -- the last bounces of a PT_RGB batch as ONE persistent
+ *            launch in which a lane keeps a path (shade, shadow ray, next ray ...) instead of a launch per bounce and kind: from the first bounce that no more
+ *            than tail_paths paths are expected to enter (by the counts of earlier batches), or from bounce k.  Same film bit for bit; measured slower on
+ *            MI355X at every threshold (docs/HISTORY.md), hence off
  *          "traversal_tree" (0/1, default 1) -- the tree tirt_lbvh_build collapses into the 4-wide traversal nodes: 1 = a binned-SAH
  *            tree over the same primitives built on the device after the LBVH, 0 = the reference's LBVH itself; results are
  *            bit-identical either way (tirt_traversal_tree_download) -- except for rays that lie, to fp32 rounding, IN the plane of a

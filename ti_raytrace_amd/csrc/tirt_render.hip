@@ -215,6 +215,7 @@ TD void shade_path(const SceneView &sc, const TileMap &tm, int P, uint32_t frame
 // steps and triangle tests run in separate loops so that lanes doing the same thing run together.
 constexpr int TR_FETCH_STRIDE = 32;           // ints between two slice cursors (one 128-byte line each)
 constexpr int TR_SLICES_MAX = 64;
+constexpr int TR_FETCH_LINES = TR_SLICES_MAX + 1;   // one cursor per slice, each in a line of its own, + the line of the drained-slices count
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef _Float16 h2v __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) int lds_int;
@@ -391,6 +392,14 @@ __global__ __launch_bounds__(TR_BLOCK, KIND == KIND_TAIL ? TR_TAIL_WAVES : TR_MI
             const int v = base + __popcll(fm & lt_mask);                  // index within the slice
             my = v < len ? (((((v >> 6) << S_LOG) + home) << 6) | (v & 63)) : count;
             if (base + n_idle >= len) {                                    // slice drained: move on
+#ifndef TR_NO_DRAINED_COUNT
+                // The wave whose fetch reached the end of a slice counts the slice as drained, and a wave that moves on looks at that count: once it
+                // says "all of them" there is nothing to look for.  Without it every wave of a launch learns that by one atomic round trip per
+                // slice, 32 in a row on 32 lines that 5 120 waves are hammering: ~0.15 ms, the better part of what a launch of few rays takes.
+                int *const c_drained = c_fetch + TR_SLICES_MAX * TR_FETCH_STRIDE;
+                if (lane == leader && base < (len > 0 ? len : 1)) atomicAdd(c_drained, 1);
+                if (__hip_atomic_load(c_drained, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > S_MASK) tried = S_MASK;
+#endif
                 home = (home + 1) & S_MASK;
                 if (++tried > S_MASK) { exhausted = true; if (COUNT) tk_exh = wall_clock64(); }
             }
@@ -983,8 +992,8 @@ int launch_trace_batch(tirt_ctx *c, const float *rays, int nr, int stack_size, i
     a.spill = c->spill.as<int>(); a.spill_depth = spill_depth;
     a.ctr = c->dev_counters.as<DevCounters>();
     a.per_ray_counts = (flags & TIRT_COUNT_NODES) ? c->tr_counts.as<int2>() : nullptr;
-    if (c->counters_mem.ensure(sizeof(int) * TR_FETCH_STRIDE * TR_SLICES_MAX)) return TIRT_ERR_HIP;
-    TIRT_HIP(hipMemsetAsync(c->counters_mem.p, 0, sizeof(int) * TR_FETCH_STRIDE * TR_SLICES_MAX, st));
+    if (c->counters_mem.ensure(sizeof(int) * TR_FETCH_STRIDE * TR_FETCH_LINES)) return TIRT_ERR_HIP;
+    TIRT_HIP(hipMemsetAsync(c->counters_mem.p, 0, sizeof(int) * TR_FETCH_STRIDE * TR_FETCH_LINES, st));
     a.fetch = c->counters_mem.as<int>();
     fill_tunables(c, a);
     int grid = (nr + TR_BLOCK - 1) / TR_BLOCK; if (grid > c->tr_grid) grid = c->tr_grid;
@@ -1011,7 +1020,7 @@ int trace_arrays_prepare(tirt_ctx *c, int lane)
     DevBuf &fetch = lane < 0 ? c->counters_mem : c->lanes[lane].counters_mem;
     int spill_depth;
     if (ensure_spill(c, spill, c->bdpt_stack, spill_depth)) return TIRT_ERR_HIP;
-    if (fetch.ensure(sizeof(int) * TR_FETCH_STRIDE * TR_SLICES_MAX)) return TIRT_ERR_HIP;
+    if (fetch.ensure(sizeof(int) * TR_FETCH_STRIDE * TR_FETCH_LINES)) return TIRT_ERR_HIP;
     return TIRT_OK;
 }
 
@@ -1029,8 +1038,8 @@ int trace_arrays(tirt_ctx *c, const float *ox, const float *oy, const float *oz,
     DevBuf &fetch = lane < 0 ? c->counters_mem : c->lanes[lane].counters_mem;
     int spill_depth;
     if (ensure_spill(c, spill, c->bdpt_stack, spill_depth)) return TIRT_ERR_HIP;      // (the integrator's stack_size: option "bdpt_stack_size")
-    if (fetch.ensure(sizeof(int) * TR_FETCH_STRIDE * TR_SLICES_MAX)) return TIRT_ERR_HIP;
-    TIRT_HIP(hipMemsetAsync(fetch.p, 0, sizeof(int) * TR_FETCH_STRIDE * TR_SLICES_MAX, st));
+    if (fetch.ensure(sizeof(int) * TR_FETCH_STRIDE * TR_FETCH_LINES)) return TIRT_ERR_HIP;
+    TIRT_HIP(hipMemsetAsync(fetch.p, 0, sizeof(int) * TR_FETCH_STRIDE * TR_FETCH_LINES, st));
     TraceArgs a = {};
     a.bvh = bvh_view(c);
     a.ox = ox; a.oy = oy; a.oz = oz; a.dx = dx; a.dy = dy; a.dz = dz; a.ray4 = ray4; a.ray_index = ray_index;
@@ -1428,7 +1437,7 @@ __global__ void k_film_spec(PathState ps, const float *fw, SpecView sp, TileMap 
 // ray-fetch cursors of the max_depth + 1 traversal launches.
 constexpr size_t LINE = 128;
 static size_t lane_counter_bytes(int max_depth)
-{ return LINE * (size_t)(max_depth + 1) + sizeof(int) * TR_FETCH_STRIDE * TR_SLICES_MAX * (size_t)(max_depth + 1); }
+{ return LINE * (size_t)(max_depth + 1) + sizeof(int) * TR_FETCH_STRIDE * TR_FETCH_LINES * (size_t)(max_depth + 1); }
 
 constexpr int PATH_WORDS = 2 * 15 + 4 + 12 + 3 + 2;  // two PathSoA + hit record + shadow ray + final radiance + the two fourth-wavelength words of PT_Spec
 static size_t path_state_bytes(size_t S) { return sizeof(float) * PATH_WORDS * ((S + 3) & ~(size_t)3); }
@@ -1525,7 +1534,7 @@ int pt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed,
         auto append_ctr = [&](int b) { return (unsigned long long *)(cm + LINE * (size_t)b); };
         auto cnt_path = [&](int b) { return (const int *)append_ctr(b - 1); };           // live paths entering bounce b >= 1
         auto cnt_shadow = [&](int b) { return (const int *)append_ctr(b) + 1; };         // shadow rays made by bounce b
-        auto fetch = [&](int launch) { return (int *)(cm + LINE * (size_t)(max_depth + 1)) + (size_t)launch * TR_FETCH_STRIDE * TR_SLICES_MAX; };
+        auto fetch = [&](int launch) { return (int *)(cm + LINE * (size_t)(max_depth + 1)) + (size_t)launch * TR_FETCH_STRIDE * TR_FETCH_LINES; };
 
         TIRT_HIP(hipStreamWaitEvent(st, c->ev_main, 0));
         hipEvent_t r0, r1;
