@@ -43,8 +43,37 @@ constexpr float EPS_UF = 0.00001f;                 // UtilsFunc.py:36
 // BDPT_Vertex.py:10-21 in 80 bytes, 16-byte aligned, every vector with a scalar that is read with it: a vertex moves as five dwordx4
 // accesses instead of 21 scalar ones, and a connection's geometry pass reads (pos, prim), (snormal, mat) and the type/delta word.
 struct alignas(16) bvert { v3 pos; int prim; v3 snormal; int mat; v3 normal; float fpdf; v3 beta; float rpdf; v3 wo; short type, delta; };
-static_assert(sizeof(bvert) == 80, "bvert is five quads");
-struct bpixel { bvert eye[BD_EYE_MAX], light[BD_LIGHT_MAX]; };       // the reference's sample / temp vertices (BDPT_RGB.py:60-64) are locals of the connection code
+static_assert(sizeof(bvert) == 80 && offsetof(bvert, rpdf) == 60 && offsetof(bvert, delta) == 78, "bvert is five quads: ... (beta, rpdf) (wo, type | delta)");
+// The vertex arrays of a batch's items in HBM: quad k (16 bytes) of vertex slot s of item `it` lies at q[(s * 5 + k) * stride + it] (eye vertices: slots 0..6, light
+// vertices: 7..12).  Lanes that hold neighbouring items read neighbouring quads: a wave's vertex load is five requests of 1 KB.  (Rounds 2-3 kept an item's 13
+// vertices together, 1 040 bytes apart from the next item's: every lane of every vertex access in a cache line of its own -- what made k_bd_step, k_bd_connect
+// and k_bd_resolve texture-address bound.)
+constexpr int BD_QUADS = 5, BD_SLOTS = BD_EYE_MAX + BD_LIGHT_MAX;
+struct BdItems { float4 *q; size_t stride; };
+constexpr size_t BD_ITEM_BYTES = sizeof(bvert) * BD_SLOTS;
+struct varr {                              // one of an item's two vertex arrays: reads of a whole vertex or of one field of it (the quad that holds it), whole-vertex and single-field stores
+    float4 *q; size_t stride;
+    TD float4 *at(int s, int k) const { return q + (size_t)(s * BD_QUADS + k) * stride; }
+    TD bvert operator[](int s) const
+    {
+        bvert v;
+#pragma unroll
+        for (int k = 0; k < BD_QUADS; k++) { const float4 x = *at(s, k); __builtin_memcpy((char *)&v + 16 * k, &x, 16); }
+        return v;
+    }
+    TD void put(int s, const bvert &v) const
+    {
+#pragma unroll
+        for (int k = 0; k < BD_QUADS; k++) { float4 x; __builtin_memcpy(&x, (const char *)&v + 16 * k, 16); *at(s, k) = x; }
+    }
+    TD float rpdf(int s) const { return ((const float *)at(s, 3))[3]; }
+    TD float fpdf(int s) const { return ((const float *)at(s, 2))[3]; }
+    TD int delta(int s) const { return (int)((const short *)at(s, 4))[7]; }
+    TD void set_rpdf(int s, float f) const { ((float *)at(s, 3))[3] = f; }                    // bvert::rpdf: last word of quad 3
+    TD void set_delta(int s, int d) const { ((short *)at(s, 4))[7] = (short)d; }              // bvert::delta: last half-word of quad 4
+};
+struct bpixel { varr eye, light; };        // (a view of one item's vertex arrays; the reference's sample / temp vertices (BDPT_RGB.py:60-64) are locals of the connection code)
+TD bpixel bd_item(const BdItems &I, size_t it) { float4 *b = I.q + it; bpixel B; B.eye.q = b; B.eye.stride = I.stride; B.light.q = b + (size_t)BD_EYE_MAX * BD_QUADS * I.stride; B.light.stride = I.stride; return B; }
 
 struct BdView { float view[12]; int W, H; };
 struct SimpleHit { float t, u, v; int prim; };
@@ -158,10 +187,10 @@ TD v3 bd_reflect(const BdCtx &c, int mat_id, float Lambda)
 
 
 // BDPT_RGB.py:300-479
-TD float bd_mis_weight(const BdCtx &c, const bpixel *P, const bvert &sample, int e, int l)
+TD float bd_mis_weight(const BdCtx &c, const bpixel &P, const bvert &sample, int e, int l)
 {
     const SceneView &s = c.sc;
-    const bvert *light = P->light, *eye = P->eye;
+    const varr light = P.light, eye = P.eye;
     float weight_sum = 0.0f;
     if (l + e != 2) {
         // The reference saves the four vertices next to the connection (ltemp, etemp, lminustemp, eminustemp), overwrites
@@ -261,22 +290,22 @@ TD float bd_mis_weight(const BdCtx &c, const bpixel *P, const bvert &sample, int
 
         float weight = 1.0f;
         for (int k = e - 1; k > 0; k--) {
-            const float rp = (k == e - 1) ? E1.rpdf : ((k == e - 2) ? E2.rpdf : eye[k].rpdf);
-            const float fp = (k == e - 1) ? E1.fpdf : ((k == e - 2) ? E2.fpdf : eye[k].fpdf);
-            const int dk = (k == e - 1) ? E1.delta : ((k == e - 2) ? E2.delta : eye[k].delta);
-            const int dk1 = (k - 1 == e - 2) ? E2.delta : eye[k - 1].delta;
+            const float rp = (k == e - 1) ? E1.rpdf : ((k == e - 2) ? E2.rpdf : eye.rpdf(k));
+            const float fp = (k == e - 1) ? E1.fpdf : ((k == e - 2) ? E2.fpdf : eye.fpdf(k));
+            const int dk = (k == e - 1) ? E1.delta : ((k == e - 2) ? E2.delta : eye.delta(k));
+            const int dk1 = (k - 1 == e - 2) ? E2.delta : eye.delta(k - 1);
             weight *= remap0(rp) / remap0(fp);
             if ((dk == 0) & (dk1 == 0)) weight_sum += weight;
         }
         weight = 1.0f;
         for (int k = l - 1; k >= 0; k--) {
-            const float rp = (k == l - 1) ? L1.rpdf : ((k == l - 2) ? L2.rpdf : light[k].rpdf);
-            const float fp = (k == l - 1) ? L1.fpdf : ((k == l - 2) ? L2.fpdf : light[k].fpdf);
-            const int dk = (k == l - 1) ? L1.delta : ((k == l - 2) ? L2.delta : light[k].delta);
+            const float rp = (k == l - 1) ? L1.rpdf : ((k == l - 2) ? L2.rpdf : light.rpdf(k));
+            const float fp = (k == l - 1) ? L1.fpdf : ((k == l - 2) ? L2.fpdf : light.fpdf(k));
+            const int dk = (k == l - 1) ? L1.delta : ((k == l - 2) ? L2.delta : light.delta(k));
             weight *= remap0(rp) / remap0(fp);
             if (k == 0) { if (dk == 0) weight_sum += weight; }
             else {
-                const int dk1 = (k - 1 == l - 2) ? L2.delta : light[k - 1].delta;
+                const int dk1 = (k - 1 == l - 2) ? L2.delta : light.delta(k - 1);
                 if ((dk == 0) & (dk1 == 0)) weight_sum += weight;
             }
         }
@@ -331,12 +360,12 @@ TD void bd_sample_light(const BdCtx &c, uint32_t pixel, uint32_t frame, uint32_t
 
 // BDPT_RGB.py:481-592
 template <bool SPEC>
-TD v3 bd_connect_path(const BdCtx &c, const bpixel *P, const bvert &EV, bvert &sample, int i, int j, int e, int l, uint32_t frame, int &nu, int &nv, Tracer &T)
+TD v3 bd_connect_path(const BdCtx &c, const bpixel &P, const bvert &EV, bvert &sample, int i, int j, int e, int l, uint32_t frame, int &nu, int &nv, Tracer &T)
 {
     const SceneView &s = c.sc;
     // private copies of the two vertices being connected (one wide load each; nothing is written to the arrays): EV = eye[e - 1] is the
     // caller's (the per-item loop keeps it across the l loop), LV is loaded here
-    const bvert LV = (l > 0) ? P->light[l - 1] : bvert();
+    const bvert LV = (l > 0) ? P.light[l - 1] : bvert();
     const uint32_t pixel = (uint32_t)(i * c.bv.H + j);
     constexpr bool spectral = SPEC;
     const float Lambda = spectral ? bd_lambda(c, pixel, frame) : 0.0f;
@@ -473,7 +502,7 @@ TD void count_rays(unsigned long long *ctr, unsigned mine)
 
 // BDPT_RGB.py:104-125 (lens vertex, camera ray) and :201-228 with Scene.sample_light (Scene.py:430-474)
 template <bool SPEC>
-__global__ void k_bd_init(BdCtx c, bpixel *items, BdStep *steps, BdRays rays, int *owner, int *alive_cnt, TileMap tm, int P, int N, uint32_t frame_begin, unsigned long long *paths)
+__global__ void k_bd_init(BdCtx c, BdItems items, BdStep *steps, BdRays rays, int *owner, int *alive_cnt, TileMap tm, int P, int N, uint32_t frame_begin, unsigned long long *paths)
 {
     const int it = blockIdx.x * blockDim.x + threadIdx.x;
     if (it >= N) return;
@@ -481,24 +510,24 @@ __global__ void k_bd_init(BdCtx c, bpixel *items, BdStep *steps, BdRays rays, in
     const int p = local_to_pixel(tm, k);
     const int i = p / c.bv.H, j = p - i * c.bv.H;
     const uint32_t pixel = (uint32_t)p, frame = frame_begin + (uint32_t)f;
-    bpixel *B = items + it;
+    const bpixel B = bd_item(items, (size_t)it);
     BdStep st;
     // eye
     {
-        bvert *eye = B->eye;
+        const varr eye = B.eye;
         const v3 origin = V(c.cam.eye[0], c.cam.eye[1], c.cam.eye[2]);
         float jx = 0.0f, jy = 0.0f;
         if (frame != 0) { jx = tm_rand(c.seed, pixel, frame, TM_DIM_JX) - 0.5f; jy = tm_rand(c.seed, pixel, frame, TM_DIM_JY) - 0.5f; }
         const v3 dir = camera_ray_direction(c.cam, i, j, jx, jy);
         bvert ev = bvert();                    // whole 80-byte stores: the fields the reference does not set are the zeros its field starts with
         ev.pos = origin; ev.normal = dir; ev.beta = V(1.0f, 1.0f, 1.0f); ev.fpdf = 1.0f; ev.type = VERTEX_LENS;
-        eye[0] = ev;
+        eye.put(0, ev);
         st.e_beta = V(1.0f, 1.0f, 1.0f); st.e_pdfFwd = 1.0f; st.e_tail = 0; st.pad_ = 0; st.eye_depth = 1;
         put_ray(rays, (size_t)it, origin, dir); owner[it] = it;
     }
     // light
     {
-        bvert *light = B->light;
+        const varr light = B.light;
         v3 lpos, lnor, ldir, emission; int lp; float choice_pdf, dir_pdf;
         bd_sample_light(c, pixel, frame, BD_DIM_LSTART, lpos, lnor, ldir, emission, lp, choice_pdf, dir_pdf);
         (void)lp;
@@ -511,7 +540,7 @@ __global__ void k_bd_init(BdCtx c, bpixel *items, BdStep *steps, BdRays rays, in
         bvert lv = bvert();
         lv.pos = lpos; lv.normal = lnor; lv.beta = beta0;
         lv.fpdf = light_pdf; lv.rpdf = 0.0f; lv.wo = ldir; lv.type = VERTEX_LIGHT;
-        light[0] = lv;
+        light.put(0, lv);
         st.l_beta = beta1; st.l_pdfFwd = dir_pdf; st.light_depth = 1;
         put_ray(rays, (size_t)N + it, lpos, ldir); owner[N + it] = N + it;
     }
@@ -525,7 +554,7 @@ __global__ void k_bd_init(BdCtx c, bpixel *items, BdStep *steps, BdRays rays, in
 // sub-paths that go on append their next ray to the list of the next depth (one atomic per wave), so the later depths launch
 // work only for what is still alive.
 template <bool SPEC>
-__global__ void k_bd_step(BdCtx c, bpixel *items, BdStep *steps, BdRays rays, const int *owner, BdRays rays_out, int *owner_out, int *alive_cnt,
+__global__ void k_bd_step(BdCtx c, BdItems items, BdStep *steps, BdRays rays, const int *owner, BdRays rays_out, int *owner_out, int *alive_cnt,
                           const float4 *hits, TileMap tm, int P, int N, uint32_t frame_begin, int depth, unsigned long long *rays_closest)
 {
     const int qi = blockIdx.x * blockDim.x + threadIdx.x;
@@ -544,7 +573,7 @@ __global__ void k_bd_step(BdCtx c, bpixel *items, BdStep *steps, BdRays rays, co
             const int f = it / P, k = it - f * P;
             const uint32_t pixel = (uint32_t)local_to_pixel(tm, k), frame = frame_begin + (uint32_t)f;
             const SceneView &s = c.sc;
-            bpixel *B = items + it;
+            const bpixel B = bd_item(items, (size_t)it);
             constexpr bool spectral = SPEC;
             const float Lambda = spectral ? bd_lambda(c, pixel, frame) : 0.0f;
             const float4 rq0 = rays.r[2 * (size_t)qi], rq1 = rays.r[2 * (size_t)qi + 1];
@@ -555,7 +584,7 @@ __global__ void k_bd_step(BdCtx c, bpixel *items, BdStep *steps, BdRays rays, co
             int final_depth = depth;              // what the reference's function returns if the loop ends here
             next_o = origin; next_d = dir;
             if (is_eye) {
-                bvert *eye = B->eye;
+                const varr eye = B.eye;
                 float pdfFwd = st->e_pdfFwd, pdfRev = 0.0f;
                 v3 beta = st->e_beta;
                 bool stored_surface = false;
@@ -595,7 +624,7 @@ __global__ void k_bd_step(BdCtx c, bpixel *items, BdStep *steps, BdRays rays, co
                                 beta = beta * (((reflect_color * bs.brdf) * absf(dot(normal, bs.next_dir))) / pdfFwd);
                                 pdfRev = disney_pdf(m, fnormal, bs.next_dir, -dir);
                             }
-                            eye[pre_depth].rpdf = pdfRev * absf(dot(to, e->normal)) * inv_dist2;
+                            eye.set_rpdf(pre_depth, pdfRev * absf(dot(to, e->normal)) * inv_dist2);
                             bool killed = false;
                             if (!spectral && bs.f_or_b < 0.0f) {          // (SPEC has no extinction roulette)
                                 const float R = tm_exp(-sh.t / m[6]);
@@ -609,11 +638,11 @@ __global__ void k_bd_step(BdCtx c, bpixel *items, BdStep *steps, BdRays rays, co
                             }
                         }
                     }
-                    eye[depth] = ev;                      // one 80-byte store
+                    eye.put(depth, ev);                   // five 16-byte stores
                 }
                 st->e_beta = beta; st->e_pdfFwd = pdfFwd; st->eye_depth = final_depth; st->e_tail = (stored_surface && final_depth == depth) ? 1 : 0;
             } else {
-                bvert *light = B->light;
+                const varr light = B.light;
                 float pdfFwd = st->l_pdfFwd, pdfRev = 0.0f;
                 v3 beta = st->l_beta;
                 if (sh.t < INF_VALUE) {
@@ -646,7 +675,7 @@ __global__ void k_bd_step(BdCtx c, bpixel *items, BdStep *steps, BdRays rays, co
                                 beta = beta * (((reflect_color * bs.brdf) * absf(dot(normal, bs.next_dir))) / pdfFwd);
                                 pdfRev = disney_pdf(m, fnormal, bs.next_dir, -dir);
                             }
-                            light[pre_depth].rpdf = pdfRev * absf(dot(to, L->normal)) * inv_dist2;
+                            light.set_rpdf(pre_depth, pdfRev * absf(dot(to, L->normal)) * inv_dist2);
                             bool killed = false;
                             if (!spectral && bs.f_or_b < 0.0f) {
                                 const float R = tm_exp(-sh.t / m[6]);
@@ -659,7 +688,7 @@ __global__ void k_bd_step(BdCtx c, bpixel *items, BdStep *steps, BdRays rays, co
                                 next_d = bs.next_dir;
                             }
                         }
-                        light[depth] = lv;
+                        light.put(depth, lv);
                     }
                 }
                 st->l_beta = beta; st->l_pdfFwd = pdfFwd; st->light_depth = final_depth;
@@ -683,18 +712,20 @@ __global__ void k_bd_step(BdCtx c, bpixel *items, BdStep *steps, BdRays rays, co
 
 // The `delta` field of an eye vertex that ended on a light is whatever an earlier frame of the same pixel left in that
 // slot (file header): replayed per pixel, in frame order, over the persistent per-pixel memory.
-__global__ void k_bd_delta(bpixel *items, const BdStep *steps, TileMap tm, int P, int F, int *delta_mem)
+__global__ void k_bd_delta(BdItems items, const BdStep *steps, TileMap tm, int P, int F, int *delta_mem)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= P) return;
     int *mem = delta_mem + (size_t)local_to_pixel(tm, k) * 8;
     for (int f = 0; f < F; f++) {
         const size_t it = (size_t)f * P + k;
-        bvert *eye = items[it].eye;
+        const varr eye = bd_item(items, it).eye;
         const int ed = steps[it].eye_depth;
         for (int v = 1; v < ed; v++) {
-            if (eye[v].type == VERTEX_SURFACE) mem[v] = eye[v].delta;
-            else if (eye[v].type == VERTEX_LIGHT) eye[v].delta = mem[v];
+            const float4 td = *eye.at(v, 4);                     // (wo, type | delta << 16)
+            const int type = (int)(short)(__float_as_uint(td.w) & 0xffffu), delta = (int)(short)(__float_as_uint(td.w) >> 16);
+            if (type == VERTEX_SURFACE) mem[v] = delta;
+            else if (type == VERTEX_LIGHT) eye.set_delta(v, mem[v]);
         }
         // v == ed: a surface vertex whose sampling ended the path (pdf 0, or the extinction roulette of a refraction) is not counted
         // in the depth, but its delta has been stored (BDPT_RGB.py:160-187); BdStep::e_tail says that slot is this item's
@@ -729,14 +760,14 @@ constexpr int BD_OWNER_BITS = 26;                  // a queued connection's owne
 // stages it (k_bd_compact makes the queue dense, k_trace answers it, k_bd_resolve -- one thread per QUEUED CONNECTION -- adds the
 // contribution); the pairs that need none (l == 0: the eye sub-path ended on an emitter) are k_bd_emitted's.
 template <bool SPEC>
-__global__ void k_bd_connect(BdCtx c, bpixel *items, const BdStep *steps, TileMap tm, int P, int N, uint32_t frame_begin,
+__global__ void k_bd_connect(BdCtx c, BdItems items, const BdStep *steps, TileMap tm, int P, int N, uint32_t frame_begin,
                              float4 *stage, unsigned long long *qmask, int *ibase, int *icount, int *scount, unsigned long long *rays_shadow)
 {
     const int it = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = it < N;
     const int lane = threadIdx.x & 63;
     int eye_depth = 0, light_depth = -1, i = 0, j = 0, p = 0, f = 0;
-    bpixel *B = items + (live ? it : 0);
+    const bpixel B = bd_item(items, (size_t)(live ? it : 0));
     if (live) {
         f = it / P; const int k = it - f * P;
         p = local_to_pixel(tm, k); i = p / c.bv.H; j = p - i * c.bv.H;
@@ -751,7 +782,7 @@ __global__ void k_bd_connect(BdCtx c, bpixel *items, const BdStep *steps, TileMa
     for (int e = 1; e <= BD_EYE_MAX; e++) {
         if (__ballot(live && e <= eye_depth) == 0ull) break;
         bvert EV = bvert();
-        if (live && e <= eye_depth) EV = B->eye[e - 1];                 // once per e, not once per pair (the kernel is bound by its vector-memory instructions)
+        if (live && e <= eye_depth) EV = B.eye[e - 1];                 // once per e, not once per pair (the kernel is bound by its vector-memory instructions)
         for (int l = 0; l <= BD_LIGHT_MAX; l++) {
             const int depth = l + e - 2;
             if (((l == 1) & (e == 1)) | (depth < 0) | (depth > BD_MAX_DEPTH)) continue;       // wave-uniform
@@ -789,12 +820,14 @@ __global__ void k_bd_connect(BdCtx c, bpixel *items, const BdStep *steps, TileMa
 // The l == 0 pairs (BDPT_RGB.py:489-491): an eye vertex that lies on an emitter contributes its beta, MIS-weighted.  A sub-path ends on
 // the emitter it meets (:152-158), so per item only e = eye_depth can be one; the light sub-path's depth does not matter (l = 0 <= any).
 template <bool SPEC>
-__global__ void k_bd_emitted(BdCtx c, const bpixel *items, const BdStep *steps, TileMap tm, int P, int N, uint32_t frame_begin, float *radiance, long frame_stride)
+__global__ void k_bd_emitted(BdCtx c, BdItems items, const BdStep *steps, TileMap tm, int P, int N, uint32_t frame_begin, float *radiance, long frame_stride)
 {
     const int it = blockIdx.x * blockDim.x + threadIdx.x;
     if (it >= N) return;
     const int e = steps[it].eye_depth;
-    if (e < 2 || e > BD_EYE_MAX || e - 2 > BD_MAX_DEPTH || items[it].eye[e - 1].type != VERTEX_LIGHT) return;          // depth = e - 2 in 0..BD_MAX_DEPTH
+    if (e < 2 || e > BD_EYE_MAX || e - 2 > BD_MAX_DEPTH) return;
+    const bpixel B = bd_item(items, (size_t)it);
+    if (B.eye[e - 1].type != VERTEX_LIGHT) return;          // depth = e - 2 in 0..BD_MAX_DEPTH
     const int f = it / P, k = it - f * P;
     const int p = local_to_pixel(tm, k), i = p / c.bv.H, j = p - i * c.bv.H;
     const uint32_t frame = frame_begin + (uint32_t)f;
@@ -802,8 +835,8 @@ __global__ void k_bd_emitted(BdCtx c, const bpixel *items, const BdStep *steps, 
     T.o = V(0.0f, 0.0f, 0.0f); T.d = T.o; T.expect = -3; T.bound = -1.0f;
     bvert sample = bvert();
     int nu = 0, nv = 0;
-    const bvert EV = items[it].eye[e - 1];
-    const v3 r = bd_connect_path<SPEC>(c, items + it, EV, sample, i, j, e, 0, frame, nu, nv, T);
+    const bvert EV = B.eye[e - 1];
+    const v3 r = bd_connect_path<SPEC>(c, B, EV, sample, i, j, e, 0, frame, nu, nv, T);
     bd_splat<SPEC>(c, radiance + (size_t)f * (size_t)frame_stride, e, nu, nv, p, frame, r);
 }
 
@@ -812,7 +845,7 @@ __global__ void k_bd_emitted(BdCtx c, const bpixel *items, const BdStep *steps, 
 // contribution and MIS weight (BDPT_RGB.py:300-479), splatted with float atomics.
 constexpr int BD_RESOLVE_CHUNK = 2048;            // queue entries a block filters at a time
 template <bool SPEC>
-__global__ void k_bd_resolve(BdCtx c, const bpixel *items, TileMap tm, int P, uint32_t frame_begin, const unsigned *qown, const int *scount,
+__global__ void k_bd_resolve(BdCtx c, BdItems items, TileMap tm, int P, uint32_t frame_begin, const unsigned *qown, const int *scount,
                              const float4 *shits, const float4 *stage, const int *qlist, float *radiance, long frame_stride)
 {
     // every branch of connect_path wants the ray's closest hit to be the expected primitive before anything else (and about half of the
@@ -851,8 +884,9 @@ __global__ void k_bd_resolve(BdCtx c, const bpixel *items, TileMap tm, int P, ui
             T.o = V(0.0f, 0.0f, 0.0f); T.d = T.o; T.expect = -3; T.bound = -1.0f;
             bvert sample = bvert();
             int nu = 0, nv = 0;
-            const bvert EV = items[it].eye[e - 1];
-            const v3 r = bd_connect_path<SPEC>(c, items + it, EV, sample, i, j, e, l, frame, nu, nv, T);
+            const bpixel B = bd_item(items, (size_t)it);
+            const bvert EV = B.eye[e - 1];
+            const v3 r = bd_connect_path<SPEC>(c, B, EV, sample, i, j, e, l, frame, nu, nv, T);
             bd_splat<SPEC>(c, radiance + (size_t)f * (size_t)frame_stride, e, nu, nv, p, frame, r);
         }
         __syncthreads();
@@ -929,7 +963,7 @@ int bdpt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t see
         // not more than the device has free right now (plus what this context's BDPT buffers hold already: growing them frees them first), less
         // 2 GB: a batch half the size is a few per cent slower, a failed hipMalloc ends the render (bench.py's profiler child, next to the
         // contexts of the other configs, ran into exactly that with 16 Mi-item batches)
-        const size_t per_item = sizeof(bpixel) + sizeof(BdStep) + sizeof(float) * (16 + 16 * BD_RAY_PAIRS) + sizeof(float4) * (2 + BD_RAY_PAIRS) + sizeof(int) * (4 + BD_RAY_PAIRS);
+        const size_t per_item = BD_ITEM_BYTES + sizeof(BdStep) + sizeof(float) * (16 + 16 * BD_RAY_PAIRS) + sizeof(float4) * (2 + BD_RAY_PAIRS) + sizeof(int) * (4 + BD_RAY_PAIRS);
         size_t free_b = 0, total_b = 0, held = 0;
         for (int l = 0; l < 2; l++) held += c->bd[l].items.bytes + c->bd[l].state.bytes + c->bd[l].rays.bytes + c->bd[l].hits.bytes + c->bd[l].qidx.bytes + c->bd[l].rad.bytes;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
@@ -949,7 +983,7 @@ int bdpt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t see
     const size_t SCAP = NMAX * BD_RAY_PAIRS;                     // at most 20 (e, l) pairs per item carry a connection ray (staging: [20][N])
     for (int l = 0; l < NL; l++) {
         auto &bl = c->bd[l];
-        if (bl.items.ensure(sizeof(bpixel) * NMAX) || bl.state.ensure(sizeof(BdStep) * NMAX) ||
+        if (bl.items.ensure(BD_ITEM_BYTES * NMAX) || bl.state.ensure(sizeof(BdStep) * NMAX) ||
             bl.rays.ensure(sizeof(float) * (8 * 2 * NMAX + 8 * SCAP)) || bl.hits.ensure(sizeof(float4) * (2 * NMAX + SCAP)) ||
             bl.qidx.ensure(sizeof(int) * (NMAX * 4 + 2 * SCAP)) || bl.ctr.ensure(256) ||
             bl.rad.ensure(sizeof(float) * 3 * (size_t)NP * (size_t)FB_alloc)) return TIRT_ERR_HIP;
@@ -985,15 +1019,16 @@ int bdpt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t see
         int *qlist = (int *)(qown + SCAP);                            // [queue place]: where the ray is staged (j * N + item)
         float4 *ehits = bl.hits.as<float4>(), *shits = ehits + 2 * NMAX;
         int *scount = bl.ctr.as<int>();
-        bpixel *items = bl.items.as<bpixel>(); BdStep *state = bl.state.as<BdStep>();
+        BdStep *state = bl.state.as<BdStep>();
         const int F = frame_count - f0 < FB ? frame_count - f0 : FB;
         const int N = F * P;
+        const BdItems items = {bl.items.as<float4>(), (size_t)N};          // (the batch's items side by side: stride = their number)
         const uint32_t frame0 = frame_begin + (uint32_t)f0;
         TIRT_HIP(hipMemsetAsync(bl.rad.p, 0, sizeof(float) * 3 * (size_t)NP * (size_t)F, st));
         // No read of a vertex field goes to a slot this item has not written (header; k_bd_delta supplies the one exception), so the
         // 1.0 KB per item need no clearing.  Option "bdpt_state_fill": 1 = zeros (the round-1..3 behaviour), 2 = 0xFF poison -- the
         // parity tests render under poison and must not see a bit change.
-        if (c->bdpt_state_fill) TIRT_HIP(hipMemsetAsync(bl.items.p, c->bdpt_state_fill == 2 ? 0xFF : 0, sizeof(bpixel) * (size_t)N, st));
+        if (c->bdpt_state_fill) TIRT_HIP(hipMemsetAsync(bl.items.p, c->bdpt_state_fill == 2 ? 0xFF : 0, BD_ITEM_BYTES * (size_t)N, st));
         TIRT_HIP(hipMemsetAsync(scount, 0, 64, st));                 // the connection-ray count and the alive counts of the depths
         // during the sub-path phase the dense connection-ray arrays and the two `expect` arrays are free: they hold the second ray list and the owners
         BdRays rset[2] = {sr, er};                                  // depth d reads rset[d & 1]
