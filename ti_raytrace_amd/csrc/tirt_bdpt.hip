@@ -483,7 +483,11 @@ TD v3 bd_connect_path(const BdCtx &c, const bpixel &P, const bvert &EV, bvert &s
 
 // ---- wavefront state ------------------------------------------------------------------------------------------
 // e_tail: slot eye[eye_depth] holds a SURFACE vertex of THIS item (its sampling ended the path, so the depth leaves it out) -- k_bd_delta
-struct BdStep { v3 e_beta; float e_pdfFwd; v3 l_beta; float l_pdfFwd; int e_tail, pad_, eye_depth, light_depth; };
+// In HBM as four arrays over the items (a sub-path's thread reads and writes ONE quad and one word, next to its neighbours'; as a 48-byte record per item
+// every field access of every lane was a request of its own): (e_beta, e_pdfFwd), (l_beta, l_pdfFwd), eye_depth | e_tail << 16, light_depth.
+struct BdSteps { float4 *eb, *lb; int *ed, *ld; };
+constexpr size_t BD_STEP_BYTES = 2 * sizeof(float4) + 2 * sizeof(int);
+inline BdSteps bd_steps(void *base, size_t n) { BdSteps S; S.eb = (float4 *)base; S.lb = S.eb + n; S.ed = (int *)(S.lb + n); S.ld = S.ed + n; return S; }
 struct BdRays { float4 *r; };             // a ray list: 32-byte records (o.xyz, d.x), (d.y, d.z, bits expect, bound) -- TraceArgs::ray4: two memory instructions per ray and side
 constexpr int BD_PAIRS = BD_EYE_MAX * (BD_LIGHT_MAX + 1);          // (e - 1) * 7 + l
 // The pairs that can carry a connection ray: l >= 1, (e, l) != (1, 1), 0 <= e + l - 2 <= BD_MAX_DEPTH -- for e = 1..6: 5, 5, 4, 3, 2, 1
@@ -502,7 +506,7 @@ TD void count_rays(unsigned long long *ctr, unsigned mine)
 
 // BDPT_RGB.py:104-125 (lens vertex, camera ray) and :201-228 with Scene.sample_light (Scene.py:430-474)
 template <bool SPEC>
-__global__ void k_bd_init(BdCtx c, BdItems items, BdStep *steps, BdRays rays, int *owner, int *alive_cnt, TileMap tm, int P, int N, uint32_t frame_begin, unsigned long long *paths)
+__global__ void k_bd_init(BdCtx c, BdItems items, BdSteps steps, BdRays rays, int *owner, int *alive_cnt, TileMap tm, int P, int N, uint32_t frame_begin, unsigned long long *paths)
 {
     const int it = blockIdx.x * blockDim.x + threadIdx.x;
     if (it >= N) return;
@@ -511,7 +515,6 @@ __global__ void k_bd_init(BdCtx c, BdItems items, BdStep *steps, BdRays rays, in
     const int i = p / c.bv.H, j = p - i * c.bv.H;
     const uint32_t pixel = (uint32_t)p, frame = frame_begin + (uint32_t)f;
     const bpixel B = bd_item(items, (size_t)it);
-    BdStep st;
     // eye
     {
         const varr eye = B.eye;
@@ -522,7 +525,7 @@ __global__ void k_bd_init(BdCtx c, BdItems items, BdStep *steps, BdRays rays, in
         bvert ev = bvert();                    // whole 80-byte stores: the fields the reference does not set are the zeros its field starts with
         ev.pos = origin; ev.normal = dir; ev.beta = V(1.0f, 1.0f, 1.0f); ev.fpdf = 1.0f; ev.type = VERTEX_LENS;
         eye.put(0, ev);
-        st.e_beta = V(1.0f, 1.0f, 1.0f); st.e_pdfFwd = 1.0f; st.e_tail = 0; st.pad_ = 0; st.eye_depth = 1;
+        steps.eb[it] = make_float4(1.0f, 1.0f, 1.0f, 1.0f); steps.ed[it] = 1;        // beta, pdfFwd; depth 1, no tail
         put_ray(rays, (size_t)it, origin, dir); owner[it] = it;
     }
     // light
@@ -541,10 +544,9 @@ __global__ void k_bd_init(BdCtx c, BdItems items, BdStep *steps, BdRays rays, in
         lv.pos = lpos; lv.normal = lnor; lv.beta = beta0;
         lv.fpdf = light_pdf; lv.rpdf = 0.0f; lv.wo = ldir; lv.type = VERTEX_LIGHT;
         light.put(0, lv);
-        st.l_beta = beta1; st.l_pdfFwd = dir_pdf; st.light_depth = 1;
+        steps.lb[it] = make_float4(beta1.x, beta1.y, beta1.z, dir_pdf); steps.ld[it] = 1;
         put_ray(rays, (size_t)N + it, lpos, ldir); owner[N + it] = N + it;
     }
-    steps[it] = st;
     if (it == 0) { atomicAdd(paths, (unsigned long long)N); alive_cnt[1] = 2 * N; }        // depth 1: every sub-path has its first ray
 }
 
@@ -554,7 +556,7 @@ __global__ void k_bd_init(BdCtx c, BdItems items, BdStep *steps, BdRays rays, in
 // sub-paths that go on append their next ray to the list of the next depth (one atomic per wave), so the later depths launch
 // work only for what is still alive.
 template <bool SPEC>
-__global__ void k_bd_step(BdCtx c, BdItems items, BdStep *steps, BdRays rays, const int *owner, BdRays rays_out, int *owner_out, int *alive_cnt,
+__global__ void k_bd_step(BdCtx c, BdItems items, BdSteps steps, BdRays rays, const int *owner, BdRays rays_out, int *owner_out, int *alive_cnt,
                           const float4 *hits, TileMap tm, int P, int N, uint32_t frame_begin, int depth, unsigned long long *rays_closest)
 {
     const int qi = blockIdx.x * blockDim.x + threadIdx.x;
@@ -567,7 +569,6 @@ __global__ void k_bd_step(BdCtx c, BdItems items, BdStep *steps, BdRays rays, co
         t = owner[qi];
         const bool is_eye = t < N;
         const int it = is_eye ? t : t - N;
-        BdStep *st = steps + it;
         {
             traced = 1;
             const int f = it / P, k = it - f * P;
@@ -585,8 +586,9 @@ __global__ void k_bd_step(BdCtx c, BdItems items, BdStep *steps, BdRays rays, co
             next_o = origin; next_d = dir;
             if (is_eye) {
                 const varr eye = B.eye;
-                float pdfFwd = st->e_pdfFwd, pdfRev = 0.0f;
-                v3 beta = st->e_beta;
+                const float4 sq = steps.eb[it];
+                float pdfFwd = sq.w, pdfRev = 0.0f;
+                v3 beta = V(sq.x, sq.y, sq.z);
                 bool stored_surface = false;
                 if (sh.t < INF_VALUE) {
                     int mat_id;
@@ -640,11 +642,12 @@ __global__ void k_bd_step(BdCtx c, BdItems items, BdStep *steps, BdRays rays, co
                     }
                     eye.put(depth, ev);                   // five 16-byte stores
                 }
-                st->e_beta = beta; st->e_pdfFwd = pdfFwd; st->eye_depth = final_depth; st->e_tail = (stored_surface && final_depth == depth) ? 1 : 0;
+                steps.eb[it] = make_float4(beta.x, beta.y, beta.z, pdfFwd); steps.ed[it] = final_depth | ((stored_surface && final_depth == depth) ? 1 << 16 : 0);
             } else {
                 const varr light = B.light;
-                float pdfFwd = st->l_pdfFwd, pdfRev = 0.0f;
-                v3 beta = st->l_beta;
+                const float4 sq = steps.lb[it];
+                float pdfFwd = sq.w, pdfRev = 0.0f;
+                v3 beta = V(sq.x, sq.y, sq.z);
                 if (sh.t < INF_VALUE) {
                     int mat_id;
                     const HitAttr h = hit_attributes_rec(s.shade_rec, origin, dir, sh.prim, sh.t, sh.u, sh.v, mat_id);
@@ -691,7 +694,7 @@ __global__ void k_bd_step(BdCtx c, BdItems items, BdStep *steps, BdRays rays, co
                         light.put(depth, lv);
                     }
                 }
-                st->l_beta = beta; st->l_pdfFwd = pdfFwd; st->light_depth = final_depth;
+                steps.lb[it] = make_float4(beta.x, beta.y, beta.z, pdfFwd); steps.ld[it] = final_depth;
             }
         }
     }
@@ -712,7 +715,7 @@ __global__ void k_bd_step(BdCtx c, BdItems items, BdStep *steps, BdRays rays, co
 
 // The `delta` field of an eye vertex that ended on a light is whatever an earlier frame of the same pixel left in that
 // slot (file header): replayed per pixel, in frame order, over the persistent per-pixel memory.
-__global__ void k_bd_delta(BdItems items, const BdStep *steps, TileMap tm, int P, int F, int *delta_mem)
+__global__ void k_bd_delta(BdItems items, BdSteps steps, TileMap tm, int P, int F, int *delta_mem)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= P) return;
@@ -720,7 +723,7 @@ __global__ void k_bd_delta(BdItems items, const BdStep *steps, TileMap tm, int P
     for (int f = 0; f < F; f++) {
         const size_t it = (size_t)f * P + k;
         const varr eye = bd_item(items, it).eye;
-        const int ed = steps[it].eye_depth;
+        const int edt = steps.ed[it], ed = edt & 0xffff;
         for (int v = 1; v < ed; v++) {
             const float4 td = *eye.at(v, 4);                     // (wo, type | delta << 16)
             const int type = (int)(short)(__float_as_uint(td.w) & 0xffffu), delta = (int)(short)(__float_as_uint(td.w) >> 16);
@@ -728,9 +731,9 @@ __global__ void k_bd_delta(BdItems items, const BdStep *steps, TileMap tm, int P
             else if (type == VERTEX_LIGHT) eye.set_delta(v, mem[v]);
         }
         // v == ed: a surface vertex whose sampling ended the path (pdf 0, or the extinction roulette of a refraction) is not counted
-        // in the depth, but its delta has been stored (BDPT_RGB.py:160-187); BdStep::e_tail says that slot is this item's
+        // in the depth, but its delta has been stored (BDPT_RGB.py:160-187); the tail bit of BdSteps::ed says that slot is this item's
         // (the vertex arrays are not cleared between batches)
-        if (ed < BD_EYE_MAX && steps[it].e_tail) mem[ed] = eye[ed].delta;
+        if (ed < BD_EYE_MAX && (edt >> 16)) mem[ed] = eye.delta(ed);
     }
 }
 
@@ -760,7 +763,7 @@ constexpr int BD_OWNER_BITS = 26;                  // a queued connection's owne
 // stages it (k_bd_compact makes the queue dense, k_trace answers it, k_bd_resolve -- one thread per QUEUED CONNECTION -- adds the
 // contribution); the pairs that need none (l == 0: the eye sub-path ended on an emitter) are k_bd_emitted's.
 template <bool SPEC>
-__global__ void k_bd_connect(BdCtx c, BdItems items, const BdStep *steps, TileMap tm, int P, int N, uint32_t frame_begin,
+__global__ void k_bd_connect(BdCtx c, BdItems items, BdSteps steps, TileMap tm, int P, int N, uint32_t frame_begin,
                              float4 *stage, unsigned long long *qmask, int *ibase, int *icount, int *scount, unsigned long long *rays_shadow)
 {
     const int it = blockIdx.x * blockDim.x + threadIdx.x;
@@ -771,7 +774,7 @@ __global__ void k_bd_connect(BdCtx c, BdItems items, const BdStep *steps, TileMa
     if (live) {
         f = it / P; const int k = it - f * P;
         p = local_to_pixel(tm, k); i = p / c.bv.H; j = p - i * c.bv.H;
-        eye_depth = steps[it].eye_depth; light_depth = steps[it].light_depth;
+        eye_depth = steps.ed[it] & 0xffff; light_depth = steps.ld[it];
     }
     const uint32_t frame = frame_begin + (uint32_t)f;
     unsigned emitted = 0;
@@ -820,11 +823,11 @@ __global__ void k_bd_connect(BdCtx c, BdItems items, const BdStep *steps, TileMa
 // The l == 0 pairs (BDPT_RGB.py:489-491): an eye vertex that lies on an emitter contributes its beta, MIS-weighted.  A sub-path ends on
 // the emitter it meets (:152-158), so per item only e = eye_depth can be one; the light sub-path's depth does not matter (l = 0 <= any).
 template <bool SPEC>
-__global__ void k_bd_emitted(BdCtx c, BdItems items, const BdStep *steps, TileMap tm, int P, int N, uint32_t frame_begin, float *radiance, long frame_stride)
+__global__ void k_bd_emitted(BdCtx c, BdItems items, BdSteps steps, TileMap tm, int P, int N, uint32_t frame_begin, float *radiance, long frame_stride)
 {
     const int it = blockIdx.x * blockDim.x + threadIdx.x;
     if (it >= N) return;
-    const int e = steps[it].eye_depth;
+    const int e = steps.ed[it] & 0xffff;
     if (e < 2 || e > BD_EYE_MAX || e - 2 > BD_MAX_DEPTH) return;
     const bpixel B = bd_item(items, (size_t)it);
     if (B.eye[e - 1].type != VERTEX_LIGHT) return;          // depth = e - 2 in 0..BD_MAX_DEPTH
@@ -844,8 +847,12 @@ __global__ void k_bd_emitted(BdCtx c, BdItems items, const BdStep *steps, TileMa
 // unoccluded, the VALU ran at 19 % of its lanes): the traced answer, then -- only if the expected primitive is what the ray met --
 // contribution and MIS weight (BDPT_RGB.py:300-479), splatted with float atomics.
 constexpr int BD_RESOLVE_CHUNK = 2048;            // queue entries a block filters at a time
+#ifndef BD_RESOLVE_WAVES
+#define BD_RESOLVE_WAVES 2
+#endif
+#define BD_RESOLVE_BOUNDS __launch_bounds__(128, BD_RESOLVE_WAVES)      // (the launches use 128-thread blocks; without a bound the compiler assumes 1 024 and keeps the kernel within 128 VGPRs by spilling 244 bytes per lane)
 template <bool SPEC>
-__global__ void k_bd_resolve(BdCtx c, BdItems items, TileMap tm, int P, uint32_t frame_begin, const unsigned *qown, const int *scount,
+__global__ BD_RESOLVE_BOUNDS void k_bd_resolve(BdCtx c, BdItems items, TileMap tm, int P, uint32_t frame_begin, const unsigned *qown, const int *scount,
                              const float4 *shits, const float4 *stage, const int *qlist, float *radiance, long frame_stride)
 {
     // every branch of connect_path wants the ray's closest hit to be the expected primitive before anything else (and about half of the
@@ -963,7 +970,7 @@ int bdpt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t see
         // not more than the device has free right now (plus what this context's BDPT buffers hold already: growing them frees them first), less
         // 2 GB: a batch half the size is a few per cent slower, a failed hipMalloc ends the render (bench.py's profiler child, next to the
         // contexts of the other configs, ran into exactly that with 16 Mi-item batches)
-        const size_t per_item = BD_ITEM_BYTES + sizeof(BdStep) + sizeof(float) * (16 + 16 * BD_RAY_PAIRS) + sizeof(float4) * (2 + BD_RAY_PAIRS) + sizeof(int) * (4 + BD_RAY_PAIRS);
+        const size_t per_item = BD_ITEM_BYTES + BD_STEP_BYTES + sizeof(float) * (16 + 16 * BD_RAY_PAIRS) + sizeof(float4) * (2 + BD_RAY_PAIRS) + sizeof(int) * (4 + BD_RAY_PAIRS);
         size_t free_b = 0, total_b = 0, held = 0;
         for (int l = 0; l < 2; l++) held += c->bd[l].items.bytes + c->bd[l].state.bytes + c->bd[l].rays.bytes + c->bd[l].hits.bytes + c->bd[l].qidx.bytes + c->bd[l].rad.bytes;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
@@ -983,7 +990,7 @@ int bdpt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t see
     const size_t SCAP = NMAX * BD_RAY_PAIRS;                     // at most 20 (e, l) pairs per item carry a connection ray (staging: [20][N])
     for (int l = 0; l < NL; l++) {
         auto &bl = c->bd[l];
-        if (bl.items.ensure(BD_ITEM_BYTES * NMAX) || bl.state.ensure(sizeof(BdStep) * NMAX) ||
+        if (bl.items.ensure(BD_ITEM_BYTES * NMAX) || bl.state.ensure(BD_STEP_BYTES * NMAX) ||
             bl.rays.ensure(sizeof(float) * (8 * 2 * NMAX + 8 * SCAP)) || bl.hits.ensure(sizeof(float4) * (2 * NMAX + SCAP)) ||
             bl.qidx.ensure(sizeof(int) * (NMAX * 4 + 2 * SCAP)) || bl.ctr.ensure(256) ||
             bl.rad.ensure(sizeof(float) * 3 * (size_t)NP * (size_t)FB_alloc)) return TIRT_ERR_HIP;
@@ -1019,10 +1026,10 @@ int bdpt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t see
         int *qlist = (int *)(qown + SCAP);                            // [queue place]: where the ray is staged (j * N + item)
         float4 *ehits = bl.hits.as<float4>(), *shits = ehits + 2 * NMAX;
         int *scount = bl.ctr.as<int>();
-        BdStep *state = bl.state.as<BdStep>();
         const int F = frame_count - f0 < FB ? frame_count - f0 : FB;
         const int N = F * P;
         const BdItems items = {bl.items.as<float4>(), (size_t)N};          // (the batch's items side by side: stride = their number)
+        const BdSteps state = bd_steps(bl.state.p, (size_t)N);
         const uint32_t frame0 = frame_begin + (uint32_t)f0;
         TIRT_HIP(hipMemsetAsync(bl.rad.p, 0, sizeof(float) * 3 * (size_t)NP * (size_t)F, st));
         // No read of a vertex field goes to a slot this item has not written (header; k_bd_delta supplies the one exception), so the
