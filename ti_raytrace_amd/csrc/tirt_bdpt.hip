@@ -496,13 +496,6 @@ constexpr int BD_RAY_PAIRS = 20;
 constexpr int bd_count_ray_pairs() { int n = 0; for (int e = 1; e <= BD_EYE_MAX; e++) for (int l = 1; l <= BD_LIGHT_MAX; l++) if (!(l == 1 && e == 1) && l + e - 2 >= 0 && l + e - 2 <= BD_MAX_DEPTH) n++; return n; }
 static_assert(bd_count_ray_pairs() == BD_RAY_PAIRS, "BD_RAY_PAIRS");
 TD void put_ray(const BdRays &r, size_t k, v3 o, v3 d) { r.r[2 * k] = make_float4(o.x, o.y, o.z, d.x); r.r[2 * k + 1] = make_float4(d.y, d.z, 0.0f, 0.0f); }
-TD void count_rays(unsigned long long *ctr, unsigned mine)
-{
-    unsigned long long v = mine;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    if ((threadIdx.x & 63) == 0 && v) atomicAdd(ctr, v);
-}
 
 // BDPT_RGB.py:104-125 (lens vertex, camera ray) and :201-228 with Scene.sample_light (Scene.py:430-474)
 template <bool SPEC>
@@ -555,13 +548,13 @@ __global__ void k_bd_init(BdCtx c, BdItems items, BdSteps steps, BdRays rays, in
 // The rays of a depth are a dense list (`rays`, `owner`: which sub-path -- t < N eye of item t, else light of item t - N); the
 // sub-paths that go on append their next ray to the list of the next depth (one atomic per wave), so the later depths launch
 // work only for what is still alive.
+constexpr int BD_STEP_BLOCK = 512;
 template <bool SPEC>
-__global__ void k_bd_step(BdCtx c, BdItems items, BdSteps steps, BdRays rays, const int *owner, BdRays rays_out, int *owner_out, int *alive_cnt,
+__global__ __launch_bounds__(BD_STEP_BLOCK) void k_bd_step(BdCtx c, BdItems items, BdSteps steps, BdRays rays, const int *owner, BdRays rays_out, int *owner_out, int *alive_cnt,
                           const float4 *hits, TileMap tm, int P, int N, uint32_t frame_begin, int depth, unsigned long long *rays_closest)
 {
     const int qi = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
-    unsigned traced = 0;
     bool go_on = false;
     v3 next_o = V(0.0f, 0.0f, 0.0f), next_d = next_o;
     int t = 0;
@@ -570,7 +563,6 @@ __global__ void k_bd_step(BdCtx c, BdItems items, BdSteps steps, BdRays rays, co
         const bool is_eye = t < N;
         const int it = is_eye ? t : t - N;
         {
-            traced = 1;
             const int f = it / P, k = it - f * P;
             const uint32_t pixel = (uint32_t)local_to_pixel(tm, k), frame = frame_begin + (uint32_t)f;
             const SceneView &s = c.sc;
@@ -698,19 +690,29 @@ __global__ void k_bd_step(BdCtx c, BdItems items, BdSteps steps, BdRays rays, co
             }
         }
     }
+    // the survivors' places in the next depth's list: ONE atomic per block (same-address atomics retire at ~11 ns each on MI355X: one per wave -- 262 k of them
+    // at depth 1 of a 8 Mi-item batch -- bounded this kernel at 2.9 ms of its 6.4; the ray count, which was a second such stream, is the list's length)
+    __shared__ int s_wc[BD_STEP_BLOCK / 64], s_base;
     const unsigned long long gm = __ballot(go_on);
-    if (gm != 0ull) {
-        const int leader = __ffsll((long long)gm) - 1;
-        int base = 0;
-        if (lane == leader) base = atomicAdd(&alive_cnt[depth + 1], __popcll(gm));
-        base = __shfl(base, leader, 64);
-        if (go_on) {
-            const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-            const size_t qo = (size_t)(base + __popcll(gm & lt));
-            put_ray(rays_out, qo, next_o, next_d); owner_out[qo] = t;
-        }
+    const int wid = threadIdx.x >> 6;
+    if (lane == 0) s_wc[wid] = __popcll(gm);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int tot = 0;
+#pragma unroll
+        for (int w = 0; w < BD_STEP_BLOCK / 64; w++) tot += s_wc[w];
+        s_base = tot ? atomicAdd(&alive_cnt[depth + 1], tot) : 0;
     }
-    count_rays(rays_closest, traced);
+    __syncthreads();
+    if (go_on) {
+        int base = s_base;
+#pragma unroll
+        for (int w = 0; w < BD_STEP_BLOCK / 64; w++) if (w < wid) base += s_wc[w];
+        const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+        const size_t qo = (size_t)(base + __popcll(gm & lt));
+        put_ray(rays_out, qo, next_o, next_d); owner_out[qo] = t;
+    }
+    if (qi == 0) atomicAdd(rays_closest, (unsigned long long)alive_cnt[depth]);          // every entry of this depth's list was a traced ray
 }
 
 // The `delta` field of an eye vertex that ended on a light is whatever an earlier frame of the same pixel left in that
@@ -762,9 +764,10 @@ constexpr int BD_OWNER_BITS = 26;                  // a queued connection's owne
 // BDPT_RGB.py:615-637, the double loop over (e, l), per item: the geometry of every connection.  A pair that needs a visibility ray
 // stages it (k_bd_compact makes the queue dense, k_trace answers it, k_bd_resolve -- one thread per QUEUED CONNECTION -- adds the
 // contribution); the pairs that need none (l == 0: the eye sub-path ended on an emitter) are k_bd_emitted's.
+constexpr int BD_CONNECT_BLOCK = 256;
 template <bool SPEC>
-__global__ void k_bd_connect(BdCtx c, BdItems items, BdSteps steps, TileMap tm, int P, int N, uint32_t frame_begin,
-                             float4 *stage, unsigned long long *qmask, int *ibase, int *icount, int *scount, unsigned long long *rays_shadow)
+__global__ __launch_bounds__(BD_CONNECT_BLOCK) void k_bd_connect(BdCtx c, BdItems items, BdSteps steps, TileMap tm, int P, int N, uint32_t frame_begin,
+                             float4 *stage, unsigned long long *qmask, int *ibase, int *icount, int *scount)
 {
     const int it = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = it < N;
@@ -814,9 +817,21 @@ __global__ void k_bd_connect(BdCtx c, BdItems items, BdSteps steps, TileMap tm, 
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
     const int total = __shfl(incl, 63, 64);
-    int base = 0;
-    if (lane == 63 && total) { base = atomicAdd(scount, total); atomicAdd(rays_shadow, (unsigned long long)total); }
-    base = __shfl(base, 63, 64);
+    // one atomic per block for the waves' places (k_bd_compact adds the queue's length to the ray counter)
+    __shared__ int s_wt[BD_CONNECT_BLOCK / 64], s_cb;
+    const int wid = threadIdx.x >> 6;
+    if (lane == 0) s_wt[wid] = total;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int tot = 0;
+#pragma unroll
+        for (int w = 0; w < BD_CONNECT_BLOCK / 64; w++) tot += s_wt[w];
+        s_cb = tot ? atomicAdd(scount, tot) : 0;
+    }
+    __syncthreads();
+    int base = s_cb;
+#pragma unroll
+    for (int w = 0; w < BD_CONNECT_BLOCK / 64; w++) if (w < wid) base += s_wt[w];
     if (live) { ibase[it] = base; icount[it] = (int)emitted; qmask[it] = pairs; }          // the wave's place in the dense queue; k_bd_compact orders it slot by slot
 }
 
@@ -904,9 +919,10 @@ __global__ BD_RESOLVE_BOUNDS void k_bd_resolve(BdCtx c, BdItems items, TileMap t
 // (the j-th rays of the items that have one take consecutive queue places, so that k_trace's lanes read neighbouring staging records), and
 // writes per place where the ray is staged (`qlist`, read by k_trace through TraceArgs::ray_index and by k_bd_resolve) and whose it is
 // (`qown`: item, pair slot).  The rays themselves stay where they are (rounds 2-3a copied them: 128 B of traffic and 32 B of state per ray).
-__global__ void k_bd_compact(int N, const int *ibase, const int *icount, const unsigned long long *qmask, int *qlist, unsigned *qown)
+__global__ void k_bd_compact(int N, const int *ibase, const int *icount, const unsigned long long *qmask, int *qlist, unsigned *qown, const int *scount, unsigned long long *rays_shadow)
 {
     const int it = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
+    if (it == 0 && *scount) atomicAdd(rays_shadow, (unsigned long long)*scount);          // the queue's length: every staged connection is a traced ray
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     const bool live = it < N;
     const int n = live ? icount[it] : 0;
@@ -1047,19 +1063,19 @@ int bdpt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t see
         for (int d = 1; d < BD_EYE_MAX; d++) {
             const BdRays &ri = rset[d & 1], &ro = rset[(d + 1) & 1];
             if (int rc = trace_arrays(c, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 2 * N, alive_cnt + d, ehits, nullptr, nullptr, false, lane, ri.r, false)) return rc;
-            if (spectral) hipLaunchKernelGGL(k_bd_step<true>, dim3((2 * N + B - 1) / B), dim3(B), 0, st, bc, items, state, ri, oset[d & 1], ro,
+            if (spectral) hipLaunchKernelGGL(k_bd_step<true>, dim3((2 * N + BD_STEP_BLOCK - 1) / BD_STEP_BLOCK), dim3(BD_STEP_BLOCK), 0, st, bc, items, state, ri, oset[d & 1], ro,
                                oset[(d + 1) & 1], alive_cnt, ehits, tm, P, N, frame0, d, &ctr->rays_closest);
-            else hipLaunchKernelGGL(k_bd_step<false>, dim3((2 * N + B - 1) / B), dim3(B), 0, st, bc, items, state, ri, oset[d & 1], ro,
+            else hipLaunchKernelGGL(k_bd_step<false>, dim3((2 * N + BD_STEP_BLOCK - 1) / BD_STEP_BLOCK), dim3(BD_STEP_BLOCK), 0, st, bc, items, state, ri, oset[d & 1], ro,
                                oset[(d + 1) & 1], alive_cnt, ehits, tm, P, N, frame0, d, &ctr->rays_closest);
         }
         if (last_delta) TIRT_HIP(hipStreamWaitEvent(st, last_delta, 0));      // the per-pixel memory is replayed in frame order
         hipLaunchKernelGGL(k_bd_delta, dim3((P + B - 1) / B), dim3(B), 0, st, items, state, tm, P, F, c->bdpt_px.as<int>());
         if (NL > 1) { TIRT_HIP(hipEventRecord(bl.delta_done, st)); last_delta = bl.delta_done; }
-        if (spectral) hipLaunchKernelGGL(k_bd_connect<true>, dim3((N + B - 1) / B), dim3(B), 0, st, bc, items, state, tm, P, N, frame0,
-                           stage, qmask, ibase, icount, scount, &ctr->rays_shadow);
-        else hipLaunchKernelGGL(k_bd_connect<false>, dim3((N + B - 1) / B), dim3(B), 0, st, bc, items, state, tm, P, N, frame0,
-                           stage, qmask, ibase, icount, scount, &ctr->rays_shadow);
-        hipLaunchKernelGGL(k_bd_compact, dim3((N + B - 1) / B), dim3(B), 0, st, N, ibase, icount, qmask, qlist, qown);
+        if (spectral) hipLaunchKernelGGL(k_bd_connect<true>, dim3((N + BD_CONNECT_BLOCK - 1) / BD_CONNECT_BLOCK), dim3(BD_CONNECT_BLOCK), 0, st, bc, items, state, tm, P, N, frame0,
+                           stage, qmask, ibase, icount, scount);
+        else hipLaunchKernelGGL(k_bd_connect<false>, dim3((N + BD_CONNECT_BLOCK - 1) / BD_CONNECT_BLOCK), dim3(BD_CONNECT_BLOCK), 0, st, bc, items, state, tm, P, N, frame0,
+                           stage, qmask, ibase, icount, scount);
+        hipLaunchKernelGGL(k_bd_compact, dim3((N + B - 1) / B), dim3(B), 0, st, N, ibase, icount, qmask, qlist, qown, scount, &ctr->rays_shadow);
         if (int rc = trace_arrays(c, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, (int)(SCAP < (size_t)N * BD_RAY_PAIRS ? SCAP : (size_t)N * BD_RAY_PAIRS), scount, shits, nullptr, nullptr, false, lane, stage, true, qlist)) return rc;
         if (spectral) hipLaunchKernelGGL(k_bd_emitted<true>, dim3((N + B - 1) / B), dim3(B), 0, st, bc, items, state, tm, P, N, frame0, bl.rad.as<float>(), 3 * NP);
         else hipLaunchKernelGGL(k_bd_emitted<false>, dim3((N + B - 1) / B), dim3(B), 0, st, bc, items, state, tm, P, N, frame0, bl.rad.as<float>(), 3 * NP);
