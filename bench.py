@@ -477,8 +477,30 @@ def _with_timeout(what, fn, seconds):
     return box.get("v")
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` typed as is (N > 1, no launcher): start one process per GPU through torch.distributed.run on
+    127.0.0.1 with a free port and this command line, pass its output through (rank 0 prints the one JSON line) and exit with
+    its code.  The parent touches neither torch nor HIP.  The reference is single-device (integrator/PT_RGB.py:44-49): there is
+    nothing to match here, only the driver's contract."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: what RCCL needs between processes on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    sys.stderr.write("bench.py: --gpus %d without a launcher: starting %s\n" % (args.gpus, " ".join(cmd[1:9])))
+    sys.stderr.flush()
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.configs_only:
+        self_launch(args)
     if args.no_roofline:            # the quick form every tool and test uses: headline number only
         args.no_configs = True
     if args.configs_only:                       # child of bdpt_roofline's profiler passes: one config, optional context options
@@ -496,10 +518,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("--gpus %d needs one process per GPU: launch with torch.distributed.run" % args.gpus)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    # a rank renders on device LOCAL_RANK when the process sees all of the node's GPUs, on its only device when the launcher
+    # gave every rank one visible device (ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES per rank): local_rank modulo what is visible
+    n_visible = torch.cuda.device_count()
+    if world > 1 and n_visible != 1 and n_visible < int(os.environ.get("LOCAL_WORLD_SIZE", world)) \
+            and os.environ.get("TIRT_BENCH_ONE_DEVICE", "0") != "1":
+        raise SystemExit("%d ranks on this node but %d visible GPUs (one process per GPU; TIRT_BENCH_ONE_DEVICE=1 + "
+                         "TIRT_BENCH_BACKEND=gloo is the self-test that shares one)" % (int(os.environ.get("LOCAL_WORLD_SIZE", world)), n_visible))
+    local_rank %= max(n_visible, 1)
     # self-test knobs (not used by the driver): TIRT_FORCE_DIST=1 exercises the RCCL path with one rank;
     # TIRT_BENCH_ONE_DEVICE=1 + TIRT_BENCH_BACKEND=gloo lets N ranks share cuda:0 on a 1-GPU box, which runs the
     # whole N-rank flow (tile split, merged submission, film reduce, max over ranks) on real hardware

@@ -39,3 +39,24 @@ def test_three_ranks_on_one_device_equal_one_process(gpu_ctx_ok, tmp_path):
     assert three["n_gpus"] == 3 and one["n_gpus"] == 1 and three["scaling"] == "strong"
     assert three["rays"] == one["rays"]                       # every pixel-sample traced exactly once across the ranks
     assert (tmp_path / "one.png").read_bytes() == (tmp_path / "three.png").read_bytes()
+
+
+def test_gpus_3_typed_without_a_launcher(gpu_ctx_ok, tmp_path):
+    """`python bench.py --gpus 3 ...` exactly as typed (no torch.distributed.run in front, no WORLD_SIZE): bench.py starts its own
+    ranks; same rays and the same PNG as one process."""
+    common = ["--steps", "2", "--warmup", "1", "--frames-per-step", "4", "--size", "320", "--ntri", "20000",
+              "--tile-size", "1024", "--no-cpu-baseline", "--no-roofline"]
+    one = run([sys.executable, "bench.py"] + common + ["--save-png", str(tmp_path / "one.png")], {}, tmp_path, "one")
+    env = {"TIRT_BENCH_ONE_DEVICE": "1", "TIRT_BENCH_BACKEND": "gloo"}
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        assert k not in os.environ
+    three = run([sys.executable, "bench.py", "--gpus", "3"] + common + ["--save-png", str(tmp_path / "three.png")], env, tmp_path, "three")
+    assert three["n_gpus"] == 3 and three["rays"] == one["rays"]
+    assert (tmp_path / "one.png").read_bytes() == (tmp_path / "three.png").read_bytes()
+
+
+def test_force_dist_one_rank_rccl(gpu_ctx_ok, tmp_path):
+    """The N > 1 code path through RCCL itself with the one rank a 1-GPU box allows: communicator set-up, hash all-gather, film reduce."""
+    r = run([sys.executable, "bench.py", "--gpus", "1", "--steps", "2", "--warmup", "1", "--frames-per-step", "4", "--size", "256",
+             "--ntri", "20000", "--no-cpu-baseline", "--no-roofline"], {"TIRT_FORCE_DIST": "1"}, tmp_path, "force")
+    assert r["n_gpus"] == 1 and r["distributed"]["rccl_ranks"] == 1 and r["distributed"]["backend"] == "nccl"

@@ -99,7 +99,12 @@ constexpr unsigned TR_H_POS = 0x7b53u, TR_H_NEG = 0xfb53u;      // fp16 +-60000
 constexpr int TR_BLOCK = TR_BLOCK_SIZE;                  // threads per persistent k_trace block
 constexpr int TIRT_MAX_DEVICES = 64;
 // dynamic LDS of a k_trace block: `depth` stack entries per lane + the LDS copy of the tree top (64-byte records)
-inline size_t trace_lds_bytes(int depth) { return sizeof(int) * (size_t)depth * TR_BLOCK + (size_t)TR_TOP_SLOTS * 64; }
+#ifdef TR_PADG
+constexpr size_t TR_LADDER_LDS = 4 * TR_BLOCK;           // bound-ladder builds only (tirt_render.hip, TR_LADDER_PADS): where the dummy gathers land
+#else
+constexpr size_t TR_LADDER_LDS = 0;
+#endif
+inline size_t trace_lds_bytes(int depth) { return sizeof(int) * (size_t)depth * TR_BLOCK + (size_t)TR_TOP_SLOTS * 64 + TR_LADDER_LDS; }
 struct BvhView {
     const float4 *wnode;
     const float4 *tri;

@@ -244,6 +244,49 @@ TD unsigned long long wave_sum(unsigned long long v)
 typedef const __attribute__((address_space(4))) TraceArgs *cold_args_t;
 #define TR_COLD(ca) cold_args_t ca = (cold_args_t)__builtin_amdgcn_kernarg_segment_ptr(); asm volatile("" : "+s"(ca))
 
+// ---- bound ladder (tools/ladder.sh, profiles/r05_bound_ladder.txt; experiments only, nothing of it in the product build) ----
+// What limits k_trace is asked of the kernel itself: -DTR_PAD=k adds k VALU instructions to every node visit that change nothing (v_fma_f32 x, x, 1.0, 0
+// on the nine grid registers of the ray: independent chains, no extra register, films stay bit-identical) -- a kernel bound by VALU issue slows down
+// from k = 0 on by k / (instructions of a visit), one with slack does not until the slack is used; -DTR_PAD_LATE puts them behind the sort (in the
+// dependent chain of the visit) instead of behind the loads (in the shadow of their latency).  -DTR_PADG=k adds k dummy gathers -- one dword from
+// k other 64-byte node records, landed in a scratch kilobyte of LDS by global_load_lds, so that no register and no wait is spent on them: load on
+// the texture-address / L1 / L2 path only (+ 3 VALU each for the address).
+#if defined(TR_PAD) || defined(TR_PADG)
+#ifndef TR_PAD
+#define TR_PAD 0
+#endif
+#ifndef TR_PADG
+#define TR_PADG 0
+#endif
+#ifdef TR_PAD_LATE
+#define TR_PAD_WHERE 1
+#else
+#define TR_PAD_WHERE 0
+#endif
+#define TR_PAD1(reg) asm volatile("v_fma_f32 %0, %0, 1.0, 0" : "+v"(reg))
+#define TR_LADDER_PADS(where)                                                                        \
+    do {                                                                                             \
+        if ((where) == TR_PAD_WHERE) {                                                               \
+            _Pragma("unroll") for (int p__ = 0; p__ < TR_PAD; p__++) {                               \
+                switch (p__ % 9) {                                                                   \
+                case 0: TR_PAD1(gAx); break; case 1: TR_PAD1(gAy); break; case 2: TR_PAD1(gAz); break;      \
+                case 3: TR_PAD1(gBnx); break; case 4: TR_PAD1(gBny); break; case 5: TR_PAD1(gBnz); break;   \
+                case 6: TR_PAD1(gBfx); break; case 7: TR_PAD1(gBfy); break; default: TR_PAD1(gBfz); break;  \
+                }                                                                                    \
+            }                                                                                        \
+        }                                                                                            \
+        if ((where) == 0) {                                                                          \
+            _Pragma("unroll") for (int g__ = 0; g__ < TR_PADG; g__++) {                              \
+                const unsigned dn__ = ((unsigned)cur + 977u * (unsigned)(g__ + 1)) & 32767u;         \
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)((const char *)b.cnode + (dn__ << 6)), \
+                    (__attribute__((address_space(3))) void *)(size_t)(top_base + (unsigned)TR_TOP_SLOTS * 64u + (unsigned)(tid & ~63) * 4u), 4, 0, 0); \
+            }                                                                                        \
+        }                                                                                            \
+    } while (0)
+#else
+#define TR_LADDER_PADS(where) do { } while (0)
+#endif
+
 #ifndef TR_TAIL_WAVES
 #define TR_TAIL_WAVES 3       // the tail kernel carries the shading code: 168 VGPRs, three 256-thread blocks per CU
 #endif
@@ -592,10 +635,55 @@ __global__ __launch_bounds__(TR_BLOCK, KIND == KIND_TAIL ? TR_TAIL_WAVES : TR_MI
                 } else {
                     // ordered mode on the quantised 4-wide nodes: four box tests, children visited near to far
                     uint4 q0, q1, q2, q3;
-                    if (cur < TR_TOP_SLOTS) {        // breadth-first numbering: the first nodes are the top of the tree, resident in LDS
-                        const lds_u4 *t = (const lds_u4 *)(size_t)(top_base + (unsigned)cur * 64u);
-                        const u4v t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3];
 #define TR_U4(v) make_uint4((v).x, (v).y, (v).z, (v).w)
+#ifndef TR_NO_EARLY_LDS_ADDR
+                    // The LDS address of the record is formed BEFORE the two branches and pinned: formed inside the LDS branch it lands on a register
+                    // the global loads of the other branch are still writing (the four quads are the same registers on both sides), and the compiler
+                    // puts s_waitcnt vmcnt(0) in front of it -- a wave with lanes on both sides (nearly every step) then read LDS only after its global
+                    // loads had returned: the two latencies in a row instead of side by side.
+                    unsigned top_addr = top_base + ((unsigned)cur << 6);
+                    asm volatile("" : "+v"(top_addr));
+#else
+                    const unsigned top_addr = top_base + (unsigned)cur * 64u;
+#endif
+#ifdef TR_ASM_FETCH
+                    // The record comes from LDS for some lanes and from global memory for the others, into the SAME sixteen registers.  Written in C++ the
+                    // compiler orders the two (a write-after-write on a register, as it sees it): s_waitcnt vmcnt(0) before the first ds_read, i.e. a wave with
+                    // lanes on both sides -- nearly every step -- pays the two latencies in a row.  The lanes are disjoint (complementary exec masks) and a
+                    // returning load writes only the lanes it was issued for, so nothing has to be ordered: both sets of loads are issued back to back here, one wait.
+                    {
+                        u4v r0__, r1__, r2__, r3__;
+                        unsigned long long sv__;
+                        const unsigned long long topm__ = ballot64(cur < TR_TOP_SLOTS);
+                        const unsigned goff__ = (unsigned)cur << 6;
+                        asm volatile(
+                            "s_mov_b64 %4, exec\n\t"
+                            "s_and_b64 exec, %4, %8\n\t"
+                            "s_cbranch_execz .Ltr_fetch_g%=\n\t"
+                            "ds_read_b128 %0, %5\n\t"
+                            "ds_read_b128 %1, %5 offset:16\n\t"
+                            "ds_read_b128 %2, %5 offset:32\n\t"
+                            "ds_read_b128 %3, %5 offset:48\n"
+                            ".Ltr_fetch_g%=:\n\t"
+                            "s_andn2_b64 exec, %4, %8\n\t"
+                            "s_cbranch_execz .Ltr_fetch_e%=\n\t"
+                            "global_load_dwordx4 %0, %6, %7\n\t"
+                            "global_load_dwordx4 %1, %6, %7 offset:16\n\t"
+                            "global_load_dwordx4 %2, %6, %7 offset:32\n\t"
+                            "global_load_dwordx4 %3, %6, %7 offset:48\n"
+                            ".Ltr_fetch_e%=:\n\t"
+                            "s_mov_b64 exec, %4\n\t"
+                            "s_waitcnt vmcnt(0) lgkmcnt(0)"
+                            : "=&v"(r0__), "=&v"(r1__), "=&v"(r2__), "=&v"(r3__), "=&s"(sv__)
+                            : "v"(top_addr), "v"(goff__), "s"(b.cnode), "s"(topm__)
+                            : "memory");
+                        q0 = TR_U4(r0__); q1 = TR_U4(r1__); q2 = TR_U4(r2__); q3 = TR_U4(r3__);
+                        if (COUNT) { if (cur < TR_TOP_SLOTS) d_outer++; }
+                    }
+#else
+                    if (cur < TR_TOP_SLOTS) {        // breadth-first numbering: the first nodes are the top of the tree, resident in LDS
+                        const lds_u4 *t = (const lds_u4 *)(size_t)top_addr;
+                        const u4v t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3];
                         q0 = TR_U4(t0); q1 = TR_U4(t1); q2 = TR_U4(t2); q3 = TR_U4(t3);
 #ifndef TR_DRAIN_DIAG
                         if (COUNT) d_outer++;
@@ -604,6 +692,8 @@ __global__ __launch_bounds__(TR_BLOCK, KIND == KIND_TAIL ? TR_TAIL_WAVES : TR_MI
                         const uint4 *w = (const uint4 *)((const char *)b.cnode + ((unsigned)cur << 6));
                         q0 = w[0]; q1 = w[1]; q2 = w[2]; q3 = w[3];
                     }
+#endif
+                    TR_LADDER_PADS(0);
                     int c0 = (int)q3.x, c1 = (int)q3.y, c2 = (int)q3.z, c3 = (int)q3.w;
                     if (COUNT) nbox += 4;
                     constexpr float MISS = 3.0e38f;
@@ -640,6 +730,7 @@ __global__ __launch_bounds__(TR_BLOCK, KIND == KIND_TAIL ? TR_TAIL_WAVES : TR_MI
                     } while (0)
                     // (nearest-only selection, 3 exchanges instead of 5, measured 5 % slower: more nodes visited)
                     TR_CE(d0, c0, d1, c1); TR_CE(d2, c2, d3, c3); TR_CE(d0, c0, d2, c2); TR_CE(d1, c1, d3, c3); TR_CE(d1, c1, d2, c2);
+                    TR_LADDER_PADS(1);
                     if (d3 < MISS) { sa += ENTRY; LDS_AT(sa) = c3; }
                     if (d2 < MISS) { sa += ENTRY; LDS_AT(sa) = c2; }
                     if (d1 < MISS) { sa += ENTRY; LDS_AT(sa) = c1; }
