@@ -266,6 +266,16 @@ int tirt_kat_math(tirt_ctx *ctx, int fn, const float *x, const float *y, float *
  *       reference's own source text)
  * in: [n*in_stride] out: [n*out_stride] */
 int tirt_kat_brdf(tirt_ctx *ctx, int which, const float *in, int in_stride, float *out, int out_stride, int n);
+/* The spectral device functions one by one, on the tables of tirt_spectral_upload (tests/test_gpu_spectral.py against tests/golden/refkat_spec.npz --
+ * values computed by the reference's own spectrum/*.py, sky/Sky.py and integrator/PT_Spec.py text).  which:
+ *   0 Spectrum.sample (Spectrum.py:44-52) in: k (0 d65 1 white 2 red 3 green), Lambda out: 1      1 HeroSample.sample (:10-16) in: k, Lambda0 out: 4
+ *   2 HeroSample.sample_xyz (:18-29) of PathTrace.sample (PT_Spec.py:131-139) in: Lambda0 out: x4,y4,z4
+ *   3 Rgb2Spec.fetch (Rgb2Spec.py:101-137) in: rgb3 out: coff3     4 Rgb2Spec.eval (:139-143) in: coff3, Lambda out: 1
+ *   5 HeroSample.srgb_to_spec (:46-58) in: srgb3, Lambda0 out: 4    6 HeroSample.sky_sample (:60-71; Sky.get_solar_radiance, sky/Sky.py:232-264) in: theta, gamma, Lambda0 out: 4
+ *   7 PathTrace.emission_to_rad (PT_Spec.py:102-109) in: emission3, Lambda out: 4     8 HeroSample.get_extinction_hero (:37-43) in: Lambda0, t out: 4
+ *   9 PathTrace.AddSplat (PT_Spec.py:141-158) in: spec4, Lambda0, coff, hdr3 out: hdr3      10 PathTrace.get_spec_power (:111-127) in: mat10, Lambda out: 4
+ *  11 HeroSample.get_rnd_hero (:31-35) in: ti.random(), Lambda0 out: index, Lambda */
+int tirt_kat_spec(tirt_ctx *ctx, int which, const float *in, int in_stride, float *out, int out_stride, int n);
 
 /* ---- native Wavefront OBJ/MTL ingest (host only; no device, no context) -----------------------------
  * Replaces the reference's use of the third-party PyWavefront 1.3.3 package in Scene.add_obj

@@ -2619,6 +2619,40 @@ void orc_kat_util(int which, const float *in, float *out)
         default: break;
     }
 }
+/* Spectral per-function entry points (tests/test_refkat.py against tests/golden/refkat_spec.npz: values computed by the reference's own
+ * spectrum modules, sky/Sky.py and integrator/PT_Spec.py text through tools/refkat).  which:
+ *   0 Spectrum.sample            in: k (0 d65 1 white 2 red 3 green), Lambda          out: 1
+ *   1 HeroSample.sample          in: k, Lambda0                                        out: 4
+ *   2 HeroSample.sample_xyz      in: Lambda0  (sensor = PathTrace.sample, :131-139)    out: x[4], y[4], z[4]
+ *   3 Rgb2Spec.fetch             in: rgb3                                              out: coff3
+ *   4 Rgb2Spec.eval              in: coff3, Lambda                                     out: 1
+ *   5 HeroSample.srgb_to_spec    in: srgb3, Lambda0                                    out: 4
+ *   6 HeroSample.sky_sample      in: theta, gamma, Lambda0                             out: 4
+ *   7 PathTrace.emission_to_rad  in: emission3, Lambda                                 out: 4
+ *   8 HeroSample.get_extinction_hero in: Lambda0, t                                    out: 4
+ *   9 PathTrace.AddSplat         in: spec4, Lambda0, coff, hdr3                        out: hdr3
+ *  10 PathTrace.get_spec_power   in: mat10, Lambda                                     out: 4
+ *  11 HeroSample.get_rnd_hero    in: ti.random(), Lambda0                              out: index, Lambda */
+void orc_kat_spec(const orc_spec *sp, int which, const float *in, float *out)
+{
+    v4s r; int nout4 = 0;
+    switch (which) {
+        case 0: out[0] = spd_sample(&sp->spd[(int)in[0]], in[1]); break;
+        case 1: r = hero_sample(&sp->spd[(int)in[0]], in[1]); nout4 = 1; break;
+        case 2: for (int k = 0; k < HERO_N; k++) { v3 c = sensor_sample(sp, in[0] + (float)k * HERO_LAMBDA_STEP); out[k] = c.x; out[4 + k] = c.y; out[8 + k] = c.z; } break;
+        case 3: { v3 c = r2s_fetch(sp, V(in[0], in[1], in[2])); out[0] = c.x; out[1] = c.y; out[2] = c.z; break; }
+        case 4: out[0] = r2s_eval(V(in[0], in[1], in[2]), in[3]); break;
+        case 5: r = srgb_to_spec(sp, V(in[0], in[1], in[2]), in[3]); nout4 = 1; break;
+        case 6: for (int k = 0; k < HERO_N; k++) out[k] = sky_radiance(sp, in[0], in[1], in[2] + (float)k * HERO_LAMBDA_STEP); break;
+        case 7: r = emission_to_rad(sp, V(in[0], in[1], in[2]), in[3]); nout4 = 1; break;
+        case 8: for (int k = 0; k < HERO_N; k++) out[k] = m_exp(-in[1] / (in[0] + (float)k * HERO_LAMBDA_STEP)); break;
+        case 9: { for (int k = 0; k < HERO_N; k++) r.v[k] = in[k]; out[0] = in[6]; out[1] = in[7]; out[2] = in[8]; spec_add_splat(sp, r, in[4], in[5], out); break; }
+        case 10: { orc_scene s; memset(&s, 0, sizeof(s)); s.material = (float *)in; r = get_spec_power(&s, sp, 0, in[10]); nout4 = 1; break; }
+        case 11: { const int index = (int)(in[0] * (float)HERO_N); out[0] = (float)index; out[1] = in[1] + (float)index * HERO_LAMBDA_STEP; break; }
+        default: break;
+    }
+    if (nout4) for (int k = 0; k < HERO_N; k++) out[k] = r.v[k];
+}
 int orc_uses_libm(void)
 {
 #ifdef ORACLE_LIBM

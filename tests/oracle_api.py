@@ -99,6 +99,7 @@ def load(libm=False, native=False):
         L.orc_kat_rand.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
         L.orc_kat_math.argtypes = [C.c_int, _f32p, _f32p, _f32p, C.c_int]
         L.orc_uses_libm.restype = C.c_int
+        L.orc_kat_spec.argtypes = [_vp, C.c_int, _f32p, _f32p]
         L.orc_spec_table_build.restype = C.c_int
         L.orc_spec_table_build.argtypes = [C.c_int, _f32p, _f32p, C.c_int, _f32p, _f32p, C.c_int]
         L.orc_spec_create.restype = _vp
@@ -248,6 +249,14 @@ class OracleScene:
         self.L.orc_pt_spec_render(self.h, self.spec, W, H, frame_begin, frame_count, seed, max_depth, stack_size,
                                   hdr.reshape(-1), p_begin, p_end, tile_rank, tile_count, tile_size, nthreads, C.byref(st))
         return hdr, st.as_dict()
+
+    def kat_spec(self, which, inp, out_stride):
+        """orc_kat_spec row by row (set_spectral first): the spectral functions one by one, layouts in oracle.c"""
+        inp = np.ascontiguousarray(inp, np.float32)
+        out = np.zeros((inp.shape[0], out_stride), np.float32)
+        for i in range(inp.shape[0]):
+            self.L.orc_kat_spec(self.spec, int(which), inp[i], out[i])
+        return out
 
     def tone_map(self, exposure, hdr):
         out = np.zeros_like(hdr)

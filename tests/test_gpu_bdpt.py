@@ -253,7 +253,7 @@ def test_bdpt_batches_shrink_to_the_free_memory(gpu_ctx_ok):
     assert rel_l2(out[1][0][m], out[0][0][m]) <= 1e-5
 
 
-@pytest.mark.parametrize("name", ["cornell", "cornell_glass"])
+@pytest.mark.parametrize("name", ["cornell", "cornell_glass", "spot_laser"])
 def test_device_bdpt_film_equals_the_reference_text_film(gpu_ctx_ok, name):
     """tests/golden/refkat_bdpt.npz: the film integrator/BDPT_RGB.py's own source text produces (executed as plain Python through the taichi
     stand-in of tools/refkat, build container only; tests/test_refkat.py has the details and holds the oracle to it)."""
@@ -263,5 +263,6 @@ def test_device_bdpt_film_equals_the_reference_text_film(gpu_ctx_ok, name):
     ex.build_scene()
     ex.integrator.render_frames(frames)
     got = ex.integrator.hdr.to_numpy()
-    rel, per = film_close(got, GB["bdpt_%s_film" % name])
+    from test_refkat import GS
+    rel, per = film_close(got, GS["bdpt_spot_laser_film"] if name == "spot_laser" else GB["bdpt_%s_film" % name])
     assert rel <= 1e-5 and per <= 1e-4, (rel, per)

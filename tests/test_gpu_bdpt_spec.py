@@ -88,3 +88,17 @@ def test_rainbow_at_the_gallery_size(gpu_ctx_ok):
     cr, cg, cb = [(cols * prof[:, k]).sum() / prof[:, k].sum() for k in range(3)]
     print("centroid columns: blue %.1f < green %.1f < red %.1f" % (cb, cg, cr))
     assert cb + 2 < cg < cr - 2
+
+
+def test_device_bdpt_spec_film_equals_the_reference_text_film(gpu_ctx_ok):
+    """tests/golden/refkat_spec.npz: the film integrator/BDPT_SPEC.py's own source text produces on example/prism_rainbow.py (16 x 16 x 4 frames; executed as
+    plain Python through the taichi stand-in of tools/refkat, build container only; tests/test_refkat.py has the details and holds the oracle to it)."""
+    from test_refkat import GS, prism_scene, prism_film_close
+    ex, W, H, frames, seed = prism_scene(device_id=0)
+    ex.integrator.seed = seed
+    ex.build_scene()
+    ex.integrator.render_frames(frames)
+    got = ex.integrator.hdr.to_numpy()
+    rel, per, n_ill = prism_film_close(got, GS["bdpt_spec_prism_film"])
+    print("BDPT_SPEC prism: device vs reference text rel-L2 %.2e, worst value %.2e" % (rel, per))
+    assert rel <= 1e-5 and per <= 1e-4

@@ -408,6 +408,32 @@ def test_batch_planning_changes_no_bit(gpu_ctx_ok):
         assert np.array_equal(f.view(np.uint32), films[0].view(np.uint32))
 
 
+@pytest.mark.parametrize("integrator", ["pt_rgb", "pt_spec"])
+def test_path_order_and_slice_layout_change_no_bit(gpu_ctx_ok, integrator):
+    """tirt_internal.h TileMap::F / TraceArgs::slices_contig: the paths of a batch numbered pixel-block major instead of frame major, and k_trace's
+    ray-fetch slices as contiguous stretches of the queue instead of interleaved chunks (each XCD then walks one region of the film): which lane
+    traces which ray changes, nothing else -- the same film bit for bit, the same ray counts, alone and together, also when the tile has partial
+    batches (7 frames cut 4 + 3) and when the local pixel count is not a multiple of 64 (the option then falls back to frame-major order)."""
+    def run(W, H, opts, frames=7):
+        ex = scenes.spectral_box(W, H, frames, device_id=0) if integrator == "pt_spec" else scenes.synthetic(W, H, frames, ntri=3000, device_id=0)
+        ex.build_scene()
+        ctx = ex.scene.ctx
+        for k, v in opts.items(): ctx.set_option(k, v)
+        ctx.set_option("batch_paths", 4 * W * H); ctx.set_option("merge_paths", 4 * W * H)
+        ctx.stats_reset()
+        if integrator == "pt_spec": ctx.pt_spec_render(0, frames, 3, 10, 64, 0)
+        else: ctx.pt_rgb_render(0, frames, 3, 15, 64, 0)
+        film = ctx.film_download(W, H)[0]
+        st = ctx.stats()
+        return film, (st["rays_closest"], st["rays_shadow"], st["paths"], st["shaded"])
+    for W, H in ((96, 96), (50, 30)):
+        base, n0 = run(W, H, {})
+        for opts in ({"path_order_blocks": 1}, {"slices_contiguous": 1}, {"path_order_blocks": 1, "slices_contiguous": 1}):
+            film, n = run(W, H, opts)
+            assert n == n0, (opts, n, n0)
+            assert np.array_equal(film.view(np.uint32), base.view(np.uint32)), opts
+
+
 @pytest.mark.parametrize("scene", ["cornell", "teapot", "synthetic", "lasers"])
 def test_tail_launch_changes_no_bit(gpu_ctx_ok, scene):
     """tirt_render.hip k_trace<KIND_TAIL>: from some bounce on, what is left of a batch runs as ONE persistent launch in which a lane keeps a path
@@ -488,7 +514,7 @@ def test_torch_cuda_still_comes_up_after_this_library(gpu_ctx_ok):
     assert pr.returncode == 0 and pr.stdout.decode().strip().endswith("8.0"), pr.stdout.decode()[-800:]
 
 
-@pytest.mark.parametrize("name", ["cornell", "sphere", "cornell_glass"])
+@pytest.mark.parametrize("name", ["cornell", "sphere", "cornell_glass", "spot_laser"])
 def test_device_film_equals_the_reference_text_film(gpu_ctx_ok, name):
     """tests/golden/refkat_render.npz: the film integrator/PT_RGB.py's own source text produces (executed as plain Python through the
     taichi stand-in of tools/refkat, build container only; tests/test_refkat.py has the details and holds the oracle to it)."""
@@ -498,5 +524,6 @@ def test_device_film_equals_the_reference_text_film(gpu_ctx_ok, name):
     ex.build_scene()
     ex.integrator.render_frames(frames)
     got = ex.integrator.hdr.to_numpy()
-    rel, per = film_close(got, GR["render_%s_film" % name])
+    from test_refkat import GS
+    rel, per = film_close(got, GS["render_spot_laser_film"] if name == "spot_laser" else GR["render_%s_film" % name])
     assert rel <= 1e-5 and per <= 1e-4, (rel, per)

@@ -99,3 +99,40 @@ def test_spectral_tiles_reassemble(gpu_ctx_ok):
         else:
             acc += h
     assert np.array_equal(acc, full)
+
+
+# ---- the device against values computed by the reference's own source text (tests/golden/refkat_spec.npz, tools/refkat/make_refkat_spec.py) ----
+import os
+GS = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "refkat_spec.npz"))
+SPEC_KATS = {0: 1, 1: 4, 2: 12, 3: 3, 4: 1, 5: 4, 6: 4, 7: 4, 8: 4, 9: 3, 10: 4, 11: 2}
+
+
+@pytest.fixture(scope="module")
+def spectral_box16_dev(gpu_ctx_ok):
+    ex = scenes.spectral_box(16, 16, 4, device_id=0)
+    ex.build_scene()                         # the device builds the RGB -> spectrum table (bit-identical to the oracle's, first test of this file)
+    return ex
+
+
+@pytest.mark.parametrize("which", sorted(SPEC_KATS))
+def test_device_spectral_functions_equal_the_reference_text(spectral_box16_dev, which):
+    """tirt_kat_spec: Spectrum.sample, HeroSample.*, Rgb2Spec.fetch / eval, the sky model, PathTrace.emission_to_rad / get_spec_power / AddSplat on the
+    device, on the tables it was given, against the reference's text (which read the table this repo's generator makes): bit for bit."""
+    ctx = spectral_box16_dev.scene.ctx
+    got = ctx.kat_spec(which, GS["spec_k%d_in" % which], SPEC_KATS[which])
+    want = GS["spec_k%d" % which]
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (which, float(np.abs(got - want).max()))
+
+
+def test_device_pt_spec_film_equals_the_reference_text_film(spectral_box16_dev):
+    """integrator/PT_Spec.py:189-279 executed from its source text (16 x 16 x 4 frames of example/spectral_box.py) against k_shade_spec / k_film_spec."""
+    ex = spectral_box16_dev
+    W, H, frames, seed = [int(x) for x in GS["render_spec_box_cfg"]]
+    ctx = ex.scene.ctx
+    ctx.film_clear()
+    ctx.pt_spec_render(0, frames, seed, 10, 64, 0)
+    got = ctx.film_download(W, H)[0]
+    want = GS["render_spec_box_film"]
+    rel = rel_l2(got, want)
+    print("PT_Spec 16x16x4: device vs reference text rel-L2 %.2e" % rel)
+    assert rel < 1e-5

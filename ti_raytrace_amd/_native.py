@@ -93,6 +93,7 @@ SIGNATURES = {
     "tirt_stats_reset": (C.c_int, [_vp]),
     "tirt_kat_math": (C.c_int, [_vp, C.c_int, _f32p, _f32p, _f32p, C.c_int]),
     "tirt_kat_brdf": (C.c_int, [_vp, C.c_int, _f32p, C.c_int, _f32p, C.c_int, C.c_int]),
+    "tirt_kat_spec": (C.c_int, [_vp, C.c_int, _f32p, C.c_int, _f32p, C.c_int, C.c_int]),
     "tirt_obj_load": (C.c_int, [C.c_char_p, C.POINTER(_vp)]),
     "tirt_obj_free": (None, [_vp]),
     "tirt_obj_material_count": (C.c_int, [_vp]),
@@ -395,6 +396,13 @@ class Context:
         n, stride = inp.shape
         out = np.zeros((n, out_stride), np.float32)
         check(lib().tirt_kat_brdf(self.handle, int(which), inp.reshape(-1), stride, out.reshape(-1), out_stride, n))
+        return out
+
+    def kat_spec(self, which, inp, out_stride):
+        inp = np.ascontiguousarray(inp, np.float32)
+        n, stride = inp.shape
+        out = np.zeros((n, out_stride), np.float32)
+        check(lib().tirt_kat_spec(self.handle, int(which), inp.reshape(-1), stride, out.reshape(-1), out_stride, n))
         return out
 
 

@@ -104,7 +104,12 @@ constexpr size_t TR_LADDER_LDS = 4 * TR_BLOCK;           // bound-ladder builds 
 #else
 constexpr size_t TR_LADDER_LDS = 0;
 #endif
-inline size_t trace_lds_bytes(int depth) { return sizeof(int) * (size_t)depth * TR_BLOCK + (size_t)TR_TOP_SLOTS * 64 + TR_LADDER_LDS; }
+#ifdef TR_COOP
+constexpr size_t TR_STAGE_LDS = (size_t)(TR_BLOCK / 64) * 4 * 1040;      // quad-cooperative record fetch: four staging regions per wave (tirt_render.hip)
+#else
+constexpr size_t TR_STAGE_LDS = 0;
+#endif
+inline size_t trace_lds_bytes(int depth) { return sizeof(int) * (size_t)depth * TR_BLOCK + (size_t)TR_TOP_SLOTS * 64 + TR_LADDER_LDS + TR_STAGE_LDS; }
 struct BvhView {
     const float4 *wnode;
     const float4 *tri;
@@ -148,7 +153,17 @@ struct PathState {
 // `blocked` (tiles of a multiple of 8 whole columns, H a multiple of 8, no partial tile): the local order inside a tile walks
 // 8 x 8 pixel blocks, so that the 64 camera rays of a wave form a compact bundle instead of a 1 x 64 strip -- the same rays, 5.5 %
 // faster through the tree (tools/exp/primary_order.py); which pixels a tile owns does not change.
-struct TileMap { int tile_rank, tile_count, tile_size, H, blocked; };
+// `F` > 0: the paths of a wavefront batch of F frames are numbered pixel-block major -- 64-path chunk c = (block of 64 local pixels c / F, frame c % F)
+// -- instead of frame major (F == 0: path s = frame * P + pixel): every contiguous stretch of the ray queue then belongs to ONE region of the film in
+// all its frames, which is what lets k_trace hand each XCD (its own L2) the rays of one part of the scene (slices_contiguous).  Needs P % 64 == 0.
+struct TileMap { int tile_rank, tile_count, tile_size, H, blocked, F; };
+TD void slot_to_frame_pixel(const TileMap &m, int P, int slot, int &f, int &k)
+{
+    if (m.F > 0) { const int c = slot >> 6, kb = c / m.F; f = c - kb * m.F; k = (kb << 6) | (slot & 63); }
+    else { f = slot / P; k = slot - f * P; }
+}
+TD int frame_pixel_to_slot(const TileMap &m, int P, int f, int k)
+{ return m.F > 0 ? ((((k >> 6) * m.F + f) << 6) | (k & 63)) : f * P + k; }
 TD int local_to_pixel(const TileMap &m, int k)
 {
     int lt = k / m.tile_size, within = k - lt * m.tile_size;
@@ -251,6 +266,7 @@ struct tirt_ctx {
     // traversal tunables (options "trace_lds_depth", "trace_refill_min", "trace_node_min", "trace_grid",
     // "trace_slices" = number of ray-fetch cursors, "shade_grid" = persistent blocks of k_shade)
     int tr_lds_depth = 16, tr_refill_min = 18, tr_node_min = 38, tr_grid = 1280, tr_slice_log2 = 5, sh_grid = 1024;
+    int path_order_blocks = 0, slices_contiguous = 0;      // options "path_order_blocks" (TileMap::F) and "slices_contiguous" (k_trace's ray-fetch slices: contiguous ranges of the queue instead of interleaved chunks)
     int tr_grid_alone = 1280;                     // "trace_grid_alone" / "trace_grid": persistent k_trace blocks of a batch submitted to an idle / a busy GPU. Both five per CU
                                                   // (tirt_create scales them by the device's CU count): blocks of the next batch's launch move in as this one's drain
     tirt::DevBuf counters_mem, spill;            // used by the batch trace entry points (main stream)

@@ -70,6 +70,10 @@ struct TraceArgs {
     // c mod S), each with its own cursor in its own 128-byte line; a wave drains its home slice and
     // then moves on to the next one.
     int *fetch; int slice_log2;
+    // slices_contig: slice h is the h-th CONTIGUOUS 1/S of the queue (of the closest-hit rays and of the shadow rays each) instead of every S-th chunk.
+    // The home slice of a wave is (4 x block + wave) mod 32 and blocks go round-robin over the eight XCDs, so slices 4x .. 4x+3 are served by XCD x
+    // first: with paths numbered pixel-block major (TileMap::F) that is one region of the film -- one part of the scene -- per L2.
+    int slices_contig;
     int lds_depth;                               // stack entries per lane kept in LDS
     int refill_min;                              // re-fetch rays when this many lanes of a wave are idle
     int node_min;                                // leave the inner-node loop below this many busy lanes
@@ -95,7 +99,7 @@ struct ShadeStep {
 TD void shade_path(const SceneView &sc, const TileMap &tm, int P, uint32_t frame_begin, uint32_t seed, int bounce, int last_bounce, int slot,
                    const v3 origin, const v3 direction, const float4 hrec, v3 throughout, v3 &radiance, float brdf_pdf, int perfect_spec, ShadeStep &s)
 {
-    const int f = slot / P, k = slot - f * P;
+    int f, k; slot_to_frame_pixel(tm, P, slot, f, k);
     const uint32_t pixel = (uint32_t)local_to_pixel(tm, k);
     const uint32_t frame = frame_begin + (uint32_t)f;
     const uint32_t dim0 = TM_DIM_BOUNCE0 + TM_DIMS_PER_BOUNCE * (uint32_t)bounce;
@@ -365,6 +369,19 @@ __global__ __launch_bounds__(TR_BLOCK, KIND == KIND_TAIL ? TR_TAIL_WAVES : TR_MI
     const unsigned top_base = (unsigned)(size_t)(lds_int *)lds_stack + (unsigned)TR_LDS_DEPTH * ENTRY;
     typedef unsigned u4v __attribute__((ext_vector_type(4)));
     typedef __attribute__((address_space(3))) u4v lds_u4;
+#ifdef TR_COOP
+    // Quad-cooperative record fetch (round 5).  What bounds this kernel is the rate at which a CU's L1 takes requests -- one 64-byte line per lane
+    // and clock, whatever the request's width (profiles/r05_bound_ladder.txt) -- and a lane that reads its 64-byte node record as four
+    // global_load_dwordx4 makes four of them for ONE line.  Here the four lanes of a quad read the four 16-byte quarters of the record ONE of them
+    // needs, in one instruction (adjacent lanes, one line: one request), four instructions for the four lanes' records, each landing through
+    // global_load_lds_dwordx4 (LDS-DMA: destination = M0 + lane x 16, no register, no VALU) in a staging region of the wave: region j holds at
+    // [quad x 64] the record of lane 4 x quad + j; a lane then reads its record from LDS.  Regions are 1 040 bytes apart so that the four lanes
+    // of a quad read different banks (ds_read_b128: sixteen lanes cover the 64 banks).
+    constexpr unsigned TR_STAGE_STRIDE = 1040u, TR_STAGE_WAVE = 4u * TR_STAGE_STRIDE;
+    const unsigned stage_base = __builtin_amdgcn_readfirstlane(top_base + (unsigned)TR_TOP_SLOTS * 64u + (unsigned)(tid >> 6) * TR_STAGE_WAVE);
+    const unsigned stage_rd = stage_base + (unsigned)(lane & 3) * TR_STAGE_STRIDE + (unsigned)(lane >> 2) * 64u;      // where this lane's record lands
+    const unsigned stage_sub = (unsigned)(lane & 3) << 4;                                                            // the quarter this lane fetches
+#endif
     if (MODE != TIRT_TRAVERSE_EXHAUSTIVE) {
         for (int k = tid; k < b.top_count * 4; k += TR_BLOCK)
         { const uint4 g = b.cnode[k]; *(lds_u4 *)(size_t)(top_base + (unsigned)k * 16u) = u4v{g.x, g.y, g.z, g.w}; }
@@ -426,14 +443,20 @@ __global__ __launch_bounds__(TR_BLOCK, KIND == KIND_TAIL ? TR_TAIL_WAVES : TR_MI
             if (COUNT) d_refills++;
 #endif
             const int leader = __ffsll((long long)fm) - 1;
-            // rays of slice `home`: its 64-ray chunks are the global chunks home, home + S, home + 2S, ...
-            const int len = (((full_chunks >> S_LOG) + (home < (full_chunks & S_MASK) ? 1 : 0)) << 6) +
-                            (home == (full_chunks & S_MASK) ? (count & 63) : 0);
+            // rays of slice `home`: its 64-ray chunks are the global chunks home, home + S, home + 2S, ... (interleaved), or the home-th contiguous
+            // stretch of the closest-hit rays followed by the home-th stretch of the shadow rays (slices_contig)
+            const bool contig = ca->slices_contig != 0;
+            const int Lc__ = ((((count_c + 63) >> 6) + S_MASK) >> S_LOG) << 6, Ls__ = ((((count_s + 63) >> 6) + S_MASK) >> S_LOG) << 6;
+            int lenc__ = count_c - home * Lc__; lenc__ = lenc__ < 0 ? 0 : (lenc__ > Lc__ ? Lc__ : lenc__);
+            int lens__ = count_s - home * Ls__; lens__ = lens__ < 0 ? 0 : (lens__ > Ls__ ? Ls__ : lens__);
+            const int len = contig ? lenc__ + lens__
+                                   : (((full_chunks >> S_LOG) + (home < (full_chunks & S_MASK) ? 1 : 0)) << 6) + (home == (full_chunks & S_MASK) ? (count & 63) : 0);
             int base = 0;
             if (lane == leader) base = atomicAdd(c_fetch + home * TR_FETCH_STRIDE, n_idle);
             base = __shfl(base, leader, 64);
             const int v = base + __popcll(fm & lt_mask);                  // index within the slice
-            my = v < len ? (((((v >> 6) << S_LOG) + home) << 6) | (v & 63)) : count;
+            if (contig) my = v < lenc__ ? home * Lc__ + v : (v < len ? count_c + home * Ls__ + (v - lenc__) : count);
+            else my = v < len ? (((((v >> 6) << S_LOG) + home) << 6) | (v & 63)) : count;
             if (base + n_idle >= len) {                                    // slice drained: move on
 #ifndef TR_NO_DRAINED_COUNT
                 // The wave whose fetch reached the end of a slice counts the slice as drained, and a wave that moves on looks at that count: once it
@@ -610,6 +633,21 @@ __global__ __launch_bounds__(TR_BLOCK, KIND == KIND_TAIL ? TR_TAIL_WAVES : TR_MI
             if (n_act < node_min_w && ballot64(have && cur < 0) != 0ull) break;
             if (wave_any((int)sa >= (int)sa_hi)) break;        // a lane's LDS stack is full: page out below (cold)
             if (COUNT) { d_it_node++; d_lanes_node += (unsigned long long)n_act; }
+#ifdef TR_COOP
+            if (MODE != TIRT_TRAVERSE_EXHAUSTIVE) {
+                // (all 64 lanes, wave-uniform control flow: a lane without node work still fetches for its quad)
+#define TR_COOP_FETCH(j__)                                                                          \
+                do {                                                                                 \
+                    const int cj__ = __builtin_amdgcn_mov_dpp(cur, (j__) * 0x55, 0xf, 0xf, true);   /* `cur` of lane j of this quad (quad_perm broadcast) */ \
+                    if (cj__ >= TR_TOP_SLOTS)                                                        \
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)((const char *)b.cnode + (((unsigned)cj__ << 6) + stage_sub)), \
+                                                         (__attribute__((address_space(3))) void *)(size_t)(stage_base + (unsigned)(j__) * TR_STAGE_STRIDE), 16, 0, 0); \
+                } while (0)
+                TR_COOP_FETCH(0); TR_COOP_FETCH(1); TR_COOP_FETCH(2); TR_COOP_FETCH(3);
+                // the wave's own LDS-DMA writes are ordered before its LDS reads by this wait and by nothing else (the compiler does not see the dependence)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+#endif
             if (act) {
                 if (MODE == TIRT_TRAVERSE_EXHAUSTIVE) {
                     // reference order on the two-child nodes: both children of every box that passes
@@ -646,7 +684,16 @@ __global__ __launch_bounds__(TR_BLOCK, KIND == KIND_TAIL ? TR_TAIL_WAVES : TR_MI
 #else
                     const unsigned top_addr = top_base + (unsigned)cur * 64u;
 #endif
-#ifdef TR_ASM_FETCH
+#if defined(TR_COOP)
+                    {
+                        // the record: from the tree-top copy (first TR_TOP_SLOTS nodes, if any are kept) or from where the quad's fetch put it
+                        const unsigned ra__ = ((unsigned)cur < (unsigned)TR_TOP_SLOTS) ? top_addr : stage_rd;
+                        const lds_u4 *t = (const lds_u4 *)(size_t)ra__;
+                        const u4v t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3];
+                        q0 = TR_U4(t0); q1 = TR_U4(t1); q2 = TR_U4(t2); q3 = TR_U4(t3);
+                        if (COUNT) { if ((unsigned)cur < (unsigned)TR_TOP_SLOTS) d_outer++; }
+                    }
+#elif defined(TR_ASM_FETCH)
                     // The record comes from LDS for some lanes and from global memory for the others, into the SAME sixteen registers.  Written in C++ the
                     // compiler orders the two (a write-after-write on a register, as it sees it): s_waitcnt vmcnt(0) before the first ds_read, i.e. a wave with
                     // lanes on both sides -- nearly every step -- pays the two latencies in a row.  The lanes are disjoint (complementary exec masks) and a
@@ -754,10 +801,40 @@ __global__ __launch_bounds__(TR_BLOCK, KIND == KIND_TAIL ? TR_TAIL_WAVES : TR_MI
             const int n_l = __popcll(ballot64(leaf_now));
             if (n_l) { d_it_leaf++; d_lanes_leaf += (unsigned long long)n_l; }
         }
+#if defined(TR_COOP) && defined(TR_COOP_LEAF)
+        // the primitive records the same way (64-byte records: TRI_STRIDE_N = 4): one request per record instead of three
+        static_assert(TRI_STRIDE == 4, "TR_COOP_LEAF needs 64-byte primitive records (-DTRI_STRIDE_N=4)");
+        if (MODE != TIRT_TRAVERSE_EXHAUSTIVE && wave_any(leaf_now)) {
+            const int ls__ = leaf_now ? ((~(from_pend ? pend : cur)) & 0x3fffffff) : -1;
+#define TR_COOP_LEAF_FETCH(j__)                                                                      \
+            do {                                                                                     \
+                const int cj__ = __builtin_amdgcn_mov_dpp(ls__, (j__) * 0x55, 0xf, 0xf, true);      \
+                if (cj__ >= 0)                                                                       \
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)((const char *)b.tri + (((unsigned)cj__ << 6) + stage_sub)), \
+                                                     (__attribute__((address_space(3))) void *)(size_t)(stage_base + (unsigned)(j__) * TR_STAGE_STRIDE), 16, 0, 0); \
+            } while (0)
+            TR_COOP_LEAF_FETCH(0); TR_COOP_LEAF_FETCH(1); TR_COOP_LEAF_FETCH(2); TR_COOP_LEAF_FETCH(3);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+#endif
         if (leaf_now) {
             const int code = ~(from_pend ? pend : cur);
+#if defined(TR_COOP) && defined(TR_COOP_LEAF)
+            float4 ta, tb, tc;
+            if (MODE != TIRT_TRAVERSE_EXHAUSTIVE) {
+                const lds_u4 *t = (const lds_u4 *)(size_t)stage_rd;
+                const u4v t0 = t[0], t1 = t[1], t2 = t[2];
+                ta = make_float4(__uint_as_float(t0.x), __uint_as_float(t0.y), __uint_as_float(t0.z), __uint_as_float(t0.w));
+                tb = make_float4(__uint_as_float(t1.x), __uint_as_float(t1.y), __uint_as_float(t1.z), __uint_as_float(t1.w));
+                tc = make_float4(__uint_as_float(t2.x), __uint_as_float(t2.y), __uint_as_float(t2.z), __uint_as_float(t2.w));
+            } else {
+                const float4 *tp = b.tri + (size_t)(code & 0x3fffffff) * TRI_STRIDE;
+                ta = tp[0]; tb = tp[1]; tc = tp[2];
+            }
+#else
             const float4 *tp = b.tri + (size_t)(code & 0x3fffffff) * TRI_STRIDE;          // records in the traversal tree's leaf order
             const float4 ta = tp[0], tb = tp[1], tc = tp[2];
+#endif
             int prim = __float_as_int(tc.w);                                              // the primitive id rides in the last word
             if (COUNT) nleaf += 1;
             const v3 o = V(r.ox, r.oy, r.oz), d = V(r.dx, r.dy, r.dz);
@@ -1025,7 +1102,7 @@ static int ensure_spill(tirt_ctx *c, DevBuf &spill, int stack_size, int &spill_d
     return spill.ensure(sizeof(int) * (size_t)(spill_depth > 0 ? spill_depth : 1) * TR_GRID_MAX * TR_BLOCK);
 }
 static void fill_tunables(const tirt_ctx *c, TraceArgs &a)
-{ a.lds_depth = c->tr_lds_depth; a.refill_min = c->tr_refill_min; a.node_min = c->tr_node_min; a.slice_log2 = c->tr_slice_log2; }
+{ a.lds_depth = c->tr_lds_depth; a.refill_min = c->tr_refill_min; a.node_min = c->tr_node_min; a.slice_log2 = c->tr_slice_log2; a.slices_contig = c->slices_contiguous; }
 
 // ---------------------------------------------------------------------------------------------
 // Batch entry points (Debug-integrator style closest hit on caller-supplied rays)
@@ -1156,7 +1233,7 @@ __global__ void k_generate(PathSoA ps, CameraView cam, TileMap tm, int P, int S,
     // k_trace / k_shade of bounce 0 know without reading 48 bytes per path back from HBM.
     int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= S) return;
-    int f = s / P, k = s - f * P;
+    int f, k; slot_to_frame_pixel(tm, P, s, f, k);
     int p = local_to_pixel(tm, k);
     int i = p / tm.H, j = p - i * tm.H;
     uint32_t frame = frame_begin + (uint32_t)f;
@@ -1302,7 +1379,7 @@ __global__ void k_film(PathState ps, TileMap tm, int P, int F, uint32_t frame_be
     float *px = hdr + (size_t)p * 3;
     float r = px[0], g = px[1], b = px[2];
     for (int f = 0; f < F; f++) {
-        int s = f * P + k;
+        int s = frame_pixel_to_slot(tm, P, f, k);
         float frame = (float)(int)(frame_begin + (uint32_t)f);
         float coff = 1.0f / (frame + 1.0f);
         r = ps.fr[s] * coff + r * (1.0f - coff);
@@ -1350,7 +1427,7 @@ __global__ __launch_bounds__(SH_BLOCK, 4) void k_shade_spec(ShadeArgs paths_in_k
             asm volatile("" :: "s"(c_slot), "s"(c_hit), "s"(c_ox), "s"(c_oy), "s"(c_oz), "s"(c_dx), "s"(c_dy), "s"(c_dz), "s"(c_tr), "s"(c_tg), "s"(c_tb),
                          "s"(c_rr), "s"(c_rg), "s"(c_rb), "s"(c_tw), "s"(c_rw));
             slot = first ? q : c_slot[q];
-            const int f = slot / P, k = slot - f * P;
+            int f, k; slot_to_frame_pixel(tm, P, slot, f, k);
             const uint32_t pixel = (uint32_t)local_to_pixel(tm, k);
             const uint32_t frame = frame_begin + (uint32_t)f;
             const uint32_t dim0 = TM_DIM_BOUNCE0 + TM_DIMS_PER_BOUNCE * (uint32_t)bounce;
@@ -1513,7 +1590,7 @@ __global__ void k_film_spec(PathState ps, const float *fw, SpecView sp, TileMap 
     float *px = hdr + (size_t)p * 3;
     float r = px[0], g = px[1], b = px[2];
     for (int f = 0; f < F; f++) {
-        const int s = f * P + k;
+        const int s = frame_pixel_to_slot(tm, P, f, k);
         const uint32_t frame = frame_begin + (uint32_t)f;
         const float coff = 1.0f / ((float)(int)frame + 1.0f);
         const float Lambda = HERO_LAMBDA_MIN + HERO_LAMBDA_STEP * tm_rand(seed, (uint32_t)p, frame, TM_DIM_SPEC_LAMBDA);
@@ -1583,7 +1660,7 @@ int pt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed,
         { int parts = c->split_lone < c->n_lanes ? c->split_lone : c->n_lanes; if (parts > frame_count) parts = frame_count; FB = (frame_count + parts - 1) / parts; }
     const SceneView sv = scene_view(c);
     const BvhView bv = bvh_view(c);
-    const TileMap tm = {c->tile_rank, c->tile_count, c->tile_size, c->H, c->tile_blocked};
+    TileMap tm = {c->tile_rank, c->tile_count, c->tile_size, c->H, c->tile_blocked, 0};
     DevCounters *ctr = c->dev_counters.as<DevCounters>();
     const int B = 256;
     collect_live_counts(c);
@@ -1620,6 +1697,7 @@ int pt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed,
         hipStream_t st = L.stream;
         const int F = (frame_count - fb < FB) ? frame_count - fb : FB;
         const int S = F * P;
+        tm.F = (c->path_order_blocks && (P & 63) == 0) ? F : 0;
         const uint32_t f0 = frame_begin + (uint32_t)fb;
         char *cm = L.counters_mem.as<char>();
         auto append_ctr = [&](int b) { return (unsigned long long *)(cm + LINE * (size_t)b); };

@@ -133,7 +133,31 @@ __global__ __launch_bounds__(64) void k_spec_table(SptArgs a)
     }
 }
 
+// known-answer evaluation of the spectral device functions (tirt_kat_spec; `which` as in include/tirt.h)
+__global__ void k_kat_spec(SpecView sp, int which, const float *in, int in_stride, float *out, int out_stride, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float *a = in + (size_t)i * in_stride;
+    float *o = out + (size_t)i * out_stride;
+    f4s r = f4_set(0.0f); bool out4 = false;
+    if (which == 0) o[0] = spd_sample(sp.spd[(int)a[0]], a[1]);
+    else if (which == 1) { r = hero_sample(sp.spd[(int)a[0]], a[1]); out4 = true; }
+    else if (which == 2) { for (int k = 0; k < HERO_N; k++) { const v3 c = sensor_sample(sp, a[0] + (float)k * HERO_LAMBDA_STEP); o[k] = c.x; o[4 + k] = c.y; o[8 + k] = c.z; } }
+    else if (which == 3) { const v3 c = r2s_fetch(sp, V(a[0], a[1], a[2])); o[0] = c.x; o[1] = c.y; o[2] = c.z; }
+    else if (which == 4) o[0] = r2s_eval(V(a[0], a[1], a[2]), a[3]);
+    else if (which == 5) { r = srgb_to_spec(sp, V(a[0], a[1], a[2]), a[3]); out4 = true; }
+    else if (which == 6) { for (int k = 0; k < HERO_N; k++) o[k] = sky_radiance(sp, a[0], a[1], a[2] + (float)k * HERO_LAMBDA_STEP); }
+    else if (which == 7) { r = emission_to_rad(sp, V(a[0], a[1], a[2]), a[3]); out4 = true; }
+    else if (which == 8) { for (int k = 0; k < HERO_N; k++) o[k] = tm_exp(-a[1] / (a[0] + (float)k * HERO_LAMBDA_STEP)); }
+    else if (which == 9) { for (int k = 0; k < HERO_N; k++) r.v[k] = a[k]; float x = a[6], y = a[7], z = a[8]; spec_add_splat(sp, r, a[4], a[5], x, y, z); o[0] = x; o[1] = y; o[2] = z; }
+    else if (which == 10) { r = get_spec_power(sp, a, a[10]); out4 = true; }
+    else if (which == 11) { const int index = (int)(a[0] * (float)HERO_N); o[0] = (float)index; o[1] = a[1] + (float)index * HERO_LAMBDA_STEP; }
+    if (out4) for (int k = 0; k < HERO_N; k++) o[k] = r.v[k];
+}
+
 }  // namespace tirt
+
 
 using namespace tirt;
 
@@ -189,6 +213,29 @@ int tirt_spec_table_build(tirt_ctx *c, int res, const float *cie_xyz, const floa
     return rc;
 }
 
+int tirt_kat_spec(tirt_ctx *c, int which, const float *in, int in_stride, float *out, int out_stride, int n)
+{
+    TIRT_REQUIRE(c && in && out && n >= 0 && which >= 0 && which <= 11, "tirt_kat_spec: bad arguments");
+    TIRT_REQUIRE(c->spec_set && c->spec_view, "tirt_kat_spec: tirt_spectral_upload first");
+    if (n == 0) return TIRT_OK;
+    TIRT_HIP(hipSetDevice(c->device));
+    DevBuf din, dout;
+    int rc = TIRT_OK;
+    if (din.ensure(sizeof(float) * (size_t)n * in_stride) || dout.ensure(sizeof(float) * (size_t)n * out_stride)) rc = TIRT_ERR_HIP;
+    if (rc == TIRT_OK) {
+        hipError_t e = hipMemcpyAsync(din.p, in, sizeof(float) * (size_t)n * in_stride, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(dout.p, 0, sizeof(float) * (size_t)n * out_stride, c->stream);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_kat_spec, dim3((n + 255) / 256), dim3(256), 0, c->stream, *(const SpecView *)c->spec_view, which, din.as<float>(), in_stride, dout.as<float>(), out_stride, n);
+            e = hipMemcpyAsync(out, dout.p, sizeof(float) * (size_t)n * out_stride, hipMemcpyDeviceToHost, c->stream);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) { set_error(std::string("tirt_kat_spec: ") + hipGetErrorString(e)); rc = TIRT_ERR_HIP; }
+    }
+    din.release(); dout.release();
+    return rc;
+}
+
 int tirt_spectral_upload(tirt_ctx *c, const tirt_spectral_t *t)
 {
     TIRT_REQUIRE(c && t && t->sensor && t->spd && t->tbl_scale && t->tbl_data && t->sky_cfg && t->sky_rad, "tirt_spectral_upload: null");
@@ -199,7 +246,7 @@ int tirt_spectral_upload(tirt_ctx *c, const tirt_spectral_t *t)
     size_t n_spd = 0;
     // the samplers index with (int)((lambda - min) / range) and clamp only the upper neighbour (Spectrum.py:sample): a table shorter than its
     // declared wavelength span would be read past its end
-    auto spans = [](float lo, float hi, float step, int n) { return step > 0.0f && hi >= lo && (double)(hi - lo) / (double)step <= (double)(n - 1) + 1.0e-3; };
+    auto spans = [](float lo, float hi, float step, int n) { return step > 0.0f && hi >= lo && (double)(hi - lo) / (double)step <= (double)(n - 1) * (1.0 + 1.0e-5) + 1.0e-3; };      // (relative: `step` arrives rounded to fp32)
     TIRT_REQUIRE(spans(t->s_min, t->s_max, t->s_range, t->n_sensor), "tirt_spectral_upload: the sensor table is shorter than (s_max - s_min) / s_range + 1");
     for (int k = 0; k < 4; k++) {
         TIRT_REQUIRE(t->spd_n[k] >= 2, "tirt_spectral_upload: a spectrum needs two samples");

@@ -49,7 +49,7 @@ template <int KIND> void run(const char *name, float *out, unsigned long long *t
     printf("%-34s", name);
     for (int wps = 1; wps <= 8; wps *= 2) {               // waves per SIMD: `wps` 256-thread blocks per CU
         const int blocks = cus * wps;
-        double best_cpi = 1e30, best_ms = 0, own_cpi = 0;
+        double best_ms = 0, own_cpi = 0;
         for (int rep = 0; rep < 3; rep++) {
             (void)hipEventRecord(e0);
             hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(256), 0, 0, out, ticks, iters, 1.0001f, 0.5f, 16u, 0x5555555555555555ull);
@@ -57,12 +57,13 @@ template <int KIND> void run(const char *name, float *out, unsigned long long *t
             float ms; (void)hipEventElapsedTime(&ms, e0, e1);
             std::vector<unsigned long long> t(2 * (size_t)blocks * 4);
             (void)hipMemcpy(t.data(), ticks, t.size() * 8, hipMemcpyDeviceToHost);
-            unsigned long long lo = ~0ull, hi = 0; double own = 0;
-            for (size_t w = 0; w < (size_t)blocks * 4; w++) { lo = std::min(lo, t[2 * w]); hi = std::max(hi, t[2 * w + 1]); own += (double)(t[2 * w + 1] - t[2 * w]); }
-            const double cpi = (double)(hi - lo) / ((double)wps * iters * 128.0);          // span cycles per wave-instruction of one SIMD
-            if (cpi < best_cpi) { best_cpi = cpi; best_ms = ms; own_cpi = own / ((double)blocks * 4) / (iters * 128.0); }
+            double own = 0;
+            for (size_t w = 0; w < (size_t)blocks * 4; w++) own += (double)(t[2 * w + 1] - t[2 * w]);
+            if (ms < best_ms || best_ms == 0) { best_ms = ms; own_cpi = own / ((double)blocks * 4) / (iters * 128.0); }
         }
-        printf("  w%d: %5.2f (wave's own %5.2f, %.2f GHz)", wps, best_cpi, own_cpi, best_cpi * wps * iters * 128.0 / (best_ms * 1e-3) / 1e9);
+        // a wave's own s_memtime ticks per instruction / waves per SIMD = ticks per instruction of the SIMD; the event time gives ns per instruction of the SIMD
+        const double ns = best_ms * 1e6 / ((double)wps * iters * 128.0);
+        printf("  w%d: %5.2f tick (own %5.2f) %5.3f ns", wps, own_cpi / wps, own_cpi, ns);
     }
     printf("\n");
 }
@@ -72,7 +73,7 @@ int main()
     const int cus = pr.multiProcessorCount;
     float *out; (void)hipMalloc(&out, sizeof(float) * (size_t)cus * 8 * 256);
     unsigned long long *ticks; (void)hipMalloc(&ticks, 16 * (size_t)cus * 8 * 4);
-    printf("%s, %d CUs; cycles per wave64 instruction per SIMD (span of the launch in s_memtime ticks / instructions of a SIMD), by waves per SIMD\n", pr.gcnArchName, cus);
+    printf("%s, %d CUs; per wave64 instruction and SIMD: s_memtime ticks (own ticks of a wave per instruction / waves per SIMD) and ns (event time), by waves per SIMD\n", pr.gcnArchName, cus);
     run<0>("v_fma_f32 v,v,v,v", out, ticks, cus); run<1>("v_fma_f32 v,v,1.0,s", out, ticks, cus); run<2>("v_fma_f32 v,v,v,0.5", out, ticks, cus);
     run<3>("v_add_f32", out, ticks, cus); run<4>("v_mul_f32", out, ticks, cus); run<5>("v_pk_fma_f32", out, ticks, cus); run<6>("v_mov_b32", out, ticks, cus);
     run<7>("v_fma_mix_f32 (f16 src0)", out, ticks, cus); run<8>("v_alignbit_b32", out, ticks, cus); run<9>("v_min_f32", out, ticks, cus);

@@ -224,13 +224,17 @@ def render_reference_text(out, W, H, frames, seed, scene_name):
             L.orc_kat_math(fn, np.array([x], np.float32), np.array([y], np.float32), o, 1)
             return o[0]
         return f
-    ti.set_math({"sin": m1(0), "cos": m1(1), "exp": m1(2), "log": m1(3), "pow": m2(4), "atan2": m2(5), "acos": m1(6)})
+    ti.set_math({"sin": m1(0), "cos": m1(1), "exp": m1(2), "log": m1(3), "pow": m2(4), "atan2": m2(5), "acos": m1(6),
+                 "tan": lambda x: np.float32(m1(0)(x) / m1(1)(x))})                  # tirt_math.h: tm_tan = tm_sin / tm_cos
 
     from common import cornell_glass_wall
     if scene_name == "cornell":
         ex = scenes.cornell_box(W, H, 4, device_id=None)
     elif scene_name == "cornell_glass":
         ex = cornell_glass_wall(W, H)
+    elif scene_name == "spot_laser":                              # the emitters without a surface: Scene.sample_li's spot / laser branches (Scene.py:491-516)
+        from common import spot_laser_scene
+        ex = spot_laser_scene(W, H)
     else:                                                          # glass + disney + sphere light + env map + smooth normals
         ex = scenes.single_model(W, H, 4, model="sphere.obj", device_id=None)
     host_only(ex, 0.8)
@@ -341,9 +345,14 @@ def render_bdpt_reference_text(out, W, H, frames, seed, scene_name):
         def f(x, y):
             o = np.zeros(1, np.float32); L.orc_kat_math(fn, np.array([x], np.float32), np.array([y], np.float32), o, 1); return o[0]
         return f
-    ti.set_math({"sin": m1(0), "cos": m1(1), "exp": m1(2), "log": m1(3), "pow": m2(4), "atan2": m2(5), "acos": m1(6)})
+    ti.set_math({"sin": m1(0), "cos": m1(1), "exp": m1(2), "log": m1(3), "pow": m2(4), "atan2": m2(5), "acos": m1(6),
+                 "tan": lambda x: np.float32(m1(0)(x) / m1(1)(x))})                  # tirt_math.h: tm_tan = tm_sin / tm_cos
     from common import cornell_glass_wall
-    ex = scenes.cornell_box(W, H, 4, device_id=None) if scene_name == "cornell" else cornell_glass_wall(W, H, integrator="bdpt")
+    if scene_name == "spot_laser":                                # Scene.sample_light's spot / laser branches (Scene.py:449-472) start light sub-paths here
+        from common import spot_laser_scene
+        ex = spot_laser_scene(W, H, integrator="bdpt")
+    else:
+        ex = scenes.cornell_box(W, H, 4, device_id=None) if scene_name == "cornell" else cornell_glass_wall(W, H, integrator="bdpt")
     host_only(ex, 0.8)
     sc = ex.scene
     orc = oa.OracleScene(sc, ex.cam)
@@ -390,7 +399,9 @@ def render_bdpt_reference_text(out, W, H, frames, seed, scene_name):
             base = (EYE + 8 * int(local("eye_path", "depth"))) if "eye_path" in names else (LIGHT + 8 * int(local("light_path", "depth")))
             dim = base + (0 if f.f_globals["__name__"] == "Glass" else 3 + k)
         elif "sample_light" in names:                                  # Scene.sample_light for the light sub-path's first vertex
-            dim = LSTART + {"get_random_light_prim_index": 0, "get_prim_random_point_normal": 1 + k, "sample_light": 3 + k}[name]
+            # sample_light's own draws in source order: the two of the cosine lobe, the two of the spot's disc, the laser's angle -- the laser takes
+            # the slot the spot's first number has (oracle.c bd_sample_light: only one of the two branches runs)
+            dim = LSTART + {"get_random_light_prim_index": 0, "get_prim_random_point_normal": 1 + k, "sample_light": (3, 4, 5, 6, 5)[k]}[name]
         elif "sample_li" in names and "connect_path" in names:         # the l == 1 connection at eye vertex e
             dim = CONNECT + 4 * int(local("connect_path", "e")) + {"get_random_light_prim_index": 0, "get_prim_random_point_normal": 1 + k}[name]
         else:

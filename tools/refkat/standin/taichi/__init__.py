@@ -68,7 +68,7 @@ def func(f): return _taichi_scope(f)
 def kernel(f): return _taichi_scope(f)
 def pyfunc(f): return f
 def data_oriented(c): return c
-def static(x): return x
+def static(*x): return x[0] if len(x) == 1 else x
 def template(): return None
 
 
@@ -242,6 +242,12 @@ class Vector:
     def cross(self, o):
         a, b = self.e, o.e
         return Vector([a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]])
+
+    def sum(self):
+        acc = self.e[0]
+        for a in self.e[1:]:
+            acc = acc + a                           # left to right, as Taichi unrolls it
+        return acc
 
     def norm_sqr(self): return self.dot(self)
     def norm(self, eps=0): return sqrt(self.norm_sqr() + eps) if eps else sqrt(self.norm_sqr())
