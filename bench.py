@@ -443,11 +443,19 @@ def cpu_baseline(args, ex, W, H, build_ms):
     _, ost = orc.render(W, H, 1, nframes, seed=args.seed, nthreads=cores)
     cpu_s = time.perf_counter() - tc
     cpu_rays = ost["rays_closest"] + ost["rays_shadow"]
+    # parallel efficiency on IDENTICAL work: the strip and frame of the one-thread probe again on all threads (best of three; 256 chunks of 64 pixels)
+    strip_s = 1e30
+    for _ in range(3):
+        ts = time.perf_counter()
+        _, sN = orc.render(W, H, 1, 1, seed=args.seed, p_begin=W * H // 2, p_end=W * H // 2 + 16384, nthreads=cores)
+        strip_s = min(strip_s, max(time.perf_counter() - ts, 1e-6))
+    assert sN["rays_closest"] == s1["rays_closest"] and sN["rays_shadow"] == s1["rays_shadow"]
     return {
         "value": round(cpu_rays / cpu_s / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
         "build": "gcc -O3 -march=native on this host" if native else "portable -O2 build shipped with the repo (native build failed)",
         "one_thread_Mrays_s": round(rate1 / 1e6, 5), "per_thread_Mrays_s": round(cpu_rays / cpu_s / cores / 1e6, 5),
-        "parallel_efficiency": round(cpu_rays / cpu_s / cores / rate1, 3), "host": host,
+        "parallel_efficiency": round(one_s / strip_s / cores, 3),
+        "parallel_efficiency_def": "time of the one-thread probe / time of the same 16384 pixels of frame 1 on all %d threads / %d" % (cores, cores), "host": host,
         "sample": "frames 1..%d of the same scene at the full %dx%d (%d paths, %d rays) in %.2f s on %d threads (dynamic 64-pixel "
                   "chunks); 1-thread rate from 16384 pixels of frame 1 in %.2f s; CPU oracle LBVH build %.3f s (GPU %.3f ms)" %
                   (nframes, W, H, ost["paths"], cpu_rays, cpu_s, cores, one_s, cpu_build_s, build_ms),
@@ -682,6 +690,18 @@ def main():
         ctx.film_import_device(film.data_ptr()) if world > 1 else None
         ctx.tone_map(0.5)
         write_png(ctx.film_download(W, H, want_hdr=False, want_rgb=True)[1], args.save_png)
+
+    # ---- the headline film itself against the CPU oracle: 2048 pixels x every frame rendered so far (warm-up + timed), bit for bit; after the
+    #      timed region, on rank 0 (whose context holds the reduced film when N > 1), before the roofline probes add frames -------------------
+    if rank == 0 and not args.no_configs:
+        n_frames_film = int(ex.cam.frame)
+        t_or = time.perf_counter()
+        hdr_now = ctx.film_download(W, H)[0]
+        p0 = (W // 2) * H + min(128, max(H - 2048, 0))
+        npx = min(2048, W * H - p0)
+        result["oracle_sample_identical"] = _oracle_run_identical(ex, W, H, n_frames_film, args.seed, hdr_now, p0, npx)
+        result["oracle_sample"] = "%d pixels from linear pixel %d x %d frames (warm-up + timed) rendered by the CPU oracle in %.1f s: film words equal bit for bit" % (
+            npx, p0, n_frames_film, time.perf_counter() - t_or)
 
     # ---- roofline for the dominant kernel (rank 0's shard, untimed extra passes) -----------------
     if not args.no_roofline and rank == 0:

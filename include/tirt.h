@@ -267,7 +267,7 @@ int tirt_kat_math(tirt_ctx *ctx, int fn, const float *x, const float *y, float *
  * in: [n*in_stride] out: [n*out_stride] */
 int tirt_kat_brdf(tirt_ctx *ctx, int which, const float *in, int in_stride, float *out, int out_stride, int n);
 /* The spectral device functions one by one, on the tables of tirt_spectral_upload (tests/test_gpu_spectral.py against tests/golden/refkat_spec.npz --
- * values computed by the reference's own spectrum/*.py, sky/Sky.py and integrator/PT_Spec.py text).  which:
+ * values computed by the reference's own spectrum modules, sky/Sky.py and integrator/PT_Spec.py text).  which:
  *   0 Spectrum.sample (Spectrum.py:44-52) in: k (0 d65 1 white 2 red 3 green), Lambda out: 1      1 HeroSample.sample (:10-16) in: k, Lambda0 out: 4
  *   2 HeroSample.sample_xyz (:18-29) of PathTrace.sample (PT_Spec.py:131-139) in: Lambda0 out: x4,y4,z4
  *   3 Rgb2Spec.fetch (Rgb2Spec.py:101-137) in: rgb3 out: coff3     4 Rgb2Spec.eval (:139-143) in: coff3, Lambda out: 1

@@ -435,7 +435,7 @@ def test_path_order_and_slice_layout_change_no_bit(gpu_ctx_ok, integrator):
 
 
 @pytest.mark.parametrize("scene", ["cornell", "teapot", "synthetic", "lasers"])
-def test_tail_launch_changes_no_bit(gpu_ctx_ok, scene):
+def test_tail_launch_changes_no_bit(gpu_ctx_ok, experiments_lib, scene):
     """tirt_render.hip k_trace<KIND_TAIL>: from some bounce on, what is left of a batch runs as ONE persistent launch in which a lane keeps a path
     (shade, shadow ray, next ray, ...) instead of one launch per bounce and kind.  Wherever the switch happens -- given ("tail_bounce"), or chosen from
     the path counts of the batches before ("tail_paths") --: the same film bit for bit, the same ray and shading counts."""

@@ -120,7 +120,7 @@ def test_traversal_tree_option_changes_no_bit(gpu_ctx_ok, make, W):
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
 
 
-def test_cost_optimal_collapse_changes_no_bit(gpu_ctx_ok):
+def test_cost_optimal_collapse_changes_no_bit(gpu_ctx_ok, experiments_lib):
     """option wide_collapse = 1 (k_wide_dp): another grouping of the same binary tree into 4-wide nodes"""
     out = []
     W = 96

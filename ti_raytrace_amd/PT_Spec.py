@@ -110,7 +110,9 @@ class PathTrace:
             self._d65_raw = self.d65.data_np.copy()          # D65 as read, before normalize_spec scales it (a second call must not take the scaled one)
         if self.rgb2spec.table_data_np is None:
             who = getattr(build_table, "__self__", None)
-            key = (64, type(who).__name__ if who is not None else getattr(build_table, "__qualname__", repr(build_table)))
+            # the device's generator (a bound method of a Context: any context builds the same bits) is one key; every other callable is its own
+            # (two lambdas defined in one function share a __qualname__ -- ADVICE r4: the key holds the function object itself, which also keeps it alive)
+            key = (64, type(who).__name__ if who is not None else getattr(build_table, "__func__", build_table))
             if key not in _TABLE_CACHE:
                 _TABLE_CACHE[key] = build_table(64, self.data_np, self.d65_from_360())
             self.rgb2spec.table_res, self.rgb2spec.table_size = 64, 64 * 64 * 64 * 9

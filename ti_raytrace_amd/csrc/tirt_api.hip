@@ -138,7 +138,7 @@ __global__ void k_smooth_normal(SceneView s, int nv, const float *compact, const
                     if (i != nb) {
                         v3 nvp = vtx_pos(s, nb);
                         v3 nn = normalized(vtx_nor(s, nb));
-                        if ((norm(v - nvp) < 0.000001f) & (dot(nn, n) > 0.5f)) {
+                        if ((int)(norm(v - nvp) < 0.000001f) & (int)(dot(nn, n) > 0.5f)) {      // (Scene.py:781: both sides evaluated, as the reference's `&` does)
                             float angle = get_prim_angle(s, prim, nvp);
                             sm = sm + (nn * angle) * get_prim_area(s, prim);
                         }
@@ -389,6 +389,12 @@ int tirt_set_option(tirt_ctx *c, const char *name, double value)
     TIRT_REQUIRE(name, "tirt_set_option: null name");
     if (!strcmp(name, "time_kernels")) { c->time_kernels = value != 0.0; return TIRT_OK; }
     if (!strcmp(name, "overlap_lanes")) { TIRT_REQUIRE(value >= 1.0 && value <= (double)TIRT_MAX_LANES, "overlap_lanes: 1..8"); if (sync_all(c)) return TIRT_ERR_HIP; c->n_lanes = (int)value; return TIRT_OK; }
+#ifndef TIRT_EXPERIMENTS
+    if (!strcmp(name, "tail_paths") || !strcmp(name, "tail_bounce") || !strcmp(name, "wide_collapse")) {
+        TIRT_REQUIRE(value == (strcmp(name, "tail_bounce") ? 0.0 : value < 0.0 ? value : 0.0), "this option is an experiment (persistent tail kernel / cost-optimal wide collapse): build with -DTIRT_EXPERIMENTS (make experiments)");
+        return TIRT_OK;
+    }
+#endif
     if (!strcmp(name, "tail_paths")) { TIRT_REQUIRE(value >= 0.0 && value <= 2147483647.0, "tail_paths: 0 (off) .. 2^31-1"); c->tail_paths = (long)value; return TIRT_OK; }
     if (!strcmp(name, "tail_bounce")) { TIRT_REQUIRE(value >= -1.0 && value <= 4095.0, "tail_bounce: -1 (chosen from tail_paths), 0 (off) or the bounce 1..max_depth-1"); c->tail_bounce = (int)value; return TIRT_OK; }
     if (!strcmp(name, "split_lone_batch")) { TIRT_REQUIRE(value >= 0.0 && value <= 8.0, "split_lone_batch: 0 (off) or the number of parts, 2..8"); c->split_lone = (int)value; return TIRT_OK; }

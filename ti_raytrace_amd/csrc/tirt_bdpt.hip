@@ -36,7 +36,7 @@ namespace tirt {
 
 constexpr int BD_MAX_DEPTH = 5;                    // BDPT_RGB.py:23
 constexpr int BD_EYE_MAX = BD_MAX_DEPTH + 2, BD_LIGHT_MAX = BD_MAX_DEPTH + 1;
-constexpr int VERTEX_NONE = 0, VERTEX_LIGHT = 1, VERTEX_LENS = 2, VERTEX_SURFACE = 3;
+[[maybe_unused]] constexpr int VERTEX_NONE = 0, VERTEX_LIGHT = 1, VERTEX_LENS = 2, VERTEX_SURFACE = 3;
 constexpr uint32_t BD_DIM_EYE = 16, BD_DIM_LSTART = 80, BD_DIM_LIGHT = 96, BD_DIM_CONNECT = 176;
 constexpr float EPS_UF = 0.00001f;                 // UtilsFunc.py:36
 

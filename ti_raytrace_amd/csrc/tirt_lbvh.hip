@@ -457,6 +457,7 @@ TD float cn_area(const float *compact, int i)
     const float dx = c[5] - c[2], dy = c[6] - c[3], dz = c[7] - c[4];
     return dx * dy + dy * dz + dz * dx;
 }
+#ifdef TIRT_EXPERIMENTS      // (option "wide_collapse": measured 1-9 % fewer visits, the same rays per second -- round 3; not in the product library)
 // Cost-optimal grouping of the binary tree into wide nodes (the dynamic programme of Ylitie, Karras, Laine 2017 for a
 // visit-count cost): every binary inner node either becomes the root of a wide node (cost: its surface area, the chance of a
 // visit) or is dissolved into the wide node above it (cost 0), under the constraint of four children per wide node.
@@ -497,6 +498,7 @@ __global__ void k_wide_dp(int N, const float *compact, const int *parent, int *f
         cur = parent[cur];
     }
 }
+#endif
 
 // level_off[L] / level_cnt[L]: first wide index and number of wide nodes of level L; queue holds the binary roots (compact
 // indices) of all wide nodes in breadth-first order (queue[w] for wide node w)
@@ -586,10 +588,11 @@ __global__ void k_wide_level(SceneView s, const int *prim_slot, const float *com
 // sizes `csize`; ends with c->ev1 recorded after the last level.
 static int build_wide(tirt_ctx *c, const float *compact, const int *csize, const int *parent, float pad, const GridMap &gm, int shapes_boxed = 0)
 {
-    const int n = c->n, N = 2 * n - 1;
+    const int n = c->n, N = 2 * n - 1; (void)N;
     hipStream_t st = c->stream;
     SceneView sv = scene_view(c);
     const int *dp_dec = nullptr;
+#ifdef TIRT_EXPERIMENTS
     if (c->wide_dp_on && parent) {
         // scratch: arrival counters [N] | choices [N] | costs [3N]
         if (c->wide_dp.ensure(sizeof(int) * 5 * (size_t)N)) return TIRT_ERR_HIP;
@@ -598,6 +601,7 @@ static int build_wide(tirt_ctx *c, const float *compact, const int *csize, const
         hipLaunchKernelGGL(k_wide_dp, dim3((N + 255) / 256), dim3(256), 0, st, N, compact, parent, flag, t, dec);
         dp_dec = dec;
     }
+#endif
     constexpr int WIDE_LEVELS_MAX = 2048;     // runs of identical Morton codes make chains: a level per three leaves of a chain
     int *lv_off = c->wide_levels.as<int>(), *lv_cnt = lv_off + (WIDE_LEVELS_MAX + 2);
     TIRT_HIP(hipMemsetAsync(c->wide_levels.p, 0, sizeof(int) * 2 * (WIDE_LEVELS_MAX + 2), st));

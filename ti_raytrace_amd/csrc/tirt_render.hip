@@ -37,6 +37,13 @@ namespace tirt {
 constexpr int TR_GRID_MAX = 2048;      // upper bound on persistent blocks (sizes the spill buffer)
 
 enum { KIND_CLOSEST = 0, KIND_SHADOW_ACC = 1, KIND_MIXED = 2, KIND_QUERY = 3, KIND_TAIL = 4 };
+// The product library is built WITHOUT -DTIRT_EXPERIMENTS: no persistent tail kernel (KIND_TAIL: built in round 4, bit-identical, slower at every
+// switch point), none of the A/B switches of this file (TR_* macros: bound ladder, quad-cooperative fetch, drain diagnostics ...).  `make experiments`
+// builds libtirt_exp.so with them; tools/ and the tests that exercise them load that library through TIRT_LIB_PATH.
+#if !defined(TIRT_EXPERIMENTS) && (defined(TR_NO_STASH) || defined(TR_DRAIN_DIAG) || defined(TR_NO_DRAINED_COUNT) || defined(TR_NODE_FRAC) || defined(TR_NO_VERIFY) || \
+    defined(TR_PAD) || defined(TR_PADG) || defined(TR_COOP) || defined(TR_NO_ASM_FETCH) || defined(TR_MIN_WAVES) || defined(TR_TAIL_WAVES))
+#error "the TR_* A/B switches of tirt_render.hip need an experiments build: add -DTIRT_EXPERIMENTS"
+#endif
 // MIXED: closest rays of bounce b + shadow rays of bounce b-1 in one launch.  QUERY: connection rays of BDPT -- "is sprim[q] the closest
 // hit, about sdist[q] away?" walked like a shadow ray (bounded), answered with the hit record (t, u, v, prim) instead of an accumulation.
 // TAIL: the rest of a PT_RGB batch in ONE launch, once few paths are left (see TailArgs): a lane keeps a PATH -- shades its hit (shade_path,
@@ -84,7 +91,9 @@ struct TraceArgs {
     // loads per ray where the arrays take six to eight (the BDPT ray lists: their kernels are bound by the number of memory instructions)
     const float4 *ray4;
     const int *ray_index;                        // KIND_QUERY: ray q is record ray_index[q] of ray4 (BDPT: the connection rays stay where they were staged; the queue is a list of places)
-    TailArgs tail;                               // KIND_TAIL
+#ifdef TIRT_EXPERIMENTS
+    TailArgs tail;                               // KIND_TAIL (by value: only experiments builds carry the larger kernel-argument segment)
+#endif
 };
 
 // One path at one bounce: what integrator/PT_RGB.py:66-132 does between the closest hit and the next one -- emission (with MIS), the glass / disney
@@ -325,7 +334,7 @@ __global__ __launch_bounds__(TR_BLOCK, KIND == KIND_TAIL ? TR_TAIL_WAVES : TR_MI
     unsigned nbox = 0, nleaf = 0;
     // KIND_TAIL: what the lane's path waits for.  0 no path; 1 closest-hit ray under way; 2 hit found (hit_t .. hit_prim), to be shaded;
     // 3 / 6 shadow ray under way (3: a next ray follows, 6: the path ends with it); 4 next ray to be set up; 5 / 7 shadow ray to be set up (-> 3 / 6)
-    int st = 0, bounce_l = 0;
+    int st = 0, bounce_l = 0; (void)bounce_l;
     unsigned n_rc = 0, n_rs = 0, n_sh = 0;
     RayCtx r = {};
     // ordered mode: the ray in the grid of the quantised nodes.  Plane h (fp16, in cells) of axis a is crossed at
@@ -470,6 +479,7 @@ __global__ __launch_bounds__(TR_BLOCK, KIND == KIND_TAIL ? TR_TAIL_WAVES : TR_MI
                 if (++tried > S_MASK) { exhausted = true; if (COUNT) tk_exh = wall_clock64(); }
             }
             }
+#ifdef TIRT_EXPERIMENTS
             if (KIND == KIND_TAIL) {
                 // a new path arrives with the closest hit of bounce `bounce0` found
                 if (!have && st == 0 && my < count) {
@@ -512,6 +522,7 @@ __global__ __launch_bounds__(TR_BLOCK, KIND == KIND_TAIL ? TR_TAIL_WAVES : TR_MI
                     }
                 }
             }
+#endif
             const bool setup_now = (KIND == KIND_TAIL) ? (!have && st >= 4) : (!have && my < count);
             if (setup_now) {
                 if (KIND == KIND_TAIL) {
@@ -674,16 +685,7 @@ __global__ __launch_bounds__(TR_BLOCK, KIND == KIND_TAIL ? TR_TAIL_WAVES : TR_MI
                     // ordered mode on the quantised 4-wide nodes: four box tests, children visited near to far
                     uint4 q0, q1, q2, q3;
 #define TR_U4(v) make_uint4((v).x, (v).y, (v).z, (v).w)
-#ifndef TR_NO_EARLY_LDS_ADDR
-                    // The LDS address of the record is formed BEFORE the two branches and pinned: formed inside the LDS branch it lands on a register
-                    // the global loads of the other branch are still writing (the four quads are the same registers on both sides), and the compiler
-                    // puts s_waitcnt vmcnt(0) in front of it -- a wave with lanes on both sides (nearly every step) then read LDS only after its global
-                    // loads had returned: the two latencies in a row instead of side by side.
-                    unsigned top_addr = top_base + ((unsigned)cur << 6);
-                    asm volatile("" : "+v"(top_addr));
-#else
-                    const unsigned top_addr = top_base + (unsigned)cur * 64u;
-#endif
+                    const unsigned top_addr = top_base + ((unsigned)cur << 6);
 #if defined(TR_COOP)
                     {
                         // the record: from the tree-top copy (first TR_TOP_SLOTS nodes, if any are kept) or from where the quad's fetch put it
@@ -693,11 +695,12 @@ __global__ __launch_bounds__(TR_BLOCK, KIND == KIND_TAIL ? TR_TAIL_WAVES : TR_MI
                         q0 = TR_U4(t0); q1 = TR_U4(t1); q2 = TR_U4(t2); q3 = TR_U4(t3);
                         if (COUNT) { if ((unsigned)cur < (unsigned)TR_TOP_SLOTS) d_outer++; }
                     }
-#elif defined(TR_ASM_FETCH)
+#elif !defined(TR_NO_ASM_FETCH)
                     // The record comes from LDS for some lanes and from global memory for the others, into the SAME sixteen registers.  Written in C++ the
                     // compiler orders the two (a write-after-write on a register, as it sees it): s_waitcnt vmcnt(0) before the first ds_read, i.e. a wave with
                     // lanes on both sides -- nearly every step -- pays the two latencies in a row.  The lanes are disjoint (complementary exec masks) and a
-                    // returning load writes only the lanes it was issued for, so nothing has to be ordered: both sets of loads are issued back to back here, one wait.
+                    // returning load writes only the lanes it was issued for, so nothing has to be ordered: both sets of loads are issued back to back here, one
+                    // wait.  +2 % on the headline (profiles/r05e: 4 525 -> 4 620 Mrays/s), films and hit records unchanged (same loads, same bits).
                     {
                         u4v r0__, r1__, r2__, r3__;
                         unsigned long long sv__;
@@ -876,35 +879,21 @@ __global__ __launch_bounds__(TR_BLOCK, KIND == KIND_TAIL ? TR_TAIL_WAVES : TR_MI
                     bmn = V(pa.x - tb.x, pa.y - tb.x, pa.z - tb.x); bmx = V(pa.x + tb.x, pa.y + tb.x, pa.z + tb.x);
                 }
                 float tn_;
-#ifdef TR_RECIP_AGAIN
-                const RayCtx rv = make_ray(o, d);           // 1/d again (same quotients) instead of three registers kept alive across the whole walk
-#else
                 const RayCtx &rv = r;
-#endif
                 const int inside = par ? slabs(rv, bmn.x, bmn.y, bmn.z, bmx.x, bmx.y, bmx.z, tn_) : slabs_fast(rv, bmn.x, bmn.y, bmn.z, bmx.x, bmx.y, bmx.z, tn_);
                 if (!inside) {
                     for (int an = b.cparent[leaf]; an >= 0; an = b.cparent[an]) {
                         const float *ab = b.compact + (size_t)an * CPN_VEC + 2;
                         if (!slabs(rv, ab[0], ab[1], ab[2], ab[3], ab[4], ab[5], tn_)) { cand = false; break; }
                     }
-#ifndef TR_NO_PRIM_RELOAD
                     // the primitive id again, from the leaf's reference row (UtilsFunc.py:get_compact_node_prim): the same number that came with the
                     // primitive record -- read here so that NOTHING of that record has to survive the walk above.  ROCm 7.2's register allocator lets
                     // the walk's row loads (global_load_dwordx4 v[8:11]) land on the register that holds the record's last word while it is still
                     // needed below (tools/dbg/prim_clobber.sh shows the ISA; 156 of 15 000 box-grazing rays on the Cornell box then kept the PREVIOUS
                     // hit's primitive id, tests/test_gpu_trace.py::test_quantised_nodes_on_grazing_rays).  Round 3 pinned the value with an empty asm.
                     prim = (int)b.compact[(size_t)leaf * CPN_VEC + 1];
-#endif
                 }
             }
-#endif
-            // (keeps `prim` in a register of its own across the ancestor walk: without this the compiler (ROCm 7.2 hipcc, -O3) lets the
-            // walk's 16-byte row loads overwrite it and an accepted hit that went through the walk keeps the PREVIOUS hit's primitive id.
-            // Re-checked at the end of round 3, after the kernel's register allocation had changed completely (TR_COLD): still needed --
-            // without it test_quantised_nodes_on_grazing_rays fails and the next test faults.  That test is the tripwire; __graft_entry__.build()
-            // warns when the compiler is not the validated one.)
-#ifdef TR_PRIM_PIN
-            asm volatile("" : "+v"(prim));
 #endif
             if (cand) {
                 hit_t = t; hit_u = u; hit_v = v; hit_prim = prim; hit_leaf = leaf;
@@ -919,6 +908,7 @@ __global__ __launch_bounds__(TR_BLOCK, KIND == KIND_TAIL ? TR_TAIL_WAVES : TR_MI
         }
 
         // ---- finished rays write back and free their lane ---------------------------------------
+#ifdef TIRT_EXPERIMENTS
         if (KIND == KIND_TAIL) {
             if (have && cur == TR_SENT && pend == 0) {
                 if (is_sh) {
@@ -936,6 +926,7 @@ __global__ __launch_bounds__(TR_BLOCK, KIND == KIND_TAIL ? TR_TAIL_WAVES : TR_MI
                 have = false; sa = sa_bottom;
             }
         } else
+#endif
         if (have && cur == TR_SENT && pend == 0) {
             TR_COLD(ca);
             float4 *const c_hit = ca->hit;
@@ -1011,8 +1002,8 @@ static unsigned long long *timeline_for(tirt_ctx *c, int flags, int grid)
     if (c->timeline_arm-- != 0) return nullptr;
     c->timeline_waves = grid * (TR_BLOCK / 64);
     if (c->timeline.ensure(sizeof(unsigned long long) * 4 * (size_t)c->timeline_waves)) { c->timeline_waves = 0; return nullptr; }
-    hipMemsetAsync(c->timeline.p, 0, sizeof(unsigned long long) * 4 * (size_t)c->timeline_waves, c->stream);
-    hipStreamSynchronize(c->stream);
+    if (hipMemsetAsync(c->timeline.p, 0, sizeof(unsigned long long) * 4 * (size_t)c->timeline_waves, c->stream) != hipSuccess ||
+        hipStreamSynchronize(c->stream) != hipSuccess) { (void)hipGetLastError(); c->timeline_waves = 0; return nullptr; }      // no timeline rather than a half-cleared one
     return c->timeline.as<unsigned long long>();
 }
 
@@ -1042,14 +1033,16 @@ static int launch_trace(tirt_ctx *c, hipStream_t stream, const TraceArgs &a, int
     return launch_trace_as<TIRT_TRAVERSE_ORDERED, false, KIND>(c, stream, a, g, b, lds);
 }
 
+#ifdef TIRT_EXPERIMENTS
 // KIND_TAIL: ordered traversal only; as many persistent blocks as are resident at once (a block that had to wait for another to end would start when the work is gone)
 static int launch_tail(tirt_ctx *c, hipStream_t stream, const TraceArgs &a, int flags, int grid_cap)
 {
     const bool cnt = (flags & TIRT_COUNT_NODES) != 0;
     const size_t lds = trace_lds_bytes(a.lds_depth);
-    static int per_cu[TIRT_MAX_DEVICES][2] = {};
+    static int per_cu[TIRT_MAX_DEVICES][2] = {}; static size_t per_cu_lds[TIRT_MAX_DEVICES][2] = {};
     const int dev = (c->device >= 0 && c->device < TIRT_MAX_DEVICES) ? c->device : 0;
-    if (per_cu[dev][cnt] == 0) {
+    if (per_cu[dev][cnt] == 0 || per_cu_lds[dev][cnt] != lds) {      // (again when trace_lds_depth changed: the resident block count depends on it)
+        per_cu_lds[dev][cnt] = lds;
         int nb = 0;
         const void *fn = cnt ? reinterpret_cast<const void *>(&k_trace<TIRT_TRAVERSE_ORDERED, true, KIND_TAIL>) : reinterpret_cast<const void *>(&k_trace<TIRT_TRAVERSE_ORDERED, false, KIND_TAIL>);
         TIRT_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1062,10 +1055,16 @@ static int launch_tail(tirt_ctx *c, hipStream_t stream, const TraceArgs &a, int 
     return launch_trace_as<TIRT_TRAVERSE_ORDERED, false, KIND_TAIL>(c, stream, a, g, b, lds);
 }
 
+#endif
+
 // The bounce from which a batch of S paths runs as one tail launch (-1: no tail).  Chosen from what earlier batches of this scene did: the first
 // bounce that no more than tail_paths paths are expected to enter.
 static int choose_tail_bounce(const tirt_ctx *c, size_t S, int max_depth, int flags, bool spectral)
 {
+#ifndef TIRT_EXPERIMENTS
+    (void)c; (void)S; (void)max_depth; (void)flags; (void)spectral;
+    return -1;
+#endif
     if (spectral || (flags & TIRT_TRAVERSE_EXHAUSTIVE) || c->time_kernels || max_depth < 2) return -1;
     if (c->tail_bounce == 0) return -1;
     if (c->tail_bounce > 0) return c->tail_bounce < max_depth ? c->tail_bounce : -1;
@@ -1758,6 +1757,7 @@ int pt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed,
             c->launches_trace_closest++;
             counts_known = b;              // append_ctr(b - 1), the paths that entered bounce b, has been written by now
 
+#ifdef TIRT_EXPERIMENTS
             if (b == tail_b) {
                 // everything that is left of the batch in one launch: the paths' state stays where it is (`in`), their shadow rays go to index q of the shadow arrays
                 TraceArgs t = a;
@@ -1770,6 +1770,9 @@ int pt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed,
                 c->launches_tail++;
                 break;
             }
+#else
+            (void)tail_b;
+#endif
 
             stamp(evh, true);
             if (spec)

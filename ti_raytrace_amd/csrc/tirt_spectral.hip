@@ -174,7 +174,7 @@ int tirt_spec_table_build(tirt_ctx *c, int res, const float *cie_xyz, const floa
     const double h = (830.0 - 360.0) / (double)(n - 1);
     for (int i = 0; i < n; i++) {
         double weight = 3.0 / 8.0 * h;
-        if ((i == 0) || (i == n - 1)) weight = weight;
+        if ((i == 0) || (i == n - 1)) { }                              // (JakobSpecTable.py:338: the end points keep 3/8 h)
         else if ((i - 1) % 3 == 2) weight = weight * 2.0;
         else weight = weight * 3.0;
         const double X = (double)cie_xyz[3 * i], Y = (double)cie_xyz[3 * i + 1], Z = (double)cie_xyz[3 * i + 2], D = (double)d65[i];
