@@ -358,7 +358,54 @@ def run_config(name, device_id, seed=1):
         r["oracle_sample"] = "whole 48x48 film x 3 spp: rel-L2 %.2e (float-atomic splats)" % rel
         r["reference_pin"] = "structure pin against image/rainbow.png: tests/test_bdpt_spec.py, tests/test_gpu_bdpt_spec.py"
         return r
+    if name == "big_scene_4M_1024x1024_32spp":       # the regime north_star describes: a tree that does not fit on the die (4 M triangles: ~0.46 GB of nodes + primitive records)
+        W = H = 1024; spp = 32
+        t0 = time.perf_counter()
+        ex = scenes.synthetic(W, H, spp, ntri=4000000, spread=0.006, device_id=device_id, seed=seed); ex.build_scene(); ex.scene.ctx.sync()
+        t_setup = time.perf_counter() - t0
+        hdr, r = timed(ex, spp, lambda: ex.integrator.render_frames(spp))
+        info = ex.scene.ctx.bvh_info()
+        r["scene"] = "synthetic random mesh, 4 000 000 triangles (scene seed 1234, s = 0.006: the headline scene's covered area per volume), PT_RGB, max_depth 15"
+        r["traversal_bytes"] = int(info["node_bytes"] + info["prim_bytes"])
+        r["setup_seconds_host_packing_and_build"] = round(t_setup, 2)
+        r["gather_ceiling_GBps_for_this_working_set"] = round(ex.scene.ctx.micro_gather_rate(info["node_bytes"] + info["prim_bytes"], 1000), 1)
+        if not os.environ.get("TIRT_BENCH_CTX_OPTS"):      # (not in the profiler children)
+            r["oracle_sample_identical"] = _oracle_run_identical(ex, W, H, spp, seed, hdr, (W // 2) * H + 128, 1024)
+            r["oracle_sample"] = "1024 pixels x 32 spp, bit for bit"
+        return r
     raise SystemExit("unknown config " + name)
+
+
+def big_scene_roofline(cfg):
+    """HBM-side traffic, L2 hit rate and L1 -> L2 request rate of k_trace on the 4 M-triangle scene (three rocprofv3 passes over a child run of the config on
+    ONE lane): the `>= 40 % of the HBM roofline` question of north_star, asked where the tree does not fit in L2 / MALL."""
+    child = [sys.executable, os.path.abspath(__file__), "--configs-only", "big_scene_4M_1024x1024_32spp:overlap_lanes=1"]
+    try:
+        k = rocprof_passes(child, [("FETCH_SIZE",), ("WRITE_SIZE",), ("TCP_TCC_READ_REQ_sum", "TCC_HIT_sum", "TCC_MISS_sum")], timeout_s=400)
+    except Exception as exc:            # noqa: BLE001
+        return {"error": "%s: %s" % (type(exc).__name__, exc)}
+    tot = {}
+    for n, v in k.items():
+        if n.startswith("k_trace"):
+            for c_, x in v.items():
+                tot[c_] = tot.get(c_, 0.0) + x
+    if not tot.get("launches"):
+        return {"error": "no k_trace dispatch in the profiler passes", "child": k.get("__child_tail")}
+    n = tot["launches"] / 2.0                                   # the child renders the job twice (warm-up + timed)
+    by = (2.0 * tot.get("FETCH_SIZE", 0.0) + tot.get("WRITE_SIZE", 0.0)) * 1024.0
+    hbm = by / tot["dur_ns"]
+    out = {"bound": "hbm", "kernel": "k_trace", "achieved": round(hbm, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm / HBM_PEAK_GBS, 4),
+           "traffic": round(by / tot["launches"]), "launches_per_job": int(n), "avg_launch_ms_profiled": round(tot["dur_ns"] / tot["launches"] / 1e6, 4),
+           "k_trace_ms_per_job_profiled": round(tot["dur_ns"] / 2e6, 3)}
+    if tot.get("TCC_HIT_sum", 0) + tot.get("TCC_MISS_sum", 0) > 0:
+        out["l2_hit_rate"] = round(tot["TCC_HIT_sum"] / (tot["TCC_HIT_sum"] + tot["TCC_MISS_sum"]), 4)
+        out["l1_to_l2_read_requests_G_per_s"] = round(tot["TCP_TCC_READ_REQ_sum"] / tot["dur_ns"], 2)
+        out["l2_miss_requests_G_per_s"] = round(tot["TCC_MISS_sum"] / tot["dur_ns"], 2)
+    if "rays" in cfg and cfg.get("seconds"):
+        out["hbm_bytes_per_ray"] = round(by / 2.0 / max(cfg["rays"], 1), 1)
+    out["source"] = ("rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE | TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum over "
+                     "`bench.py --configs-only big_scene_4M_1024x1024_32spp:overlap_lanes=1` (one lane, profiled durations; FETCH_SIZE x 2: gfx950)")
+    return out
 
 
 def bdpt_roofline(device_id):
@@ -781,9 +828,21 @@ def main():
                                          "issue_busy_if_timed_region_ran_at_2.4_GHz": round(need_ms * pmc["clock_GHz_profiled"] / 2.4 / result["ms_per_step"], 4),
                                          "def": "sum over the loop's kernels of SQ_INSTS_VALU per step x measured cycles per instruction / (1024 SIMDs x "
                                                 "measured clock), divided by the timed ms_per_step (batches overlapped)"}
+        # Round 5: WHICH ceiling binds was asked of the kernel itself (profiles/r05_bound_ladder.txt): 64 extra VALU instructions per node visit (+59 % of a
+        # visit's 109) cost the step 5.4 %, ONE extra record gather per visit costs it 27 % -- linear from the first one on.  The kernel is bound by the
+        # path its record gathers take, L1 (TCP) -> L2 requests, not by VALU issue (whose busy counter reads 0.89 here and 1.28 on k_generate: uncalibrated).
+        # fractions.gather = L1 -> L2 read traffic of a launch (TCP_TCC_READ_REQ, bytes per request calibrated on k_film) / its duration, against the rate
+        # at which THIS device gathers random 64-byte records from an L2-resident array (tirt_micro_gather_rate, 2 MB, measured in this run) -- the
+        # kernel's own access pattern at its best.  tools/micro/ta_cost.hip: that rate is set per record (line), not per request or byte.
+        if l2 and peak_l2 > 0:
+            fr["gather"] = round(l2["GBps"] / peak_l2, 4)
         known = {k: v for k, v in fr.items() if v is not None}
-        bound = max(known, key=known.get) if known else "valu"
-        if bound == "valu" and valu:
+        bound = "gather" if fr.get("gather") else (max(known, key=known.get) if known else "valu")
+        if bound == "gather":
+            top = {"achieved": round(l2["GBps"] / 64.0, 2), "peak": round(peak_l2 / 64.0, 2), "frac": fr["gather"],
+                   "unit": "G 64-byte lines/s from L1 to L2 (achieved: TCP_TCC_READ_REQ of the launch; peak: this device's measured rate of random 64-byte record gathers "
+                           "from an L2-resident array, 4 x global_load_dwordx4 per record as a node fetch does)"}
+        elif bound == "valu" and valu:
             # VALU issue is the bound; an issue slot whose lanes are masked off is not work, so what is counted is LANE-instructions: the wave
             # instructions the kernel issues x the share of their 64 lanes that are active, against the rate at which this instruction mix would
             # leave the VALUs with every lane active and no idle cycle.  frac = issue_busy x lane_util.
@@ -804,15 +863,20 @@ def main():
             "achieved": top["achieved"], "peak": top["peak"], "unit": top["unit"], "frac": top["frac"],
             "traffic": tr_bytes,
             "fractions": fr, "hbm": hbm, "l2": l2, "valu": valu,
-            "frac_def": "issue_busy x lane_util of the dominant kernel when VALU issue is the bound (`fractions.valu` is issue_busy alone: that picks the bound)",
+            "frac_def": "L1 -> L2 read traffic per launch / launch duration / the measured L2-resident record-gather rate of this device (`fractions.gather`); "
+                        "`fractions.valu` (issue busy, uncalibrated counter) and `valu.useful_lane_throughput` are printed beside it",
+            "bound_evidence": {"ladder": "profiles/r05_bound_ladder.txt", "valu_pad_64_instructions_per_node_visit": "+5.4 % ms/step", "one_extra_record_gather_per_node_visit": "+27.1 % ms/step",
+                               "two": "+51.3 %", "four": "+98.9 %", "eight": "+203 %", "cost_model": "tools/micro/ta_cost.hip: a scattered record costs 0.95 ns per CU whatever "
+                               "its width, +0.07 ns per further request to the same line; quad-cooperative fetches do not change it (profiles/r05b)"},
             # the same against the guide's issue peak (a wave64 VALU instruction every 2 cycles: MI355X_MICROARCH.md's 157.3 TFLOP/s FP32); this mix
             # (v_fma_mix, v_min3 / v_max3, v_cndmask, v_alignbit) issues at ~4
             "frac_vs_guide_issue_peak": round(valu["rate_frac_of_fp32_peak"] * valu["lane_util"], 4) if valu else None,
             "why_not_hbm": ("north_star's >= 40 % of the HBM roofline does not apply to this kernel at this scene size: what it walks (2.7 MB of nodes + 4.8 MB of "
                             "primitive records) stays in L2 / LDS (hit rate in `l2`), so its HBM-side traffic is the ray and hit streams only -- counter traffic / "
-                            "gathered bytes = `hbm_over_gathered` -- and no re-read is wasted; the ceiling it does sit at is VALU issue" ),
+                            "gathered bytes = `hbm_over_gathered` -- and no re-read is wasted; the ceiling it does sit at is the L1 -> L2 request path of its record gathers "
+                            "(`bound_evidence`); configs.big_scene_4M_1024x1024_32spp is the same kernel on a tree that does not fit on the die"),
             "hbm_over_gathered": round(tr_bytes / max(gather_bytes / n_launch, 1.0), 4) if tr_bytes else None,
-            "hbm_GBps": hbm["GBps"] if hbm else None, "hbm_frac": fr["hbm"], "l2_frac": fr["l2"], "valu_frac": fr["valu"],
+            "hbm_GBps": hbm["GBps"] if hbm else None, "hbm_frac": fr["hbm"], "l2_frac": fr["l2"], "valu_frac": fr["valu"], "gather_frac": fr.get("gather"),
             # the records the launch gathers from global memory against the two ceilings of that access pattern measured in THIS run
             # (random 64-byte records, 4 x dwordx4 per lane: from an array of the traversal data's size, and from 2 MB = L2-resident);
             # both fractions are printed, neither is chosen after the fact
@@ -865,7 +929,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_configs:
         cfgs = {}
         for name in ("config1_cornell_512x512_512spp", "config2_teapot_1024x1024_64spp", "config5_veach_bdpt_512x512_64spp", "spectral_cornell_512x512_64spp",
-                     "prism_rainbow_bdpt_spec_512x512_64spp"):
+                     "prism_rainbow_bdpt_spec_512x512_64spp", "big_scene_4M_1024x1024_32spp"):
             try:
                 cfgs[name] = run_config(name, local_rank, args.seed)
             except Exception as exc:        # noqa: BLE001 -- one failing config must not hide the headline line
@@ -874,6 +938,8 @@ def main():
         cfgs["config3_headline"] = "this line's `value` (%d steps x %d frames of the 100k scene)" % (args.steps, fps)
         if not args.no_traffic:
             cfgs["config5_veach_bdpt_512x512_64spp"]["roofline"] = bdpt_roofline(local_rank)
+            if "error" not in cfgs["big_scene_4M_1024x1024_32spp"]:
+                cfgs["big_scene_4M_1024x1024_32spp"]["roofline"] = big_scene_roofline(cfgs["big_scene_4M_1024x1024_32spp"])
         # LBVH build (a4..a8) + traversal tree at 1 M primitives, second build of each kind (HIP events on the context's stream)
         try:
             big = scenes.synthetic(64, 64, 4, ntri=1000000, spread=0.012, device_id=local_rank)

@@ -522,6 +522,8 @@ def test_device_film_equals_the_reference_text_film(gpu_ctx_ok, name):
     ex, W, H, frames, seed = reference_text_scene(name, device_id=0)
     ex.integrator.seed = seed
     ex.build_scene()
+    if name == "spot_laser":                 # (a bare Example.example: the scene classes of scenes.py do this in their build_scene)
+        ex.scene.total_area(); ex.frame_camera(0.8)
     ex.integrator.render_frames(frames)
     got = ex.integrator.hdr.to_numpy()
     from test_refkat import GS
