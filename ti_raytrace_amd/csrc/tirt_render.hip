@@ -41,7 +41,7 @@ enum { KIND_CLOSEST = 0, KIND_SHADOW_ACC = 1, KIND_MIXED = 2, KIND_QUERY = 3, KI
 // switch point), none of the A/B switches of this file (TR_* macros: bound ladder, quad-cooperative fetch, drain diagnostics ...).  `make experiments`
 // builds libtirt_exp.so with them; tools/ and the tests that exercise them load that library through TIRT_LIB_PATH.
 #if !defined(TIRT_EXPERIMENTS) && (defined(TR_NO_STASH) || defined(TR_DRAIN_DIAG) || defined(TR_NO_DRAINED_COUNT) || defined(TR_NODE_FRAC) || defined(TR_NO_VERIFY) || \
-    defined(TR_PAD) || defined(TR_PADG) || defined(TR_COOP) || defined(TR_NO_ASM_FETCH) || defined(TR_MIN_WAVES) || defined(TR_TAIL_WAVES))
+    defined(TR_PAD) || defined(TR_PADG) || defined(TR_COOP) || defined(TR_NO_NT_STREAMS) || defined(TR_NO_ASM_FETCH) || defined(TR_MIN_WAVES) || defined(TR_TAIL_WAVES))
 #error "the TR_* A/B switches of tirt_render.hip need an experiments build: add -DTIRT_EXPERIMENTS"
 #endif
 // MIXED: closest rays of bounce b + shadow rays of bounce b-1 in one launch.  QUERY: connection rays of BDPT -- "is sprim[q] the closest
@@ -276,7 +276,11 @@ typedef const __attribute__((address_space(4))) TraceArgs *cold_args_t;
 #else
 #define TR_PAD_WHERE 0
 #endif
+#ifdef TR_PAD_MAX          // the pad as an instruction of the node step's own class (v_max / v_min / v_cmp / v_cndmask / v_alignbit / v_fma_mix issue at half the rate of v_fma / v_add: tools/micro/valu_issue.hip)
+#define TR_PAD1(reg) asm volatile("v_max_f32 %0, %0, %0" : "+v"(reg))
+#else
 #define TR_PAD1(reg) asm volatile("v_fma_f32 %0, %0, 1.0, 0" : "+v"(reg))
+#endif
 #define TR_LADDER_PADS(where)                                                                        \
     do {                                                                                             \
         if ((where) == TR_PAD_WHERE) {                                                               \
@@ -538,9 +542,14 @@ __global__ __launch_bounds__(TR_BLOCK, KIND == KIND_TAIL ? TR_TAIL_WAVES : TR_MI
                     const float4 r0 = c_ray4[2 * ri], r1 = c_ray4[2 * ri + 1];
                     o = V(r0.x, r0.y, r0.z); d = V(r0.w, r1.x, r1.y); rec_expect = __float_as_int(r1.z); rec_bound = r1.w;
                 } else {
-                    o = mixed_sh ? V(c_sox[q], c_soy[q], c_soz[q])
-                                 : ((KIND == KIND_CLOSEST && c_ox == nullptr) ? V(ca->eye[0], ca->eye[1], ca->eye[2]) : V(c_ox[q], c_oy[q], c_oz[q]));
-                    d = mixed_sh ? V(c_sdx[q], c_sdy[q], c_sdz[q]) : V(c_dx[q], c_dy[q], c_dz[q]);
+#ifndef TR_NO_NT_STREAMS      // ray and hit records are a stream (written once, read once a launch later): non-temporal, so that they do not displace the BVH in L1 / L2 (+0.7 %, profiles/r05l)
+#define TR_LDS_(p) __builtin_nontemporal_load(&(p))
+#else
+#define TR_LDS_(p) (p)
+#endif
+                    o = mixed_sh ? V(TR_LDS_(c_sox[q]), TR_LDS_(c_soy[q]), TR_LDS_(c_soz[q]))
+                                 : ((KIND == KIND_CLOSEST && c_ox == nullptr) ? V(ca->eye[0], ca->eye[1], ca->eye[2]) : V(TR_LDS_(c_ox[q]), TR_LDS_(c_oy[q]), TR_LDS_(c_oz[q])));
+                    d = mixed_sh ? V(TR_LDS_(c_sdx[q]), TR_LDS_(c_sdy[q]), TR_LDS_(c_sdz[q])) : V(TR_LDS_(c_dx[q]), TR_LDS_(c_dy[q]), TR_LDS_(c_dz[q]));
                 }
                 r = make_ray(o, d);
                 par = ray_has_parallel_axis(r);
@@ -549,8 +558,8 @@ __global__ __launch_bounds__(TR_BLOCK, KIND == KIND_TAIL ? TR_TAIL_WAVES : TR_MI
                 cull_far = 3.0e38f; settle = -1.0f; expect = -3;
                 float t_bound = -1.0f;
                 if (MAY_SHADOW && is_sh) {
-                    expect = from_rec ? rec_expect : c_sprim[q];
-                    if (BOUNDED) t_bound = from_rec ? rec_bound : c_sdist[q];
+                    expect = from_rec ? rec_expect : TR_LDS_(c_sprim[q]);
+                    if (BOUNDED) t_bound = from_rec ? rec_bound : TR_LDS_(c_sdist[q]);
                 }
                 if (MODE != TIRT_TRAVERSE_EXHAUSTIVE) {
                     // margin in cells, the same on all axes: 0.25 + 0.25 per root-box extent between the origin and the
@@ -836,6 +845,7 @@ __global__ __launch_bounds__(TR_BLOCK, KIND == KIND_TAIL ? TR_TAIL_WAVES : TR_MI
             }
 #else
             const float4 *tp = b.tri + (size_t)(code & 0x3fffffff) * TRI_STRIDE;          // records in the traversal tree's leaf order
+            // (the records themselves must NOT be loaded non-temporally: -25 %, profiles/r05m -- their residency in L2 is what the kernel lives on)
             const float4 ta = tp[0], tb = tp[1], tc = tp[2];
 #endif
             int prim = __float_as_int(tc.w);                                              // the primitive id rides in the last word
@@ -937,13 +947,17 @@ __global__ __launch_bounds__(TR_BLOCK, KIND == KIND_TAIL ? TR_TAIL_WAVES : TR_MI
             const float *const c_scw = MAY_SHADOW ? ca->scw : nullptr;
             if (MAY_SHADOW) asm volatile("" :: "s"(c_hit), "s"(c_sdst), "s"(c_rr), "s"(c_rg), "s"(c_rb), "s"(c_fr), "s"(c_fg), "s"(c_fb), "s"(c_scr), "s"(c_scg), "s"(c_scb), "s"(c_scw));      // one batch of scalar loads (as in the refill)
             if (!(MAY_SHADOW && is_sh) || KIND == KIND_QUERY) {
+#ifndef TR_NO_NT_STREAMS
+                { typedef float f4n __attribute__((ext_vector_type(4))); f4n hv__ = {hit_t, hit_u, hit_v, __int_as_float(hit_prim)}; __builtin_nontemporal_store(hv__, (f4n *)&c_hit[q]); }
+#else
                 c_hit[q] = make_float4(hit_t, hit_u, hit_v, __int_as_float(hit_prim));
+#endif
             } else if (hit_prim == expect) {                 // integrator/PT_RGB.py:105-109
-                const int dst = c_sdst[q];
+                const int dst = TR_LDS_(c_sdst[q]);
                 float *pr = dst >= 0 ? c_rr + dst : c_fr + ~dst;
                 float *pg = dst >= 0 ? c_rg + dst : c_fg + ~dst;
                 float *pb = dst >= 0 ? c_rb + dst : c_fb + ~dst;
-                *pr = *pr + c_scr[q]; *pg = *pg + c_scg[q]; *pb = *pb + c_scb[q];
+                *pr = *pr + TR_LDS_(c_scr[q]); *pg = *pg + TR_LDS_(c_scg[q]); *pb = *pb + TR_LDS_(c_scb[q]);
                 if (c_scw) { float *pw = dst >= 0 ? ca->rw + dst : ca->fw + ~dst; *pw = *pw + c_scw[q]; }
             }
             if (COUNT) {
@@ -1242,7 +1256,7 @@ __global__ void k_generate(PathSoA ps, CameraView cam, TileMap tm, int P, int S,
         jy = tm_rand(seed, (uint32_t)p, frame, TM_DIM_JY) - 0.5f;
     }
     v3 d = camera_ray_direction(cam, i, j, jx, jy);
-    ps.dx[s] = d.x; ps.dy[s] = d.y; ps.dz[s] = d.z;
+    __builtin_nontemporal_store(d.x, &ps.dx[s]); __builtin_nontemporal_store(d.y, &ps.dy[s]); __builtin_nontemporal_store(d.z, &ps.dz[s]);      // (a stream: k_trace reads it once)
     if (s == 0) atomicAdd(&ctr->paths, (unsigned long long)S);
 }
 
@@ -1265,6 +1279,13 @@ __global__ void k_generate(PathSoA ps, CameraView cam, TileMap tm, int P, int S,
 struct ShadeArgs { PathState ps; PathSoA in, out; };
 typedef const __attribute__((address_space(4))) ShadeArgs *cold_shade_t;
 #define SH_COLD(ca) cold_shade_t ca = (cold_shade_t)__builtin_amdgcn_kernarg_segment_ptr(); asm volatile("" : "+s"(ca))
+#ifndef TR_NO_NT_STREAMS      // path state is a stream (written once, read once a launch later): keep it from displacing the BVH in L1 / L2
+#define SH_LD(x) __builtin_nontemporal_load(&(x))
+#define SH_ST(x, v) __builtin_nontemporal_store((v), &(x))
+#else
+#define SH_LD(x) (x)
+#define SH_ST(x, v) ((x) = (v))
+#endif
 __global__ __launch_bounds__(SH_BLOCK, SH_MIN_WAVES) void k_shade(ShadeArgs paths_in_kernarg_segment, SceneView sc, TileMap tm, int P,
                                                    uint32_t frame_begin, uint32_t seed, int bounce, int last_bounce,
                                                    const int *count_ptr, int count_fixed, unsigned long long *append_ctr,
@@ -1294,14 +1315,20 @@ __global__ __launch_bounds__(SH_BLOCK, SH_MIN_WAVES) void k_shade(ShadeArgs path
             const float *const c_pdf = ca->in.brdf_pdf;
             asm volatile("" :: "s"(c_slot), "s"(c_flags), "s"(c_hit), "s"(c_ox), "s"(c_oy), "s"(c_oz), "s"(c_dx), "s"(c_dy), "s"(c_dz), "s"(c_tr), "s"(c_tg), "s"(c_tb),
                          "s"(c_rr), "s"(c_rg), "s"(c_rb), "s"(c_pdf));
-            slot = first ? q : c_slot[q];
-            const v3 origin = first ? eye : V(c_ox[q], c_oy[q], c_oz[q]);
-            const v3 direction = V(c_dx[q], c_dy[q], c_dz[q]);
+            slot = first ? q : SH_LD(c_slot[q]);
+            const v3 origin = first ? eye : V(SH_LD(c_ox[q]), SH_LD(c_oy[q]), SH_LD(c_oz[q]));
+            const v3 direction = V(SH_LD(c_dx[q]), SH_LD(c_dy[q]), SH_LD(c_dz[q]));
+#ifndef TR_NO_NT_STREAMS
+            typedef float f4nt__ __attribute__((ext_vector_type(4)));
+            const f4nt__ hnt__ = __builtin_nontemporal_load((const f4nt__ *)&c_hit[q]);
+            const float4 hrec = make_float4(hnt__.x, hnt__.y, hnt__.z, hnt__.w);
+#else
             const float4 hrec = c_hit[q];
-            v3 throughout = first ? V(1.0f, 1.0f, 1.0f) : V(c_tr[q], c_tg[q], c_tb[q]);
-            radiance = first ? V(0.0f, 0.0f, 0.0f) : V(c_rr[q], c_rg[q], c_rb[q]);
-            float brdf_pdf = first ? 1.0f : c_pdf[q];
-            int perfect_spec = first ? 1 : (int)(c_flags[q] & 1u);
+#endif
+            v3 throughout = first ? V(1.0f, 1.0f, 1.0f) : V(SH_LD(c_tr[q]), SH_LD(c_tg[q]), SH_LD(c_tb[q]));
+            radiance = first ? V(0.0f, 0.0f, 0.0f) : V(SH_LD(c_rr[q]), SH_LD(c_rg[q]), SH_LD(c_rb[q]));
+            float brdf_pdf = first ? 1.0f : SH_LD(c_pdf[q]);
+            int perfect_spec = first ? 1 : (int)(SH_LD(c_flags[q]) & 1u);
             ShadeStep ss;
             shade_path(sc, tm, P, frame_begin, seed, bounce, last_bounce, slot, origin, direction, hrec, throughout, radiance, brdf_pdf, perfect_spec, ss);
             want_next = ss.want_next; want_shadow = ss.want_shadow; if (ss.shaded) n_shaded++;
@@ -1335,16 +1362,16 @@ __global__ __launch_bounds__(SH_BLOCK, SH_MIN_WAVES) void k_shade(ShadeArgs path
             float *const o_pdf = ca->out.brdf_pdf; uint32_t *const o_flags = ca->out.flags; int *const o_slot = ca->out.slot;
             asm volatile("" :: "s"(o_ox), "s"(o_oy), "s"(o_oz), "s"(o_dx), "s"(o_dy), "s"(o_dz), "s"(o_tr), "s"(o_tg), "s"(o_tb), "s"(o_rr), "s"(o_rg), "s"(o_rb),
                          "s"(o_pdf), "s"(o_flags), "s"(o_slot));
-            o_ox[qn] = next_o.x; o_oy[qn] = next_o.y; o_oz[qn] = next_o.z;
-            o_dx[qn] = next_d.x; o_dy[qn] = next_d.y; o_dz[qn] = next_d.z;
-            o_tr[qn] = next_thr.x; o_tg[qn] = next_thr.y; o_tb[qn] = next_thr.z;
-            o_rr[qn] = radiance.x; o_rg[qn] = radiance.y; o_rb[qn] = radiance.z;
-            o_pdf[qn] = next_pdf; o_flags[qn] = (uint32_t)next_spec; o_slot[qn] = slot;
+            SH_ST(o_ox[qn], next_o.x); SH_ST(o_oy[qn], next_o.y); SH_ST(o_oz[qn], next_o.z);
+            SH_ST(o_dx[qn], next_d.x); SH_ST(o_dy[qn], next_d.y); SH_ST(o_dz[qn], next_d.z);
+            SH_ST(o_tr[qn], next_thr.x); SH_ST(o_tg[qn], next_thr.y); SH_ST(o_tb[qn], next_thr.z);
+            SH_ST(o_rr[qn], radiance.x); SH_ST(o_rg[qn], radiance.y); SH_ST(o_rb[qn], radiance.z);
+            SH_ST(o_pdf[qn], next_pdf); SH_ST(o_flags[qn], (uint32_t)next_spec); SH_ST(o_slot[qn], slot);
         } else if (live) {
             SH_COLD(ca);
             float *const f_r = ca->ps.fr, *const f_g = ca->ps.fg, *const f_b = ca->ps.fb;
             asm volatile("" :: "s"(f_r), "s"(f_g), "s"(f_b));
-            f_r[slot] = radiance.x; f_g[slot] = radiance.y; f_b[slot] = radiance.z;
+            SH_ST(f_r[slot], radiance.x); SH_ST(f_g[slot], radiance.y); SH_ST(f_b[slot], radiance.z);
         }
         if (want_shadow) {
             SH_COLD(ca);
@@ -1352,11 +1379,11 @@ __global__ __launch_bounds__(SH_BLOCK, SH_MIN_WAVES) void k_shade(ShadeArgs path
             float *const s_cr = ca->ps.scr, *const s_cg = ca->ps.scg, *const s_cb = ca->ps.scb, *const s_dist = ca->ps.sdist;
             int *const s_prim = ca->ps.sprim, *const s_dst = ca->ps.sdst;
             asm volatile("" :: "s"(s_ox), "s"(s_oy), "s"(s_oz), "s"(s_dx), "s"(s_dy), "s"(s_dz), "s"(s_cr), "s"(s_cg), "s"(s_cb), "s"(s_dist), "s"(s_prim), "s"(s_dst));
-            s_ox[qs] = sh_o.x; s_oy[qs] = sh_o.y; s_oz[qs] = sh_o.z;
-            s_dx[qs] = sh_d.x; s_dy[qs] = sh_d.y; s_dz[qs] = sh_d.z;
-            s_cr[qs] = sh_c.x; s_cg[qs] = sh_c.y; s_cb[qs] = sh_c.z;
-            s_prim[qs] = sh_expect; s_dist[qs] = sh_dist;
-            s_dst[qs] = want_next ? qn : ~slot;
+            SH_ST(s_ox[qs], sh_o.x); SH_ST(s_oy[qs], sh_o.y); SH_ST(s_oz[qs], sh_o.z);
+            SH_ST(s_dx[qs], sh_d.x); SH_ST(s_dy[qs], sh_d.y); SH_ST(s_dz[qs], sh_d.z);
+            SH_ST(s_cr[qs], sh_c.x); SH_ST(s_cg[qs], sh_c.y); SH_ST(s_cb[qs], sh_c.z);
+            SH_ST(s_prim[qs], sh_expect); SH_ST(s_dist[qs], sh_dist);
+            SH_ST(s_dst[qs], want_next ? qn : ~slot);
         }
     }
     // statistics: one global atomic per block (through LDS), not per wave -- same-address atomics retire at ~11 ns
@@ -1381,9 +1408,9 @@ __global__ void k_film(PathState ps, TileMap tm, int P, int F, uint32_t frame_be
         int s = frame_pixel_to_slot(tm, P, f, k);
         float frame = (float)(int)(frame_begin + (uint32_t)f);
         float coff = 1.0f / (frame + 1.0f);
-        r = ps.fr[s] * coff + r * (1.0f - coff);
-        g = ps.fg[s] * coff + g * (1.0f - coff);
-        b = ps.fb[s] * coff + b * (1.0f - coff);
+        r = __builtin_nontemporal_load(&ps.fr[s]) * coff + r * (1.0f - coff);
+        g = __builtin_nontemporal_load(&ps.fg[s]) * coff + g * (1.0f - coff);
+        b = __builtin_nontemporal_load(&ps.fb[s]) * coff + b * (1.0f - coff);
     }
     px[0] = r; px[1] = g; px[2] = b;
 }
@@ -1433,7 +1460,13 @@ __global__ __launch_bounds__(SH_BLOCK, 4) void k_shade_spec(ShadeArgs paths_in_k
             const float Lambda = HERO_LAMBDA_MIN + HERO_LAMBDA_STEP * tm_rand(seed, pixel, frame, TM_DIM_SPEC_LAMBDA);     // PT_Spec.py:191
             const v3 origin = first ? eye : V(c_ox[q], c_oy[q], c_oz[q]);
             const v3 direction = V(c_dx[q], c_dy[q], c_dz[q]);
+#ifndef TR_NO_NT_STREAMS
+            typedef float f4nt__ __attribute__((ext_vector_type(4)));
+            const f4nt__ hnt__ = __builtin_nontemporal_load((const f4nt__ *)&c_hit[q]);
+            const float4 hrec = make_float4(hnt__.x, hnt__.y, hnt__.z, hnt__.w);
+#else
             const float4 hrec = c_hit[q];
+#endif
             const float t = hrec.x;
             f4s throughout = f4_set(1.0f);
             if (!first) {
