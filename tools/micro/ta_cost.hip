@@ -25,6 +25,34 @@ __global__ __launch_bounds__(256) void k(const uint32_t *rec, uint32_t mask, int
     }
     out[blockIdx.x * 256 + threadIdx.x] = (float)acc;
 }
+// 128-byte records (two adjacent 64-byte lines, 128-byte aligned): does the second half cost a second gather?
+template <int N>          // N x dwordx4 from the start of the record
+__global__ __launch_bounds__(256) void k128(const uint32_t *rec, uint32_t mask, int iters, float *out)
+{
+    uint32_t s = mix(blockIdx.x * 256 + threadIdx.x + 1);
+    uint32_t acc = 0;
+    for (int it = 0; it < iters; it++) {
+        s = mix(s + it);
+        const uint32_t *p = rec + (size_t)(s & mask) * 32;
+#pragma unroll
+        for (int j = 0; j < N; j++) { const uint4 v = *(const uint4 *)(p + 4 * j); acc += v.x ^ v.y ^ v.z ^ v.w; }
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = (float)acc;
+}
+template <int N> void run128(const uint32_t *rec, uint32_t nrec128, float *out, int cus)
+{
+    const int blocks = cus * 6, iters = 2000;
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    float best = 1e9f;
+    for (int rep = 0; rep < 3; rep++) {
+        (void)hipEventRecord(e0);
+        hipLaunchKernelGGL((k128<N>), dim3(blocks), dim3(256), 0, 0, rec, nrec128 - 1, iters, out);
+        (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+        float ms; (void)hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
+    }
+    const double recs = (double)blocks * 256 * iters;
+    printf("  128-byte records, %d x dwordx4 (%3d B read): %7.3f ms  %6.1f Grecords/s  %5.2f ns per record per CU\n", N, 16 * N, best, recs / best / 1e6, best * 1e6 * cus / recs);
+}
 template <int WIDTH, int N> void run(const uint32_t *rec, uint32_t nrec, float *out, int cus)
 {
     const int blocks = cus * 6, iters = 2000;
@@ -53,6 +81,7 @@ int main(int argc, char **argv)
         run<4, 4>(rec, nrec, out, cus); run<4, 3>(rec, nrec, out, cus); run<4, 2>(rec, nrec, out, cus); run<4, 1>(rec, nrec, out, cus);
         run<2, 4>(rec, nrec, out, cus); run<2, 2>(rec, nrec, out, cus); run<2, 1>(rec, nrec, out, cus);
         run<1, 4>(rec, nrec, out, cus); run<1, 2>(rec, nrec, out, cus); run<1, 1>(rec, nrec, out, cus);
+        run128<8>(rec, nrec / 2, out, cus); run128<6>(rec, nrec / 2, out, cus); run128<5>(rec, nrec / 2, out, cus); run128<4>(rec, nrec / 2, out, cus);
         (void)hipFree(rec);
         if (argc > 1) break;
     }
