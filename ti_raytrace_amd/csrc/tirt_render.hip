@@ -41,7 +41,7 @@ enum { KIND_CLOSEST = 0, KIND_SHADOW_ACC = 1, KIND_MIXED = 2, KIND_QUERY = 3, KI
 // switch point), none of the A/B switches of this file (TR_* macros: bound ladder, quad-cooperative fetch, drain diagnostics ...).  `make experiments`
 // builds libtirt_exp.so with them; tools/ and the tests that exercise them load that library through TIRT_LIB_PATH.
 #if !defined(TIRT_EXPERIMENTS) && (defined(TR_NO_STASH) || defined(TR_DRAIN_DIAG) || defined(TR_NO_DRAINED_COUNT) || defined(TR_NODE_FRAC) || defined(TR_NO_VERIFY) || \
-    defined(TR_PAD) || defined(TR_PADG) || defined(TR_COOP) || defined(TR_SETPRIO) || defined(TR_NO_NT_STREAMS) || defined(TR_NO_ASM_FETCH) || defined(TR_MIN_WAVES) || defined(TR_TAIL_WAVES))
+    defined(TR_PAD) || defined(TR_PADG) || defined(TR_COOP) || defined(TR_NO_NT_STREAMS) || defined(TR_NO_ASM_FETCH) || defined(TR_MIN_WAVES) || defined(TR_TAIL_WAVES))
 #error "the TR_* A/B switches of tirt_render.hip need an experiments build: add -DTIRT_EXPERIMENTS"
 #endif
 // MIXED: closest rays of bounce b + shadow rays of bounce b-1 in one launch.  QUERY: connection rays of BDPT -- "is sprim[q] the closest
@@ -311,9 +311,6 @@ template <int MODE, bool COUNT, int KIND>
 __global__ __launch_bounds__(TR_BLOCK, KIND == KIND_TAIL ? TR_TAIL_WAVES : TR_MIN_WAVES) void k_trace(TraceArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) int lds_stack[];      // [lds_depth][TR_BLOCK]
-#ifdef TR_SETPRIO
-    __builtin_amdgcn_s_setprio(TR_SETPRIO);       // A/B: traversal waves first at a SIMD's issue port (shading waves of the batch next door take what is left)
-#endif
     const int TR_LDS_DEPTH = a.lds_depth;
     constexpr bool MAY_SHADOW = (KIND != KIND_CLOSEST);
 #ifndef TR_NO_STASH
