@@ -22,7 +22,7 @@ def test_header_and_binding_agree():
 
 
 def test_library_exports_every_declared_symbol():
-    lib = ctypes.CDLL(_native.LIB_PATH)
+    lib = _native.lib()            # (through the package's loader: a bare CDLL here would map the system HIP runtime beside the one PyTorch ships)
     for name in declared_symbols():
         assert hasattr(lib, name), name
     lib.tirt_version.restype = ctypes.c_int

@@ -148,9 +148,12 @@ def _check_one_hip_runtime():
     except OSError:
         return
     if len({os.path.realpath(p) for p in libs}) > 1:
+        msg = ("two HIP runtimes are mapped into this process (%s): libtirt.so and PyTorch will not see each other's device memory; "
+               "set TIRT_SYSTEM_HIP=1 (and import torch after this package), or make the SONAMEs agree" % ", ".join(libs))
+        if os.environ.get("TIRT_ALLOW_TWO_HIP_RUNTIMES", "0") in ("", "0"):       # loud by default (round-4 review); a process that never hands device pointers across may opt out
+            raise TirtError(msg + " -- or TIRT_ALLOW_TWO_HIP_RUNTIMES=1 if the two never exchange device pointers")
         import warnings
-        warnings.warn("two HIP runtimes are mapped into this process (%s): libtirt.so and PyTorch will not see each other's device memory; "
-                      "set TIRT_SYSTEM_HIP=1 (and import torch after this package), or make the SONAMEs agree" % ", ".join(libs), RuntimeWarning)
+        warnings.warn(msg, RuntimeWarning)
 
 
 def lib():
