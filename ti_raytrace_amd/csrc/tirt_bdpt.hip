@@ -503,7 +503,7 @@ __global__ void k_bd_init(BdCtx c, BdItems items, BdSteps steps, BdRays rays, in
 {
     const int it = blockIdx.x * blockDim.x + threadIdx.x;
     if (it >= N) return;
-    const int f = it / P, k = it - f * P;
+    int f, k; slot_to_frame_pixel(tm, P, it, f, k);
     const int p = local_to_pixel(tm, k);
     const int i = p / c.bv.H, j = p - i * c.bv.H;
     const uint32_t pixel = (uint32_t)p, frame = frame_begin + (uint32_t)f;
@@ -563,7 +563,7 @@ __global__ __launch_bounds__(BD_STEP_BLOCK) void k_bd_step(BdCtx c, BdItems item
         const bool is_eye = t < N;
         const int it = is_eye ? t : t - N;
         {
-            const int f = it / P, k = it - f * P;
+            int f, k; slot_to_frame_pixel(tm, P, it, f, k);
             const uint32_t pixel = (uint32_t)local_to_pixel(tm, k), frame = frame_begin + (uint32_t)f;
             const SceneView &s = c.sc;
             const bpixel B = bd_item(items, (size_t)it);
@@ -723,7 +723,7 @@ __global__ void k_bd_delta(BdItems items, BdSteps steps, TileMap tm, int P, int 
     if (k >= P) return;
     int *mem = delta_mem + (size_t)local_to_pixel(tm, k) * 8;
     for (int f = 0; f < F; f++) {
-        const size_t it = (size_t)f * P + k;
+        const size_t it = (size_t)frame_pixel_to_slot(tm, P, f, k);
         const varr eye = bd_item(items, it).eye;
         const int edt = steps.ed[it], ed = edt & 0xffff;
         for (int v = 1; v < ed; v++) {
@@ -775,7 +775,7 @@ __global__ __launch_bounds__(BD_CONNECT_BLOCK) void k_bd_connect(BdCtx c, BdItem
     int eye_depth = 0, light_depth = -1, i = 0, j = 0, p = 0, f = 0;
     const bpixel B = bd_item(items, (size_t)(live ? it : 0));
     if (live) {
-        f = it / P; const int k = it - f * P;
+        int k; slot_to_frame_pixel(tm, P, it, f, k);
         p = local_to_pixel(tm, k); i = p / c.bv.H; j = p - i * c.bv.H;
         eye_depth = steps.ed[it] & 0xffff; light_depth = steps.ld[it];
     }
@@ -846,7 +846,7 @@ __global__ void k_bd_emitted(BdCtx c, BdItems items, BdSteps steps, TileMap tm, 
     if (e < 2 || e > BD_EYE_MAX || e - 2 > BD_MAX_DEPTH) return;
     const bpixel B = bd_item(items, (size_t)it);
     if (B.eye[e - 1].type != VERTEX_LIGHT) return;          // depth = e - 2 in 0..BD_MAX_DEPTH
-    const int f = it / P, k = it - f * P;
+    int f, k; slot_to_frame_pixel(tm, P, it, f, k);
     const int p = local_to_pixel(tm, k), i = p / c.bv.H, j = p - i * c.bv.H;
     const uint32_t frame = frame_begin + (uint32_t)f;
     Tracer T; T.phase = 1; T.want = false; T.res.t = INF_VALUE; T.res.u = 0.0f; T.res.v = 0.0f; T.res.prim = -1;
@@ -899,7 +899,7 @@ __global__ BD_RESOLVE_BOUNDS void k_bd_resolve(BdCtx c, BdItems items, TileMap t
             const unsigned own = qown[q];
             const int it = (int)(own & ((1u << BD_OWNER_BITS) - 1u)), slot = (int)(own >> BD_OWNER_BITS);
             const int e = slot / (BD_LIGHT_MAX + 1) + 1, l = slot - (e - 1) * (BD_LIGHT_MAX + 1);
-            const int f = it / P, kk = it - f * P;
+            int f, kk; slot_to_frame_pixel(tm, P, it, f, kk);
             const int p = local_to_pixel(tm, kk), i = p / c.bv.H, j = p - i * c.bv.H;
             const uint32_t frame = frame_begin + (uint32_t)f;
             Tracer T; T.phase = 1; T.want = false; T.res.t = hr.x; T.res.u = hr.y; T.res.v = hr.z; T.res.prim = __float_as_int(hr.w);
@@ -1019,7 +1019,7 @@ int bdpt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t see
     for (int k = 0; k < 12; k++) bc.bv.view[k] = c->view[k];
     bc.bv.W = c->W; bc.bv.H = c->H;
     DevCounters *ctr = c->dev_counters.as<DevCounters>();
-    const TileMap tm = {c->tile_rank, c->tile_count, c->tile_size, c->H, c->tile_blocked, 0};
+    TileMap tm = {c->tile_rank, c->tile_count, c->tile_size, c->H, c->tile_blocked, 0, 0};
     const int B = 128;
     // everything queued on the main stream so far precedes the lanes' work
     if (NL > 1) { TIRT_HIP(hipEventRecord(c->ev_main, c->stream)); for (int l = 0; l < NL; l++) TIRT_HIP(hipStreamWaitEvent(c->lanes[l].stream, c->ev_main, 0)); }
@@ -1044,6 +1044,7 @@ int bdpt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t see
         int *scount = bl.ctr.as<int>();
         const int F = frame_count - f0 < FB ? frame_count - f0 : FB;
         const int N = F * P;
+        tm.F = (c->path_order_blocks && (P & 63) == 0) ? F : 0;          // items numbered pixel-block major (tirt_internal.h, TileMap::F): the frames of a pixel block are neighbours in every ray list
         const BdItems items = {bl.items.as<float4>(), (size_t)N};          // (the batch's items side by side: stride = their number)
         const BdSteps state = bd_steps(bl.state.p, (size_t)N);
         const uint32_t frame0 = frame_begin + (uint32_t)f0;
