@@ -413,8 +413,7 @@ def test_path_order_and_slice_layout_change_no_bit(gpu_ctx_ok, integrator):
     """tirt_internal.h TileMap::F / TraceArgs::slices_contig: the paths of a batch numbered pixel-block major instead of frame major, and k_trace's
     ray-fetch slices as contiguous stretches of the queue instead of interleaved chunks (each XCD then walks one region of the film): which lane
     traces which ray changes, nothing else -- the same film bit for bit, the same ray counts, alone and together, also when the tile has partial
-    batches (7 frames cut 4 + 3: frames per wave fall back to a divisor of a batch's frame count) and when the local pixel count is not a multiple of 64 (frame-major order then).
-    `path_frames_per_wave` G: a wave holds 64 / G pixels in G consecutive frames (camera rays of one pixel differ by their jitter only)."""
+    batches (7 frames cut 4 + 3) and when the local pixel count is not a multiple of 64 (frame-major order then)."""
     def run(W, H, opts, frames=7):
         ex = scenes.spectral_box(W, H, frames, device_id=0) if integrator == "pt_spec" else scenes.synthetic(W, H, frames, ntri=3000, device_id=0)
         ex.build_scene()
@@ -429,8 +428,7 @@ def test_path_order_and_slice_layout_change_no_bit(gpu_ctx_ok, integrator):
         return film, (st["rays_closest"], st["rays_shadow"], st["paths"], st["shaded"])
     for W, H in ((96, 96), (50, 30)):
         base, n0 = run(W, H, {})
-        for opts in ({"path_order_blocks": 0}, {"slices_contiguous": 1}, {"path_order_blocks": 1, "slices_contiguous": 1}, {"path_frames_per_wave": 4},
-                     {"path_frames_per_wave": 2, "slices_contiguous": 1}, {"path_frames_per_wave": 64}):
+        for opts in ({"path_order_blocks": 0}, {"slices_contiguous": 1}, {"path_order_blocks": 1, "slices_contiguous": 1}):
             film, n = run(W, H, opts)
             assert n == n0, (opts, n, n0)
             assert np.array_equal(film.view(np.uint32), base.view(np.uint32)), opts

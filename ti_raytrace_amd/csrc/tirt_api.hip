@@ -430,7 +430,6 @@ int tirt_set_option(tirt_ctx *c, const char *name, double value)
     }
     if (!strcmp(name, "shade_grid")) { TIRT_REQUIRE(value >= 1 && value <= 65536, "shade_grid: 1..65536"); c->sh_grid = (int)value; c->grid_user = true; return TIRT_OK; }
     if (!strcmp(name, "path_order_blocks")) { c->path_order_blocks = value != 0.0; return TIRT_OK; }
-    if (!strcmp(name, "path_frames_per_wave")) { int g = 0; while ((1 << g) < (int)value && g < 6) g++; TIRT_REQUIRE((1 << g) == (int)value, "path_frames_per_wave: 1, 2, 4 ... 64"); c->path_frames_log2 = g; return TIRT_OK; }
     if (!strcmp(name, "slices_contiguous")) { c->slices_contiguous = value != 0.0; return TIRT_OK; }
     if (!strcmp(name, "trace_grid_alone")) { TIRT_REQUIRE(value >= 1 && value <= 2048, "trace_grid_alone: 1..2048"); c->tr_grid_alone = (int)value; return TIRT_OK; }
     if (!strcmp(name, "trace_grid")) { TIRT_REQUIRE(value >= 1 && value <= 2048, "trace_grid: 1..2048"); c->tr_grid = (int)value; c->grid_user = true; return TIRT_OK; }

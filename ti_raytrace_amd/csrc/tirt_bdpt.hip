@@ -1019,7 +1019,7 @@ int bdpt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t see
     for (int k = 0; k < 12; k++) bc.bv.view[k] = c->view[k];
     bc.bv.W = c->W; bc.bv.H = c->H;
     DevCounters *ctr = c->dev_counters.as<DevCounters>();
-    TileMap tm = {c->tile_rank, c->tile_count, c->tile_size, c->H, c->tile_blocked, 0, 0};
+    TileMap tm = {c->tile_rank, c->tile_count, c->tile_size, c->H, c->tile_blocked, 0};
     const int B = 128;
     // everything queued on the main stream so far precedes the lanes' work
     if (NL > 1) { TIRT_HIP(hipEventRecord(c->ev_main, c->stream)); for (int l = 0; l < NL; l++) TIRT_HIP(hipStreamWaitEvent(c->lanes[l].stream, c->ev_main, 0)); }

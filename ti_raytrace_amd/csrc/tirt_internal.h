@@ -156,25 +156,16 @@ struct PathState {
 // `F` > 0: the paths of a wavefront batch of F frames are numbered pixel-block major -- 64-path chunk c = (block of 64 local pixels c / F, frame c % F)
 // -- instead of frame major (F == 0: path s = frame * P + pixel): every contiguous stretch of the ray queue then belongs to ONE region of the film in
 // all its frames, which is what lets k_trace hand each XCD (its own L2) the rays of one part of the scene (slices_contiguous).  Needs P % 64 == 0.
-// `gl` (log2 G, G = 1, 2, 4 ... 64 frames per wave, F a multiple of G): a wave's 64 paths are 64 / G neighbouring pixels in G consecutive frames instead of 64 pixels of one
-// frame -- camera rays of one pixel differ by their jitter only, so the lanes of a bounce-0 wave ask for the same node records (one request per line and instruction).
-struct TileMap { int tile_rank, tile_count, tile_size, H, blocked, F, gl; };
+struct TileMap { int tile_rank, tile_count, tile_size, H, blocked, F; };
 TD void slot_to_frame_pixel(const TileMap &m, int P, int slot, int &f, int &k)
 {
-    if (m.F > 0) {
-        const int c = slot >> 6, l = slot & 63, G = 1 << m.gl, w = c & (G - 1), sc = c >> m.gl, fgn = m.F >> m.gl;      // chunk c = wave w of super-chunk sc (64 pixels x G frames)
-        const int kb = sc / fgn, fg = sc - kb * fgn;
-        f = (fg << m.gl) | (l & (G - 1));
-        k = (kb << 6) | (w << (6 - m.gl)) | (l >> m.gl);
-    } else { f = slot / P; k = slot - f * P; }
+    if (m.F > 0) { const int c = slot >> 6, kb = c / m.F; f = c - kb * m.F; k = (kb << 6) | (slot & 63); }
+    else { f = slot / P; k = slot - f * P; }
 }
 TD int frame_pixel_to_slot(const TileMap &m, int P, int f, int k)
-{
-    if (m.F <= 0) return f * P + k;
-    const int G = 1 << m.gl, kl = k & 63, w = kl >> (6 - m.gl), l = ((kl & ((64 >> m.gl) - 1)) << m.gl) | (f & (G - 1));
-    const int c = ((((k >> 6) * (m.F >> m.gl)) + (f >> m.gl)) << m.gl) | w;
-    return (c << 6) | l;
-}
+{ return m.F > 0 ? ((((k >> 6) * m.F + f) << 6) | (k & 63)) : f * P + k; }
+// (Measured and dropped in round 5: a wave holding 64 / G pixels in G frames instead of 64 pixels of one frame -- no gain for G <= 8, slower beyond -- and the 8 x 8 blocks of
+// 4 .. 128 neighbouring tiles walked row by row, so that what is in flight is a compact patch of the film: no gain, and its index arithmetic cost every kernel 1 %.)
 TD int local_to_pixel(const TileMap &m, int k)
 {
     int lt = k / m.tile_size, within = k - lt * m.tile_size;
@@ -277,7 +268,7 @@ struct tirt_ctx {
     // traversal tunables (options "trace_lds_depth", "trace_refill_min", "trace_node_min", "trace_grid",
     // "trace_slices" = number of ray-fetch cursors, "shade_grid" = persistent blocks of k_shade)
     int tr_lds_depth = 16, tr_refill_min = 18, tr_node_min = 38, tr_grid = 1280, tr_slice_log2 = 5, sh_grid = 1024;
-    int path_order_blocks = 1, slices_contiguous = 0, path_frames_log2 = 0;      // options "path_order_blocks" (TileMap::F) and "slices_contiguous" (k_trace's ray-fetch slices: contiguous ranges of the queue instead of interleaved chunks)
+    int path_order_blocks = 1, slices_contiguous = 0;      // options "path_order_blocks" (TileMap::F) and "slices_contiguous" (k_trace's ray-fetch slices: contiguous ranges of the queue instead of interleaved chunks)
     int tr_grid_alone = 1280;                     // "trace_grid_alone" / "trace_grid": persistent k_trace blocks of a batch submitted to an idle / a busy GPU. Both five per CU
                                                   // (tirt_create scales them by the device's CU count): blocks of the next batch's launch move in as this one's drain
     tirt::DevBuf counters_mem, spill;            // used by the batch trace entry points (main stream)

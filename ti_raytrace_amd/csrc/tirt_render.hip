@@ -1692,7 +1692,7 @@ int pt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed,
         { int parts = c->split_lone < c->n_lanes ? c->split_lone : c->n_lanes; if (parts > frame_count) parts = frame_count; FB = (frame_count + parts - 1) / parts; }
     const SceneView sv = scene_view(c);
     const BvhView bv = bvh_view(c);
-    TileMap tm = {c->tile_rank, c->tile_count, c->tile_size, c->H, c->tile_blocked, 0, 0};
+    TileMap tm = {c->tile_rank, c->tile_count, c->tile_size, c->H, c->tile_blocked, 0};
     DevCounters *ctr = c->dev_counters.as<DevCounters>();
     const int B = 256;
     collect_live_counts(c);
@@ -1730,7 +1730,6 @@ int pt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed,
         const int F = (frame_count - fb < FB) ? frame_count - fb : FB;
         const int S = F * P;
         tm.F = (c->path_order_blocks && (P & 63) == 0) ? F : 0;
-        tm.gl = c->path_frames_log2; while (tm.gl > 0 && (F & ((1 << tm.gl) - 1)) != 0) tm.gl--;      // (frames per wave: a divisor of the batch's frame count)
         const uint32_t f0 = frame_begin + (uint32_t)fb;
         char *cm = L.counters_mem.as<char>();
         auto append_ctr = [&](int b) { return (unsigned long long *)(cm + LINE * (size_t)b); };
