@@ -431,8 +431,8 @@ int tirt_set_option(tirt_ctx *c, const char *name, double value)
     if (!strcmp(name, "shade_grid")) { TIRT_REQUIRE(value >= 1 && value <= 65536, "shade_grid: 1..65536"); c->sh_grid = (int)value; c->grid_user = true; return TIRT_OK; }
     if (!strcmp(name, "path_order_blocks")) { c->path_order_blocks = value != 0.0; return TIRT_OK; }
     if (!strcmp(name, "slices_contiguous")) { c->slices_contiguous = value != 0.0; return TIRT_OK; }
-    if (!strcmp(name, "trace_grid_alone")) { TIRT_REQUIRE(value >= 1 && value <= 2048, "trace_grid_alone: 1..2048"); c->tr_grid_alone = (int)value; return TIRT_OK; }
-    if (!strcmp(name, "trace_grid")) { TIRT_REQUIRE(value >= 1 && value <= 2048, "trace_grid: 1..2048"); c->tr_grid = (int)value; c->grid_user = true; return TIRT_OK; }
+    if (!strcmp(name, "trace_grid_alone")) { TIRT_REQUIRE(value >= 1 && value <= 16384, "trace_grid_alone: 1..16384"); c->tr_grid_alone = (int)value; return TIRT_OK; }
+    if (!strcmp(name, "trace_grid")) { TIRT_REQUIRE(value >= 1 && value <= 16384, "trace_grid: 1..16384"); c->tr_grid = (int)value; c->grid_user = true; return TIRT_OK; }
     set_error(std::string("tirt_set_option: unknown option ") + name);
     return TIRT_ERR_ARG;
 }
