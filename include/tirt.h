@@ -95,17 +95,16 @@ int tirt_sync(tirt_ctx *ctx);
  *            204 B of HBM each, lanes hold 1.5 x that)
  *          "split_lone_batch" (0 = off, or the number of parts 2..8; default 0 since round 3) -- a context that owns 1/6 or less of the film
  *            (tile_count >= 6) and whose whole job is one batch runs it as that many smaller batches on as many lanes
- *          "tail_paths" (default 0 = off) / "tail_bounce" (-1 = chosen, 0 = never, k = from bounce k) -- the last bounces of a PT_RGB batch as ONE persistent
- *            launch in which a lane keeps a path (shade, shadow ray, next ray ...) instead of a launch per bounce and kind: from the first bounce that no more
- *            than tail_paths paths are expected to enter (by the counts of earlier batches), or from bounce k.  Same film bit for bit; measured slower on
- *            MI355X at every threshold (docs/HISTORY.md), hence off
+ *          "path_order_blocks" (0/1, default 1 since round 5) -- the paths of a wavefront batch numbered pixel-block major (64-path chunk = one 8 x 8 pixel block
+ *            of one frame, the frames of a block next to each other) instead of frame major: +1.5 % on the headline scene, +5 % on a 4 M-triangle one; same film
+ *          "slices_contiguous" (0/1, default 0) -- k_trace's ray-fetch slices as contiguous stretches of the queue (each XCD one region of the film); no gain measured
+ *          "tail_paths" / "tail_bounce", "wide_collapse" -- EXPERIMENTS (the last bounces of a batch as one persistent launch; cost-optimal grouping into 4-wide nodes):
+ *            only in a library built with -DTIRT_EXPERIMENTS (`make experiments`); the product library answers them with an error unless the value means "off"
  *          "traversal_tree" (0/1, default 1) -- the tree tirt_lbvh_build collapses into the 4-wide traversal nodes: 1 = a binned-SAH
  *            tree over the same primitives built on the device after the LBVH, 0 = the reference's LBVH itself; results are
  *            bit-identical either way (tirt_traversal_tree_download) -- except for rays that lie, to fp32 rounding, IN the plane of a
  *            triangle: there the reference's Moller-Trumbore divides by a determinant of rounding noise and which "hit" such a ray
  *            gets depends on the visiting order (none in any render); takes effect at the next tirt_lbvh_build
- *          "wide_collapse" (0/1, default 0) -- how the binary tree is grouped into 4-wide nodes: 0 = greedily by surface area, 1 = the
- *            grouping of least total node area (dynamic programme); same results, 1-9 % fewer node visits, no measurable gain
  *          "bdpt_mem_budget" -- bytes a BDPT call may take for its batch state even when more is free (0 = off; tests)
  *          "bdpt_batch_items" -- (frame, pixel) items per BDPT wavefront batch (default 16 Mi, ~2.3 KB of HBM each: 39 GB; 5 Mi = 12 GB runs config 5 at 2 900 Mrays/s), shared by the two batches in flight on render lanes 0 and 1
  *            (config 5, round 3: 4 Mi 2 890, 8 Mi 2 900, 16 Mi 2 995, 32 Mi 2 980 Mrays/s; 256 frames: 8 Mi 2 912, 16 Mi 2 923, 32 Mi 3 032)
