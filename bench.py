@@ -833,17 +833,19 @@ def main():
         # Round 5: WHICH ceiling binds was asked of the kernel itself (profiles/r05_bound_ladder.txt): 64 extra VALU instructions per node visit (+59 % of a
         # visit's 109) cost the step 5.4 %, ONE extra record gather per visit costs it 27 % -- linear from the first one on.  The kernel is bound by the
         # path its record gathers take, L1 (TCP) -> L2 requests, not by VALU issue (whose busy counter reads 0.89 here and 1.28 on k_generate: uncalibrated).
-        # fractions.gather = L1 -> L2 read traffic of a launch (TCP_TCC_READ_REQ, bytes per request calibrated on k_film) / its duration, against the rate
-        # at which THIS device gathers random 64-byte records from an L2-resident array (tirt_micro_gather_rate, 2 MB, measured in this run) -- the
-        # kernel's own access pattern at its best.  tools/micro/ta_cost.hip: that rate is set per record (line), not per request or byte.
-        if l2 and peak_l2 > 0:
-            fr["gather"] = round(l2["GBps"] / peak_l2, 4)
+        # fractions.gather = the records the launch gathers from global memory (ALGORITHMIC bytes: 64 B per node visit that the LDS copy of the tree top does not
+        # serve, 48 B per primitive test, 40 B per ray -- device counters of the same frames) / its duration, against the rate at which THIS device gathers random
+        # 64-byte records from an L2-resident array with the node fetch's own four loads per record (tirt_micro_gather_rate, 2 MB, measured in this run): like
+        # against like.  (Until mid round 5 this compared the launch's L1 -> L2 read BYTES with that rate -- but a request on that path is 128 bytes, so a 64-byte
+        # record moves 128: the 0.8 that gave was a unit mismatch.  In requests: `l1_l2_requests` below.)  tools/micro/ta_cost.hip: the rate is set per lane and record.
+        if achieved > 0 and peak_l2 > 0:
+            fr["gather"] = round(achieved / peak_l2, 4)
         known = {k: v for k, v in fr.items() if v is not None}
         bound = "gather" if fr.get("gather") else (max(known, key=known.get) if known else "valu")
         if bound == "gather":
-            top = {"achieved": round(l2["GBps"] / 64.0, 2), "peak": round(peak_l2 / 64.0, 2), "frac": fr["gather"],
-                   "unit": "G 64-byte lines/s from L1 to L2 (achieved: TCP_TCC_READ_REQ of the launch; peak: this device's measured rate of random 64-byte record gathers "
-                           "from an L2-resident array, 4 x global_load_dwordx4 per record as a node fetch does)"}
+            top = {"achieved": round(achieved, 1), "peak": round(peak_l2, 1), "frac": fr["gather"],
+                   "unit": "GB/s of gathered records (achieved: algorithmic bytes of the launch's node / primitive / ray records / launch duration; peak: this device's measured "
+                           "rate of random 64-byte record gathers from an L2-resident array, 4 x global_load_dwordx4 per record as a node fetch does)"}
         elif bound == "valu" and valu:
             # VALU issue is the bound; an issue slot whose lanes are masked off is not work, so what is counted is LANE-instructions: the wave
             # instructions the kernel issues x the share of their 64 lanes that are active, against the rate at which this instruction mix would
@@ -865,8 +867,14 @@ def main():
             "achieved": top["achieved"], "peak": top["peak"], "unit": top["unit"], "frac": top["frac"],
             "traffic": tr_bytes,
             "fractions": fr, "hbm": hbm, "l2": l2, "valu": valu,
-            "frac_def": "L1 -> L2 read traffic per launch / launch duration / the measured L2-resident record-gather rate of this device (`fractions.gather`); "
+            "frac_def": "algorithmic gathered record bytes per launch / launch duration / the measured L2-resident record-gather rate of this device (`fractions.gather`); "
                         "`fractions.valu` (issue busy, uncalibrated counter) and `valu.useful_lane_throughput` are printed beside it",
+            # the same path in REQUESTS: what the launch sends from L1 to L2 (TCP_TCC_READ_REQ; 128 bytes each, calibrated on k_film) against the request rate of the
+            # L2-resident record gather (one request per record there: tools/micro/ta_cost.hip under rocprofv3); neighbouring node records share 128-byte lines
+            "l1_l2_requests": ({"G_per_s": round(l2["GBps"] / max(pmc.get("l2_bytes_per_request_calibrated_on_k_film", 128.0), 1.0), 2),
+                                "peak_G_per_s": round(peak_l2 / 64.0, 2), "frac": round(l2["GBps"] / max(pmc.get("l2_bytes_per_request_calibrated_on_k_film", 128.0), 1.0) / (peak_l2 / 64.0), 4),
+                                "bytes_per_request": pmc.get("l2_bytes_per_request_calibrated_on_k_film"),
+                                "per_ray": round(pmc["l2_read_bytes_per_launch"] / max(pmc.get("l2_bytes_per_request_calibrated_on_k_film", 128.0), 1.0) * n_launch / max(rays_o, 1), 2)} if (l2 and ok and peak_l2 > 0) else None),
             "bound_evidence": {"ladder": "profiles/r05_bound_ladder.txt", "valu_pad_64_instructions_per_node_visit": "+5.4 % ms/step", "one_extra_record_gather_per_node_visit": "+27.1 % ms/step",
                                "two": "+51.3 %", "four": "+98.9 %", "eight": "+203 %", "cost_model": "tools/micro/ta_cost.hip: a scattered record costs 0.95 ns per CU whatever "
                                "its width, +0.07 ns per further request to the same line; quad-cooperative fetches do not change it (profiles/r05b)"},
