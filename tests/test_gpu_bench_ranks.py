@@ -60,3 +60,20 @@ def test_force_dist_one_rank_rccl(gpu_ctx_ok, tmp_path):
     r = run([sys.executable, "bench.py", "--gpus", "1", "--steps", "2", "--warmup", "1", "--frames-per-step", "4", "--size", "256",
              "--ntri", "20000", "--no-cpu-baseline", "--no-roofline"], {"TIRT_FORCE_DIST": "1"}, tmp_path, "force")
     assert r["n_gpus"] == 1 and r["distributed"]["rccl_ranks"] == 1 and r["distributed"]["backend"] == "nccl"
+
+
+def test_bench_line_carries_the_contract_fields(gpu_ctx_ok, tmp_path):
+    """One JSON line, last on stdout, with the driver's fields, a `roofline` object measured in this run (HIP-event launch duration, rocprofv3 --pmc child
+    passes for the traffic) and a `cpu_baseline` object (the CPU oracle on a bounded sample); small sizes, same code path as the default run."""
+    r = run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--frames-per-step", "8", "--size", "256", "--ntri", "20000",
+             "--no-configs", "--cpu-target-s", "1.5"], {}, tmp_path, "contract")
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in r, k
+    assert r["unit"] == "Mrays/s" and r["n_gpus"] == 1 and r["steps"] == 2 and r["dtype"] == "f32" and r["vs_baseline"] is None and "workload" in r["config"]
+    roof = r["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "fractions", "bound_evidence"):
+        assert k in roof, k
+    assert roof["bound"] == "gather" and 0.05 < roof["frac"] < 1.5 and roof["traffic"] and roof["traffic"] > 0
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
+    cb = r["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
