@@ -88,8 +88,8 @@ int tirt_sync(tirt_ctx *ctx);
  *            until this many pixel-samples are pending (default 32 Mi = one full batch; 0 submits every call at once);
  *            every other entry point submits what is pending first
  *          "job_frames" -- hint: frames the whole job will render (0 = unknown, default).  With it (and no explicit batch_paths)
- *            the job is cut into as few wavefront batches as fit 128 Mi pixel-samples each, at least two, a multiple of the
- *            lane count beyond four; lane buffers are sized for that and only as many lanes get one (a 512^2 x 8 spp job does
+ *            the job is cut into as few wavefront batches as fit 128 Mi pixel-samples each, at least two, run two at a time
+ *            (round 5: a 640 Mi-sample job as 5 x 128 Mi instead of 8 x 80 Mi on four lanes: +1.7 %); lane buffers are sized for that and only as many lanes get one (a 512^2 x 8 spp job does
  *            not allocate 32 Mi-path lanes).  Set it before the first render call of the job
  *          "batch_paths" -- pixel-samples kept in flight per wavefront batch (default 32 Mi, or planned from "job_frames";
  *            204 B of HBM each, lanes hold 1.5 x that)

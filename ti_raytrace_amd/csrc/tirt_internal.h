@@ -317,9 +317,10 @@ int lbvh_build(tirt_ctx *c);
 // Pixel-samples per wavefront batch and the lanes they run on.  Without a hint: batch_paths (32 Mi) on all lanes.  With the
 // "job_frames" hint and no explicit batch_paths, the job is cut into as few batches as fit 128 Mi paths each, at least two (two
 // batches of the largest size overlap each other's per-bounce tails as well as four smaller ones, and every launch is
-// fuller), in multiples of the lane count beyond that so that no batch runs alone at the end.  Measured on one GPU with a
+// fuller), two at a time beyond that.  Measured on one GPU with a
 // 256 Mi-path job: 8 x 32 Mi 3 965, 4 x 64 Mi 4 037, 2 x 128 Mi 4 071 Mrays/s; rank 0's share of a 2 / 4 / 8-GPU job is
-// best as two batches as well (2 x 64, 2 x 32, 2 x 16 Mi).
+// best as two batches as well (2 x 64, 2 x 32, 2 x 16 Mi).  A 640 Mi-path job (round 5, profiles/r05ad_*): 8 x 80 Mi on four lanes
+// (the rule until then: a multiple of the lane count) 4 645, 5 x 128 Mi or 6 x 107 Mi two or three at a time 4 700 Mrays/s.
 struct BatchPlan { size_t batch; int lanes; };
 inline BatchPlan plan_batches(const tirt_ctx *c)
 {
@@ -328,10 +329,10 @@ inline BatchPlan plan_batches(const tirt_ctx *c)
         const size_t P = (size_t)c->npix_local, J = (size_t)c->job_frames * P, MAXB = (size_t)128 << 20;
         if (J >= ((size_t)24 << 20)) {
             const size_t nb_min = (J + MAXB - 1) / MAXB, L = (size_t)(c->n_lanes > 0 ? c->n_lanes : 1);
-            const size_t nb = nb_min <= 2 ? 2 : (nb_min <= L ? nb_min : L * ((nb_min + L - 1) / L));
+            const size_t nb = nb_min <= 2 ? 2 : nb_min;
             size_t frames = ((size_t)c->job_frames + nb - 1) / nb;
             p.batch = frames * P;
-            p.lanes = (int)(nb < L ? nb : L);
+            p.lanes = (int)(L < 2 ? L : 2);
         }
     }
     return p;
