@@ -420,6 +420,7 @@ int tirt_set_option(tirt_ctx *c, const char *name, double value)
     if (!strcmp(name, "trace_node_min")) { TIRT_REQUIRE(value >= 1 && value <= 64, "trace_node_min: 1..64"); c->tr_node_min = (int)value; return TIRT_OK; }
     if (!strcmp(name, "bdpt_bounded")) { c->bdpt_bounded = value != 0.0 ? 1 : 0; return TIRT_OK; }
     if (!strcmp(name, "bdpt_state_fill")) { TIRT_REQUIRE(value == 0.0 || value == 1.0 || value == 2.0, "bdpt_state_fill: 0 (none), 1 (zeros) or 2 (poison)"); c->bdpt_state_fill = (int)value; return TIRT_OK; }
+    if (!strcmp(name, "bdpt_lanes")) { TIRT_REQUIRE(value >= 1.0 && value <= 4.0, "bdpt_lanes: 1..4"); if (sync_all(c)) return TIRT_ERR_HIP; c->bdpt_lanes = (int)value; return TIRT_OK; }
     if (!strcmp(name, "bdpt_batch_items")) { TIRT_REQUIRE(value >= 1.0 && value <= 1.0e9, "bdpt_batch_items out of range"); c->bdpt_batch_items = (size_t)value; return TIRT_OK; }
     if (!strcmp(name, "bdpt_mem_budget")) { TIRT_REQUIRE(value >= 0, "bdpt_mem_budget: bytes >= 0"); c->bdpt_mem_budget = (size_t)value; return TIRT_OK; }
     if (!strcmp(name, "trace_slices")) {

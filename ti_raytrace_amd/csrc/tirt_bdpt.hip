@@ -32,6 +32,10 @@
 #include "tirt_internal.h"
 #include "tirt_spectral.h"
 
+#if (defined(BDX_NO_ATOMIC) || defined(BDX_NO_MIS) || defined(BDX_NO_PRESUM) || defined(BD_RESOLVE_WAVES)) && !defined(TIRT_EXPERIMENTS)
+#error "the BDX_* / BD_RESOLVE_* switches are ablations of k_bd_resolve: build them with -DTIRT_EXPERIMENTS (make experiments EXTRA=...)"
+#endif
+
 namespace tirt {
 
 constexpr int BD_MAX_DEPTH = 5;                    // BDPT_RGB.py:23
@@ -111,7 +115,9 @@ TD float disney_pdf(const float *m, v3 N, v3 Vv, v3 L)
     return pdf;
 }
 TD const float *mat_row(const SceneView &s, int mat_id) { return s.material + (size_t)mat_id * MAT_VEC; }
-TD v3 mat_lrgb(const SceneView &s, int mat_id) { const float *m = mat_row(s, mat_id); return srgb_to_lrgb(V(m[2], m[3], m[4])); }
+// UF.srgb_to_lrgb(material colour): the per-material table the upload fills with that very function (tirt_api.hip, k_material_lrgb) -- inline it is three f64 pow
+// polynomials per call, and connect_path alone has four call sites (round 5)
+TD v3 mat_lrgb(const SceneView &s, int mat_id) { const float *t = s.mat_lrgb + (size_t)mat_id * 3; return V(t[0], t[1], t[2]); }
 
 // Camera.py:144-158
 TD v3 get_image_point(const CameraView &cam, const BdView &bv, v3 p, int &u, int &v)
@@ -174,15 +180,14 @@ TD float bd_reflect_power(const SceneView &s, const SpecView &sp, int mat_id, fl
     const float *m = s.material + (size_t)mat_id * MAT_VEC;
     const v3 mat_color = V(m[2], m[3], m[4]);
     if ((int)m[0] == MAT_LIGHT) return bd_light_power(sp, mat_color, Lambda);
-    return r2s_eval(r2s_fetch(sp, srgb_to_lrgb(mat_color)), Lambda);
+    return r2s_eval(r2s_fetch(sp, mat_lrgb(s, mat_id)), Lambda);
 }
 // what BDPT_RGB multiplies a path's throughput with at a surface of material mat_id: its linear colour / its power at the wavelength
 template <bool SPEC>
 TD v3 bd_reflect(const BdCtx &c, int mat_id, float Lambda)
 {
     if (SPEC) { const float p = bd_reflect_power(c.sc, *c.spec, mat_id, Lambda); return V(p, p, p); }
-    const float *m = c.sc.material + (size_t)mat_id * MAT_VEC;
-    return srgb_to_lrgb(V(m[2], m[3], m[4]));
+    return mat_lrgb(c.sc, mat_id);
 }
 
 
@@ -477,7 +482,12 @@ TD v3 bd_connect_path(const BdCtx &c, const bpixel &P, const bvert &EV, bvert &s
         }
     }
     float misweight = 1.0f;
-    if ((radiance.x > 0.0f) & (radiance.y > 0.0f) & (radiance.z > 0.0f)) misweight = bd_mis_weight(c, P, sample, e, l);
+#ifdef BDX_NO_MIS
+    if (radiance.x == -12345.0f) misweight =
+#else
+    if ((radiance.x > 0.0f) & (radiance.y > 0.0f) & (radiance.z > 0.0f)) misweight =
+#endif
+        bd_mis_weight(c, P, sample, e, l);
     return radiance * misweight;
 }
 
@@ -605,7 +615,7 @@ __global__ __launch_bounds__(BD_STEP_BLOCK) void k_bd_step(BdCtx c, BdItems item
                     } else {
                         e->beta = beta * absf(dot(dir, normal));
                         e->type = VERTEX_SURFACE; stored_surface = true;
-                        const v3 reflect_color = spectral ? bd_reflect<SPEC>(c, mat_id, Lambda) : srgb_to_lrgb(mat_color);
+                        const v3 reflect_color = spectral ? bd_reflect<SPEC>(c, mat_id, Lambda) : mat_lrgb(s, mat_id);
                         int delta = 0;
                         const bsample bs = bd_sample(s, dir, normal, fnormal, mat_id, mat_type, c.seed, pixel, frame, BD_DIM_EYE + 8u * (uint32_t)depth, delta, spectral, Lambda);
                         e->delta = delta;
@@ -646,7 +656,6 @@ __global__ __launch_bounds__(BD_STEP_BLOCK) void k_bd_step(BdCtx c, BdItems item
                     const v3 normal = h.nor, pos = h.pos;
                     const v3 fnormal = normal * signf(dot(-dir, h.gnor));
                     const float *m = mat_row(s, mat_id);
-                    const v3 mat_color = V(m[2], m[3], m[4]);
                     const int mat_type = (int)m[0];
                     if (mat_type != MAT_LIGHT) {
                         bvert lv = bvert(); bvert *L = &lv;
@@ -657,7 +666,7 @@ __global__ __launch_bounds__(BD_STEP_BLOCK) void k_bd_step(BdCtx c, BdItems item
                         const float inv_dist2 = 1.0f / (dist * dist);
                         to = to / dist;
                         L->fpdf *= absf(dot(to, light[pre_depth].normal)) * inv_dist2;
-                        const v3 reflect_color = spectral ? bd_reflect<SPEC>(c, mat_id, Lambda) : srgb_to_lrgb(mat_color);
+                        const v3 reflect_color = spectral ? bd_reflect<SPEC>(c, mat_id, Lambda) : mat_lrgb(s, mat_id);
                         int delta = 0;
                         const bsample bs = bd_sample(s, dir, normal, fnormal, mat_id, mat_type, c.seed, pixel, frame, BD_DIM_LIGHT + 8u * (uint32_t)depth, delta, spectral, Lambda);
                         L->delta = delta;
@@ -741,11 +750,12 @@ __global__ void k_bd_delta(BdItems items, BdSteps steps, TileMap tm, int P, int 
 
 // AddSplat (BDPT_RGB.py:594-613; SPEC: BDPT_SPEC.py:178-181): a contribution goes to the film pixel of its sample, or -- a light sub-path
 // vertex seen through the lens (e == 1) -- to the pixel it projects to, with float atomics.
+// where a contribution goes (pixel index, -1: nowhere) and, SPEC, what arrives there: the sensor's response at the wavelength, as clamped sRGB, times the range
 template <bool SPEC>
-TD void bd_splat(const BdCtx &c, float *rad, int e, int nu, int nv, int p, uint32_t frame, v3 r)
+TD long bd_splat_target(const BdCtx &c, int e, int nu, int nv, int p, uint32_t frame, v3 &r)
 {
     const long q = (e == 1) ? ((nu >= 0) ? (long)nu * c.bv.H + nv : -1) : (long)p;
-    if (SPEC) {          // the sensor's response at the wavelength, as clamped sRGB, times the range
+    if (SPEC) {
         const SpecView &sp = *c.spec;
         const v3 xyz = sensor_sample(sp, bd_lambda(c, (uint32_t)p, frame));
         const float range = sp.s_max - sp.s_min;
@@ -754,9 +764,23 @@ TD void bd_splat(const BdCtx &c, float *rad, int e, int nu, int nv, int p, uint3
         const float cb = (0.055648f * xyz.x + -0.204043f * xyz.y) + 1.057311f * xyz.z;
         r = V((clampf(cr, 0.0f, 1000.0f) * range) * r.x, (clampf(cg, 0.0f, 1000.0f) * range) * r.x, (clampf(cb, 0.0f, 1000.0f) * range) * r.x);
     }
+    return q;
+}
+TD void bd_splat_add(float *rad, long q, v3 r)
+{
+#ifdef BDX_NO_ATOMIC
+    if (q >= 0 && r.x == -12345.0f && r.y == -2.0f && r.z == -3.0f) {
+#else
     if (q >= 0 && (r.x != 0.0f || r.y != 0.0f || r.z != 0.0f)) {
+#endif
         atomicAdd(&rad[3 * q], r.x); atomicAdd(&rad[3 * q + 1], r.y); atomicAdd(&rad[3 * q + 2], r.z);
     }
+}
+template <bool SPEC>
+TD void bd_splat(const BdCtx &c, float *rad, int e, int nu, int nv, int p, uint32_t frame, v3 r)
+{
+    const long q = bd_splat_target<SPEC>(c, e, nu, nv, p, frame, r);
+    bd_splat_add(rad, q, r);
 }
 
 constexpr int BD_OWNER_BITS = 26;                  // a queued connection's owner word: item | pair slot << 26 (49 slots; a batch holds < 2^26 items)
@@ -861,55 +885,110 @@ __global__ void k_bd_emitted(BdCtx c, BdItems items, BdSteps steps, TileMap tm, 
 // Pass 1 of a connection, one thread per queued connection ray (per item, 27 pair slots of which at most 20 and on average ~7 carry a ray and ~4 of those are
 // unoccluded, the VALU ran at 19 % of its lanes): the traced answer, then -- only if the expected primitive is what the ray met --
 // contribution and MIS weight (BDPT_RGB.py:300-479), splatted with float atomics.
-constexpr int BD_RESOLVE_CHUNK = 2048;            // queue entries a block filters at a time
+//
+// Every branch of connect_path wants the ray's closest hit to be the expected primitive before anything else (and about half of the connections
+// are occluded), so a block first lists the unoccluded ones of BD_RESOLVE_ITEMS items in LDS and then works through the list with all its lanes.
+// The list is ITEM by item (round 5): the four or so connections of an item sit in neighbouring lanes, a wave of 64 connections belongs to ~16
+// neighbouring items, and the ~22 vertex quads a connection reads are lines that the same wave-instruction's other lanes want too -- ~130 lines
+// per 64 connections, each fetched once.  Rounds 3-4 listed a 2 048-entry chunk of the queue in QUEUE order (the j-th rays of 64 items side by side):
+// a wave's lanes then belonged to ~110 items and every round over the same items fetched their lines again (43.5 GB per 8 Mi-item launch for 8.7 GB
+// of vertices: the working set of the blocks in flight is four times an XCD's L2).
+constexpr int BD_RESOLVE_ITEMS = 128;             // items a block lists at a time: two of k_bd_connect's waves, one per wave of the block
 #ifndef BD_RESOLVE_WAVES
 #define BD_RESOLVE_WAVES 2
 #endif
-#define BD_RESOLVE_BOUNDS __launch_bounds__(128, BD_RESOLVE_WAVES)      // (the launches use 128-thread blocks; said so, the compiler schedules the kernel within 128 VGPRs a little better: config 5 + 2 %, three A/B pairs)
+#define BD_RESOLVE_BOUNDS __launch_bounds__(BD_RESOLVE_ITEMS, BD_RESOLVE_WAVES)      // (said so, the compiler schedules the kernel within 128 VGPRs a little better: config 5 + 2 %, three A/B pairs)
 template <bool SPEC>
-__global__ BD_RESOLVE_BOUNDS void k_bd_resolve(BdCtx c, BdItems items, TileMap tm, int P, uint32_t frame_begin, const unsigned *qown, const int *scount,
-                             const float4 *shits, const float4 *stage, const int *qlist, float *radiance, long frame_stride)
+__global__ BD_RESOLVE_BOUNDS void k_bd_resolve(BdCtx c, BdItems items, TileMap tm, int P, int N, uint32_t frame_begin, const int *ibase, const int *icount,
+                             const unsigned long long *qmask, const float4 *shits, const float4 *stage, float *radiance, long frame_stride)
 {
-    // every branch of connect_path wants the ray's closest hit to be the expected primitive before anything else (and about half of the
-    // connections are occluded): a block first filters a chunk of the queue into a list of those in LDS, then works through the list
-    // with all its lanes
-    __shared__ int s_list[BD_RESOLVE_CHUNK];
-    __shared__ int s_n;
-    const int count = *scount, lane = threadIdx.x & 63;
+    __shared__ int2 s_list[BD_RESOLVE_ITEMS * BD_RAY_PAIRS];        // (queue place, item | pair slot << 26) of the unoccluded connections, item by item
+    __shared__ int s_wn[BD_RESOLVE_ITEMS / 64];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    for (long c0 = (long)blockIdx.x * BD_RESOLVE_CHUNK; c0 < count; c0 += (long)gridDim.x * BD_RESOLVE_CHUNK) {
-        if (threadIdx.x == 0) s_n = 0;
+    const int groups = (N + BD_RESOLVE_ITEMS - 1) / BD_RESOLVE_ITEMS;
+    for (int g = blockIdx.x; g < groups; g += (int)gridDim.x) {
+        // a wave takes the 64 items of one of k_bd_connect's waves, lane = item, and walks their rays the way k_bd_compact numbered them: the
+        // j-th rays of the items that have one are consecutive queue places from the wave's base on
+        const int it = g * BD_RESOLVE_ITEMS + (int)threadIdx.x;
+        const bool live = it < N;
+        const int n = live ? icount[it] : 0;
+        const unsigned long long pairs = (n > 0) ? qmask[it] : 0ull;
+        int off0 = live ? ibase[it] : 0;
+        off0 = __shfl(off0, 0, 64);
+        unsigned ok = 0u;                                  // bit j: my j-th ray met the primitive it was aimed at
+        int off = off0;
+        for (int j = 0; j < BD_RAY_PAIRS; j++) {
+            const unsigned long long m = __ballot(n > j);
+            if (m == 0ull) break;
+            if (n > j) {
+                const size_t q = (size_t)(off + __popcll(m & lt)), k = (size_t)j * (size_t)N + (size_t)it;
+                if (__float_as_int(shits[q].w) == __float_as_int(stage[2 * k + 1].z)) ok |= 1u << j;
+            }
+            off += __popcll(m);
+        }
+        const int mine = __popc(ok);
+        int incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
+        if (lane == 63) s_wn[wid] = incl;
         __syncthreads();
-        for (int r = 0; r < BD_RESOLVE_CHUNK; r += (int)blockDim.x) {
-            const long q = c0 + r + threadIdx.x;
-            const bool m = q < count && __float_as_int(shits[q].w) == __float_as_int(stage[2 * (size_t)qlist[q] + 1].z);
-            const unsigned long long bm = __ballot(m);
-            if (bm == 0ull) continue;
-            const int leader = __ffsll((long long)bm) - 1;
-            int base = 0;
-            if (lane == leader) base = atomicAdd(&s_n, __popcll(bm));
-            base = __shfl(base, leader, 64);
-            if (m) s_list[base + __popcll(bm & lt)] = (int)(q - c0);
+        int w = incl - mine, total = 0;
+#pragma unroll
+        for (int x = 0; x < BD_RESOLVE_ITEMS / 64; x++) { if (x < wid) w += s_wn[x]; total += s_wn[x]; }
+        unsigned long long rest = pairs;
+        off = off0;
+        for (int j = 0; j < BD_RAY_PAIRS; j++) {
+            const unsigned long long m = __ballot(n > j);
+            if (m == 0ull) break;
+            if (n > j) {
+                const int slot = __ffsll((long long)rest) - 1;
+                rest &= rest - 1ull;
+                if ((ok >> j) & 1u) s_list[w++] = make_int2(off + __popcll(m & lt), (int)((unsigned)it | ((unsigned)slot << BD_OWNER_BITS)));
+            }
+            off += __popcll(m);
         }
         __syncthreads();
-        const int n = s_n;
-        for (int k = threadIdx.x; k < n; k += (int)blockDim.x) {
-            const long q = c0 + s_list[k];
-            const float4 hr = shits[q];
-            const unsigned own = qown[q];
-            const int it = (int)(own & ((1u << BD_OWNER_BITS) - 1u)), slot = (int)(own >> BD_OWNER_BITS);
+        for (int k0 = 0; k0 < total; k0 += (int)blockDim.x) {
+          const int k = k0 + (int)threadIdx.x;
+          long long key = -1; v3 r = V(0.0f, 0.0f, 0.0f);           // the word of the batch's radiance planes the contribution goes to / 3
+          if (k < total) {
+            const int2 en = s_list[k];
+            const float4 hr = shits[en.x];
+            const unsigned own = (unsigned)en.y;
+            const int ci = (int)(own & ((1u << BD_OWNER_BITS) - 1u)), slot = (int)(own >> BD_OWNER_BITS);
             const int e = slot / (BD_LIGHT_MAX + 1) + 1, l = slot - (e - 1) * (BD_LIGHT_MAX + 1);
-            int f, kk; slot_to_frame_pixel(tm, P, it, f, kk);
+            int f, kk; slot_to_frame_pixel(tm, P, ci, f, kk);
             const int p = local_to_pixel(tm, kk), i = p / c.bv.H, j = p - i * c.bv.H;
             const uint32_t frame = frame_begin + (uint32_t)f;
             Tracer T; T.phase = 1; T.want = false; T.res.t = hr.x; T.res.u = hr.y; T.res.v = hr.z; T.res.prim = __float_as_int(hr.w);
             T.o = V(0.0f, 0.0f, 0.0f); T.d = T.o; T.expect = -3; T.bound = -1.0f;
             bvert sample = bvert();
             int nu = 0, nv = 0;
-            const bpixel B = bd_item(items, (size_t)it);
+            const bpixel B = bd_item(items, (size_t)ci);
             const bvert EV = B.eye[e - 1];
-            const v3 r = bd_connect_path<SPEC>(c, B, EV, sample, i, j, e, l, frame, nu, nv, T);
-            bd_splat<SPEC>(c, radiance + (size_t)f * (size_t)frame_stride, e, nu, nv, p, frame, r);
+            r = bd_connect_path<SPEC>(c, B, EV, sample, i, j, e, l, frame, nu, nv, T);
+            const long q = bd_splat_target<SPEC>(c, e, nu, nv, p, frame, r);
+            if (q >= 0) key = (long long)f * (long long)(frame_stride / 3) + q;
+          }
+          // The e >= 2 connections of an item all add to the item's own pixel and sit in neighbouring lanes: one atomic per run of equal targets instead of one per
+          // connection (a third of the atomics; the kernel is 19 % faster without any).  A run's sum is formed pairwise, so the film differs from per-connection
+          // atomics in the last bits -- as it does from run to run anyway (header).
+#ifndef BDX_NO_PRESUM
+          {
+            const long long kp = __shfl_up(key, 1, 64);
+            const unsigned long long heads = __ballot(lane == 0 || kp != key);
+            const unsigned long long above = (lane == 63) ? 0ull : (heads >> (lane + 1));
+            const int run = above ? (__ffsll((long long)above) - 1) : (63 - lane);        // lanes after mine with my target
+#pragma unroll
+            for (int d = 1; d <= 16; d <<= 1) {            // a run is at most the 20 connections of an item
+                const float vx = __shfl_down(r.x, d, 64), vy = __shfl_down(r.y, d, 64), vz = __shfl_down(r.z, d, 64);
+                if (d <= run) { r.x += vx; r.y += vy; r.z += vz; }
+            }
+            if (!((heads >> lane) & 1ull)) key = -1;
+          }
+#endif
+          bd_splat_add(radiance, key, r);
         }
         __syncthreads();
     }
@@ -917,16 +996,15 @@ __global__ BD_RESOLVE_BOUNDS void k_bd_resolve(BdCtx c, BdItems items, TileMap t
 
 // staging slots [j][item] -> dense connection-ray queue.  The queue is a list of PLACES: a wave numbers the rays of its 64 items slot by slot
 // (the j-th rays of the items that have one take consecutive queue places, so that k_trace's lanes read neighbouring staging records), and
-// writes per place where the ray is staged (`qlist`, read by k_trace through TraceArgs::ray_index and by k_bd_resolve) and whose it is
-// (`qown`: item, pair slot).  The rays themselves stay where they are (rounds 2-3a copied them: 128 B of traffic and 32 B of state per ray).
-__global__ void k_bd_compact(int N, const int *ibase, const int *icount, const unsigned long long *qmask, int *qlist, unsigned *qown, const int *scount, unsigned long long *rays_shadow)
+// writes per place where the ray is staged (`qlist`, read by k_trace through TraceArgs::ray_index; k_bd_resolve walks the items' rays the same
+// way and needs no list).  The rays themselves stay where they are (rounds 2-3a copied them: 128 B of traffic and 32 B of state per ray).
+__global__ void k_bd_compact(int N, const int *ibase, const int *icount, int *qlist, const int *scount, unsigned long long *rays_shadow)
 {
     const int it = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
     if (it == 0 && *scount) atomicAdd(rays_shadow, (unsigned long long)*scount);          // the queue's length: every staged connection is a traced ray
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     const bool live = it < N;
     const int n = live ? icount[it] : 0;
-    unsigned long long rest = (n > 0) ? qmask[it] : 0ull;          // the pair slots of this item's rays, lowest first
     int off = live ? ibase[it] : 0;
     off = __shfl(off, 0, 64);                           // lane 0 of a wave is live whenever any lane is
     for (int j = 0; j < BD_RAY_PAIRS; j++) {
@@ -935,8 +1013,6 @@ __global__ void k_bd_compact(int N, const int *ibase, const int *icount, const u
         if (n > j) {
             const size_t k = (size_t)j * (size_t)N + it, q = (size_t)(off + __popcll(m & lt_mask));
             qlist[q] = (int)k;                                             // the ray stays where it was staged: the queue is a list of places (k_trace reads through it)
-            qown[q] = (unsigned)it | ((unsigned)(__ffsll((long long)rest) - 1) << BD_OWNER_BITS);
-            rest &= rest - 1ull;
         }
         off += __popcll(m);
     }
@@ -974,10 +1050,11 @@ int bdpt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t see
     int FB = (int)(c->bdpt_batch_items / (size_t)P); if (FB < 1) FB = 1; if (FB > frame_count) FB = frame_count;
     int NL = 1;
     if (c->n_lanes >= 2 && !c->time_kernels && frame_count >= 2 && (size_t)frame_count * P >= ((size_t)1 << 20)) {
-        NL = 2;
-        int half = (int)(c->bdpt_batch_items / 2 / (size_t)P); if (half < 1) half = 1;
-        if (FB > half) FB = half;                                   // the two lanes share the batch budget
-        if (FB > (frame_count + 1) / 2) FB = (frame_count + 1) / 2;
+        NL = c->bdpt_lanes < c->n_lanes ? c->bdpt_lanes : c->n_lanes;
+        if (NL > frame_count) NL = frame_count;
+        int share = (int)(c->bdpt_batch_items / (size_t)NL / (size_t)P); if (share < 1) share = 1;
+        if (FB > share) FB = share;                                 // the lanes share the batch budget
+        if (FB > (frame_count + NL - 1) / NL) FB = (frame_count + NL - 1) / NL;
     }
     // the traversal's own buffers first (stack spill: ~2 GB per lane at bdpt_stack_size 1024), so that the measurement below sees them and a
     // failed allocation leaves the film untouched (they used to be allocated inside the batch loop, after the guard)
@@ -986,9 +1063,9 @@ int bdpt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t see
         // not more than the device has free right now (plus what this context's BDPT buffers hold already: growing them frees them first), less
         // 2 GB: a batch half the size is a few per cent slower, a failed hipMalloc ends the render (bench.py's profiler child, next to the
         // contexts of the other configs, ran into exactly that with 16 Mi-item batches)
-        const size_t per_item = BD_ITEM_BYTES + BD_STEP_BYTES + sizeof(float) * (16 + 16 * BD_RAY_PAIRS) + sizeof(float4) * (2 + BD_RAY_PAIRS) + sizeof(int) * (4 + BD_RAY_PAIRS);
+        const size_t per_item = BD_ITEM_BYTES + BD_STEP_BYTES + sizeof(float) * (16 + 8 * BD_RAY_PAIRS) + sizeof(float4) * (2 + BD_RAY_PAIRS) + sizeof(int) * (4 + BD_RAY_PAIRS);       // = the ensure() calls below
         size_t free_b = 0, total_b = 0, held = 0;
-        for (int l = 0; l < 2; l++) held += c->bd[l].items.bytes + c->bd[l].state.bytes + c->bd[l].rays.bytes + c->bd[l].hits.bytes + c->bd[l].qidx.bytes + c->bd[l].rad.bytes;
+        for (int l = 0; l < 4; l++) held += c->bd[l].items.bytes + c->bd[l].state.bytes + c->bd[l].rays.bytes + c->bd[l].hits.bytes + c->bd[l].qidx.bytes + c->bd[l].rad.bytes;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
             size_t avail = free_b + held > ((size_t)2 << 30) ? free_b + held - ((size_t)2 << 30) : 0;
             if (c->bdpt_mem_budget && avail > c->bdpt_mem_budget) avail = c->bdpt_mem_budget;      // option "bdpt_mem_budget": pretend the device has only this much left
@@ -1008,7 +1085,7 @@ int bdpt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t see
         auto &bl = c->bd[l];
         if (bl.items.ensure(BD_ITEM_BYTES * NMAX) || bl.state.ensure(BD_STEP_BYTES * NMAX) ||
             bl.rays.ensure(sizeof(float) * (8 * 2 * NMAX + 8 * SCAP)) || bl.hits.ensure(sizeof(float4) * (2 * NMAX + SCAP)) ||
-            bl.qidx.ensure(sizeof(int) * (NMAX * 4 + 2 * SCAP)) || bl.ctr.ensure(256) ||
+            bl.qidx.ensure(sizeof(int) * (NMAX * 4 + SCAP)) || bl.ctr.ensure(256) ||
             bl.rad.ensure(sizeof(float) * 3 * (size_t)NP * (size_t)FB_alloc)) return TIRT_ERR_HIP;
         if (!bl.delta_done) TIRT_HIP(hipEventCreateWithFlags(&bl.delta_done, hipEventDisableTiming));
         if (!bl.film_done) TIRT_HIP(hipEventCreateWithFlags(&bl.film_done, hipEventDisableTiming));
@@ -1026,8 +1103,8 @@ int bdpt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t see
     hipEvent_t last_delta = nullptr, last_film = nullptr;
     int batch = 0;
     for (int f0 = 0; f0 < frame_count; f0 += FB, batch++) {
-        const int lane = NL > 1 ? (batch & 1) : -1;
-        auto &bl = c->bd[NL > 1 ? (batch & 1) : 0];
+        const int lane = NL > 1 ? (batch % NL) : -1;
+        auto &bl = c->bd[NL > 1 ? (batch % NL) : 0];
         hipStream_t st = lane < 0 ? c->stream : c->lanes[lane].stream;
         float *rf = bl.rays.as<float>();
         BdRays er = {(float4 *)rf};                                  // 2 N records
@@ -1038,8 +1115,7 @@ int bdpt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t see
         int *sexpect = (int *)(gf + 16 * NMAX), *gexpect = (int *)(gf + 18 * NMAX);
         unsigned long long *qmask = bl.qidx.as<unsigned long long>();          // [item]: the pairs that have a connection ray
         int *ibase = bl.qidx.as<int>() + NMAX * 2, *icount = ibase + NMAX;
-        unsigned *qown = (unsigned *)(icount + NMAX);                // [queue place]: item | pair slot << 26
-        int *qlist = (int *)(qown + SCAP);                            // [queue place]: where the ray is staged (j * N + item)
+        int *qlist = icount + NMAX;                                   // [queue place]: where the ray is staged (j * N + item)
         float4 *ehits = bl.hits.as<float4>(), *shits = ehits + 2 * NMAX;
         int *scount = bl.ctr.as<int>();
         const int F = frame_count - f0 < FB ? frame_count - f0 : FB;
@@ -1076,15 +1152,15 @@ int bdpt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t see
                            stage, qmask, ibase, icount, scount);
         else hipLaunchKernelGGL(k_bd_connect<false>, dim3((N + BD_CONNECT_BLOCK - 1) / BD_CONNECT_BLOCK), dim3(BD_CONNECT_BLOCK), 0, st, bc, items, state, tm, P, N, frame0,
                            stage, qmask, ibase, icount, scount);
-        hipLaunchKernelGGL(k_bd_compact, dim3((N + B - 1) / B), dim3(B), 0, st, N, ibase, icount, qmask, qlist, qown, scount, &ctr->rays_shadow);
+        hipLaunchKernelGGL(k_bd_compact, dim3((N + B - 1) / B), dim3(B), 0, st, N, ibase, icount, qlist, scount, &ctr->rays_shadow);
         if (int rc = trace_arrays(c, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, (int)(SCAP < (size_t)N * BD_RAY_PAIRS ? SCAP : (size_t)N * BD_RAY_PAIRS), scount, shits, nullptr, nullptr, false, lane, stage, true, qlist)) return rc;
         if (spectral) hipLaunchKernelGGL(k_bd_emitted<true>, dim3((N + B - 1) / B), dim3(B), 0, st, bc, items, state, tm, P, N, frame0, bl.rad.as<float>(), 3 * NP);
         else hipLaunchKernelGGL(k_bd_emitted<false>, dim3((N + B - 1) / B), dim3(B), 0, st, bc, items, state, tm, P, N, frame0, bl.rad.as<float>(), 3 * NP);
         {
-            size_t rg = ((size_t)N * 8 + B - 1) / B;                 // grid-stride over the queue (its length is on the device): ~7 rays per item
+            size_t rg = ((size_t)N + BD_RESOLVE_ITEMS - 1) / BD_RESOLVE_ITEMS;            // grid-stride over groups of BD_RESOLVE_ITEMS items
             if (rg > 8192) rg = 8192;
-            if (spectral) hipLaunchKernelGGL(k_bd_resolve<true>, dim3((unsigned)rg), dim3(B), 0, st, bc, items, tm, P, frame0, qown, scount, shits, stage, qlist, bl.rad.as<float>(), 3 * NP);
-            else hipLaunchKernelGGL(k_bd_resolve<false>, dim3((unsigned)rg), dim3(B), 0, st, bc, items, tm, P, frame0, qown, scount, shits, stage, qlist, bl.rad.as<float>(), 3 * NP);
+            if (spectral) hipLaunchKernelGGL(k_bd_resolve<true>, dim3((unsigned)rg), dim3(BD_RESOLVE_ITEMS), 0, st, bc, items, tm, P, N, frame0, ibase, icount, qmask, shits, stage, bl.rad.as<float>(), 3 * NP);
+            else hipLaunchKernelGGL(k_bd_resolve<false>, dim3((unsigned)rg), dim3(BD_RESOLVE_ITEMS), 0, st, bc, items, tm, P, N, frame0, ibase, icount, qmask, shits, stage, bl.rad.as<float>(), 3 * NP);
         }
         if (last_film) TIRT_HIP(hipStreamWaitEvent(st, last_film, 0));        // the running mean applies the frames in order
         for (int f = 0; f < F; f++) {

@@ -285,7 +285,8 @@ struct tirt_ctx {
     // wavefront batch state (vertex arrays per (frame, pixel), step state, rays, hits, queue indices, counters, per-frame radiance) of the
     // two BDPT lanes: consecutive batches alternate between them, on the streams of render lanes 0 and 1, so that the traversal
     // launches of one batch (VALU-bound) run next to the vertex / connection kernels of the other (HBM-bound)
-    struct BdLane { tirt::DevBuf items, state, rays, hits, qidx, ctr, rad; hipEvent_t delta_done = nullptr, film_done = nullptr; } bd[2];
+    struct BdLane { tirt::DevBuf items, state, rays, hits, qidx, ctr, rad; hipEvent_t delta_done = nullptr, film_done = nullptr; } bd[4];
+    int bdpt_lanes = 2;                           // option "bdpt_lanes": BDPT batches in flight (1..4, not more than overlap_lanes)
     int bdpt_state_fill = 0;                       // option "bdpt_state_fill" (diagnostic): 0 = vertex arrays not cleared per batch, 1 = zeros, 2 = 0xFF poison
     size_t bdpt_batch_items = (size_t)16 << 20;   // option "bdpt_batch_items": (frame, pixel) items per wavefront batch
     size_t bdpt_mem_budget = 0;                    // option "bdpt_mem_budget" (bytes, 0 = off): upper bound on what a BDPT call may take for its batch state, as if the device had only that much free (tests)
