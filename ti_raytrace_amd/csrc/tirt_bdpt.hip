@@ -893,17 +893,24 @@ __global__ void k_bd_emitted(BdCtx c, BdItems items, BdSteps steps, TileMap tm, 
 // per 64 connections, each fetched once.  Rounds 3-4 listed a 2 048-entry chunk of the queue in QUEUE order (the j-th rays of 64 items side by side):
 // a wave's lanes then belonged to ~110 items and every round over the same items fetched their lines again (43.5 GB per 8 Mi-item launch for 8.7 GB
 // of vertices: the working set of the blocks in flight is four times an XCD's L2).
-constexpr int BD_RESOLVE_ITEMS = 128;             // items a block lists at a time: two of k_bd_connect's waves, one per wave of the block
+constexpr int BD_RESOLVE_ITEMS = 128;
+static_assert(BD_RESOLVE_ITEMS == 128, "k_bd_resolve's list entries hold the item in seven bits");             // items a block lists at a time: two of k_bd_connect's waves, one per wave of the block
 #ifndef BD_RESOLVE_WAVES
-#define BD_RESOLVE_WAVES 2
+#define BD_RESOLVE_WAVES 4
 #endif
-#define BD_RESOLVE_BOUNDS __launch_bounds__(BD_RESOLVE_ITEMS, BD_RESOLVE_WAVES)      // (said so, the compiler schedules the kernel within 128 VGPRs a little better: config 5 + 2 %, three A/B pairs)
+#ifdef BD_RESOLVE_VGPR
+#define BD_RESOLVE_BOUNDS __launch_bounds__(BD_RESOLVE_ITEMS) __attribute__((amdgpu_waves_per_eu(BD_RESOLVE_VGPR, BD_RESOLVE_VGPR)))
+#else
+#define BD_RESOLVE_BOUNDS __launch_bounds__(BD_RESOLVE_ITEMS, BD_RESOLVE_WAVES)
+#endif      // (said so, the compiler schedules the kernel within 128 VGPRs a little better: config 5 + 2 %, three A/B pairs)
 template <bool SPEC>
 __global__ BD_RESOLVE_BOUNDS void k_bd_resolve(BdCtx c, BdItems items, TileMap tm, int P, int N, uint32_t frame_begin, const int *ibase, const int *icount,
                              const unsigned long long *qmask, const float4 *shits, const float4 *stage, float *radiance, long frame_stride)
 {
-    __shared__ int2 s_list[BD_RESOLVE_ITEMS * BD_RAY_PAIRS];        // (queue place, item | pair slot << 26) of the unoccluded connections, item by item
-    __shared__ int s_wn[BD_RESOLVE_ITEMS / 64];
+    // the unoccluded connections, item by item: item of the group | pair slot << 7 | queue place from the base of the item's wave on << 13 (< 64 x 20).  One word each: at
+    // eight bytes the list alone (20 KB) held a CU to seven blocks
+    __shared__ unsigned s_list[BD_RESOLVE_ITEMS * BD_RAY_PAIRS];
+    __shared__ int s_wn[BD_RESOLVE_ITEMS / 64], s_off0[BD_RESOLVE_ITEMS / 64];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     const int groups = (N + BD_RESOLVE_ITEMS - 1) / BD_RESOLVE_ITEMS;
@@ -931,7 +938,7 @@ __global__ BD_RESOLVE_BOUNDS void k_bd_resolve(BdCtx c, BdItems items, TileMap t
         int incl = mine;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
-        if (lane == 63) s_wn[wid] = incl;
+        if (lane == 63) { s_wn[wid] = incl; s_off0[wid] = off0; }
         __syncthreads();
         int w = incl - mine, total = 0;
 #pragma unroll
@@ -944,7 +951,7 @@ __global__ BD_RESOLVE_BOUNDS void k_bd_resolve(BdCtx c, BdItems items, TileMap t
             if (n > j) {
                 const int slot = __ffsll((long long)rest) - 1;
                 rest &= rest - 1ull;
-                if ((ok >> j) & 1u) s_list[w++] = make_int2(off + __popcll(m & lt), (int)((unsigned)it | ((unsigned)slot << BD_OWNER_BITS)));
+                if ((ok >> j) & 1u) s_list[w++] = threadIdx.x | ((unsigned)slot << 7) | ((unsigned)(off - off0 + __popcll(m & lt)) << 13);
             }
             off += __popcll(m);
         }
@@ -953,10 +960,9 @@ __global__ BD_RESOLVE_BOUNDS void k_bd_resolve(BdCtx c, BdItems items, TileMap t
           const int k = k0 + (int)threadIdx.x;
           long long key = -1; v3 r = V(0.0f, 0.0f, 0.0f);           // the word of the batch's radiance planes the contribution goes to / 3
           if (k < total) {
-            const int2 en = s_list[k];
-            const float4 hr = shits[en.x];
-            const unsigned own = (unsigned)en.y;
-            const int ci = (int)(own & ((1u << BD_OWNER_BITS) - 1u)), slot = (int)(own >> BD_OWNER_BITS);
+            const unsigned en = s_list[k];
+            const int il = (int)(en & 127u), slot = (int)((en >> 7) & 63u), ci = g * BD_RESOLVE_ITEMS + il;
+            const float4 hr = shits[s_off0[il >> 6] + (int)(en >> 13)];
             const int e = slot / (BD_LIGHT_MAX + 1) + 1, l = slot - (e - 1) * (BD_LIGHT_MAX + 1);
             int f, kk; slot_to_frame_pixel(tm, P, ci, f, kk);
             const int p = local_to_pixel(tm, kk), i = p / c.bv.H, j = p - i * c.bv.H;
