@@ -5,6 +5,7 @@ timeout 900 python bench.py > gpurun_out/${T}_bench_default.json.log 2> gpurun_o
 TIRT_FORCE_DIST=1 timeout 600 python bench.py --no-cpu-baseline --no-configs --no-traffic > gpurun_out/${T}_bench_force_dist_one_rank_rccl.json.log 2>&1
 for n in 1 2 4 8; do timeout 300 python bench.py --no-cpu-baseline --no-roofline --emulate-world $n 2>/dev/null | tail -1; done > gpurun_out/${T}_emulated_rank_scaling.log
 for s in 4 8 16 32; do timeout 300 python bench.py --no-cpu-baseline --no-roofline --emulate-world 8 --steps $s 2>/dev/null | tail -1; done > gpurun_out/${T}_emulated_8_ranks_steps_4_8_16_32.log
+for n in 1 2 4 8; do timeout 300 python bench.py --no-cpu-baseline --no-roofline --no-configs --steps 20 --warmup 5 --emulate-world $n 2>/dev/null | tail -1; done > gpurun_out/${T}_emulated_rank_scaling_driver_command_steps20.log
 timeout 300 python tools/timeline.py 0 1 4 8 > gpurun_out/${T}_wave_timeline.txt 2>&1
 timeout 200 python tools/dbg/long_rays.py > gpurun_out/${T}_long_rays.txt 2>&1
 timeout 200 python tools/dbg/ray_kinds.py > gpurun_out/${T}_ray_kinds.txt 2>&1
