@@ -243,6 +243,11 @@ int tirt_micro_gather_rate(tirt_ctx *ctx, uint64_t working_set_bytes, int iters,
  * tirt_trace_timeline copies up to max_waves records to `out` and reports how many the launch had.  (No reference counterpart: bench / tools.) */
 int tirt_trace_timeline(tirt_ctx *ctx, uint64_t *out, int max_waves, int *n_waves);
 
+/* Diagnostics of the camera rays' candidate lists (option "primary_beams", csrc/tirt_pvb.hip): out[0] = local pixels that have a list, out[1] = leaves on
+ * all lists, out[2] = pixels whose five probe rays all hit, out[3] = camera rays since the lists were made that found no hit on their pixel's list and were
+ * traced by k_trace, out[4] = camera rays that went through the lists.  Waits for pending work.  (No reference counterpart: bench / tests.) */
+int tirt_primary_beam_stats(tirt_ctx *ctx, uint64_t out[5]);
+
 /* Fills *out.  Returns TIRT_ERR_STACK (with *out filled in) when stack_overflow > 0: rays dropped subtrees, what was
  * rendered since the last tirt_stats_reset is wrong -- the reference prints "overflow, need larger stack" (Scene.py:741). */
 int tirt_stats(tirt_ctx *ctx, tirt_stats_t *out);

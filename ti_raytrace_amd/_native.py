@@ -89,6 +89,7 @@ SIGNATURES = {
     "tirt_bvh_info": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
     "tirt_micro_gather_rate": (C.c_int, [_vp, C.c_uint64, C.c_int, C.POINTER(C.c_double)]),
     "tirt_trace_timeline": (C.c_int, [_vp, C.POINTER(C.c_uint64), C.c_int, C.POINTER(C.c_int)]),
+    "tirt_primary_beam_stats": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
     "tirt_stats": (C.c_int, [_vp, C.POINTER(Stats)]),
     "tirt_stats_reset": (C.c_int, [_vp]),
     "tirt_kat_math": (C.c_int, [_vp, C.c_int, _f32p, _f32p, _f32p, C.c_int]),
@@ -369,6 +370,12 @@ class Context:
         out = np.zeros((max_waves, 4), np.uint64); n = C.c_int(0)
         check(lib().tirt_trace_timeline(self.handle, out.ctypes.data_as(C.POINTER(C.c_uint64)), int(max_waves), C.byref(n)))
         return out[:min(n.value, max_waves)]
+
+    def primary_beam_stats(self):
+        """Diagnostics of the camera rays' candidate lists (tirt.h, tirt_primary_beam_stats)."""
+        out = (C.c_uint64 * 5)()
+        check(lib().tirt_primary_beam_stats(self.handle, out))
+        return {"pixels_with_list": int(out[0]), "leaves_listed": int(out[1]), "pixels_all_probes_hit": int(out[2]), "rays_to_k_trace": int(out[3]), "rays": int(out[4])}
 
     def micro_gather_rate(self, working_set_bytes, iters=2000):
         v = C.c_double(0.0)

@@ -339,7 +339,7 @@ void tirt_destroy(tirt_ctx *c)
                       &c->keys_b, &c->vals_a, &c->vals_b, &c->hist, &c->morton_sorted, &c->bvh_node, &c->compact, &c->parent,
                       &c->flag, &c->subtree, &c->build_status, &c->leaf_compact, &c->wnode, &c->tri, &c->prim_slot, &c->cnode, &c->cparent, &c->csize, &c->wide_queue, &c->wide_levels, &c->sah_compact, &c->sah_csize, &c->sah_parent, &c->wide_dp, &c->sah_box, &c->sah_idx, &c->sah_tasks, &c->sah_counts, &c->hdr, &c->rgb,
                       &c->counters_mem, &c->spill, &c->tr_rays,
-                      &c->tr_out, &c->tr_prim, &c->tr_counts, &c->dev_counters, &c->bdpt_px, &c->timeline};
+                      &c->tr_out, &c->tr_prim, &c->tr_counts, &c->dev_counters, &c->bdpt_px, &c->timeline, &c->pvb_count, &c->pvb_cand, &c->pvb_bound, &c->pvb_tmp, &c->pvb_stat};
     for (DevBuf *b : bufs) b->release();
     for (auto &bl : c->bd) {
         DevBuf *bb[] = {&bl.items, &bl.state, &bl.rays, &bl.hits, &bl.qidx, &bl.ctr, &bl.rad};
@@ -420,6 +420,8 @@ int tirt_set_option(tirt_ctx *c, const char *name, double value)
     if (!strcmp(name, "trace_node_min")) { TIRT_REQUIRE(value >= 1 && value <= 64, "trace_node_min: 1..64"); c->tr_node_min = (int)value; return TIRT_OK; }
     if (!strcmp(name, "bdpt_bounded")) { c->bdpt_bounded = value != 0.0 ? 1 : 0; return TIRT_OK; }
     if (!strcmp(name, "bdpt_state_fill")) { TIRT_REQUIRE(value == 0.0 || value == 1.0 || value == 2.0, "bdpt_state_fill: 0 (none), 1 (zeros) or 2 (poison)"); c->bdpt_state_fill = (int)value; return TIRT_OK; }
+    if (!strcmp(name, "primary_beams")) { TIRT_REQUIRE(value == 0.0 || value == 1.0, "primary_beams: 0 or 1"); if (flush_pending(c)) return TIRT_ERR_HIP; c->primary_beams = (int)value; return TIRT_OK; }
+    if (!strcmp(name, "primary_beams_min_frames")) { TIRT_REQUIRE(value >= 1.0 && value <= 1.0e6, "primary_beams_min_frames out of range"); if (flush_pending(c)) return TIRT_ERR_HIP; c->primary_beams_min_frames = (int)value; return TIRT_OK; }
     if (!strcmp(name, "bdpt_lanes")) { TIRT_REQUIRE(value >= 1.0 && value <= 4.0, "bdpt_lanes: 1..4"); if (sync_all(c)) return TIRT_ERR_HIP; c->bdpt_lanes = (int)value; return TIRT_OK; }
     if (!strcmp(name, "bdpt_batch_items")) { TIRT_REQUIRE(value >= 1.0 && value <= 1.0e9, "bdpt_batch_items out of range"); c->bdpt_batch_items = (size_t)value; return TIRT_OK; }
     if (!strcmp(name, "bdpt_mem_budget")) { TIRT_REQUIRE(value >= 0, "bdpt_mem_budget: bytes >= 0"); c->bdpt_mem_budget = (size_t)value; return TIRT_OK; }
@@ -816,6 +818,18 @@ int tirt_stats(tirt_ctx *c, tirt_stats_t *out)
         TIRT_HIP(hipStreamSynchronize(c->stream));
         return TIRT_ERR_STACK;
     }
+    return TIRT_OK;
+}
+
+int tirt_primary_beam_stats(tirt_ctx *c, uint64_t out[5])
+{
+    TIRT_REQUIRE(c && out, "tirt_primary_beam_stats: null arguments");
+    for (int k = 0; k < 5; k++) out[k] = 0;
+    if (sync_all(c)) return TIRT_ERR_HIP;
+    if (!c->pvb_stat.p) return TIRT_OK;
+    unsigned long long h[5];
+    TIRT_HIP(hipMemcpy(h, c->pvb_stat.p, sizeof(h), hipMemcpyDeviceToHost));
+    for (int k = 0; k < 5; k++) out[k] = h[k];
     return TIRT_OK;
 }
 

@@ -293,6 +293,12 @@ struct tirt_ctx {
     int bdpt_stack = 64;                           // option "bdpt_stack_size": traversal stack entries of BDPT's rays (BDPT.__init__'s stack_size; LDS part + paged spill)
     int bdpt_bounded = 1;                          // option "bdpt_bounded": connection rays stop at their target distance
 
+    // primary visibility through pixel beams (tirt_pvb.hip): per local pixel the leaves its camera rays can hit first, made once per (build, camera, film)
+    struct PvbKey { tirt::CameraView cam; unsigned long long build; int W, H, tile_rank, tile_count, tile_size, tile_blocked, P; } pvb_key;
+    bool pvb_valid = false; int primary_beams = 1, primary_beams_min_frames = 8;      // options "primary_beams" (0 = off) and "primary_beams_min_frames" (batches of fewer frames trace their camera rays the ordinary way)
+    unsigned long long build_serial = 0;          // counts lbvh_build calls
+    tirt::DevBuf pvb_count, pvb_cand, pvb_bound, pvb_tmp, pvb_stat;
+
     // PT_Spec tables (tirt_spectral_upload): CIE observer, spectra, Rgb2Spec table, sky configuration -- one buffer, views in spec_host
     tirt::DevBuf spec_dev;                      // the SpecView again, in device memory (BDPT_SPEC)
     tirt::DevBuf spec_mem; bool spec_set = false; void *spec_view = nullptr;      // spec_view: a heap tirt::SpecView (tirt_spectral.h) with device pointers
@@ -358,6 +364,10 @@ int bdpt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t see
 int trace_arrays(tirt_ctx *c, const float *ox, const float *oy, const float *oz, const float *dx, const float *dy, const float *dz,
                  int count, const int *count_ptr, float4 *hit, const int *expect, const float *bound, bool count_rays, int lane = -1,
                  const float4 *ray4 = nullptr, bool query = false, const int *ray_index = nullptr);      // (ray_index: TraceArgs) ray4: the rays as 32-byte records (TraceArgs::ray4); query: bounded queries whose expect / bound ride in the records
+int pvb_prepare(tirt_ctx *c);                          // tirt_pvb.hip
+void pvb_launch_cand(tirt_ctx *c, hipStream_t st, const BvhView &bv, const float *dx, const float *dy, const float *dz, const TileMap &tm, int P, int S,
+                     float4 *hit, int *fb_count, int *fb_slot, float *fb_dx, float *fb_dy, float *fb_dz, DevCounters *ctr);
+void pvb_launch_scatter(hipStream_t st, const int *fb_count, const int *fb_slot, const float4 *fb_hit, float4 *hit);
 int trace_arrays_prepare(tirt_ctx *c, int lane);      // allocates what trace_arrays needs on that lane (stack spill, fetch cursors)
 int ensure_counters(tirt_ctx *c);
 int ensure_shade_records(tirt_ctx *c);

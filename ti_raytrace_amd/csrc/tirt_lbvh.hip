@@ -772,6 +772,7 @@ int lbvh_build(tirt_ctx *c)
     TIRT_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));
     c->ms_build = ms;
     TIRT_HIP(hipGetLastError());
+    c->build_serial++;
     c->built = true;
     return TIRT_OK;
 }

@@ -1,0 +1,310 @@
+// Primary visibility through pixel beams (round 5): the camera rays of a batch are the same few thousand beams over and over.
+//
+// A wavefront batch holds F frames of the same P pixels: F camera rays per pixel that differ only in their sub-pixel jitter
+// (Camera.py:135-137) and walk the same top of the tree to the same handful of leaves -- a third of all the rays of PT_RGB (the
+// headline scene: 33.5 M of 97 M per step, 4.3 of 19 ms of traversal).  What the F rays of a pixel can possibly hit is a property of
+// the PIXEL (camera, scene), not of the frame:
+//
+//   pvb_prepare   once per (scene build, camera, film / tiles):
+//     k_pvb_probes    five rays per pixel -- its centre and its corners -- traced by k_trace like any other ray;
+//     k_pvb_beam      bound(pixel) = the farthest of their hit distances (x 1.0001); the pyramid of the pixel (its corner
+//                     directions moved outward by a twentieth of a pixel) is walked down the quantised 4-wide tree and every LEAF
+//                     whose box -- enlarged by k_trace's own margin -- it meets nearer than bound goes on the pixel's list
+//                     (at most PVB_CMAX; a longer list: the pixel is left to k_trace);
+//   per batch, instead of the bounce-0 launch of k_trace:
+//     k_pvb_cand      one thread per camera ray: the primitive tests of its pixel's list -- k_trace's leaf step word for word:
+//                     Moller-Trumbore / sphere, `0 < t < hit_t` with the equal-distance rule, the `slabs` verification of the
+//                     leaf's exact box and, failing that, of its ancestors --, hit record written if the hit lies within bound;
+//                     the other rays (no hit within bound: they slipped past what the probes saw) are appended to a list,
+//     k_trace         over that list (directions compacted into the idle `out` arrays of the batch, hits into the idle shadow
+//                     arrays), k_pvb_scatter puts its hit records where bounce 0 expects them.
+//
+// Why the hit records are the ones k_trace writes, bit for bit.  k_trace's answer for a ray is the minimum (distance, then larger
+// leaf index) over the VERIFIED primitive hits of all leaves it reaches, and it reaches every leaf whose enlarged boxes (its own
+// and its ancestors') the ray enters before `hit_t x 1.0001`.  A ray of the pixel lies inside the pyramid; a box it enters at
+// distance t is met by the pyramid at a point whose projection on the pyramid's axis is <= t (Cauchy-Schwarz), so every leaf that
+// could hold a verified hit at distance <= bound is on the list, with all the leaves in front of it.  If the best verified hit of
+// the list lies within bound it is therefore k_trace's; if not, k_trace is asked.  A list made with bound = infinity (some probe
+// left the scene) and not cut short is complete: a miss on it is a miss.  Rays that fail `slabs` on the root's exact box miss, as in
+// k_trace (KIND_CLOSEST).  A camera further than TR_FAR_RHO extents from the scene (k_trace stops culling by distance there) gets no lists.
+#include "tirt_internal.h"
+#include <cstring>
+
+namespace tirt {
+
+constexpr int PVB_CMAX = 24;                        // leaves on a pixel's list
+constexpr int PVB_STACK = 96;                       // node stack of a beam walk (4-wide tree: three entries per level at most)
+constexpr float PVB_WIDEN = 0.55f;                  // the pyramid's corners in pixels from the centre (the jitter is [-0.5, 0.5))
+constexpr int PVB_BLOCK = 1024;                      // threads of a k_pvb_cand block
+constexpr float PVB_FAR_RHO = 8.0f;                 // = TR_FAR_RHO (tirt_render.hip)
+
+struct PvbView { const int *count; const int2 *cand; const float *bound; };     // [P], [PVB_CMAX][P] (leaf code, bits of the nearest distance any ray of the pixel can reach the leaf's box at), [P]; count < 0: no list
+
+__global__ void k_pvb_probes(CameraView cam, TileMap tm, int P, float4 *rays)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= P) return;
+    const int p = local_to_pixel(tm, k), i = p / tm.H, j = p - i * tm.H;
+    for (int pr = 0; pr < 5; pr++) {
+        const float jx = pr == 0 ? 0.0f : (((pr - 1) & 1) ? 0.5f : -0.5f), jy = pr == 0 ? 0.0f : (((pr - 1) & 2) ? 0.5f : -0.5f);
+        const v3 d = camera_ray_direction(cam, i, j, jx, jy);
+        const size_t r = (size_t)pr * P + k;
+        rays[2 * r] = make_float4(cam.eye[0], cam.eye[1], cam.eye[2], d.x);
+        rays[2 * r + 1] = make_float4(d.y, d.z, 0.0f, 0.0f);
+    }
+}
+
+TD float h2f(unsigned h) { return (float)__builtin_bit_cast(_Float16, (unsigned short)h); }
+
+__global__ void k_pvb_beam(BvhView b, CameraView cam, TileMap tm, int P, const float4 *probe_hits, int *count, int2 *cand, float *bound_out,
+                           unsigned long long *stat)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= P) return;
+    const int p = local_to_pixel(tm, k), i = p / tm.H, j = p - i * tm.H;
+    float bound = 0.0f;
+    for (int pr = 0; pr < 5; pr++) {
+        const float4 h = probe_hits[(size_t)pr * P + k];
+        bound = (__float_as_int(h.w) >= 0 && h.x < INF_VALUE) ? maxf(bound, h.x) : INF_VALUE;
+        if (!(bound < INF_VALUE)) break;
+    }
+    if (bound < INF_VALUE) bound = bound * 1.0001f;
+    const v3 eye = V(cam.eye[0], cam.eye[1], cam.eye[2]);
+    const v3 cell = V(b.cell[0], b.cell[1], b.cell[2]), gmin = V(b.grid_min[0], b.grid_min[1], b.grid_min[2]);
+    // k_trace's margin around a box, in cells (0.25 + 0.25 per root-box extent between the eye and the grid), and a little more
+    const float rho = maxf(maxf(absf(gmin.x - eye.x) * b.inv_extent[0], absf(gmin.y - eye.y) * b.inv_extent[1]), absf(gmin.z - eye.z) * b.inv_extent[2]);
+    const float mc = 0.30f + 0.25f * rho;
+    int n = 0;
+    bool whole = rho <= PVB_FAR_RHO;
+    if (whole) {
+        v3 dg[4];
+        const float W = PVB_WIDEN;
+        const float cx[4] = {-W, W, W, -W}, cy[4] = {-W, -W, W, W};
+        for (int q = 0; q < 4; q++) { const v3 d = camera_ray_direction(cam, i, j, cx[q], cy[q]); dg[q] = V(d.x / cell.x, d.y / cell.y, d.z / cell.z); }
+        const v3 dc = camera_ray_direction(cam, i, j, 0.0f, 0.0f);
+        const v3 dcg = V(dc.x / cell.x, dc.y / cell.y, dc.z / cell.z);
+        const v3 og = V((eye.x - gmin.x) / cell.x, (eye.y - gmin.y) / cell.y, (eye.z - gmin.z) / cell.z);
+        v3 nrm[4]; float eps[4];
+        for (int q = 0; q < 4; q++) {
+            v3 nn = cross(dg[q], dg[(q + 1) & 3]);
+            if (dot(nn, dcg) < 0.0f) nn = -nn;                       // inward
+            nrm[q] = nn;
+            // rounding of the plane expression: 1e-5 of its terms' magnitude at the far end of the grid (the widening of the pyramid is 5e-5 of the distance)
+            eps[q] = 1.0e-5f * (absf(nn.x) + absf(nn.y) + absf(nn.z)) * (absf(og.x) + absf(og.y) + absf(og.z) + 3.0f * (TR_GRID_HALF + 2.0f));
+        }
+        const v3 ac = V(dc.x * cell.x, dc.y * cell.y, dc.z * cell.z);           // projection on the axis, per cell
+        const float abase = dot(gmin - eye, dc);
+        int stack[PVB_STACK]; int sp = 0;
+        int lcode[PVB_CMAX]; float lnear[PVB_CMAX];
+        int cur = b.root_qcode;
+        // a one-primitive scene: the root IS the leaf
+        if (cur < 0) { if (cur != (int)0x80000000 && cur != TR_EMPTY) { lcode[0] = cur; lnear[0] = 0.0f; n = 1; } cur = (int)0x80000000; }
+        while (cur >= 0 || sp > 0) {
+            if (cur < 0) cur = stack[--sp];
+            const uint4 *w = (const uint4 *)((const char *)b.cnode + ((size_t)(unsigned)cur << 6));
+            const uint4 q0 = w[0], q1 = w[1], q2 = w[2], q3 = w[3];
+            const unsigned wx[4] = {q0.x, q0.w, q1.z, q2.y}, wy[4] = {q0.y, q1.x, q1.w, q2.z}, wz[4] = {q0.z, q1.y, q2.x, q2.w};
+            const int cc[4] = {(int)q3.x, (int)q3.y, (int)q3.z, (int)q3.w};
+            cur = (int)0x80000000;
+            for (int ch = 0; ch < 4; ch++) {
+                const int code = cc[ch];
+                if (code == TR_EMPTY) continue;
+                const float lx = h2f(wx[ch] & 0xffffu) - mc, hx = h2f(wx[ch] >> 16) + mc;
+                const float ly = h2f(wy[ch] & 0xffffu) - mc, hy = h2f(wy[ch] >> 16) + mc;
+                const float lz = h2f(wz[ch] & 0xffffu) - mc, hz = h2f(wz[ch] >> 16) + mc;
+                if (!(lx <= hx && ly <= hy && lz <= hz)) continue;
+                bool out = false;
+                for (int q = 0; q < 4; q++) {
+                    const v3 nn = nrm[q];
+                    const float s = nn.x * ((nn.x >= 0.0f ? hx : lx) - og.x) + nn.y * ((nn.y >= 0.0f ? hy : ly) - og.y) + nn.z * ((nn.z >= 0.0f ? hz : lz) - og.z);
+                    out = out || (s < -eps[q]);
+                }
+                if (out) continue;
+                // nearest any ray of the pyramid can reach the box: the least projection of the box on the axis (<= the distance along any unit direction)
+                const float nearp = abase + ac.x * (ac.x >= 0.0f ? lx : hx) + ac.y * (ac.y >= 0.0f ? ly : hy) + ac.z * (ac.z >= 0.0f ? lz : hz);
+                if (nearp > bound) continue;
+                if (code >= 0) {
+                    if (cur < 0) cur = code;
+                    else if (sp < PVB_STACK) stack[sp++] = code;
+                    else whole = false;
+                } else {
+                    if (n < PVB_CMAX) { lcode[n] = code; lnear[n] = maxf(nearp, 0.0f); }
+                    n++;
+                }
+            }
+            if (!whole || n > PVB_CMAX) break;
+        }
+        if (n > PVB_CMAX) whole = false;
+        if (whole) {
+            // nearest first: a ray that has a hit stops at the first leaf that lies beyond it (k_pvb_cand)
+            for (int a = 1; a < n; a++) {
+                const int cd = lcode[a]; const float nr = lnear[a];
+                int z = a - 1;
+                while (z >= 0 && lnear[z] > nr) { lcode[z + 1] = lcode[z]; lnear[z + 1] = lnear[z]; z--; }
+                lcode[z + 1] = cd; lnear[z + 1] = nr;
+            }
+            for (int a = 0; a < n; a++) cand[(size_t)a * P + k] = make_int2(lcode[a], __float_as_int(lnear[a]));
+        }
+    }
+    count[k] = whole ? n : -1;
+    bound_out[k] = bound;
+    if (stat) {
+        // (diagnostics: pixels with a list, leaves on the lists, pixels whose probes all hit)
+        const unsigned long long m = __ballot(whole);
+        unsigned long long s = whole ? (unsigned long long)n : 0ull;
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+        const unsigned long long mb = __ballot(whole && bound < INF_VALUE);
+        if ((threadIdx.x & 63) == 0) { atomicAdd(&stat[0], (unsigned long long)__popcll(m)); atomicAdd(&stat[1], s); atomicAdd(&stat[2], (unsigned long long)__popcll(mb)); }
+    }
+}
+
+// One camera ray against its pixel's list (see the header); the unresolved ones are appended to (fb_slot, fb_d*).
+__global__ __launch_bounds__(PVB_BLOCK) void k_pvb_cand(BvhView b, PvbView pv, const float *dx, const float *dy, const float *dz, v3 eye, TileMap tm, int P, int S,
+                                                  float4 *hit, int *fb_count, int *fb_slot, float *fb_dx, float *fb_dy, float *fb_dz, DevCounters *ctr,
+                                                  unsigned long long *stat)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
+    const bool live = s < S;
+    int f = 0, k = 0;
+    if (live) slot_to_frame_pixel(tm, P, s, f, k);
+    const v3 d = live ? V(__builtin_nontemporal_load(&dx[s]), __builtin_nontemporal_load(&dy[s]), __builtin_nontemporal_load(&dz[s])) : V(0.0f, 0.0f, 1.0f);
+    const RayCtx r = make_ray(eye, d);
+    const bool par = ray_has_parallel_axis(r);
+    int n = live ? pv.count[k] : 0;
+    const float bound = live ? pv.bound[k] : 0.0f;
+    bool resolved = live && n >= 0;
+    // k_trace's first step for a camera ray: the root's exact box (and a NaN ray misses)
+    bool dead = false;
+    if (live) {
+        float tn;
+        if (!slabs(r, b.root_min[0], b.root_min[1], b.root_min[2], b.root_max[0], b.root_max[1], b.root_max[2], tn)) dead = true;
+        if (!((d.x == d.x) & (d.y == d.y) & (d.z == d.z))) dead = true;
+    }
+    if (dead) { n = 0; resolved = true; }
+    if (!resolved) n = 0;
+    float hit_t = INF_VALUE, hit_u = 0.0f, hit_v = 0.0f; int hit_prim = -1, hit_leaf = -1;
+    for (int c = 0; c < PVB_CMAX; c++) {
+        // (the lists are sorted by the distance at which a ray of the pixel can reach the leaf's box at the earliest: beyond the hit so far, nothing on the rest of the list can win or tie)
+        int2 en = make_int2(0, 0x7f800000);
+        if (c < n) en = pv.cand[(size_t)c * P + k];
+        const bool go = c < n && __int_as_float(en.y) <= hit_t;
+        if (!go) n = 0;
+        if (__ballot(go) == 0ull) break;
+        if (go) {
+            const int code = ~en.x;
+            const float4 *tp = b.tri + (size_t)(code & 0x3fffffff) * TRI_STRIDE;
+            const float4 ta = tp[0], tb = tp[1], tc = tp[2];
+            int prim = __float_as_int(tc.w);
+            const bool is_tri = ((code >> 30) & 1) == 0;
+            const v3 pa = V(ta.x, ta.y, ta.z), pb = V(tb.x, tb.y, tb.z), pc = V(tc.x, tc.y, tc.z);
+            float t, u, v;
+            if (is_tri) t = intersect_tri_packed(eye, d, pa, pb - pa, pc - pa, u, v);
+            else {
+                u = 0.0f; v = 0.0f; t = INF_VALUE;
+                if ((int)tb.y == SHAPE_SPHERE) { const v3 oc = pa - eye; if (dot(d, oc) > 0.0f) { float ccv; t = intersect_sphere(eye, d, pa, tb.x, ccv); } }
+            }
+            const int leaf = __float_as_int(ta.w);
+            bool cand = (t > 0.0f) & ((t < hit_t) | ((t == hit_t) & (hit_leaf >= 0) & (leaf > hit_leaf)));
+            if (cand) {
+                v3 bmn, bmx;
+                if (is_tri) {
+                    bmn = V(__builtin_fminf(__builtin_fminf(pa.x, pb.x), pc.x), __builtin_fminf(__builtin_fminf(pa.y, pb.y), pc.y), __builtin_fminf(__builtin_fminf(pa.z, pb.z), pc.z));
+                    bmx = V(__builtin_fmaxf(__builtin_fmaxf(pa.x, pb.x), pc.x), __builtin_fmaxf(__builtin_fmaxf(pa.y, pb.y), pc.y), __builtin_fmaxf(__builtin_fmaxf(pa.z, pb.z), pc.z));
+                } else { bmn = V(pa.x - tb.x, pa.y - tb.x, pa.z - tb.x); bmx = V(pa.x + tb.x, pa.y + tb.x, pa.z + tb.x); }
+                float tn_;
+                const int inside = par ? slabs(r, bmn.x, bmn.y, bmn.z, bmx.x, bmx.y, bmx.z, tn_) : slabs_fast(r, bmn.x, bmn.y, bmn.z, bmx.x, bmx.y, bmx.z, tn_);
+                if (!inside) {
+                    for (int an = b.cparent[leaf]; an >= 0; an = b.cparent[an]) {
+                        const float *ab = b.compact + (size_t)an * CPN_VEC + 2;
+                        if (!slabs(r, ab[0], ab[1], ab[2], ab[3], ab[4], ab[5], tn_)) { cand = false; break; }
+                    }
+                    prim = (int)b.compact[(size_t)leaf * CPN_VEC + 1];
+                }
+            }
+            if (cand) { hit_t = t; hit_u = u; hit_v = v; hit_prim = prim; hit_leaf = leaf; }
+        }
+    }
+    // within bound: k_trace's answer (a list made without a bound is complete: whatever it says holds)
+    if (resolved && !dead && !(hit_t <= bound) && bound < INF_VALUE) resolved = false;
+    if (resolved) {
+        typedef float f4n __attribute__((ext_vector_type(4)));
+        f4n hv = {hit_t, hit_u, hit_v, __int_as_float(hit_prim)};
+        __builtin_nontemporal_store(hv, (f4n *)&hit[s]);
+    }
+    // the leftover rays of the BLOCK take their places in the list with one atomic (same-address atomics retire at ~11 ns each: one per wave -- four fifths
+    // of the waves have a leftover ray -- made this kernel 2.9 ms long)
+    const bool fb = live && !resolved;
+    const unsigned long long fm = __ballot(fb);
+    __shared__ int s_wn[PVB_BLOCK / 64], s_base;
+    const int wid = threadIdx.x >> 6;
+    if (lane == 0) s_wn[wid] = __popcll(fm);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int tot = 0;
+#pragma unroll
+        for (int w = 0; w < PVB_BLOCK / 64; w++) tot += s_wn[w];
+        s_base = tot ? atomicAdd(fb_count, tot) : 0;
+        if (stat && tot) atomicAdd(&stat[3], (unsigned long long)tot);
+    }
+    __syncthreads();
+    if (fb) {
+        const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+        int at = s_base + __popcll(fm & lt);
+        for (int w = 0; w < wid; w++) at += s_wn[w];
+        fb_slot[at] = s; fb_dx[at] = d.x; fb_dy[at] = d.y; fb_dz[at] = d.z;
+    }
+    if (s == 0 && ctr) atomicAdd(&ctr->rays_closest, (unsigned long long)S);
+    if (stat && s == 0) atomicAdd(&stat[4], (unsigned long long)S);
+}
+
+__global__ void k_pvb_scatter(const int *fb_count, const int *fb_slot, const float4 *fb_hit, float4 *hit)
+{
+    const int n = *fb_count;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) hit[fb_slot[i]] = fb_hit[i];
+}
+
+// (re)builds the pixels' lists when the scene, the camera or the film changed since they were made; on the main stream
+int pvb_prepare(tirt_ctx *c)
+{
+    const int P = (int)c->npix_local;
+    tirt_ctx::PvbKey key;
+    memset(&key, 0, sizeof(key));
+    key.cam = c->cam; key.build = c->build_serial; key.W = c->W; key.H = c->H; key.tile_rank = c->tile_rank; key.tile_count = c->tile_count;
+    key.tile_size = c->tile_size; key.tile_blocked = c->tile_blocked; key.P = P;
+    if (c->pvb_valid && !memcmp(&key, &c->pvb_key, sizeof(key))) return TIRT_OK;
+    c->pvb_valid = false;
+    if (P <= 0) return TIRT_OK;
+    if (c->pvb_count.ensure(sizeof(int) * (size_t)P) || c->pvb_bound.ensure(sizeof(float) * (size_t)P) || c->pvb_cand.ensure(sizeof(int2) * (size_t)PVB_CMAX * P) ||
+        c->pvb_tmp.ensure((sizeof(float4) * 2 + sizeof(float4)) * 5 * (size_t)P) || c->pvb_stat.ensure(64)) return TIRT_ERR_HIP;
+    if (int rc = trace_arrays_prepare(c, -1)) return rc;
+    hipStream_t st = c->stream;
+    TileMap tm = {c->tile_rank, c->tile_count, c->tile_size, c->H, c->tile_blocked, 0};
+    float4 *rays = c->pvb_tmp.as<float4>(), *hits = rays + 10 * (size_t)P;
+    const int B = 256;
+    TIRT_HIP(hipMemsetAsync(c->pvb_stat.p, 0, 64, st));
+    hipLaunchKernelGGL(k_pvb_probes, dim3((P + B - 1) / B), dim3(B), 0, st, c->cam, tm, P, rays);
+    if (int rc = trace_arrays(c, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 5 * P, nullptr, hits, nullptr, nullptr, false, -1, rays)) return rc;
+    hipLaunchKernelGGL(k_pvb_beam, dim3((P + 63) / 64), dim3(64), 0, st, bvh_view(c), c->cam, tm, P, hits, c->pvb_count.as<int>(), c->pvb_cand.as<int2>(),
+                       c->pvb_bound.as<float>(), c->pvb_stat.as<unsigned long long>());
+    TIRT_HIP(hipGetLastError());
+    memcpy(&c->pvb_key, &key, sizeof(key)); c->pvb_valid = true;
+    return TIRT_OK;
+}
+
+// bounce 0 of a batch of S camera rays (directions in `dx ..`, hit records to `hit`) against the pixels' lists; the rays left over are appended to (fb_slot, fb_d*):
+// pt_render traces them with k_trace and calls pvb_launch_scatter
+void pvb_launch_cand(tirt_ctx *c, hipStream_t st, const BvhView &bv, const float *dx, const float *dy, const float *dz, const TileMap &tm, int P, int S,
+                     float4 *hit, int *fb_count, int *fb_slot, float *fb_dx, float *fb_dy, float *fb_dz, DevCounters *ctr)
+{
+    PvbView pv = {c->pvb_count.as<int>(), c->pvb_cand.as<int2>(), c->pvb_bound.as<float>()};
+    v3 eye; eye.x = c->cam.eye[0]; eye.y = c->cam.eye[1]; eye.z = c->cam.eye[2];
+    const int B = PVB_BLOCK;
+    hipLaunchKernelGGL(k_pvb_cand, dim3((S + B - 1) / B), dim3(B), 0, st, bv, pv, dx, dy, dz, eye, tm, P, S, hit, fb_count, fb_slot, fb_dx, fb_dy, fb_dz,
+                       ctr, c->pvb_stat.as<unsigned long long>());
+}
+void pvb_launch_scatter(hipStream_t st, const int *fb_count, const int *fb_slot, const float4 *fb_hit, float4 *hit)
+{
+    hipLaunchKernelGGL(k_pvb_scatter, dim3(2048), dim3(256), 0, st, fb_count, fb_slot, fb_hit, hit);
+}
+
+}  // namespace tirt

@@ -1696,6 +1696,12 @@ int pt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed,
     DevCounters *ctr = c->dev_counters.as<DevCounters>();
     const int B = 256;
     collect_live_counts(c);
+    // the pixels' candidate lists for the camera rays (tirt_pvb.hip), made on the main stream when the scene, the camera or the film changed since
+    bool beams_ready = false;
+    if (c->primary_beams && FB >= c->primary_beams_min_frames && !(flags & (TIRT_TRAVERSE_EXHAUSTIVE | TIRT_COUNT_NODES))) {
+        if (int rc = pvb_prepare(c)) return rc;
+        beams_ready = c->pvb_valid;
+    }
     // everything queued on the main stream (uploads, film clear, tone map) precedes the lanes' work
     TIRT_HIP(hipEventRecord(c->ev_main, c->stream));
     int n_lanes = c->time_kernels ? 1 : c->n_lanes;
@@ -1730,6 +1736,7 @@ int pt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed,
         const int F = (frame_count - fb < FB) ? frame_count - fb : FB;
         const int S = F * P;
         tm.F = (c->path_order_blocks && (P & 63) == 0) ? F : 0;
+        const bool use_beams = beams_ready && F >= c->primary_beams_min_frames;
         const uint32_t f0 = frame_begin + (uint32_t)fb;
         char *cm = L.counters_mem.as<char>();
         auto append_ctr = [&](int b) { return (unsigned long long *)(cm + LINE * (size_t)b); };
@@ -1785,6 +1792,17 @@ int pt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed,
             fill_tunables(c, a);
             a.timeline = timeline_for(c, flags, grid_full);
             stamp(evc, true);
+            if (b == 0 && use_beams) {
+                // camera rays: each against the list of leaves its pixel's rays can hit first (tirt_pvb.hip); those that find nothing there go to k_trace.  Scratch the
+                // batch does not touch before shade(0): the `out` arrays (slots, directions of the leftover rays), the shadow-ray arrays (their hit records)
+                int *const fb_count = (int *)append_ctr(0) + 4;          // (zeroed with the batch's counters; words 0, 1 of the line: the appends of bounce 0)
+                float4 *const fb_hit = (float4 *)L.ps.sox;               // sox, soy, soz, sdx: four consecutive arrays of the lane's pitch
+                pvb_launch_cand(c, st, bv, in.dx, in.dy, in.dz, tm, P, S, L.ps.hit, fb_count, (int *)out.ox, out.dx, out.dy, out.dz, ctr);
+                TraceArgs a2 = a;
+                a2.dx = out.dx; a2.dy = out.dy; a2.dz = out.dz; a2.count_ptr = fb_count; a2.count_fixed = S; a2.hit = fb_hit; a2.no_ray_count = 1; a2.timeline = nullptr;
+                if (int rc = launch_trace<KIND_CLOSEST>(c, st, a2, flags, grid_full)) return rc;
+                pvb_launch_scatter(st, fb_count, (const int *)out.ox, fb_hit, L.ps.hit);
+            } else
             if (int rc = (b == 0) ? launch_trace<KIND_CLOSEST>(c, st, a, flags, grid_full) : launch_trace<KIND_MIXED>(c, st, a, flags, grid_full)) return rc;
             stamp(evc, false);
             c->launches_trace_closest++;
