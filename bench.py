@@ -718,7 +718,7 @@ def main():
                         "(%d steps x %d frames), max_depth 15, render seed %d" %
                         (args.ntri, W, H, args.steps * fps, args.steps, fps, args.seed),
             "parallelism": "pixel tiles of %d round-robin over %d GPU(s), replicated BVH, one RCCL film reduce" % (args.tile_size, world),
-            "traversal": "ordered+t-culled over 4-wide nodes collapsed from a device-built binned-SAH tree; every hit verified against the reference's LBVH (bit-identical to its exhaustive order except for rays lying in a triangle's plane to fp32 rounding, DESIGN.md section 2: none in a render)",
+            "traversal": "ordered+t-culled over 4-wide nodes collapsed from a device-built binned-SAH tree; every hit verified against the reference's LBVH (bit-identical to its exhaustive order except for rays lying in a triangle's plane to fp32 rounding, DESIGN.md section 2: none in a render); the camera rays (a third of all rays) against per-pixel lists of the leaves they can hit first, the rest of them through the same traversal (csrc/tirt_pvb.hip: same hit records bit for bit)",
         },
         "rays": {"closest": int(rays_closest), "shadow": int(rays_shadow), "paths": int(paths),
                  "rays_per_path": round((rays_closest + rays_shadow) / max(paths, 1.0), 3)},
@@ -726,6 +726,15 @@ def main():
         "build_detail": build_detail,
         "scene_setup_wall_s": round(build_wall, 3),
     }
+    try:
+        pb = ctx.primary_beam_stats()
+        if pb["rays"]:
+            result["primary_beams"] = {"pixels_with_list": pb["pixels_with_list"], "leaves_per_listed_pixel": round(pb["leaves_listed"] / max(pb["pixels_with_list"], 1), 2),
+                                       "camera_rays_through_lists": pb["rays"], "of_them_to_k_trace": pb["rays_to_k_trace"],
+                                       "share_to_k_trace": round(pb["rays_to_k_trace"] / max(pb["rays"], 1), 4),
+                                       "def": "rank 0, since the lists were made (warm-up + timed): tirt.h tirt_primary_beam_stats"}
+    except Exception as e:                      # (diagnostics only)
+        result["primary_beams"] = {"error": str(e)}
     if dist_info is not None:
         red_t = torch.tensor([reduce_ms], dtype=torch.float64, device="cuda")
         if world > 1:
