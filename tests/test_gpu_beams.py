@@ -82,6 +82,24 @@ def test_beams_follow_the_camera_and_the_scene(gpu_ctx_ok):
     assert n1 == n0 and same(small_on, small_off)
 
 
+def test_camera_moves_while_batches_are_in_flight(gpu_ctx_ok):
+    """tirt_camera_set submits what is pending and does not wait: the new lists must not be written under the batches that still read the old ones.
+    Four camera poses, 40 frames each into ONE film, nothing synchronised in between -- against the same sequence with the lists off."""
+    W = H = 256
+    films = []
+    for beams in (0, 1):
+        ex = scenes.synthetic(W, H, 160, ntri=20000, device_id=0)
+        ex.build_scene()
+        ctx = ex.scene.ctx
+        ctx.set_option("primary_beams", beams)
+        for pose in range(4):
+            ctx.pt_rgb_render(40 * pose, 40, 7, 15, 64, 0)
+            ex.cam.yaw += 0.15; ex.cam.update()
+        films.append(ctx.film_download(W, H)[0])
+        if beams: assert ctx.primary_beam_stats()["rays"] > 0
+    assert same(films[0], films[1])
+
+
 def test_beams_with_tiles_of_several_ranks(gpu_ctx_ok):
     """a rank's tiles (round robin, ragged last tile, blocked and linear pixel order inside a tile): lists per LOCAL pixel"""
     W = H = 64

@@ -278,6 +278,9 @@ int pvb_prepare(tirt_ctx *c)
         c->pvb_tmp.ensure((sizeof(float4) * 2 + sizeof(float4)) * 5 * (size_t)P) || c->pvb_stat.ensure(64)) return TIRT_ERR_HIP;
     if (int rc = trace_arrays_prepare(c, -1)) return rc;
     hipStream_t st = c->stream;
+    // batches still in flight on the lanes read the old lists (a camera move submits what is pending and does not wait): the film updates are chained in
+    // submission order, so the last one's event covers them all
+    if (c->last_film) TIRT_HIP(hipStreamWaitEvent(st, c->last_film, 0));
     TileMap tm = {c->tile_rank, c->tile_count, c->tile_size, c->H, c->tile_blocked, 0};
     float4 *rays = c->pvb_tmp.as<float4>(), *hits = rays + 10 * (size_t)P;
     const int B = 256;
