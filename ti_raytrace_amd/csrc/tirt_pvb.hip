@@ -165,8 +165,10 @@ __global__ __launch_bounds__(PVB_BLOCK) void k_pvb_cand(BvhView b, PvbView pv, c
 {
     const int s = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
     const bool live = s < S;
-    int f = 0, k = 0;
-    if (live) slot_to_frame_pixel(tm, P, s, f, k);
+    // the ray's local pixel (the frame is not needed).  Pixel-block-major numbering (TileMap::F): the 64-path chunk is the wave's, its division by F scalar
+    int k = 0;
+    if (tm.F > 0) { const int ch = __builtin_amdgcn_readfirstlane(s >> 6); k = ((ch / tm.F) << 6) | (s & 63); }
+    else if (live) { int f; slot_to_frame_pixel(tm, P, s, f, k); }
     const v3 d = live ? V(__builtin_nontemporal_load(&dx[s]), __builtin_nontemporal_load(&dy[s]), __builtin_nontemporal_load(&dz[s])) : V(0.0f, 0.0f, 1.0f);
     const RayCtx r = make_ray(eye, d);
     const bool par = ray_has_parallel_axis(r);
