@@ -9,8 +9,9 @@
 //     k_pvb_probes    five rays per pixel -- its centre and its corners -- traced by k_trace like any other ray;
 //     k_pvb_beam      bound(pixel) = the farthest of their hit distances (x 1.0001); the pyramid of the pixel (its corner
 //                     directions moved outward by a twentieth of a pixel) is walked down the quantised 4-wide tree and every LEAF
-//                     whose box -- enlarged by k_trace's own margin -- it meets nearer than bound goes on the pixel's list
-//                     (at most PVB_CMAX; a longer list: the pixel is left to k_trace);
+//                     whose box -- enlarged by k_trace's own margin -- it meets nearer than bound, and whose triangle does not lie
+//                     wholly outside one of its faces, goes on the pixel's list, nearest first (at most PVB_CMAX; a longer list:
+//                     the pixel is left to k_trace);
 //   per batch, instead of the bounce-0 launch of k_trace:
 //     k_pvb_cand      one thread per camera ray: the primitive tests of its pixel's list -- k_trace's leaf step word for word:
 //                     Moller-Trumbore / sphere, `0 < t < hit_t` with the equal-distance rule, the `slabs` verification of the
@@ -128,7 +129,29 @@ __global__ void k_pvb_beam(BvhView b, CameraView cam, TileMap tm, int P, const f
                     else if (sp < PVB_STACK) stack[sp++] = code;
                     else whole = false;
                 } else {
-                    if (n < PVB_CMAX) { lcode[n] = code; lnear[n] = maxf(nearp, 0.0f); }
+                    // a triangle leaf: the triangle itself against the pyramid (its box met it; all three corners outside one face: no ray of the pixel
+                    // comes nearer to it than the widening of the pyramid, a twentieth of a pixel -- the primitive test's own slack is 1e-6 of the
+                    // distance), and the least projection of its corners on the axis instead of its box's (no point of it is nearer)
+                    float nr = nearp;
+                    const int lc = ~code;
+                    if (((lc >> 30) & 1) == 0) {
+                        const float4 *tp = b.tri + (size_t)(lc & 0x3fffffff) * TRI_STRIDE;
+                        const float4 ta = tp[0], tb = tp[1], tc = tp[2];
+                        const v3 w0 = V(ta.x, ta.y, ta.z), w1 = V(tb.x, tb.y, tb.z), w2 = V(tc.x, tc.y, tc.z);
+                        const v3 g0 = V((w0.x - eye.x) / cell.x, (w0.y - eye.y) / cell.y, (w0.z - eye.z) / cell.z);
+                        const v3 g1 = V((w1.x - eye.x) / cell.x, (w1.y - eye.y) / cell.y, (w1.z - eye.z) / cell.z);
+                        const v3 g2 = V((w2.x - eye.x) / cell.x, (w2.y - eye.y) / cell.y, (w2.z - eye.z) / cell.z);
+                        bool off = false;
+                        for (int q = 0; q < 4; q++) {
+                            const float e = eps[q] + 0.05f * (absf(nrm[q].x) + absf(nrm[q].y) + absf(nrm[q].z));      // (+ a twentieth of a cell)
+                            off = off || (dot(nrm[q], g0) < -e && dot(nrm[q], g1) < -e && dot(nrm[q], g2) < -e);
+                        }
+                        if (off) continue;
+                        const float pr = __builtin_fminf(__builtin_fminf(dot(w0 - eye, dc), dot(w1 - eye, dc)), dot(w2 - eye, dc));
+                        nr = maxf(nr, pr - 1.0e-4f * absf(pr) - 1.0e-6f);
+                        if (nr > bound) continue;
+                    }
+                    if (n < PVB_CMAX) { lcode[n] = code; lnear[n] = maxf(nr, 0.0f); }
                     n++;
                 }
             }
