@@ -100,6 +100,30 @@ def test_camera_moves_while_batches_are_in_flight(gpu_ctx_ok):
     assert same(films[0], films[1])
 
 
+@pytest.mark.parametrize("name", ["soup", "cornell", "teapot", "slivers"])
+def test_many_camera_poses(gpu_ctx_ok, name):
+    """orbit angles, eye distances from inside the scene to seven extents away (beyond eight: no lists), three film shapes: film and ray counts with
+    the lists on = off, every pose (tools/dbg/pvb_stress.py is the longer version)"""
+    rng = np.random.default_rng(7)
+    make = {"soup": lambda W, H: scenes.synthetic(W, H, 8, ntri=30000, device_id=0), "cornell": lambda W, H: scenes.cornell_box(W, H, 8, device_id=0),
+            "teapot": lambda W, H: scenes.single_model(W, H, 8, device_id=0), "slivers": lambda W, H: tiny_scene(3000, seed=11, W=W, H=H, spread=0.9, device_id=0)}[name]
+    for W, H in ((192, 192), (320, 64), (56, 200)):
+        ex = make(W, H); ex.build_scene(); ctx = ex.scene.ctx
+        ctx.set_option("primary_beams_min_frames", 1)
+        for pose in range(8):
+            ex.cam.yaw = float(rng.uniform(0, 6.28)); ex.cam.pitch = float(rng.uniform(-1.2, 1.2))
+            ex.frame_camera(float(rng.choice([0.05, 0.2, 0.5, 0.8, 1.5, 3.0, 7.0])))
+            res = []
+            for beams in (0, 1):
+                ctx.set_option("primary_beams", beams)
+                ctx.film_clear(); ctx.stats_reset()
+                ctx.pt_rgb_render(0, 8, 11 + pose, 15, 64, 0)
+                st = ctx.stats()
+                res.append((ctx.film_download(W, H)[0].view(np.uint32).copy(), st["rays_closest"], st["rays_shadow"], st["stack_overflow"]))
+            assert res[0][1:] == res[1][1:], (W, H, pose, ex.cam.yaw, ex.cam.pitch, ex.cam.scale)
+            assert np.array_equal(res[0][0], res[1][0]), (W, H, pose, ex.cam.yaw, ex.cam.pitch, ex.cam.scale)
+
+
 def test_beams_with_tiles_of_several_ranks(gpu_ctx_ok):
     """a rank's tiles (round robin, ragged last tile, blocked and linear pixel order inside a tile): lists per LOCAL pixel"""
     W = H = 64
