@@ -640,6 +640,7 @@ int exp_wide_from_tree(tirt_ctx *c, const float *compact_host, const int *csize_
     const float pad = 1.0e-4f * sqrtf(ex * ex + ey * ey + ez * ez);
     GridMap gm;
     for (int k = 0; k < 3; k++) { gm.g0[k] = c->grid_min[k]; gm.inv_cell[k] = c->grid_inv_cell[k]; }
+    c->build_serial++;                       // (another traversal tree: the camera rays' candidate lists belong to the old one, tirt_pvb.hip)
     return build_wide(c, alt_compact.as<float>(), alt_csize.as<int>(), nullptr, pad, gm);
 }
 #endif
