@@ -773,9 +773,13 @@ def main():
         alg_shadow = 32.0 * c["box_shadow"] + 36.0 * c["leaf_shadow"] + 48.0 * c["rays_shadow"]
         ctx.set_option("time_kernels", 1)            # per-kernel HIP events; runs the batches on ONE lane (no overlap)
         ctx.stats_reset()
+        pb0 = ctx.primary_beam_stats()
         ctx.pt_rgb_render(f0, probe_frames, args.seed, 15, 64, _native.TRAVERSE_ORDERED | _native.COUNT_NODES)
         ctx.sync()
         co = ctx.stats()
+        pb1 = ctx.primary_beam_stats()
+        # camera rays that went through their pixels' candidate lists (k_pvb_cand) are not k_trace's: its launches of this pass traced the rest
+        listed = (pb1["rays"] - pb0["rays"]) - (pb1["rays_to_k_trace"] - pb0["rays_to_k_trace"]) if pb1["rays"] >= pb0["rays"] else 0
         ctx.stats_reset()
         ctx.pt_rgb_render(f0, probe_frames, args.seed, 15, 64, 0)
         ctx.sync()
@@ -783,7 +787,7 @@ def main():
         ctx.set_option("time_kernels", 0)
         n_launch = max(t["launches_trace_closest"] + t["launches_trace_shadow"], 1)
         avg_ms = (t["ms_trace_closest"] + t["ms_trace_shadow"]) / n_launch
-        rays_o = co["rays_closest"] + co["rays_shadow"]
+        rays_o = co["rays_closest"] + co["rays_shadow"] - listed          # the rays k_trace traced in that pass
         # what the launch gathers from global memory: 64 B per 4-wide node visit that is not served by the LDS copy of
         # the tree top, 48 B per primitive test, 24 B ray fetch + 16 B hit record per ray
         node_visits = (co["box_closest"] + co["box_shadow"]) / 4.0
@@ -872,7 +876,7 @@ def main():
             top = {"achieved": round(achieved, 1), "peak": round(peak_ws, 1), "unit": "GB/s", "frac": round(achieved / peak_ws, 4) if peak_ws > 0 else None}
         alg_trace = alg_closest + alg_shadow
         result["roofline"] = {
-            "bound": bound, "kernel": "k_trace<ordered> (closest-hit + NEE shadow rays)",
+            "bound": bound, "kernel": "k_trace<ordered> (closest-hit + NEE shadow rays; of the camera rays only those their pixels' candidate lists leave over: k_pvb_cand is not in these launches)",
             "achieved": top["achieved"], "peak": top["peak"], "unit": top["unit"], "frac": top["frac"],
             "traffic": tr_bytes,
             "fractions": fr, "hbm": hbm, "l2": l2, "valu": valu,
@@ -908,6 +912,7 @@ def main():
             "k_shade": shade_ceilings(pmc.get("k_shade") if ok else None),
             "traffic_detail": pmc, "bvh": info,
             "avg_launch_ms": round(avg_ms, 5), "launches": int(n_launch),
+            "rays_traced_by_k_trace_in_these_launches": int(rays_o), "camera_rays_resolved_by_candidate_lists": int(listed),
             "node_visits_per_ray": round(node_visits / max(rays_o, 1), 2),
             "lds_node_visits_per_ray": round(lds_visits / max(rays_o, 1), 2),
             "prim_tests_per_ray": round((co["leaf_closest"] + co["leaf_shadow"]) / max(rays_o, 1), 2),

@@ -1698,7 +1698,7 @@ int pt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed,
     collect_live_counts(c);
     // the pixels' candidate lists for the camera rays (tirt_pvb.hip), made on the main stream when the scene, the camera or the film changed since
     bool beams_ready = false;
-    if (c->primary_beams && FB >= c->primary_beams_min_frames && !(flags & (TIRT_TRAVERSE_EXHAUSTIVE | TIRT_COUNT_NODES))) {
+    if (c->primary_beams && FB >= c->primary_beams_min_frames && !(flags & TIRT_TRAVERSE_EXHAUSTIVE)) {
         if (int rc = pvb_prepare(c)) return rc;
         beams_ready = c->pvb_valid;
     }
@@ -1791,7 +1791,7 @@ int pt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed,
             a.scount_ptr = (b == 0) ? nullptr : cnt_shadow(b - 1);
             fill_tunables(c, a);
             a.timeline = timeline_for(c, flags, grid_full);
-            stamp(evc, true);
+            if (!(b == 0 && use_beams)) stamp(evc, true);
             if (b == 0 && use_beams) {
                 // camera rays: each against the list of leaves its pixel's rays can hit first (tirt_pvb.hip); those that find nothing there go to k_trace.  Scratch the
                 // batch does not touch before shade(0): the `out` arrays (slots, directions of the leftover rays), the shadow-ray arrays (their hit records)
@@ -1799,12 +1799,14 @@ int pt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed,
                 float4 *const fb_hit = (float4 *)L.ps.sox;               // sox, soy, soz, sdx: four consecutive arrays of the lane's pitch
                 pvb_launch_cand(c, st, bv, in.dx, in.dy, in.dz, tm, P, S, L.ps.hit, fb_count, (int *)out.ox, out.dx, out.dy, out.dz, ctr);
                 TraceArgs a2 = a;
-                a2.dx = out.dx; a2.dy = out.dy; a2.dz = out.dz; a2.count_ptr = fb_count; a2.count_fixed = S; a2.hit = fb_hit; a2.no_ray_count = 1; a2.timeline = nullptr;
+                a2.dx = out.dx; a2.dy = out.dy; a2.dz = out.dz; a2.count_ptr = fb_count; a2.count_fixed = S; a2.hit = fb_hit; a2.no_ray_count = 1;
+                stamp(evc, true);                                      // (the traversal timers and counters see k_trace's launch, not the list pass)
                 if (int rc = launch_trace<KIND_CLOSEST>(c, st, a2, flags, grid_full)) return rc;
+                stamp(evc, false);
                 pvb_launch_scatter(st, fb_count, (const int *)out.ox, fb_hit, L.ps.hit);
             } else
             if (int rc = (b == 0) ? launch_trace<KIND_CLOSEST>(c, st, a, flags, grid_full) : launch_trace<KIND_MIXED>(c, st, a, flags, grid_full)) return rc;
-            stamp(evc, false);
+            if (!(b == 0 && use_beams)) stamp(evc, false);
             c->launches_trace_closest++;
             counts_known = b;              // append_ctr(b - 1), the paths that entered bounce b, has been written by now
 
