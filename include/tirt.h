@@ -109,7 +109,7 @@ int tirt_sync(tirt_ctx *ctx);
  *          "primary_beams" -- (round 5, default 1) camera rays against per-pixel lists of the leaves they can hit first instead of the bounce-0 traversal launch
  *            (csrc/tirt_pvb.hip: the lists are made once per build / camera / film from five probe rays and a walk of the pixel's pyramid; rays that find no hit
  *            on their list are traced the ordinary way; the same hit records bit for bit: +15 % on the headline scene); 0 = off.  "primary_beams_min_frames"
- *            (default 32): batches of fewer frames keep the ordinary launch (making the lists costs ~8 ms at 1024^2)
+ *            (default 16): batches of fewer frames keep the ordinary launch (making the lists costs 1.2 ms at 1024^2)
  *          "bdpt_batch_items" -- (frame, pixel) items per BDPT wavefront batch (default 16 Mi, ~2.2 KB of HBM each: 38 GB; 5 Mi = 12 GB runs config 5 at 2 900 Mrays/s), shared by the batches in flight on render lanes 0 and 1 ("bdpt_lanes", 1..4, default 2: three or four measured no faster)
  *            (config 5, round 3: 4 Mi 2 890, 8 Mi 2 900, 16 Mi 2 995, 32 Mi 2 980 Mrays/s; 256 frames: 8 Mi 2 912, 16 Mi 2 923, 32 Mi 3 032)
  *            A call never sizes its batches beyond what hipMemGetInfo reports free (less 2 GB): next to other users of the device it renders in smaller batches.

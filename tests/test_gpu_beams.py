@@ -165,14 +165,14 @@ def test_beams_in_pt_spec(gpu_ctx_ok):
 
 
 def test_short_calls_skip_the_lists(gpu_ctx_ok):
-    """a batch of fewer than primary_beams_min_frames frames (default 32: making the lists costs what they save on ~90 frames of a 1024^2 film) traces its
+    """a batch of fewer than primary_beams_min_frames frames (default 16: making the lists costs what they save on ~13 frames of a 1024^2 film) traces its
     camera rays the ordinary way"""
     W = H = 64
     ex = scenes.cornell_box(W, H, 4, device_id=0)
     ex.build_scene()
     ctx = ex.scene.ctx
     ctx.set_option("merge_paths", 0)
-    ctx.pt_rgb_render(0, 31, 1, 15, 64, 0)
+    ctx.pt_rgb_render(0, 15, 1, 15, 64, 0)
     assert ctx.primary_beam_stats()["rays"] == 0
-    ctx.pt_rgb_render(31, 32, 1, 15, 64, 0)
-    assert ctx.primary_beam_stats()["rays"] == 32 * W * H
+    ctx.pt_rgb_render(15, 16, 1, 15, 64, 0)
+    assert ctx.primary_beam_stats()["rays"] == 16 * W * H

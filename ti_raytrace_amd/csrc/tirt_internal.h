@@ -295,7 +295,7 @@ struct tirt_ctx {
 
     // primary visibility through pixel beams (tirt_pvb.hip): per local pixel the leaves its camera rays can hit first, made once per (build, camera, film)
     struct PvbKey { tirt::CameraView cam; unsigned long long build; int W, H, tile_rank, tile_count, tile_size, tile_blocked, P; } pvb_key;
-    bool pvb_valid = false; int primary_beams = 1, primary_beams_min_frames = 32;      // options "primary_beams" (0 = off) and "primary_beams_min_frames" (batches of fewer frames trace their camera rays the ordinary way)
+    bool pvb_valid = false; int primary_beams = 1, primary_beams_min_frames = 16;      // options "primary_beams" (0 = off) and "primary_beams_min_frames" (batches of fewer frames trace their camera rays the ordinary way)
     unsigned long long build_serial = 0;          // counts lbvh_build calls
     tirt::DevBuf pvb_count, pvb_cand, pvb_bound, pvb_tmp, pvb_stat;
 

@@ -57,27 +57,37 @@ __global__ void k_pvb_probes(CameraView cam, TileMap tm, int P, float4 *rays)
 
 TD float h2f(unsigned h) { return (float)__builtin_bit_cast(_Float16, (unsigned short)h); }
 
-__global__ void k_pvb_beam(BvhView b, CameraView cam, TileMap tm, int P, const float4 *probe_hits, int *count, int2 *cand, float *bound_out,
-                           unsigned long long *stat)
+// One WAVE walks the tree for its 64 neighbouring pixels (an 8 x 8 block of the film when the tiles are blocked): one node stack for the wave, a node's record loaded once,
+// every lane tests the node's four boxes against ITS pixel's pyramid and a child is pushed if any lane's pyramid meets it (a lane whose pyramid missed the parent misses the
+// children too -- the boxes nest --, and a leaf too many on a list would only cost its test).  The first version gave every pixel its own walk and its own stack in scratch
+// memory: 5.2 ms for a 1024^2 film against this one's ~1 (`profiles/r05ar_*`).
+__global__ __launch_bounds__(64) void k_pvb_beam(BvhView b, CameraView cam, TileMap tm, int P, const float4 *probe_hits, int *count, int2 *cand, float *bound_out,
+                                                 unsigned long long *stat)
 {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= P) return;
-    const int p = local_to_pixel(tm, k), i = p / tm.H, j = p - i * tm.H;
+    __shared__ int s_stack[PVB_STACK];
+    __shared__ int2 s_list[PVB_CMAX * 64];                 // [entry][lane]
+    const int lane = threadIdx.x, k = blockIdx.x * 64 + lane;
+    const bool live = k < P;
+    const int p = local_to_pixel(tm, live ? k : 0), i = p / tm.H, j = p - i * tm.H;
     float bound = 0.0f;
-    for (int pr = 0; pr < 5; pr++) {
-        const float4 h = probe_hits[(size_t)pr * P + k];
-        bound = (__float_as_int(h.w) >= 0 && h.x < INF_VALUE) ? maxf(bound, h.x) : INF_VALUE;
-        if (!(bound < INF_VALUE)) break;
+    if (live) {
+        for (int pr = 0; pr < 5; pr++) {
+            const float4 h = probe_hits[(size_t)pr * P + k];
+            bound = (__float_as_int(h.w) >= 0 && h.x < INF_VALUE) ? maxf(bound, h.x) : INF_VALUE;
+            if (!(bound < INF_VALUE)) break;
+        }
+        if (bound < INF_VALUE) bound = bound * 1.0001f;
     }
-    if (bound < INF_VALUE) bound = bound * 1.0001f;
     const v3 eye = V(cam.eye[0], cam.eye[1], cam.eye[2]);
     const v3 cell = V(b.cell[0], b.cell[1], b.cell[2]), gmin = V(b.grid_min[0], b.grid_min[1], b.grid_min[2]);
     // k_trace's margin around a box, in cells (0.25 + 0.25 per root-box extent between the eye and the grid), and a little more
     const float rho = maxf(maxf(absf(gmin.x - eye.x) * b.inv_extent[0], absf(gmin.y - eye.y) * b.inv_extent[1]), absf(gmin.z - eye.z) * b.inv_extent[2]);
     const float mc = 0.30f + 0.25f * rho;
     int n = 0;
-    bool whole = rho <= PVB_FAR_RHO;
-    if (whole) {
+    const bool near_enough = rho <= PVB_FAR_RHO;            // (wave-uniform)
+    bool open = live && near_enough;                        // this lane still collects leaves
+    bool stack_over = false;
+    if (near_enough) {
         v3 dg[4];
         const float W = PVB_WIDEN;
         const float cx[4] = {-W, W, W, -W}, cy[4] = {-W, -W, W, W};
@@ -95,18 +105,19 @@ __global__ void k_pvb_beam(BvhView b, CameraView cam, TileMap tm, int P, const f
         }
         const v3 ac = V(dc.x * cell.x, dc.y * cell.y, dc.z * cell.z);           // projection on the axis, per cell
         const float abase = dot(gmin - eye, dc);
-        int stack[PVB_STACK]; int sp = 0;
-        int lcode[PVB_CMAX]; float lnear[PVB_CMAX];
-        int cur = b.root_qcode;
+        int sp = 0;                                         // (wave-uniform: every push below is decided by a ballot)
+        const int root = b.root_qcode;
         // a one-primitive scene: the root IS the leaf
-        if (cur < 0) { if (cur != (int)0x80000000 && cur != TR_EMPTY) { lcode[0] = cur; lnear[0] = 0.0f; n = 1; } cur = (int)0x80000000; }
-        while (cur >= 0 || sp > 0) {
-            if (cur < 0) cur = stack[--sp];
-            const uint4 *w = (const uint4 *)((const char *)b.cnode + ((size_t)(unsigned)cur << 6));
+        if (root < 0) { if (root != (int)0x80000000 && root != TR_EMPTY && open) { s_list[lane] = make_int2(root, 0); n = 1; } }
+        else { s_stack[0] = root; sp = 1; }
+        while (sp > 0) {
+            if (__ballot(open) == 0ull) break;
+            const int node = __builtin_amdgcn_readfirstlane(s_stack[--sp]);
+            const uint4 *w = (const uint4 *)((const char *)b.cnode + ((size_t)(unsigned)node << 6));
             const uint4 q0 = w[0], q1 = w[1], q2 = w[2], q3 = w[3];
             const unsigned wx[4] = {q0.x, q0.w, q1.z, q2.y}, wy[4] = {q0.y, q1.x, q1.w, q2.z}, wz[4] = {q0.z, q1.y, q2.x, q2.w};
             const int cc[4] = {(int)q3.x, (int)q3.y, (int)q3.z, (int)q3.w};
-            cur = (int)0x80000000;
+#pragma unroll
             for (int ch = 0; ch < 4; ch++) {
                 const int code = cc[ch];
                 if (code == TR_EMPTY) continue;
@@ -115,69 +126,71 @@ __global__ void k_pvb_beam(BvhView b, CameraView cam, TileMap tm, int P, const f
                 const float lz = h2f(wz[ch] & 0xffffu) - mc, hz = h2f(wz[ch] >> 16) + mc;
                 if (!(lx <= hx && ly <= hy && lz <= hz)) continue;
                 bool out = false;
+#pragma unroll
                 for (int q = 0; q < 4; q++) {
                     const v3 nn = nrm[q];
-                    const float s = nn.x * ((nn.x >= 0.0f ? hx : lx) - og.x) + nn.y * ((nn.y >= 0.0f ? hy : ly) - og.y) + nn.z * ((nn.z >= 0.0f ? hz : lz) - og.z);
-                    out = out || (s < -eps[q]);
+                    const float sd = nn.x * ((nn.x >= 0.0f ? hx : lx) - og.x) + nn.y * ((nn.y >= 0.0f ? hy : ly) - og.y) + nn.z * ((nn.z >= 0.0f ? hz : lz) - og.z);
+                    out = out || (sd < -eps[q]);
                 }
-                if (out) continue;
                 // nearest any ray of the pyramid can reach the box: the least projection of the box on the axis (<= the distance along any unit direction)
                 const float nearp = abase + ac.x * (ac.x >= 0.0f ? lx : hx) + ac.y * (ac.y >= 0.0f ? ly : hy) + ac.z * (ac.z >= 0.0f ? lz : hz);
-                if (nearp > bound) continue;
+                bool pass = open && !out && !(nearp > bound);
+                if (__ballot(pass) == 0ull) continue;
                 if (code >= 0) {
-                    if (cur < 0) cur = code;
-                    else if (sp < PVB_STACK) stack[sp++] = code;
-                    else whole = false;
-                } else {
-                    // a triangle leaf: the triangle itself against the pyramid (its box met it; all three corners outside one face: no ray of the pixel
-                    // comes nearer to it than the widening of the pyramid, a twentieth of a pixel -- the primitive test's own slack is 1e-6 of the
-                    // distance), and the least projection of its corners on the axis instead of its box's (no point of it is nearer)
-                    float nr = nearp;
-                    const int lc = ~code;
-                    if (((lc >> 30) & 1) == 0) {
-                        const float4 *tp = b.tri + (size_t)(lc & 0x3fffffff) * TRI_STRIDE;
-                        const float4 ta = tp[0], tb = tp[1], tc = tp[2];
-                        const v3 w0 = V(ta.x, ta.y, ta.z), w1 = V(tb.x, tb.y, tb.z), w2 = V(tc.x, tc.y, tc.z);
-                        const v3 g0 = V((w0.x - eye.x) / cell.x, (w0.y - eye.y) / cell.y, (w0.z - eye.z) / cell.z);
-                        const v3 g1 = V((w1.x - eye.x) / cell.x, (w1.y - eye.y) / cell.y, (w1.z - eye.z) / cell.z);
-                        const v3 g2 = V((w2.x - eye.x) / cell.x, (w2.y - eye.y) / cell.y, (w2.z - eye.z) / cell.z);
-                        bool off = false;
-                        for (int q = 0; q < 4; q++) {
-                            const float e = eps[q] + 0.05f * (absf(nrm[q].x) + absf(nrm[q].y) + absf(nrm[q].z));      // (+ a twentieth of a cell)
-                            off = off || (dot(nrm[q], g0) < -e && dot(nrm[q], g1) < -e && dot(nrm[q], g2) < -e);
-                        }
-                        if (off) continue;
-                        const float pr = __builtin_fminf(__builtin_fminf(dot(w0 - eye, dc), dot(w1 - eye, dc)), dot(w2 - eye, dc));
-                        nr = maxf(nr, pr - 1.0e-4f * absf(pr) - 1.0e-6f);
-                        if (nr > bound) continue;
+                    if (sp < PVB_STACK) { s_stack[sp] = code; sp++; } else stack_over = true;
+                    continue;
+                }
+                // a triangle leaf: the triangle itself against the pyramid (its box met it; all three corners outside one face: no ray of the pixel
+                // comes nearer to it than the widening of the pyramid, a twentieth of a pixel -- the primitive test's own slack is 1e-6 of the
+                // distance), and the least projection of its corners on the axis instead of its box's (no point of it is nearer)
+                float nr = nearp;
+                const int lc = ~code;
+                if (((lc >> 30) & 1) == 0) {
+                    const float4 *tp = b.tri + (size_t)(lc & 0x3fffffff) * TRI_STRIDE;
+                    const float4 ta = tp[0], tb = tp[1], tc = tp[2];
+                    const v3 w0 = V(ta.x, ta.y, ta.z), w1 = V(tb.x, tb.y, tb.z), w2 = V(tc.x, tc.y, tc.z);
+                    const v3 g0 = V((w0.x - eye.x) / cell.x, (w0.y - eye.y) / cell.y, (w0.z - eye.z) / cell.z);
+                    const v3 g1 = V((w1.x - eye.x) / cell.x, (w1.y - eye.y) / cell.y, (w1.z - eye.z) / cell.z);
+                    const v3 g2 = V((w2.x - eye.x) / cell.x, (w2.y - eye.y) / cell.y, (w2.z - eye.z) / cell.z);
+                    bool off = false;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const float e = eps[q] + 0.05f * (absf(nrm[q].x) + absf(nrm[q].y) + absf(nrm[q].z));      // (+ a twentieth of a cell)
+                        off = off || (dot(nrm[q], g0) < -e && dot(nrm[q], g1) < -e && dot(nrm[q], g2) < -e);
                     }
-                    if (n < PVB_CMAX) { lcode[n] = code; lnear[n] = maxf(nr, 0.0f); }
+                    const float pr = __builtin_fminf(__builtin_fminf(dot(w0 - eye, dc), dot(w1 - eye, dc)), dot(w2 - eye, dc));
+                    nr = maxf(nr, pr - 1.0e-4f * absf(pr) - 1.0e-6f);
+                    pass = pass && !off && !(nr > bound);
+                }
+                if (pass) {
+                    if (n < PVB_CMAX) s_list[n * 64 + lane] = make_int2(code, __float_as_int(maxf(nr, 0.0f)));
                     n++;
+                    if (n > PVB_CMAX) open = false;         // more leaves than a list holds: the pixel is left to k_trace
                 }
             }
-            if (!whole || n > PVB_CMAX) break;
-        }
-        if (n > PVB_CMAX) whole = false;
-        if (whole) {
-            // nearest first: a ray that has a hit stops at the first leaf that lies beyond it (k_pvb_cand)
-            for (int a = 1; a < n; a++) {
-                const int cd = lcode[a]; const float nr = lnear[a];
-                int z = a - 1;
-                while (z >= 0 && lnear[z] > nr) { lcode[z + 1] = lcode[z]; lnear[z + 1] = lnear[z]; z--; }
-                lcode[z + 1] = cd; lnear[z + 1] = nr;
-            }
-            for (int a = 0; a < n; a++) cand[(size_t)a * P + k] = make_int2(lcode[a], __float_as_int(lnear[a]));
+            if (stack_over) break;
         }
     }
-    count[k] = whole ? n : -1;
-    bound_out[k] = bound;
+    const bool whole = live && near_enough && !stack_over && n <= PVB_CMAX;
+    if (whole) {
+        // nearest first: a ray that has a hit stops at the first leaf that lies beyond it (k_pvb_cand)
+        for (int a = 1; a < n; a++) {
+            const int2 e = s_list[a * 64 + lane];
+            const float nr = __int_as_float(e.y);
+            int z = a - 1;
+            while (z >= 0 && __int_as_float(s_list[z * 64 + lane].y) > nr) { s_list[(z + 1) * 64 + lane] = s_list[z * 64 + lane]; z--; }
+            s_list[(z + 1) * 64 + lane] = e;
+        }
+        for (int a = 0; a < n; a++) cand[(size_t)a * P + k] = s_list[a * 64 + lane];
+    }
+    if (live) { count[k] = whole ? n : -1; bound_out[k] = bound; }
     if (stat) {
         // (diagnostics: pixels with a list, leaves on the lists, pixels whose probes all hit)
         const unsigned long long m = __ballot(whole);
-        unsigned long long s = whole ? (unsigned long long)n : 0ull;
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+        unsigned long long sm = whole ? (unsigned long long)n : 0ull;
+        for (int o = 32; o > 0; o >>= 1) sm += __shfl_down(sm, o, 64);
         const unsigned long long mb = __ballot(whole && bound < INF_VALUE);
-        if ((threadIdx.x & 63) == 0) { atomicAdd(&stat[0], (unsigned long long)__popcll(m)); atomicAdd(&stat[1], s); atomicAdd(&stat[2], (unsigned long long)__popcll(mb)); }
+        if (lane == 0) { atomicAdd(&stat[0], (unsigned long long)__popcll(m)); atomicAdd(&stat[1], sm); atomicAdd(&stat[2], (unsigned long long)__popcll(mb)); }
     }
 }
 

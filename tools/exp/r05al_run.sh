@@ -6,7 +6,7 @@ tail -1 /tmp/pv$pb.log | cut -c1-200
 python - <<PY
 import csv,glob
 f=glob.glob("/tmp/pv$pb/**/*kernel_stats.csv",recursive=True)[0]
-for r in list(csv.DictReader(open(f)))[:6]: print("   %-40s x%-4s total %8.3f ms  avg %8.4f ms" % (r["Name"].replace("tirt::","").split("(")[0][:40], r["Calls"], float(r["TotalDurationNs"])/1e6, float(r["AverageNs"])/1e6))
+for r in [x for x in csv.DictReader(open(f)) if "pvb" in x["Name"] or "k_trace" in x["Name"]]: print("   %-40s x%-4s total %8.3f ms  avg %8.4f ms" % (r["Name"].replace("tirt::","").split("(")[0][:40], r["Calls"], float(r["TotalDurationNs"])/1e6, float(r["AverageNs"])/1e6))
 PY
 done
 for pb in; do python $R/bench.py --no-cpu-baseline --no-roofline --no-configs --steps 20 --warmup 5 --opt primary_beams=$pb | tail -1 | cut -c90-220; done
