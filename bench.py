@@ -761,6 +761,22 @@ def main():
         result["oracle_sample"] = "%d pixels from linear pixel %d x %d frames (warm-up + timed) rendered by the CPU oracle in %.1f s: film words equal bit for bit" % (
             npx, p0, n_frames_film, time.perf_counter() - t_or)
 
+    # ---- the same steps with the camera rays' candidate lists switched off (one GPU only; after the timed region and the oracle sample): what `value` would be
+    #      if bounce 0 went through k_trace like every other bounce -- the lists are a per-camera structure made in the warm-up, like the BVH, and `value` uses them
+    if rank == 0 and world == 1 and not force_dist and isinstance(result.get("primary_beams"), dict) and "error" not in result["primary_beams"]:
+        try:
+            ctx.set_option("primary_beams", 0)
+            run_steps(1); ctx.sync()
+            ctx.stats_reset()
+            t0 = time.perf_counter()
+            run_steps(args.steps); ctx.sync()
+            dt = time.perf_counter() - t0
+            st0 = ctx.stats()
+            result["primary_beams"]["value_with_the_lists_off"] = round((st0["rays_closest"] + st0["rays_shadow"]) / dt / 1e6, 3)
+            result["primary_beams"]["ms_per_step_with_the_lists_off"] = round(dt * 1e3 / max(args.steps, 1), 4)
+        finally:
+            ctx.set_option("primary_beams", 1)
+
     # ---- roofline for the dominant kernel (rank 0's shard, untimed extra passes) -----------------
     if not args.no_roofline and rank == 0:
         probe_frames = fps
