@@ -213,7 +213,7 @@ def measure_trace_counters(args):
         # every kernel of the wavefront loop, both profiled steps: what one step asks of the VALUs (for `whole_job` in the roofline object)
         per = {}
         for name, v in k.items():
-            if name.startswith(("k_trace", "k_shade", "k_generate", "k_film")) and v.get("SQ_INSTS_VALU", 0) > 0:
+            if name.startswith(("k_trace", "k_shade", "k_generate", "k_film", "k_pvb_cand", "k_pvb_scatter")) and v.get("SQ_INSTS_VALU", 0) > 0:
                 per[name] = round(v["SQ_INSTS_VALU"] / 2.0)
         out["valu_wave_insts_per_step_by_kernel"] = per
     bytes_per_req = 64.0
