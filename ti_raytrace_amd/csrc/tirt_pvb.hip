@@ -7,11 +7,12 @@
 //
 //   pvb_prepare   once per (scene build, camera, film / tiles):
 //     k_pvb_probes    five rays per pixel -- its centre and its corners -- traced by k_trace like any other ray;
-//     k_pvb_beam      bound(pixel) = the farthest of their hit distances (x 1.0001); the pyramid of the pixel (its corner
+//     k_pvb_beam      bound(pixel) = the farthest of their hit distances x 1.5 (PVB_REACH); the pyramid of the pixel (its corner
 //                     directions moved outward by a twentieth of a pixel) is walked down the quantised 4-wide tree and every LEAF
 //                     whose box -- enlarged by k_trace's own margin -- it meets nearer than bound, and whose triangle does not lie
-//                     wholly outside one of its faces, goes on the pixel's list, nearest first (at most PVB_CMAX; a longer list:
-//                     the pixel is left to k_trace);
+//                     wholly outside one of its faces, goes on the pixel's list, nearest first.  A list holds PVB_CMAX leaves: when
+//                     one more turns up the farthest goes and the pixel's bound comes in to just below it (the list stays complete
+//                     up to its bound);
 //   per batch, instead of the bounce-0 launch of k_trace:
 //     k_pvb_cand      one thread per camera ray: the primitive tests of its pixel's list -- k_trace's leaf step word for word:
 //                     Moller-Trumbore / sphere, `0 < t < hit_t` with the equal-distance rule, the `slabs` verification of the
@@ -36,6 +37,7 @@ namespace tirt {
 constexpr int PVB_CMAX = 24;                        // leaves on a pixel's list (12: 3 % of the headline's pixels without a list, -1.3 %; 48: no gain -- profiles/r05an_*)
 constexpr int PVB_STACK = 96;                       // node stack of a beam walk (4-wide tree: three entries per level at most)
 constexpr float PVB_WIDEN = 0.55f;                  // the pyramid's corners in pixels from the centre (the jitter is [-0.5, 0.5))
+constexpr float PVB_REACH = 1.5f;                   // a pixel's list reaches this far beyond the farthest probe hit (1.0001: 1.4 % of the camera rays find nothing on their list, 1.25: 0.10 %, 1.5: 0.08 %; profiles/r05an_*)
 constexpr int PVB_BLOCK = 1024;                      // threads of a k_pvb_cand block
 constexpr float PVB_FAR_RHO = 8.0f;                 // = TR_FAR_RHO (tirt_render.hip)
 
@@ -76,7 +78,7 @@ __global__ __launch_bounds__(64) void k_pvb_beam(BvhView b, CameraView cam, Tile
             bound = (__float_as_int(h.w) >= 0 && h.x < INF_VALUE) ? maxf(bound, h.x) : INF_VALUE;
             if (!(bound < INF_VALUE)) break;
         }
-        if (bound < INF_VALUE) bound = bound * 1.0001f;
+        if (bound < INF_VALUE) bound = bound * PVB_REACH;
     }
     const v3 eye = V(cam.eye[0], cam.eye[1], cam.eye[2]);
     const v3 cell = V(b.cell[0], b.cell[1], b.cell[2]), gmin = V(b.grid_min[0], b.grid_min[1], b.grid_min[2]);
@@ -163,16 +165,27 @@ __global__ __launch_bounds__(64) void k_pvb_beam(BvhView b, CameraView cam, Tile
                     pass = pass && !off && !(nr > bound);
                 }
                 if (pass) {
-                    if (n < PVB_CMAX) s_list[n * 64 + lane] = make_int2(code, __float_as_int(maxf(nr, 0.0f)));
-                    n++;
-                    if (n > PVB_CMAX) open = false;         // more leaves than a list holds: the pixel is left to k_trace
+                    const float nr0 = maxf(nr, 0.0f);
+                    if (n < PVB_CMAX) { s_list[n * 64 + lane] = make_int2(code, __float_as_int(nr0)); n++; }
+                    else {
+                        // more leaves than a list holds: the farthest one goes (this leaf or one on the list) and the pixel's bound comes in to just below where it
+                        // started -- the list stays complete up to its bound, the rays that find nothing that near are k_trace's
+                        int far = -1; float fn = nr0;
+                        for (int a = 0; a < PVB_CMAX; a++) { const float x = __int_as_float(s_list[a * 64 + lane].y); if (x > fn) { fn = x; far = a; } }
+                        if (far >= 0) s_list[far * 64 + lane] = make_int2(code, __float_as_int(nr0));
+                        bound = __builtin_fminf(bound, fn * 0.999999f);
+                    }
                 }
             }
             if (stack_over) break;
         }
     }
-    const bool whole = live && near_enough && !stack_over && n <= PVB_CMAX;
+    const bool whole = live && near_enough && !stack_over;
     if (whole) {
+        // (a bound that came in while the list was made: what lies beyond it is of no use)
+        int m = 0;
+        for (int a = 0; a < n; a++) { const int2 e = s_list[a * 64 + lane]; if (__int_as_float(e.y) <= bound) { s_list[m * 64 + lane] = e; m++; } }
+        n = m;
         // nearest first: a ray that has a hit stops at the first leaf that lies beyond it (k_pvb_cand)
         for (int a = 1; a < n; a++) {
             const int2 e = s_list[a * 64 + lane];
