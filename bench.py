@@ -763,7 +763,8 @@ def main():
 
     # ---- the same steps with the camera rays' candidate lists switched off (one GPU only; after the timed region and the oracle sample): what `value` would be
     #      if bounce 0 went through k_trace like every other bounce -- the lists are a per-camera structure made in the warm-up, like the BVH, and `value` uses them
-    if rank == 0 and world == 1 and not force_dist and isinstance(result.get("primary_beams"), dict) and "error" not in result["primary_beams"]:
+    # (not in the profiler children and tuning runs, which pass --no-roofline: their kernel statistics are of the timed configuration only)
+    if rank == 0 and world == 1 and not force_dist and not args.no_roofline and isinstance(result.get("primary_beams"), dict) and "error" not in result["primary_beams"]:
         try:
             ctx.set_option("primary_beams", 0)
             run_steps(1); ctx.sync()
