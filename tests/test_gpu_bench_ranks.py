@@ -73,7 +73,7 @@ def test_bench_line_carries_the_contract_fields(gpu_ctx_ok, tmp_path):
     roof = r["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "fractions", "bound_evidence"):
         assert k in roof, k
-    assert roof["bound"] == "gather" and 0.05 < roof["frac"] < 1.5 and roof["traffic"] and roof["traffic"] > 0
+    assert roof["bound"] == "gather" and 0.01 < roof["frac"] < 1.5 and roof["traffic"] and roof["traffic"] > 0
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
     cb = r["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
