@@ -104,12 +104,7 @@ constexpr size_t TR_LADDER_LDS = 4 * TR_BLOCK;           // bound-ladder builds 
 #else
 constexpr size_t TR_LADDER_LDS = 0;
 #endif
-#ifdef TR_COOP
-constexpr size_t TR_STAGE_LDS = (size_t)(TR_BLOCK / 64) * 4 * 1040;      // quad-cooperative record fetch: four staging regions per wave (tirt_render.hip)
-#else
-constexpr size_t TR_STAGE_LDS = 0;
-#endif
-inline size_t trace_lds_bytes(int depth) { return sizeof(int) * (size_t)depth * TR_BLOCK + (size_t)TR_TOP_SLOTS * 64 + TR_LADDER_LDS + TR_STAGE_LDS; }
+inline size_t trace_lds_bytes(int depth) { return sizeof(int) * (size_t)depth * TR_BLOCK + (size_t)TR_TOP_SLOTS * 64 + TR_LADDER_LDS; }
 struct BvhView {
     const float4 *wnode;
     const float4 *tri;
@@ -125,6 +120,79 @@ struct BvhView {
     // a ray that starts too far away for that box to be safe (cull_far < 0, k_trace) gets these leaves pushed at its start.
     int far_qcode;                // where a far-origin ray starts: root_qcode, or the first of the chain nodes that hold the padded analytic spheres beside the root (lbvh_build)
 };
+
+// ---- what k_trace (ordered and exhaustive), k_pvb_beam and k_pvb_cand must agree on to the last bit: ONE definition each ----
+constexpr float TR_FAR_RHO = 8.0f;            // ordered traversal: rays starting further than this many root-box extents from the grid do not cull by distance (and a camera out there gets no candidate lists)
+// Conservative margin of the quantised boxes, in cells: 0.25 + 0.25 per root-box extent between the origin and the grid (largest axis).  It has to cover (i) the
+// rounding of q * gA + gB (<= 0.016 cells per extent of distance) and (ii) what the reference's primitive tests accept outside a leaf box: Moller-Trumbore works on
+// o - v0 and is off by ~5e-7 of the origin's distance IN EVERY DIRECTION (0.03 cells per extent).  k_pvb_beam lists leaves for k_trace's walk and adds TR_MARGIN_BEAM_EXTRA.
+constexpr float TR_MARGIN_CELLS = 0.25f, TR_MARGIN_PER_RHO = 0.25f, TR_MARGIN_BEAM_EXTRA = 0.05f;
+TD float trace_origin_rho(const BvhView &b, float ox, float oy, float oz)
+{ return maxf(maxf(absf(b.grid_min[0] - ox) * b.inv_extent[0], absf(b.grid_min[1] - oy) * b.inv_extent[1]), absf(b.grid_min[2] - oz) * b.inv_extent[2]); }
+TD float trace_margin_cells(float rho) { return TR_MARGIN_CELLS + TR_MARGIN_PER_RHO * rho; }
+
+// One leaf of the traversal tree against one ray: the reference's primitive test (Scene.py:529-638 intersect_prim: Moller-Trumbore on E1 = v1 - v0, E2 = v2 - v0, or
+// the analytic sphere), its acceptance rule `0 < t < hit_t` (Scene.py:702-744) with the equal-distance rule of the reference's visiting order (the candidate with the
+// larger compact-node index wins), and -- VERIFY, the ordered walk and the candidate lists -- the proof that the reference would have REACHED this leaf: `slabs` on the
+// leaf's exact box (it implies every ancestor's: `slabs` is monotone in the plane positions), else `slabs` on every proper ancestor (compact_node rows along cparent).
+// `code` = ~(child code of the leaf) = record slot | shape << 30.  Returns whether the hit (hit_t .. hit_leaf) was replaced.  Used by k_trace and k_pvb_cand: one
+// leaf step, so the two cannot drift apart (they did not in round 5, but only the on / off tests said so).
+template <bool VERIFY>
+TD bool trace_leaf_step(const BvhView &b, const RayCtx &r, const bool par, const int code, float &hit_t, float &hit_u, float &hit_v, int &hit_prim, int &hit_leaf)
+{
+    const float4 *tp = b.tri + (size_t)(code & 0x3fffffff) * TRI_STRIDE;          // records in the traversal tree's leaf order
+    // (the records themselves must NOT be loaded non-temporally: -25 %, profiles/r05m -- their residency in L2 is what the kernel lives on)
+    const float4 ta = tp[0], tb = tp[1], tc = tp[2];
+    int prim = __float_as_int(tc.w);                                              // the primitive id rides in the last word
+    const v3 o = V(r.ox, r.oy, r.oz), d = V(r.dx, r.dy, r.dz);
+    const bool is_tri = ((code >> 30) & 1) == 0;
+    const v3 pa = V(ta.x, ta.y, ta.z), pb = V(tb.x, tb.y, tb.z), pc = V(tc.x, tc.y, tc.z);
+    float t, u, v;
+    bool sph = false;
+    if (is_tri) {
+        t = intersect_tri_packed(o, d, pa, pb - pa, pc - pa, u, v);          // E1 = v2 - v1, E2 = v3 - v1 (Scene.py:608-609)
+    } else {
+        // Analytic sphere (Scene.py:565-596).  Its root is t = (-b - sqrt(b^2 - 4ac)) / 2 / a with b = -2 (d . oc), a = d . d > 0: for
+        // d . oc <= 0 the numerator is a non-positive number minus a square root -- t <= 0, or NaN -- and such a t is never a
+        // candidate (0 < t < hit_t).  Exactly so in fp32 (signs, no rounding involved), so the two square roots and two divisions
+        // (~80 instructions, which the whole wave would issue for one lane) are only run for rays that head towards the centre.
+        u = 0.0f; v = 0.0f; t = INF_VALUE;
+        if ((int)tb.y == SHAPE_SPHERE) { const v3 oc = pa - o; sph = dot(d, oc) > 0.0f; }
+    }
+    if (__builtin_amdgcn_ballot_w64(sph) != 0ull) { if (sph) { float cc; t = intersect_sphere(o, d, pa, tb.x, cc); } }
+    const int leaf = __float_as_int(ta.w);
+    // reference: accept iff 0 < t < hit_t (so never t >= INF_VALUE); equal-t candidates: see above
+    bool cand = (t > 0.0f) & ((t < hit_t) | ((t == hit_t) & (hit_leaf >= 0) & (leaf > hit_leaf)));
+    if (VERIFY && cand) {
+        // the leaf's exact box is the min / max of the three positions just loaded (accel/LBvh.py:397-426; spheres: centre -+ r)
+        v3 bmn, bmx;
+        if (is_tri) {
+            // v_min3_f32 / v_max3_f32 (6 instructions, not 24 compare + select): positions are never NaN, and which of
+            // -0 / +0 comes out of a tie changes no comparison of `slabs`
+            bmn = V(__builtin_fminf(__builtin_fminf(pa.x, pb.x), pc.x), __builtin_fminf(__builtin_fminf(pa.y, pb.y), pc.y), __builtin_fminf(__builtin_fminf(pa.z, pb.z), pc.z));
+            bmx = V(__builtin_fmaxf(__builtin_fmaxf(pa.x, pb.x), pc.x), __builtin_fmaxf(__builtin_fmaxf(pa.y, pb.y), pc.y), __builtin_fmaxf(__builtin_fmaxf(pa.z, pb.z), pc.z));
+        } else {
+            bmn = V(pa.x - tb.x, pa.y - tb.x, pa.z - tb.x); bmx = V(pa.x + tb.x, pa.y + tb.x, pa.z + tb.x);
+        }
+        float tn_;
+        const int inside = par ? slabs(r, bmn.x, bmn.y, bmn.z, bmx.x, bmx.y, bmx.z, tn_) : slabs_fast(r, bmn.x, bmn.y, bmn.z, bmx.x, bmx.y, bmx.z, tn_);
+        if (!inside) {
+            // a hit within rounding distance of the leaf box's boundary: the ancestors are asked one by one
+            for (int an = b.cparent[leaf]; an >= 0; an = b.cparent[an]) {
+                const float *ab = b.compact + (size_t)an * CPN_VEC + 2;
+                if (!slabs(r, ab[0], ab[1], ab[2], ab[3], ab[4], ab[5], tn_)) { cand = false; break; }
+            }
+            // the primitive id again, from the leaf's reference row (UtilsFunc.py:get_compact_node_prim): the same number that came with the
+            // primitive record -- read here so that NOTHING of that record has to survive the walk above.  ROCm 7.2's register allocator lets
+            // the walk's row loads (global_load_dwordx4 v[8:11]) land on the register that holds the record's last word while it is still
+            // needed below (tools/dbg/prim_clobber.sh shows the ISA; 156 of 15 000 box-grazing rays on the Cornell box then kept the PREVIOUS
+            // hit's primitive id, tests/test_gpu_trace.py::test_quantised_nodes_on_grazing_rays).  Round 3 pinned the value with an empty asm.
+            prim = (int)b.compact[(size_t)leaf * CPN_VEC + 1];
+        }
+    }
+    if (cand) { hit_t = t; hit_u = u; hit_v = v; hit_prim = prim; hit_leaf = leaf; }
+    return cand;
+}
 
 // Wavefront state, struct-of-arrays in HBM.  Live paths are kept DENSE: every bounce the shade
 // kernel writes the surviving paths' state into the other PathSoA at consecutive indices

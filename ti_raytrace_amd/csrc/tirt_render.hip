@@ -38,11 +38,12 @@ constexpr int TR_GRID_MAX = 2048;      // upper bound on persistent blocks (size
 
 enum { KIND_CLOSEST = 0, KIND_SHADOW_ACC = 1, KIND_MIXED = 2, KIND_QUERY = 3, KIND_TAIL = 4 };
 // The product library is built WITHOUT -DTIRT_EXPERIMENTS: no persistent tail kernel (KIND_TAIL: built in round 4, bit-identical, slower at every
-// switch point), none of the A/B switches of this file (TR_* macros: bound ladder, quad-cooperative fetch, drain diagnostics ...).  `make experiments`
-// builds libtirt_exp.so with them; tools/ and the tests that exercise them load that library through TIRT_LIB_PATH.
-#if !defined(TIRT_EXPERIMENTS) && (defined(TR_NO_STASH) || defined(TR_DRAIN_DIAG) || defined(TR_NO_DRAINED_COUNT) || defined(TR_NODE_FRAC) || defined(TR_NO_VERIFY) || \
-    defined(TR_PAD) || defined(TR_PADG) || defined(TR_COOP) || defined(TR_NO_NT_STREAMS) || defined(TR_NO_ASM_FETCH) || defined(TR_MIN_WAVES) || defined(TR_TAIL_WAVES))
-#error "the TR_* A/B switches of tirt_render.hip need an experiments build: add -DTIRT_EXPERIMENTS"
+// switch point) and no bound ladder (TR_PAD / TR_PADG).  `make experiments` builds libtirt_exp.so with them; tools/ and the tests that exercise them
+// load that library through TIRT_LIB_PATH.  The A/B switches of rounds 3-5 whose question is settled (stash, drained-slices count, node-loop
+// threshold, quad-cooperative fetch, non-temporal streams, asm record fetch, drain diagnostics, no-verify) left this file in round 6:
+// tools/exp/patches/r06_settled_ab_switches_of_k_trace.patch puts them back.
+#if !defined(TIRT_EXPERIMENTS) && (defined(TR_PAD) || defined(TR_PADG))
+#error "the bound ladder (TR_PAD / TR_PADG) needs an experiments build: add -DTIRT_EXPERIMENTS"
 #endif
 // MIXED: closest rays of bounce b + shadow rays of bounce b-1 in one launch.  QUERY: connection rays of BDPT -- "is sprim[q] the closest
 // hit, about sdist[q] away?" walked like a shadow ray (bounded), answered with the hit record (t, u, v, prim) instead of an accumulation.
@@ -234,7 +235,6 @@ typedef _Float16 h2v __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) int lds_int;
 constexpr int TR_PAGE = 8;                    // stack entries moved per page-out / page-in
 constexpr int TR_SENT = (int)0x80000000;      // "stack empty": never a node index nor a leaf code
-constexpr float TR_FAR_RHO = 8.0f;            // ordered traversal: rays starting further than this many root-box extents from the grid do not cull by distance
 
 TD unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 TD bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
@@ -246,9 +246,7 @@ TD unsigned long long wave_sum(unsigned long long v)
     return v;
 }
 
-#ifndef TR_MIN_WAVES
-#define TR_MIN_WAVES 6        // 80 VGPRs: five 256-thread blocks per CU and room for a shading wave per SIMD (tirt_internal.h, TR_TOP_CAP)
-#endif
+constexpr int TR_MIN_WAVES = 6;        // 80 VGPRs: five 256-thread blocks per CU and room for a shading wave per SIMD (tirt_internal.h, TR_TOP_CAP)
 // The arguments a ray only needs when it is fetched, written back or paged (40 pointers, the grid constants) are NOT read from the by-value
 // argument: held in SGPRs across the whole walk they overflow the scalar register file, and the compiler parks them in VGPR lanes --
 // v_writelane / v_readlane, VALU instructions, ~245 of them per refill of a kernel that is bound by VALU issue.  They are read from the
@@ -304,20 +302,14 @@ typedef const __attribute__((address_space(4))) TraceArgs *cold_args_t;
 #define TR_LADDER_PADS(where) do { } while (0)
 #endif
 
-#ifndef TR_TAIL_WAVES
-#define TR_TAIL_WAVES 3       // the tail kernel carries the shading code: 168 VGPRs, three 256-thread blocks per CU
-#endif
+constexpr int TR_TAIL_WAVES = 3;       // the tail kernel carries the shading code: 168 VGPRs, three 256-thread blocks per CU
 template <int MODE, bool COUNT, int KIND>
 __global__ __launch_bounds__(TR_BLOCK, KIND == KIND_TAIL ? TR_TAIL_WAVES : TR_MIN_WAVES) void k_trace(TraceArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) int lds_stack[];      // [lds_depth][TR_BLOCK]
     const int TR_LDS_DEPTH = a.lds_depth;
     constexpr bool MAY_SHADOW = (KIND != KIND_CLOSEST);
-#ifndef TR_NO_STASH
     constexpr bool STASH = (MODE != TIRT_TRAVERSE_EXHAUSTIVE);
-#else
-    constexpr bool STASH = false;
-#endif
     constexpr bool BOUNDED = MAY_SHADOW && (MODE != TIRT_TRAVERSE_EXHAUSTIVE);
     const int count_c = (KIND == KIND_SHADOW_ACC || KIND == KIND_QUERY) ? 0 : (a.count_ptr ? *a.count_ptr : a.count_fixed);
     const int count_s = (KIND == KIND_CLOSEST || KIND == KIND_TAIL) ? 0 : (KIND == KIND_MIXED ? *a.scount_ptr : (a.count_ptr ? *a.count_ptr : a.count_fixed));
@@ -382,19 +374,6 @@ __global__ __launch_bounds__(TR_BLOCK, KIND == KIND_TAIL ? TR_TAIL_WAVES : TR_MI
     const unsigned top_base = (unsigned)(size_t)(lds_int *)lds_stack + (unsigned)TR_LDS_DEPTH * ENTRY;
     typedef unsigned u4v __attribute__((ext_vector_type(4)));
     typedef __attribute__((address_space(3))) u4v lds_u4;
-#ifdef TR_COOP
-    // Quad-cooperative record fetch (round 5).  What bounds this kernel is the rate at which a CU's L1 takes requests -- one 64-byte line per lane
-    // and clock, whatever the request's width (profiles/r05_bound_ladder.txt) -- and a lane that reads its 64-byte node record as four
-    // global_load_dwordx4 makes four of them for ONE line.  Here the four lanes of a quad read the four 16-byte quarters of the record ONE of them
-    // needs, in one instruction (adjacent lanes, one line: one request), four instructions for the four lanes' records, each landing through
-    // global_load_lds_dwordx4 (LDS-DMA: destination = M0 + lane x 16, no register, no VALU) in a staging region of the wave: region j holds at
-    // [quad x 64] the record of lane 4 x quad + j; a lane then reads its record from LDS.  Regions are 1 040 bytes apart so that the four lanes
-    // of a quad read different banks (ds_read_b128: sixteen lanes cover the 64 banks).
-    constexpr unsigned TR_STAGE_STRIDE = 1040u, TR_STAGE_WAVE = 4u * TR_STAGE_STRIDE;
-    const unsigned stage_base = __builtin_amdgcn_readfirstlane(top_base + (unsigned)TR_TOP_SLOTS * 64u + (unsigned)(tid >> 6) * TR_STAGE_WAVE);
-    const unsigned stage_rd = stage_base + (unsigned)(lane & 3) * TR_STAGE_STRIDE + (unsigned)(lane >> 2) * 64u;      // where this lane's record lands
-    const unsigned stage_sub = (unsigned)(lane & 3) << 4;                                                            // the quarter this lane fetches
-#endif
     if (MODE != TIRT_TRAVERSE_EXHAUSTIVE) {
         for (int k = tid; k < b.top_count * 4; k += TR_BLOCK)
         { const uint4 g = b.cnode[k]; *(lds_u4 *)(size_t)(top_base + (unsigned)k * 16u) = u4v{g.x, g.y, g.z, g.w}; }
@@ -452,9 +431,7 @@ __global__ __launch_bounds__(TR_BLOCK, KIND == KIND_TAIL ? TR_TAIL_WAVES : TR_MI
             int my = count;
             if (fm != 0ull && !exhausted) {
             const int n_idle = __popcll(fm);
-#ifndef TR_DRAIN_DIAG
             if (COUNT) d_refills++;
-#endif
             const int leader = __ffsll((long long)fm) - 1;
             // rays of slice `home`: its 64-ray chunks are the global chunks home, home + S, home + 2S, ... (interleaved), or the home-th contiguous
             // stretch of the closest-hit rays followed by the home-th stretch of the shadow rays (slices_contig)
@@ -471,14 +448,12 @@ __global__ __launch_bounds__(TR_BLOCK, KIND == KIND_TAIL ? TR_TAIL_WAVES : TR_MI
             if (contig) my = v < lenc__ ? home * Lc__ + v : (v < len ? count_c + home * Ls__ + (v - lenc__) : count);
             else my = v < len ? (((((v >> 6) << S_LOG) + home) << 6) | (v & 63)) : count;
             if (base + n_idle >= len) {                                    // slice drained: move on
-#ifndef TR_NO_DRAINED_COUNT
                 // The wave whose fetch reached the end of a slice counts the slice as drained, and a wave that moves on looks at that count: once it
                 // says "all of them" there is nothing to look for.  Without it every wave of a launch learns that by one atomic round trip per
                 // slice, 32 in a row on 32 lines that 5 120 waves are hammering: ~0.15 ms, the better part of what a launch of few rays takes.
                 int *const c_drained = c_fetch + TR_SLICES_MAX * TR_FETCH_STRIDE;
                 if (lane == leader && base < (len > 0 ? len : 1)) atomicAdd(c_drained, 1);
                 if (__hip_atomic_load(c_drained, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > S_MASK) tried = S_MASK;
-#endif
                 home = (home + 1) & S_MASK;
                 if (++tried > S_MASK) { exhausted = true; if (COUNT) tk_exh = wall_clock64(); }
             }
@@ -542,11 +517,7 @@ __global__ __launch_bounds__(TR_BLOCK, KIND == KIND_TAIL ? TR_TAIL_WAVES : TR_MI
                     const float4 r0 = c_ray4[2 * ri], r1 = c_ray4[2 * ri + 1];
                     o = V(r0.x, r0.y, r0.z); d = V(r0.w, r1.x, r1.y); rec_expect = __float_as_int(r1.z); rec_bound = r1.w;
                 } else {
-#ifndef TR_NO_NT_STREAMS      // ray and hit records are a stream (written once, read once a launch later): non-temporal, so that they do not displace the BVH in L1 / L2 (+0.7 %, profiles/r05l)
 #define TR_LDS_(p) __builtin_nontemporal_load(&(p))
-#else
-#define TR_LDS_(p) (p)
-#endif
                     o = mixed_sh ? V(TR_LDS_(c_sox[q]), TR_LDS_(c_soy[q]), TR_LDS_(c_soz[q]))
                                  : ((KIND == KIND_CLOSEST && c_ox == nullptr) ? V(ca->eye[0], ca->eye[1], ca->eye[2]) : V(TR_LDS_(c_ox[q]), TR_LDS_(c_oy[q]), TR_LDS_(c_oz[q])));
                     d = mixed_sh ? V(TR_LDS_(c_sdx[q]), TR_LDS_(c_sdy[q]), TR_LDS_(c_sdz[q])) : V(TR_LDS_(c_dx[q]), TR_LDS_(c_dy[q]), TR_LDS_(c_dz[q]));
@@ -615,15 +586,6 @@ __global__ __launch_bounds__(TR_BLOCK, KIND == KIND_TAIL ? TR_TAIL_WAVES : TR_MI
             }
         }
         if (ballot64(have) == 0ull) { if (exhausted && !(KIND == KIND_TAIL && wave_any(st != 0))) break; continue; }
-#ifdef TR_DRAIN_DIAG
-        // diagnostic build (tools/timeline.py, counting launches): what a wave holds once the queue is empty -- outer iterations, busy lanes, and how
-        // many of them have at least one / two / four entries above the sentinel of their stack (work another lane could take over)
-        if (COUNT && exhausted) {
-            const int dep__ = (int)(sa - sa_bottom) >> 10;
-            d_refills++; d_outer += (unsigned long long)(have ? 1 : 0);
-            sum_box_s += (have && dep__ >= 1) ? 1 : 0; sum_leaf_s += (have && dep__ >= 2) ? 1 : 0; sum_leaf += (have && dep__ >= 4) ? 1 : 0;
-        }
-#endif
 
         // ---- inner nodes.  Lanes that reached a leaf (or finished) wait here; the loop goes on
         // while at least node_min lanes still have inner-node work, or nobody is waiting at all.
@@ -641,9 +603,7 @@ __global__ __launch_bounds__(TR_BLOCK, KIND == KIND_TAIL ? TR_TAIL_WAVES : TR_MI
         // rays (the end of a launch, no refill any more) would leave it for every single leaf, so the threshold is also bounded by 3/4 of
         // the lanes that hold a ray at all (1/2 and 5/8: no gain, 7/8: half of it; a lone batch -- one rank's share of an 8-GPU job --
         // 3.13 -> 3.06 ms per step, four overlapped batches unchanged: profiles/r04g_node_threshold_ab.log)
-#ifndef TR_NODE_FRAC
-#define TR_NODE_FRAC 6
-#endif
+        constexpr int TR_NODE_FRAC = 6;
         int node_min_w = (__popcll(ballot64(have)) * TR_NODE_FRAC) >> 3; node_min_w = node_min_w < a.node_min ? node_min_w : a.node_min;
         for (;;) {
             const bool act = cur >= 0;
@@ -653,21 +613,6 @@ __global__ __launch_bounds__(TR_BLOCK, KIND == KIND_TAIL ? TR_TAIL_WAVES : TR_MI
             if (n_act < node_min_w && ballot64(have && cur < 0) != 0ull) break;
             if (wave_any((int)sa >= (int)sa_hi)) break;        // a lane's LDS stack is full: page out below (cold)
             if (COUNT) { d_it_node++; d_lanes_node += (unsigned long long)n_act; }
-#ifdef TR_COOP
-            if (MODE != TIRT_TRAVERSE_EXHAUSTIVE) {
-                // (all 64 lanes, wave-uniform control flow: a lane without node work still fetches for its quad)
-#define TR_COOP_FETCH(j__)                                                                          \
-                do {                                                                                 \
-                    const int cj__ = __builtin_amdgcn_mov_dpp(cur, (j__) * 0x55, 0xf, 0xf, true);   /* `cur` of lane j of this quad (quad_perm broadcast) */ \
-                    if (cj__ >= TR_TOP_SLOTS)                                                        \
-                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)((const char *)b.cnode + (((unsigned)cj__ << 6) + stage_sub)), \
-                                                         (__attribute__((address_space(3))) void *)(size_t)(stage_base + (unsigned)(j__) * TR_STAGE_STRIDE), 16, 0, 0); \
-                } while (0)
-                TR_COOP_FETCH(0); TR_COOP_FETCH(1); TR_COOP_FETCH(2); TR_COOP_FETCH(3);
-                // the wave's own LDS-DMA writes are ordered before its LDS reads by this wait and by nothing else (the compiler does not see the dependence)
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-#endif
             if (act) {
                 if (MODE == TIRT_TRAVERSE_EXHAUSTIVE) {
                     // reference order on the two-child nodes: both children of every box that passes
@@ -695,16 +640,6 @@ __global__ __launch_bounds__(TR_BLOCK, KIND == KIND_TAIL ? TR_TAIL_WAVES : TR_MI
                     uint4 q0, q1, q2, q3;
 #define TR_U4(v) make_uint4((v).x, (v).y, (v).z, (v).w)
                     const unsigned top_addr = top_base + ((unsigned)cur << 6);
-#if defined(TR_COOP)
-                    {
-                        // the record: from the tree-top copy (first TR_TOP_SLOTS nodes, if any are kept) or from where the quad's fetch put it
-                        const unsigned ra__ = ((unsigned)cur < (unsigned)TR_TOP_SLOTS) ? top_addr : stage_rd;
-                        const lds_u4 *t = (const lds_u4 *)(size_t)ra__;
-                        const u4v t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3];
-                        q0 = TR_U4(t0); q1 = TR_U4(t1); q2 = TR_U4(t2); q3 = TR_U4(t3);
-                        if (COUNT) { if ((unsigned)cur < (unsigned)TR_TOP_SLOTS) d_outer++; }
-                    }
-#elif !defined(TR_NO_ASM_FETCH)
                     // The record comes from LDS for some lanes and from global memory for the others, into the SAME sixteen registers.  Written in C++ the
                     // compiler orders the two (a write-after-write on a register, as it sees it): s_waitcnt vmcnt(0) before the first ds_read, i.e. a wave with
                     // lanes on both sides -- nearly every step -- pays the two latencies in a row.  The lanes are disjoint (complementary exec masks) and a
@@ -739,19 +674,6 @@ __global__ __launch_bounds__(TR_BLOCK, KIND == KIND_TAIL ? TR_TAIL_WAVES : TR_MI
                         q0 = TR_U4(r0__); q1 = TR_U4(r1__); q2 = TR_U4(r2__); q3 = TR_U4(r3__);
                         if (COUNT) { if (cur < TR_TOP_SLOTS) d_outer++; }
                     }
-#else
-                    if (cur < TR_TOP_SLOTS) {        // breadth-first numbering: the first nodes are the top of the tree, resident in LDS
-                        const lds_u4 *t = (const lds_u4 *)(size_t)top_addr;
-                        const u4v t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3];
-                        q0 = TR_U4(t0); q1 = TR_U4(t1); q2 = TR_U4(t2); q3 = TR_U4(t3);
-#ifndef TR_DRAIN_DIAG
-                        if (COUNT) d_outer++;
-#endif
-                    } else {
-                        const uint4 *w = (const uint4 *)((const char *)b.cnode + ((unsigned)cur << 6));
-                        q0 = w[0]; q1 = w[1]; q2 = w[2]; q3 = w[3];
-                    }
-#endif
                     TR_LADDER_PADS(0);
                     int c0 = (int)q3.x, c1 = (int)q3.y, c2 = (int)q3.z, c3 = (int)q3.w;
                     if (COUNT) nbox += 4;
@@ -813,41 +735,11 @@ __global__ __launch_bounds__(TR_BLOCK, KIND == KIND_TAIL ? TR_TAIL_WAVES : TR_MI
             const int n_l = __popcll(ballot64(leaf_now));
             if (n_l) { d_it_leaf++; d_lanes_leaf += (unsigned long long)n_l; }
         }
-#if defined(TR_COOP) && defined(TR_COOP_LEAF)
-        // the primitive records the same way (64-byte records: TRI_STRIDE_N = 4): one request per record instead of three
-        static_assert(TRI_STRIDE == 4, "TR_COOP_LEAF needs 64-byte primitive records (-DTRI_STRIDE_N=4)");
-        if (MODE != TIRT_TRAVERSE_EXHAUSTIVE && wave_any(leaf_now)) {
-            const int ls__ = leaf_now ? ((~(from_pend ? pend : cur)) & 0x3fffffff) : -1;
-#define TR_COOP_LEAF_FETCH(j__)                                                                      \
-            do {                                                                                     \
-                const int cj__ = __builtin_amdgcn_mov_dpp(ls__, (j__) * 0x55, 0xf, 0xf, true);      \
-                if (cj__ >= 0)                                                                       \
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)((const char *)b.tri + (((unsigned)cj__ << 6) + stage_sub)), \
-                                                     (__attribute__((address_space(3))) void *)(size_t)(stage_base + (unsigned)(j__) * TR_STAGE_STRIDE), 16, 0, 0); \
-            } while (0)
-            TR_COOP_LEAF_FETCH(0); TR_COOP_LEAF_FETCH(1); TR_COOP_LEAF_FETCH(2); TR_COOP_LEAF_FETCH(3);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-#endif
         if (leaf_now) {
             const int code = ~(from_pend ? pend : cur);
-#if defined(TR_COOP) && defined(TR_COOP_LEAF)
-            float4 ta, tb, tc;
-            if (MODE != TIRT_TRAVERSE_EXHAUSTIVE) {
-                const lds_u4 *t = (const lds_u4 *)(size_t)stage_rd;
-                const u4v t0 = t[0], t1 = t[1], t2 = t[2];
-                ta = make_float4(__uint_as_float(t0.x), __uint_as_float(t0.y), __uint_as_float(t0.z), __uint_as_float(t0.w));
-                tb = make_float4(__uint_as_float(t1.x), __uint_as_float(t1.y), __uint_as_float(t1.z), __uint_as_float(t1.w));
-                tc = make_float4(__uint_as_float(t2.x), __uint_as_float(t2.y), __uint_as_float(t2.z), __uint_as_float(t2.w));
-            } else {
-                const float4 *tp = b.tri + (size_t)(code & 0x3fffffff) * TRI_STRIDE;
-                ta = tp[0]; tb = tp[1]; tc = tp[2];
-            }
-#else
             const float4 *tp = b.tri + (size_t)(code & 0x3fffffff) * TRI_STRIDE;          // records in the traversal tree's leaf order
             // (the records themselves must NOT be loaded non-temporally: -25 %, profiles/r05m -- their residency in L2 is what the kernel lives on)
             const float4 ta = tp[0], tb = tp[1], tc = tp[2];
-#endif
             int prim = __float_as_int(tc.w);                                              // the primitive id rides in the last word
             if (COUNT) nleaf += 1;
             const v3 o = V(r.ox, r.oy, r.oz), d = V(r.dx, r.dy, r.dz);
@@ -870,7 +762,6 @@ __global__ __launch_bounds__(TR_BLOCK, KIND == KIND_TAIL ? TR_TAIL_WAVES : TR_MI
             if (from_pend) pend = 0; else TR_POP(cur);
             // reference: accept iff 0 < t < hit_t (so never t >= INF_VALUE); equal-t candidates: see header
             bool cand = (t > 0.0f) & ((t < hit_t) | ((t == hit_t) & (hit_leaf >= 0) & (leaf > hit_leaf)));
-#ifndef TR_NO_VERIFY
             if (MODE != TIRT_TRAVERSE_EXHAUSTIVE && cand) {
                 // The quantised boxes that led here contain the reference's: would the reference have visited this leaf
                 // (Scene.py:702-744: every proper ancestor's box passes `slabs`)?  The leaf's own exact box passing implies
@@ -904,7 +795,6 @@ __global__ __launch_bounds__(TR_BLOCK, KIND == KIND_TAIL ? TR_TAIL_WAVES : TR_MI
                     prim = (int)b.compact[(size_t)leaf * CPN_VEC + 1];
                 }
             }
-#endif
             if (cand) {
                 hit_t = t; hit_u = u; hit_v = v; hit_prim = prim; hit_leaf = leaf;
                 lim = __builtin_fminf(__builtin_fminf(cull_far < 0.0f ? INF_VALUE : hit_t * 1.0001f, __builtin_fabsf(cull_far)), INF_VALUE);      // (v_min: a canonical value, so the node loop does not re-canonicalise it every step)
@@ -947,11 +837,7 @@ __global__ __launch_bounds__(TR_BLOCK, KIND == KIND_TAIL ? TR_TAIL_WAVES : TR_MI
             const float *const c_scw = MAY_SHADOW ? ca->scw : nullptr;
             if (MAY_SHADOW) asm volatile("" :: "s"(c_hit), "s"(c_sdst), "s"(c_rr), "s"(c_rg), "s"(c_rb), "s"(c_fr), "s"(c_fg), "s"(c_fb), "s"(c_scr), "s"(c_scg), "s"(c_scb), "s"(c_scw));      // one batch of scalar loads (as in the refill)
             if (!(MAY_SHADOW && is_sh) || KIND == KIND_QUERY) {
-#ifndef TR_NO_NT_STREAMS
                 { typedef float f4n __attribute__((ext_vector_type(4))); f4n hv__ = {hit_t, hit_u, hit_v, __int_as_float(hit_prim)}; __builtin_nontemporal_store(hv__, (f4n *)&c_hit[q]); }
-#else
-                c_hit[q] = make_float4(hit_t, hit_u, hit_v, __int_as_float(hit_prim));
-#endif
             } else if (hit_prim == expect) {                 // integrator/PT_RGB.py:105-109
                 const int dst = TR_LDS_(c_sdst[q]);
                 float *pr = dst >= 0 ? c_rr + dst : c_fr + ~dst;
@@ -961,10 +847,8 @@ __global__ __launch_bounds__(TR_BLOCK, KIND == KIND_TAIL ? TR_TAIL_WAVES : TR_MI
                 if (c_scw) { float *pw = dst >= 0 ? ca->rw + dst : ca->fw + ~dst; *pw = *pw + c_scw[q]; }
             }
             if (COUNT) {
-#ifndef TR_DRAIN_DIAG
                 if (MAY_SHADOW && is_sh) { sum_box_s += nbox; sum_leaf_s += nleaf; }
                 else { sum_box += nbox; sum_leaf += nleaf; }
-#endif
                 if (ca->per_ray_counts) ca->per_ray_counts[q] = make_int2((int)nbox, (int)nleaf);
             }
             if (n_overflow) n_over++;
@@ -1279,13 +1163,8 @@ __global__ void k_generate(PathSoA ps, CameraView cam, TileMap tm, int P, int S,
 struct ShadeArgs { PathState ps; PathSoA in, out; };
 typedef const __attribute__((address_space(4))) ShadeArgs *cold_shade_t;
 #define SH_COLD(ca) cold_shade_t ca = (cold_shade_t)__builtin_amdgcn_kernarg_segment_ptr(); asm volatile("" : "+s"(ca))
-#ifndef TR_NO_NT_STREAMS      // path state is a stream (written once, read once a launch later): keep it from displacing the BVH in L1 / L2
 #define SH_LD(x) __builtin_nontemporal_load(&(x))
 #define SH_ST(x, v) __builtin_nontemporal_store((v), &(x))
-#else
-#define SH_LD(x) (x)
-#define SH_ST(x, v) ((x) = (v))
-#endif
 __global__ __launch_bounds__(SH_BLOCK, SH_MIN_WAVES) void k_shade(ShadeArgs paths_in_kernarg_segment, SceneView sc, TileMap tm, int P,
                                                    uint32_t frame_begin, uint32_t seed, int bounce, int last_bounce,
                                                    const int *count_ptr, int count_fixed, unsigned long long *append_ctr,
@@ -1318,13 +1197,9 @@ __global__ __launch_bounds__(SH_BLOCK, SH_MIN_WAVES) void k_shade(ShadeArgs path
             slot = first ? q : SH_LD(c_slot[q]);
             const v3 origin = first ? eye : V(SH_LD(c_ox[q]), SH_LD(c_oy[q]), SH_LD(c_oz[q]));
             const v3 direction = V(SH_LD(c_dx[q]), SH_LD(c_dy[q]), SH_LD(c_dz[q]));
-#ifndef TR_NO_NT_STREAMS
             typedef float f4nt__ __attribute__((ext_vector_type(4)));
             const f4nt__ hnt__ = __builtin_nontemporal_load((const f4nt__ *)&c_hit[q]);
             const float4 hrec = make_float4(hnt__.x, hnt__.y, hnt__.z, hnt__.w);
-#else
-            const float4 hrec = c_hit[q];
-#endif
             v3 throughout = first ? V(1.0f, 1.0f, 1.0f) : V(SH_LD(c_tr[q]), SH_LD(c_tg[q]), SH_LD(c_tb[q]));
             radiance = first ? V(0.0f, 0.0f, 0.0f) : V(SH_LD(c_rr[q]), SH_LD(c_rg[q]), SH_LD(c_rb[q]));
             float brdf_pdf = first ? 1.0f : SH_LD(c_pdf[q]);
@@ -1460,13 +1335,9 @@ __global__ __launch_bounds__(SH_BLOCK, 4) void k_shade_spec(ShadeArgs paths_in_k
             const float Lambda = HERO_LAMBDA_MIN + HERO_LAMBDA_STEP * tm_rand(seed, pixel, frame, TM_DIM_SPEC_LAMBDA);     // PT_Spec.py:191
             const v3 origin = first ? eye : V(c_ox[q], c_oy[q], c_oz[q]);
             const v3 direction = V(c_dx[q], c_dy[q], c_dz[q]);
-#ifndef TR_NO_NT_STREAMS
             typedef float f4nt__ __attribute__((ext_vector_type(4)));
             const f4nt__ hnt__ = __builtin_nontemporal_load((const f4nt__ *)&c_hit[q]);
             const float4 hrec = make_float4(hnt__.x, hnt__.y, hnt__.z, hnt__.w);
-#else
-            const float4 hrec = c_hit[q];
-#endif
             const float t = hrec.x;
             f4s throughout = f4_set(1.0f);
             if (!first) {

@@ -77,6 +77,8 @@ static float tri_hit(const float *o, const float *d, const float *v)
 }
 /* mode 0: children sorted by entry distance; 1: fixed octant order.  quant > 0: child boxes snapped outward to a grid of `quant` cells per axis of the
  * PARENT's box (8-bit nodes: 255).  out: [0] wide visits mean, [1] leaf tests mean, [2] child boxes hit per visit, [3] chain p50, [4] p99, [5] p99.9, [6] max, [7] hits;  per_ray[nr] chain */
+static float g_margin = 0.0f;      /* every child box grown by this much on every side (absolute units): what a box test of lower precision has to add to stay conservative */
+void set_margin(float m) { g_margin = m; }
 void simulate_wide(const float *compact, int nrows, int k, int mode, int quant, const int *ref_tri, const float *tris, const float *rays, int nr, double *out, int *per_ray)
 {
     g_compact = compact;
@@ -100,6 +102,7 @@ void simulate_wide(const float *compact, int nrows, int k, int mode, int quant, 
                     o[a] = pb[a] + floorf((b[a] - pb[a]) / cell) * cell;
                     o[3 + a] = pb[a] + ceilf((b[3 + a] - pb[a]) / cell) * cell;
                 } else { o[a] = b[a]; o[3 + a] = b[3 + a]; }
+                o[a] -= g_margin; o[3 + a] += g_margin;
             }
         }
     }

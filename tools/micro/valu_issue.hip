@@ -36,6 +36,23 @@ __global__ __launch_bounds__(256) void k(float *out, unsigned long long *ticks, 
         if (KIND == 12) { REP16(asm volatile(A8("v_and_b32", ", %8") : OUT8 : "v"(u));) }
         if (KIND == 13) { REP16(asm volatile(A8("v_add_u32", ", %8") : OUT8 : "v"(u));) }
         if (KIND == 14) { REP16(asm volatile(A8("v_min3_i32", ", %8, %9") : OUT8 : "v"(a), "v"(b));) }
+        // round 6: the packed-fp16 instructions a two-children-at-once box test would be made of, and what would surround them
+        if (KIND == 16) { REP16(asm volatile(A8("v_pk_fma_f16", ", %8, %9") : OUT8 : "v"(a), "v"(b));) }
+        if (KIND == 17) { REP16(asm volatile(A8("v_pk_min_f16", ", %8") : OUT8 : "v"(a));) }
+        if (KIND == 18) { REP16(asm volatile(A8("v_pk_max_f16", ", %8") : OUT8 : "v"(a));) }
+        if (KIND == 19) { REP16(asm volatile(A8("v_pk_add_f16", ", %8 neg_lo:[0,1] neg_hi:[0,1]") : OUT8 : "v"(a));) }
+        if (KIND == 20) { REP16(asm volatile(A8("v_perm_b32", ", %8, %9") : OUT8 : "v"(a), "v"(u));) }
+        if (KIND == 21) { REP16(asm volatile(A8("v_cvt_f32_f16", "") : OUT8);) }
+        if (KIND == 22) { REP16(asm volatile(A8("v_min_u32", ", %8") : OUT8 : "v"(u));) }
+        if (KIND == 23) { REP16(asm volatile(A8("v_pk_min_u16", ", %8") : OUT8 : "v"(u));) }
+        if (KIND == 24) { REP16(asm volatile(A8("v_pk_ashrrev_i16", ", 15") : OUT8);) }
+        if (KIND == 25) { REP16(asm volatile(A8("v_or_b32", ", %8") : OUT8 : "v"(u));) }
+        if (KIND == 26) { REP16(asm volatile(A8("v_lshl_or_b32", ", %8, %9") : OUT8 : "v"(u), "v"(a));) }
+        if (KIND == 27) { REP16(asm volatile(A8("v_bfi_b32", ", %8, %9") : OUT8 : "v"(u), "v"(a));) }
+        if (KIND == 28) { REP16(asm volatile(A8("v_med3_f32", ", %8, %9") : OUT8 : "v"(a), "v"(b));) }
+        if (KIND == 29) { REP16(asm volatile(A8("v_max_f32", ", %8") : OUT8 : "v"(a));) }
+        if (KIND == 30) { REP16(asm volatile(A8("v_min_i32", ", %8") : OUT8 : "v"(u));) }
+        if (KIND == 31) { REP16(asm volatile(A8("v_pk_mul_f16", ", %8") : OUT8 : "v"(a));) }
         if (KIND == 15) { REP16(asm volatile("v_cmp_lt_f32 vcc, %0, %8\n v_cmp_lt_f32 vcc, %1, %8\n v_cmp_lt_f32 vcc, %2, %8\n v_cmp_lt_f32 vcc, %3, %8\n v_cmp_lt_f32 vcc, %4, %8\n v_cmp_lt_f32 vcc, %5, %8\n v_cmp_lt_f32 vcc, %6, %8\n v_cmp_lt_f32 vcc, %7, %8" : OUT8 : "v"(a) : "vcc");) }
     }
     const unsigned long long t1 = __builtin_readcyclecounter();
@@ -79,5 +96,9 @@ int main()
     run<7>("v_fma_mix_f32 (f16 src0)", out, ticks, cus); run<8>("v_alignbit_b32", out, ticks, cus); run<9>("v_min_f32", out, ticks, cus);
     run<10>("v_cndmask_b32 (sgpr mask)", out, ticks, cus); run<11>("v_max3_f32", out, ticks, cus); run<12>("v_and_b32", out, ticks, cus); run<13>("v_add_u32", out, ticks, cus);
     run<14>("v_min3_i32", out, ticks, cus); run<15>("v_cmp_lt_f32 vcc", out, ticks, cus);
+    run<16>("v_pk_fma_f16", out, ticks, cus); run<17>("v_pk_min_f16", out, ticks, cus); run<18>("v_pk_max_f16", out, ticks, cus); run<19>("v_pk_add_f16 (neg src1)", out, ticks, cus);
+    run<31>("v_pk_mul_f16", out, ticks, cus); run<20>("v_perm_b32", out, ticks, cus); run<21>("v_cvt_f32_f16", out, ticks, cus); run<22>("v_min_u32", out, ticks, cus); run<30>("v_min_i32", out, ticks, cus);
+    run<23>("v_pk_min_u16", out, ticks, cus); run<24>("v_pk_ashrrev_i16", out, ticks, cus); run<25>("v_or_b32", out, ticks, cus); run<26>("v_lshl_or_b32", out, ticks, cus);
+    run<27>("v_bfi_b32", out, ticks, cus); run<28>("v_med3_f32", out, ticks, cus); run<29>("v_max_f32", out, ticks, cus);
     return 0;
 }
