@@ -109,7 +109,9 @@ int tirt_sync(tirt_ctx *ctx);
  *          "primary_beams" -- (round 5, default 1) camera rays against per-pixel lists of the leaves they can hit first instead of the bounce-0 traversal launch
  *            (csrc/tirt_pvb.hip: the lists are made once per build / camera / film from five probe rays and a walk of the pixel's pyramid; rays that find no hit
  *            on their list are traced the ordinary way; the same hit records bit for bit: +15 % on the headline scene); 0 = off.  "primary_beams_min_frames"
- *            (default 16): batches of fewer frames keep the ordinary launch (making the lists costs 1.2 ms at 1024^2)
+ *            (default 16): batches of fewer frames keep the ordinary launch (making the lists costs 1.2 ms at 1024^2).  "primary_beams_rebuild" (any value):
+ *            the lists are forgotten and made again by the next batch that uses them (bench.py times a build inside its clock).  When the memory for the
+ *            lists is not to be had the render goes on without them (tirt_primary_beam_stats out[7]).
  *          "bdpt_batch_items" -- (frame, pixel) items per BDPT wavefront batch (default 16 Mi, ~2.2 KB of HBM each: 38 GB; 5 Mi = 12 GB runs config 5 at 2 900 Mrays/s), shared by the batches in flight on render lanes 0 and 1 ("bdpt_lanes", 1..4, default 2: three or four measured no faster)
  *            (config 5, round 3: 4 Mi 2 890, 8 Mi 2 900, 16 Mi 2 995, 32 Mi 2 980 Mrays/s; 256 frames: 8 Mi 2 912, 16 Mi 2 923, 32 Mi 3 032)
  *            A call never sizes its batches beyond what hipMemGetInfo reports free (less 2 GB): next to other users of the device it renders in smaller batches.
@@ -249,8 +251,11 @@ int tirt_trace_timeline(tirt_ctx *ctx, uint64_t *out, int max_waves, int *n_wave
 
 /* Diagnostics of the camera rays' candidate lists (option "primary_beams", csrc/tirt_pvb.hip): out[0] = local pixels that have a list, out[1] = leaves on
  * all lists, out[2] = pixels whose five probe rays all hit, out[3] = camera rays since the lists were made that found no hit on their pixel's list and were
- * traced by k_trace, out[4] = camera rays that went through the lists.  Waits for pending work.  (No reference counterpart: bench / tests.) */
-int tirt_primary_beam_stats(tirt_ctx *ctx, uint64_t out[5]);
+ * traced by k_trace, out[4] = camera rays that went through the lists; since the last tirt_stats_reset: out[5] = list builds (one per change of build /
+ * camera / film seen by a batch that uses lists, or after option "primary_beams_rebuild"), out[6] = their device time in nanoseconds (HIP events on the
+ * context's stream: probe rays + the walk of the pixels' pyramids), out[7] = builds given up for lack of memory (the camera rays then take the ordinary
+ * launch).  Waits for pending work.  (No reference counterpart: bench / tests.) */
+int tirt_primary_beam_stats(tirt_ctx *ctx, uint64_t out[8]);
 
 /* Fills *out.  Returns TIRT_ERR_STACK (with *out filled in) when stack_overflow > 0: rays dropped subtrees, what was
  * rendered since the last tirt_stats_reset is wrong -- the reference prints "overflow, need larger stack" (Scene.py:741). */

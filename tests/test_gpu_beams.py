@@ -29,7 +29,25 @@ def same(a, b):
     return np.array_equal(a.view(np.uint32), b.view(np.uint32))
 
 
+def one_primitive(W, H, n, kind):
+    """A scene whose LBVH root IS its only leaf: k_trace goes straight to the primitive test and a hit outside the leaf's box has no ancestor to be
+    refused by, so the list pass must not reject rays on the root's box either.  `tri`: one large triangle under the env map (no emitter: no NEE);
+    `sphere`: the sphere light alone (the analytic-sphere leaf)."""
+    from ti_raytrace_amd import Example, PT_RGB, SceneData as SCD
+    ex = Example.example(W, H, n, 0)
+    if kind == "tri":
+        mat = SCD.Material(); mat.type = SCD.MAT_DISNEY; mat.setMetal(0.0); mat.setRough(0.5); mat.setColor([0.8, 0.7, 0.6, 1.0]); mat.alebdoTex = -1
+        ex.scene.add_mesh(np.asarray([[[-1.0, -0.7, 0.1], [1.1, -0.6, -0.2], [0.05, 0.9, 0.3]]], np.float32), mat)
+        ex.scene.add_env(scenes.asset("image", "env.png"), 2.0)
+    else:
+        ex.add_sphere_light(pos=(0.1, 0.2, -0.1), radius=0.75, emission=5.0)
+    ex.integrator = PT_RGB.PathTrace(W, H, ex.cam, ex.scene, 64)
+    return ex
+
+
 SCENES = {
+    "one_triangle": lambda W, H, n: one_primitive(W, H, n, "tri"),
+    "one_sphere": lambda W, H, n: one_primitive(W, H, n, "sphere"),
     "cornell": lambda W, H, n: scenes.cornell_box(W, H, n, device_id=0),
     "teapot_glass_env": lambda W, H, n: scenes.single_model(W, H, n, device_id=0),
     "mesh_20k": lambda W, H, n: scenes.synthetic(W, H, n, ntri=20000, device_id=0),

@@ -373,9 +373,10 @@ class Context:
 
     def primary_beam_stats(self):
         """Diagnostics of the camera rays' candidate lists (tirt.h, tirt_primary_beam_stats)."""
-        out = (C.c_uint64 * 5)()
+        out = (C.c_uint64 * 8)()
         check(lib().tirt_primary_beam_stats(self.handle, out))
-        return {"pixels_with_list": int(out[0]), "leaves_listed": int(out[1]), "pixels_all_probes_hit": int(out[2]), "rays_to_k_trace": int(out[3]), "rays": int(out[4])}
+        return {"pixels_with_list": int(out[0]), "leaves_listed": int(out[1]), "pixels_all_probes_hit": int(out[2]), "rays_to_k_trace": int(out[3]), "rays": int(out[4]),
+                "list_builds": int(out[5]), "list_build_ms": out[6] * 1.0e-6, "list_builds_skipped": int(out[7])}
 
     def micro_gather_rate(self, working_set_bytes, iters=2000):
         v = C.c_double(0.0)

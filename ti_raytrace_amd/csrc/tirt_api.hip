@@ -339,7 +339,7 @@ void tirt_destroy(tirt_ctx *c)
                       &c->keys_b, &c->vals_a, &c->vals_b, &c->hist, &c->morton_sorted, &c->bvh_node, &c->compact, &c->parent,
                       &c->flag, &c->subtree, &c->build_status, &c->leaf_compact, &c->wnode, &c->tri, &c->prim_slot, &c->cnode, &c->cparent, &c->csize, &c->wide_queue, &c->wide_levels, &c->sah_compact, &c->sah_csize, &c->sah_parent, &c->wide_dp, &c->sah_box, &c->sah_idx, &c->sah_tasks, &c->sah_counts, &c->hdr, &c->rgb,
                       &c->counters_mem, &c->spill, &c->tr_rays,
-                      &c->tr_out, &c->tr_prim, &c->tr_counts, &c->dev_counters, &c->bdpt_px, &c->timeline, &c->pvb_count, &c->pvb_cand, &c->pvb_bound, &c->pvb_tmp, &c->pvb_stat};
+                      &c->tr_out, &c->tr_prim, &c->tr_counts, &c->dev_counters, &c->bdpt_px, &c->timeline, &c->pvb_set[0].count, &c->pvb_set[0].cand, &c->pvb_set[0].bound, &c->pvb_set[1].count, &c->pvb_set[1].cand, &c->pvb_set[1].bound, &c->pvb_stat};
     for (DevBuf *b : bufs) b->release();
     for (auto &bl : c->bd) {
         DevBuf *bb[] = {&bl.items, &bl.state, &bl.rays, &bl.hits, &bl.qidx, &bl.ctr, &bl.rad};
@@ -421,6 +421,8 @@ int tirt_set_option(tirt_ctx *c, const char *name, double value)
     if (!strcmp(name, "bdpt_bounded")) { c->bdpt_bounded = value != 0.0 ? 1 : 0; return TIRT_OK; }
     if (!strcmp(name, "bdpt_state_fill")) { TIRT_REQUIRE(value == 0.0 || value == 1.0 || value == 2.0, "bdpt_state_fill: 0 (none), 1 (zeros) or 2 (poison)"); c->bdpt_state_fill = (int)value; return TIRT_OK; }
     if (!strcmp(name, "primary_beams")) { TIRT_REQUIRE(value == 0.0 || value == 1.0, "primary_beams: 0 or 1"); if (flush_pending(c)) return TIRT_ERR_HIP; c->primary_beams = (int)value; return TIRT_OK; }
+    // "primary_beams_rebuild": forget the camera rays' candidate lists -- the next batch that uses lists makes them again (bench.py: a list build inside its clock)
+    if (!strcmp(name, "primary_beams_rebuild")) { if (flush_pending(c)) return TIRT_ERR_HIP; c->pvb_valid = false; return TIRT_OK; }
     if (!strcmp(name, "primary_beams_min_frames")) { TIRT_REQUIRE(value >= 1.0 && value <= 1.0e6, "primary_beams_min_frames out of range"); if (flush_pending(c)) return TIRT_ERR_HIP; c->primary_beams_min_frames = (int)value; return TIRT_OK; }
     if (!strcmp(name, "bdpt_lanes")) { TIRT_REQUIRE(value >= 1.0 && value <= 4.0, "bdpt_lanes: 1..4"); if (sync_all(c)) return TIRT_ERR_HIP; c->bdpt_lanes = (int)value; return TIRT_OK; }
     if (!strcmp(name, "bdpt_batch_items")) { TIRT_REQUIRE(value >= 1.0 && value <= 1.0e9, "bdpt_batch_items out of range"); c->bdpt_batch_items = (size_t)value; return TIRT_OK; }
@@ -821,11 +823,24 @@ int tirt_stats(tirt_ctx *c, tirt_stats_t *out)
     return TIRT_OK;
 }
 
-int tirt_primary_beam_stats(tirt_ctx *c, uint64_t out[5])
+static void drain_pvb_events(tirt_ctx *c)
+{
+    for (auto &pr : c->pvb_ev) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) c->pvb_build_ns += (unsigned long long)((double)ms * 1.0e6);
+        (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second);
+    }
+    c->pvb_ev.clear();
+    (void)hipGetLastError();
+}
+
+int tirt_primary_beam_stats(tirt_ctx *c, uint64_t out[8])
 {
     TIRT_REQUIRE(c && out, "tirt_primary_beam_stats: null arguments");
-    for (int k = 0; k < 5; k++) out[k] = 0;
+    for (int k = 0; k < 8; k++) out[k] = 0;
     if (sync_all(c)) return TIRT_ERR_HIP;
+    drain_pvb_events(c);
+    out[5] = c->pvb_builds; out[6] = c->pvb_build_ns; out[7] = c->pvb_skipped;
     if (!c->pvb_stat.p) return TIRT_OK;
     unsigned long long h[5];
     TIRT_HIP(hipMemcpy(h, c->pvb_stat.p, sizeof(h), hipMemcpyDeviceToHost));
@@ -854,6 +869,7 @@ int tirt_stats_reset(tirt_ctx *c)
     TIRT_HIP(hipStreamSynchronize(c->stream));
     c->ms_render = c->ms_trace_closest = c->ms_trace_shadow = c->ms_shade = 0.0;
     c->launches_trace_closest = c->launches_trace_shadow = c->launches_shade = 0; c->launches_tail = 0;
+    drain_pvb_events(c); c->pvb_builds = c->pvb_build_ns = c->pvb_skipped = 0;
     return TIRT_OK;
 }
 

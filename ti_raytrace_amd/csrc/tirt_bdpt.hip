@@ -987,7 +987,7 @@ __global__ BD_RESOLVE_BOUNDS void k_bd_resolve(BdCtx c, BdItems items, TileMap t
             const unsigned long long above = (lane == 63) ? 0ull : (heads >> (lane + 1));
             const int run = above ? (__ffsll((long long)above) - 1) : (63 - lane);        // lanes after mine with my target
 #pragma unroll
-            for (int d = 1; d <= 16; d <<= 1) {            // a run is at most the 20 connections of an item
+            for (int d = 1; d <= 32; d <<= 1) {            // a run is usually the <= 20 connections of one item, but e == 1 connections of the NEXT items can project onto the same (frame, pixel) and extend it: d = 32 sums any run a wave can hold (with d <= 16 a run of more than 32 lanes would have lost its tail)
                 const float vx = __shfl_down(r.x, d, 64), vy = __shfl_down(r.y, d, 64), vz = __shfl_down(r.z, d, 64);
                 if (d <= run) { r.x += vx; r.y += vy; r.z += vz; }
             }

@@ -365,7 +365,13 @@ struct tirt_ctx {
     struct PvbKey { tirt::CameraView cam; unsigned long long build; int W, H, tile_rank, tile_count, tile_size, tile_blocked, P; } pvb_key;
     bool pvb_valid = false; int primary_beams = 1, primary_beams_min_frames = 16;      // options "primary_beams" (0 = off) and "primary_beams_min_frames" (batches of fewer frames trace their camera rays the ordinary way)
     unsigned long long build_serial = 0;          // counts lbvh_build calls
-    tirt::DevBuf pvb_count, pvb_cand, pvb_bound, pvb_tmp, pvb_stat;
+    // two sets of lists: a rebuild (camera move) writes the set the batches in flight are NOT reading, so it waits only for the batches of the camera before last
+    // (one set made every camera move wait for all earlier batches to drain); `busy` = film_done of the last batch that read the set
+    struct PvbSet { tirt::DevBuf count, cand, bound; hipEvent_t busy = nullptr; } pvb_set[2];
+    int pvb_cur = 0;                              // the set pvb_key describes
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pvb_ev;      // HIP events around every list build since the last tirt_stats_reset (read by tirt_primary_beam_stats)
+    unsigned long long pvb_builds = 0, pvb_build_ns = 0, pvb_skipped = 0;      // list builds since the reset, their device time, builds given up for lack of memory
+    tirt::DevBuf pvb_stat;
 
     // PT_Spec tables (tirt_spectral_upload): CIE observer, spectra, Rgb2Spec table, sky configuration -- one buffer, views in spec_host
     tirt::DevBuf spec_dev;                      // the SpecView again, in device memory (BDPT_SPEC)

@@ -14,7 +14,7 @@
 //                     one more turns up the farthest goes and the pixel's bound comes in to just below it (the list stays complete
 //                     up to its bound);
 //   per batch, instead of the bounce-0 launch of k_trace:
-//     k_pvb_cand      one thread per camera ray: the primitive tests of its pixel's list -- k_trace's leaf step word for word:
+//     k_pvb_cand      one thread per camera ray: the primitive tests of its pixel's list -- k_trace's leaf step (trace_leaf_step, the same function):
 //                     Moller-Trumbore / sphere, `0 < t < hit_t` with the equal-distance rule, the `slabs` verification of the
 //                     leaf's exact box and, failing that, of its ancestors --, hit record written if the hit lies within bound;
 //                     the other rays (no hit within bound: they slipped past what the probes saw) are appended to a list,
@@ -39,7 +39,6 @@ constexpr int PVB_STACK = 96;                       // node stack of a beam walk
 constexpr float PVB_WIDEN = 0.55f;                  // the pyramid's corners in pixels from the centre (the jitter is [-0.5, 0.5))
 constexpr float PVB_REACH = 1.5f;                   // a pixel's list reaches this far beyond the farthest probe hit (1.0001: 1.4 % of the camera rays find nothing on their list, 1.25: 0.10 %, 1.5: 0.08 %; profiles/r05an_*)
 constexpr int PVB_BLOCK = 1024;                      // threads of a k_pvb_cand block
-constexpr float PVB_FAR_RHO = 8.0f;                 // = TR_FAR_RHO (tirt_render.hip)
 
 struct PvbView { const int *count; const int2 *cand; const float *bound; };     // [P], [PVB_CMAX][P] (leaf code, bits of the nearest distance any ray of the pixel can reach the leaf's box at), [P]; count < 0: no list
 
@@ -82,11 +81,11 @@ __global__ __launch_bounds__(64) void k_pvb_beam(BvhView b, CameraView cam, Tile
     }
     const v3 eye = V(cam.eye[0], cam.eye[1], cam.eye[2]);
     const v3 cell = V(b.cell[0], b.cell[1], b.cell[2]), gmin = V(b.grid_min[0], b.grid_min[1], b.grid_min[2]);
-    // k_trace's margin around a box, in cells (0.25 + 0.25 per root-box extent between the eye and the grid), and a little more
-    const float rho = maxf(maxf(absf(gmin.x - eye.x) * b.inv_extent[0], absf(gmin.y - eye.y) * b.inv_extent[1]), absf(gmin.z - eye.z) * b.inv_extent[2]);
-    const float mc = 0.30f + 0.25f * rho;
+    // k_trace's margin around a box, in cells (trace_margin_cells of the eye's distance from the grid: tirt_internal.h), and a little more
+    const float rho = trace_origin_rho(b, eye.x, eye.y, eye.z);
+    const float mc = trace_margin_cells(rho) + TR_MARGIN_BEAM_EXTRA;
     int n = 0;
-    const bool near_enough = rho <= PVB_FAR_RHO;            // (wave-uniform)
+    const bool near_enough = rho <= TR_FAR_RHO;            // (wave-uniform)
     bool open = live && near_enough;                        // this lane still collects leaves
     bool stack_over = false;
     if (near_enough) {
@@ -224,11 +223,12 @@ __global__ __launch_bounds__(PVB_BLOCK) void k_pvb_cand(BvhView b, PvbView pv, c
     int n = live ? pv.count[k] : 0;
     const float bound = live ? pv.bound[k] : 0.0f;
     bool resolved = live && n >= 0;
-    // k_trace's first step for a camera ray: the root's exact box (and a NaN ray misses)
+    // k_trace's first step for a camera ray: the root's exact box -- when the root is an inner node: in a one-primitive scene the root IS the leaf, k_trace
+    // goes straight to the primitive test and a hit that fails the leaf's box has no ancestor to be refused by -- and a NaN ray misses
     bool dead = false;
     if (live) {
         float tn;
-        if (!slabs(r, b.root_min[0], b.root_min[1], b.root_min[2], b.root_max[0], b.root_max[1], b.root_max[2], tn)) dead = true;
+        if (b.root_qcode >= 0 && !slabs(r, b.root_min[0], b.root_min[1], b.root_min[2], b.root_max[0], b.root_max[1], b.root_max[2], tn)) dead = true;
         if (!((d.x == d.x) & (d.y == d.y) & (d.z == d.z))) dead = true;
     }
     if (dead) { n = 0; resolved = true; }
@@ -241,39 +241,7 @@ __global__ __launch_bounds__(PVB_BLOCK) void k_pvb_cand(BvhView b, PvbView pv, c
         const bool go = c < n && __int_as_float(en.y) <= hit_t;
         if (!go) n = 0;
         if (__ballot(go) == 0ull) break;
-        if (go) {
-            const int code = ~en.x;
-            const float4 *tp = b.tri + (size_t)(code & 0x3fffffff) * TRI_STRIDE;
-            const float4 ta = tp[0], tb = tp[1], tc = tp[2];
-            int prim = __float_as_int(tc.w);
-            const bool is_tri = ((code >> 30) & 1) == 0;
-            const v3 pa = V(ta.x, ta.y, ta.z), pb = V(tb.x, tb.y, tb.z), pc = V(tc.x, tc.y, tc.z);
-            float t, u, v;
-            if (is_tri) t = intersect_tri_packed(eye, d, pa, pb - pa, pc - pa, u, v);
-            else {
-                u = 0.0f; v = 0.0f; t = INF_VALUE;
-                if ((int)tb.y == SHAPE_SPHERE) { const v3 oc = pa - eye; if (dot(d, oc) > 0.0f) { float ccv; t = intersect_sphere(eye, d, pa, tb.x, ccv); } }
-            }
-            const int leaf = __float_as_int(ta.w);
-            bool cand = (t > 0.0f) & ((t < hit_t) | ((t == hit_t) & (hit_leaf >= 0) & (leaf > hit_leaf)));
-            if (cand) {
-                v3 bmn, bmx;
-                if (is_tri) {
-                    bmn = V(__builtin_fminf(__builtin_fminf(pa.x, pb.x), pc.x), __builtin_fminf(__builtin_fminf(pa.y, pb.y), pc.y), __builtin_fminf(__builtin_fminf(pa.z, pb.z), pc.z));
-                    bmx = V(__builtin_fmaxf(__builtin_fmaxf(pa.x, pb.x), pc.x), __builtin_fmaxf(__builtin_fmaxf(pa.y, pb.y), pc.y), __builtin_fmaxf(__builtin_fmaxf(pa.z, pb.z), pc.z));
-                } else { bmn = V(pa.x - tb.x, pa.y - tb.x, pa.z - tb.x); bmx = V(pa.x + tb.x, pa.y + tb.x, pa.z + tb.x); }
-                float tn_;
-                const int inside = par ? slabs(r, bmn.x, bmn.y, bmn.z, bmx.x, bmx.y, bmx.z, tn_) : slabs_fast(r, bmn.x, bmn.y, bmn.z, bmx.x, bmx.y, bmx.z, tn_);
-                if (!inside) {
-                    for (int an = b.cparent[leaf]; an >= 0; an = b.cparent[an]) {
-                        const float *ab = b.compact + (size_t)an * CPN_VEC + 2;
-                        if (!slabs(r, ab[0], ab[1], ab[2], ab[3], ab[4], ab[5], tn_)) { cand = false; break; }
-                    }
-                    prim = (int)b.compact[(size_t)leaf * CPN_VEC + 1];
-                }
-            }
-            if (cand) { hit_t = t; hit_u = u; hit_v = v; hit_prim = prim; hit_leaf = leaf; }
-        }
+        if (go) (void)trace_leaf_step<true>(b, r, par, ~en.x, hit_t, hit_u, hit_v, hit_prim, hit_leaf);      // k_trace's leaf step itself (tirt_internal.h)
     }
     // within bound: k_trace's answer (a list made without a bound is complete: whatever it says holds)
     if (resolved && !dead && !(hit_t <= bound) && bound < INF_VALUE) resolved = false;
@@ -314,7 +282,9 @@ __global__ void k_pvb_scatter(const int *fb_count, const int *fb_slot, const flo
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) hit[fb_slot[i]] = fb_hit[i];
 }
 
-// (re)builds the pixels' lists when the scene, the camera or the film changed since they were made; on the main stream
+// (re)builds the pixels' lists when the scene, the camera or the film changed since they were made; on the main stream.  The lists are an optimisation: when their
+// memory is not to be had (430 B per pixel while they are made, 216 B afterwards) the render goes on without them -- pvb_valid stays false, the camera rays take the
+// ordinary bounce-0 launch (a failed allocation here used to fail a render that k_trace alone could do).
 int pvb_prepare(tirt_ctx *c)
 {
     const int P = (int)c->npix_local;
@@ -325,22 +295,42 @@ int pvb_prepare(tirt_ctx *c)
     if (c->pvb_valid && !memcmp(&key, &c->pvb_key, sizeof(key))) return TIRT_OK;
     c->pvb_valid = false;
     if (P <= 0) return TIRT_OK;
-    if (c->pvb_count.ensure(sizeof(int) * (size_t)P) || c->pvb_bound.ensure(sizeof(float) * (size_t)P) || c->pvb_cand.ensure(sizeof(int2) * (size_t)PVB_CMAX * P) ||
-        c->pvb_tmp.ensure((sizeof(float4) * 2 + sizeof(float4)) * 5 * (size_t)P) || c->pvb_stat.ensure(64)) return TIRT_ERR_HIP;
-    if (int rc = trace_arrays_prepare(c, -1)) return rc;
+    tirt_ctx::PvbSet &ps = c->pvb_set[c->pvb_cur ^ 1];          // the set no batch submitted since the last rebuild reads
     hipStream_t st = c->stream;
-    // batches still in flight on the lanes read the old lists (a camera move submits what is pending and does not wait): the film updates are chained in
-    // submission order, so the last one's event covers them all
-    if (c->last_film) TIRT_HIP(hipStreamWaitEvent(st, c->last_film, 0));
+    // the probe rays, their hit records: scratch of this call only (stream-ordered allocation: no synchronisation, gone when the walk is over)
+    void *tmp = nullptr;
+    const size_t tmp_bytes = (sizeof(float4) * 2 + sizeof(float4)) * 5 * (size_t)P;
+    auto without = [&](const char *what) {
+        (void)hipGetLastError();                               // the failure is handled: leave no sticky error behind
+        c->pvb_skipped++;
+        set_error(std::string("primary_beams: no candidate lists for this camera (") + what + "); the camera rays take the ordinary launch");
+        if (tmp) (void)hipFreeAsync(tmp, st);
+        return TIRT_OK;
+    };
+    if (ps.count.ensure(sizeof(int) * (size_t)P) || ps.bound.ensure(sizeof(float) * (size_t)P) || ps.cand.ensure(sizeof(int2) * (size_t)PVB_CMAX * P) || c->pvb_stat.ensure(64))
+        return without("list memory");
+    if (hipMallocAsync(&tmp, tmp_bytes, st) != hipSuccess) { tmp = nullptr; return without("probe scratch"); }
+    if (trace_arrays_prepare(c, -1)) return without("traversal buffers");
+    // batches still in flight read the OTHER set (a camera move submits what is pending and does not wait); this one was last read by the batches of the camera
+    // before last: the film updates are chained in submission order, so the event of the last of them covers them all
+    if (ps.busy && hipStreamWaitEvent(st, ps.busy, 0) != hipSuccess) return without("event");
     TileMap tm = {c->tile_rank, c->tile_count, c->tile_size, c->H, c->tile_blocked, 0};
-    float4 *rays = c->pvb_tmp.as<float4>(), *hits = rays + 10 * (size_t)P;
+    float4 *rays = (float4 *)tmp, *hits = rays + 10 * (size_t)P;
     const int B = 256;
-    TIRT_HIP(hipMemsetAsync(c->pvb_stat.p, 0, 64, st));
+    if (hipMemsetAsync(c->pvb_stat.p, 0, 64, st) != hipSuccess) return without("memset");
+    // what a list build costs on the device (tirt_primary_beam_stats: builds and their time since the last tirt_stats_reset -- bench.py puts a build inside its clock)
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) (void)hipEventRecord(e0, st);
+    else { if (e0) (void)hipEventDestroy(e0); e0 = e1 = nullptr; (void)hipGetLastError(); }
     hipLaunchKernelGGL(k_pvb_probes, dim3((P + B - 1) / B), dim3(B), 0, st, c->cam, tm, P, rays);
-    if (int rc = trace_arrays(c, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 5 * P, nullptr, hits, nullptr, nullptr, false, -1, rays)) return rc;
-    hipLaunchKernelGGL(k_pvb_beam, dim3((P + 63) / 64), dim3(64), 0, st, bvh_view(c), c->cam, tm, P, hits, c->pvb_count.as<int>(), c->pvb_cand.as<int2>(),
-                       c->pvb_bound.as<float>(), c->pvb_stat.as<unsigned long long>());
+    if (int rc = trace_arrays(c, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 5 * P, nullptr, hits, nullptr, nullptr, false, -1, rays)) { (void)hipFreeAsync(tmp, st); if (e0) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); } return rc; }
+    hipLaunchKernelGGL(k_pvb_beam, dim3((P + 63) / 64), dim3(64), 0, st, bvh_view(c), c->cam, tm, P, hits, ps.count.as<int>(), ps.cand.as<int2>(),
+                       ps.bound.as<float>(), c->pvb_stat.as<unsigned long long>());
+    if (e0) { (void)hipEventRecord(e1, st); c->pvb_ev.push_back({e0, e1}); }
+    c->pvb_builds++;
+    TIRT_HIP(hipFreeAsync(tmp, st));
     TIRT_HIP(hipGetLastError());
+    c->pvb_cur ^= 1; ps.busy = nullptr;
     memcpy(&c->pvb_key, &key, sizeof(key)); c->pvb_valid = true;
     return TIRT_OK;
 }
@@ -350,7 +340,8 @@ int pvb_prepare(tirt_ctx *c)
 void pvb_launch_cand(tirt_ctx *c, hipStream_t st, const BvhView &bv, const float *dx, const float *dy, const float *dz, const TileMap &tm, int P, int S,
                      float4 *hit, int *fb_count, int *fb_slot, float *fb_dx, float *fb_dy, float *fb_dz, DevCounters *ctr)
 {
-    PvbView pv = {c->pvb_count.as<int>(), c->pvb_cand.as<int2>(), c->pvb_bound.as<float>()};
+    const tirt_ctx::PvbSet &ps = c->pvb_set[c->pvb_cur];
+    PvbView pv = {ps.count.as<int>(), ps.cand.as<int2>(), ps.bound.as<float>()};
     v3 eye; eye.x = c->cam.eye[0]; eye.y = c->cam.eye[1]; eye.z = c->cam.eye[2];
     const int B = PVB_BLOCK;
     hipLaunchKernelGGL(k_pvb_cand, dim3((S + B - 1) / B), dim3(B), 0, st, bv, pv, dx, dy, dz, eye, tm, P, S, hit, fb_count, fb_slot, fb_dx, fb_dy, fb_dz,

@@ -533,13 +533,10 @@ __global__ __launch_bounds__(TR_BLOCK, KIND == KIND_TAIL ? TR_TAIL_WAVES : TR_MI
                     if (BOUNDED) t_bound = from_rec ? rec_bound : TR_LDS_(c_sdist[q]);
                 }
                 if (MODE != TIRT_TRAVERSE_EXHAUSTIVE) {
-                    // margin in cells, the same on all axes: 0.25 + 0.25 per root-box extent between the origin and the
-                    // grid (largest axis).  It has to cover (i) the rounding of q * gA + gB (<= 0.016 cells per extent of
-                    // distance) and (ii) what the reference's primitive tests accept outside a leaf box: Moller-Trumbore
-                    // works on o - v0 and is off by ~5e-7 of the origin's distance IN EVERY DIRECTION (0.03 cells per extent)
+                    // margin in cells, the same on all axes (trace_margin_cells, tirt_internal.h: what it has to cover); rho = trace_origin_rho's expression on the cold arguments
                     const float relx__ = c_gm0 - o.x, rely__ = c_gm1 - o.y, relz__ = c_gm2 - o.z;
                     const float rho__ = maxf(maxf(absf(relx__) * c_ie0, absf(rely__) * c_ie1), absf(relz__) * c_ie2);
-                    const float mc__ = 0.25f + 0.25f * rho__;
+                    const float mc__ = trace_margin_cells(rho__);
                     // From far away the reference's Moller-Trumbore returns distances that are rounding noise (its o - v0 carries
                     // |o - v0| * 2^-24, divided by a determinant of the order of the triangle's area): a small or edge-on triangle
                     // seen from hundreds of extents away can "hit" tens of units in FRONT of the surface the ray really meets first,
@@ -736,69 +733,15 @@ __global__ __launch_bounds__(TR_BLOCK, KIND == KIND_TAIL ? TR_TAIL_WAVES : TR_MI
             if (n_l) { d_it_leaf++; d_lanes_leaf += (unsigned long long)n_l; }
         }
         if (leaf_now) {
+            // trace_leaf_step (tirt_internal.h): the reference's primitive test, its acceptance rule with the equal-distance rule, and -- ordered walk -- the proof
+            // that the reference would have visited this leaf (`slabs` on its exact box, else on every ancestor); shared with k_pvb_cand
             const int code = ~(from_pend ? pend : cur);
-            const float4 *tp = b.tri + (size_t)(code & 0x3fffffff) * TRI_STRIDE;          // records in the traversal tree's leaf order
-            // (the records themselves must NOT be loaded non-temporally: -25 %, profiles/r05m -- their residency in L2 is what the kernel lives on)
-            const float4 ta = tp[0], tb = tp[1], tc = tp[2];
-            int prim = __float_as_int(tc.w);                                              // the primitive id rides in the last word
             if (COUNT) nleaf += 1;
-            const v3 o = V(r.ox, r.oy, r.oz), d = V(r.dx, r.dy, r.dz);
-            const bool is_tri = ((code >> 30) & 1) == 0;
-            const v3 pa = V(ta.x, ta.y, ta.z), pb = V(tb.x, tb.y, tb.z), pc = V(tc.x, tc.y, tc.z);
-            float t, u, v;
-            bool sph = false;
-            if (is_tri) {
-                t = intersect_tri_packed(o, d, pa, pb - pa, pc - pa, u, v);          // E1 = v2 - v1, E2 = v3 - v1 (Scene.py:608-609)
-            } else {
-                // Analytic sphere (Scene.py:565-596).  Its root is t = (-b - sqrt(b^2 - 4ac)) / 2 / a with b = -2 (d . oc), a = d . d > 0: for
-                // d . oc <= 0 the numerator is a non-positive number minus a square root -- t <= 0, or NaN -- and such a t is never a
-                // candidate (0 < t < hit_t).  Exactly so in fp32 (signs, no rounding involved), so the two square roots and two divisions
-                // (~80 instructions, which the whole wave would issue for one lane) are only run for rays that head towards the centre.
-                u = 0.0f; v = 0.0f; t = INF_VALUE;
-                if ((int)tb.y == SHAPE_SPHERE) { const v3 oc = pa - o; sph = dot(d, oc) > 0.0f; }
-            }
-            if (wave_any(sph)) { if (sph) { float cc; t = intersect_sphere(o, d, pa, tb.x, cc); } }
-            const int leaf = __float_as_int(ta.w);
+            const bool accepted = trace_leaf_step<MODE != TIRT_TRAVERSE_EXHAUSTIVE>(b, r, par, code, hit_t, hit_u, hit_v, hit_prim, hit_leaf);
             if (from_pend) pend = 0; else TR_POP(cur);
-            // reference: accept iff 0 < t < hit_t (so never t >= INF_VALUE); equal-t candidates: see header
-            bool cand = (t > 0.0f) & ((t < hit_t) | ((t == hit_t) & (hit_leaf >= 0) & (leaf > hit_leaf)));
-            if (MODE != TIRT_TRAVERSE_EXHAUSTIVE && cand) {
-                // The quantised boxes that led here contain the reference's: would the reference have visited this leaf
-                // (Scene.py:702-744: every proper ancestor's box passes `slabs`)?  The leaf's own exact box passing implies
-                // it (the outer of two nested boxes passes whenever the inner one does: `slabs` is monotone in the planes);
-                // that box is the min / max of the three positions just loaded (accel/LBvh.py:397-426; spheres: centre -+ r).
-                // Otherwise -- a hit within rounding distance of the leaf box's boundary -- the ancestors are asked one by one.
-                v3 bmn, bmx;
-                if (is_tri) {
-                    // v_min3_f32 / v_max3_f32 (6 instructions, not 24 compare + select): positions are never NaN, and which of
-                    // -0 / +0 comes out of a tie changes no comparison of `slabs`
-#define TR_MIN3(a, b, c) __builtin_fminf(__builtin_fminf((a), (b)), (c))
-#define TR_MAX3(a, b, c) __builtin_fmaxf(__builtin_fmaxf((a), (b)), (c))
-                    bmn = V(TR_MIN3(pa.x, pb.x, pc.x), TR_MIN3(pa.y, pb.y, pc.y), TR_MIN3(pa.z, pb.z, pc.z));
-                    bmx = V(TR_MAX3(pa.x, pb.x, pc.x), TR_MAX3(pa.y, pb.y, pc.y), TR_MAX3(pa.z, pb.z, pc.z));
-                } else {
-                    bmn = V(pa.x - tb.x, pa.y - tb.x, pa.z - tb.x); bmx = V(pa.x + tb.x, pa.y + tb.x, pa.z + tb.x);
-                }
-                float tn_;
-                const RayCtx &rv = r;
-                const int inside = par ? slabs(rv, bmn.x, bmn.y, bmn.z, bmx.x, bmx.y, bmx.z, tn_) : slabs_fast(rv, bmn.x, bmn.y, bmn.z, bmx.x, bmx.y, bmx.z, tn_);
-                if (!inside) {
-                    for (int an = b.cparent[leaf]; an >= 0; an = b.cparent[an]) {
-                        const float *ab = b.compact + (size_t)an * CPN_VEC + 2;
-                        if (!slabs(rv, ab[0], ab[1], ab[2], ab[3], ab[4], ab[5], tn_)) { cand = false; break; }
-                    }
-                    // the primitive id again, from the leaf's reference row (UtilsFunc.py:get_compact_node_prim): the same number that came with the
-                    // primitive record -- read here so that NOTHING of that record has to survive the walk above.  ROCm 7.2's register allocator lets
-                    // the walk's row loads (global_load_dwordx4 v[8:11]) land on the register that holds the record's last word while it is still
-                    // needed below (tools/dbg/prim_clobber.sh shows the ISA; 156 of 15 000 box-grazing rays on the Cornell box then kept the PREVIOUS
-                    // hit's primitive id, tests/test_gpu_trace.py::test_quantised_nodes_on_grazing_rays).  Round 3 pinned the value with an empty asm.
-                    prim = (int)b.compact[(size_t)leaf * CPN_VEC + 1];
-                }
-            }
-            if (cand) {
-                hit_t = t; hit_u = u; hit_v = v; hit_prim = prim; hit_leaf = leaf;
+            if (accepted) {
                 lim = __builtin_fminf(__builtin_fminf(cull_far < 0.0f ? INF_VALUE : hit_t * 1.0001f, __builtin_fabsf(cull_far)), INF_VALUE);      // (v_min: a canonical value, so the node loop does not re-canonicalise it every step)
-                if (BOUNDED && prim != expect && t < settle) { cur = TR_SENT; paged = 0; pend = 0; }      // answer settled: "occluded"
+                if (BOUNDED && hit_prim != expect && hit_t < settle) { cur = TR_SENT; paged = 0; pend = 0; }      // answer settled: "occluded"
             }
         }
 
@@ -1746,6 +1689,7 @@ int pt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed,
             L.counts_pending = true; L.counts_S = S; L.counts_known = counts_known;
         }
         c->last_film = L.film_done;
+        if (use_beams) c->pvb_set[c->pvb_cur].busy = L.film_done;      // the last batch that reads this set of candidate lists (pvb_prepare)
         TIRT_HIP(hipEventRecord(r1, st));
         if (c->time_kernels) {
             TIRT_HIP(hipStreamSynchronize(st));
