@@ -60,6 +60,8 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # one HW queue per render lane; before HIP initialises
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+# configs whose traversal data does not fit on the die: name -> (triangles, vertex spread, pixels of the oracle sample)
+BIG_SCENES = {"big_scene_4M_1024x1024_32spp": (4000000, 0.006, 1024), "big_scene_16M_1024x1024_32spp": (16000000, 0.003, 512)}
 
 
 def parse():
@@ -358,30 +360,33 @@ def run_config(name, device_id, seed=1):
         r["oracle_sample"] = "whole 48x48 film x 3 spp: rel-L2 %.2e (float-atomic splats)" % rel
         r["reference_pin"] = "structure pin against image/rainbow.png: tests/test_bdpt_spec.py, tests/test_gpu_bdpt_spec.py"
         return r
-    if name == "big_scene_4M_1024x1024_32spp":       # the regime north_star describes: a tree that does not fit on the die (4 M triangles: ~0.46 GB of nodes + primitive records)
+    if name in BIG_SCENES:       # the regime north_star describes: a tree that does not fit on the die (4 M triangles: 0.30 GB of nodes + primitive records ~ the 256 MiB Infinity Cache; 16 M: 1.2 GB, far beyond it)
+        ntri, spread, npx = BIG_SCENES[name]
         W = H = 1024; spp = 32
         t0 = time.perf_counter()
-        ex = scenes.synthetic(W, H, spp, ntri=4000000, spread=0.006, device_id=device_id, seed=seed); ex.build_scene(); ex.scene.ctx.sync()
+        ex = scenes.synthetic(W, H, spp, ntri=ntri, spread=spread, device_id=device_id, seed=seed); ex.build_scene(); ex.scene.ctx.sync()
         t_setup = time.perf_counter() - t0
         hdr, r = timed(ex, spp, lambda: ex.integrator.render_frames(spp))
         info = ex.scene.ctx.bvh_info()
-        r["scene"] = "synthetic random mesh, 4 000 000 triangles (scene seed 1234, s = 0.006: the headline scene's covered area per volume), PT_RGB, max_depth 15"
+        r["scene"] = "synthetic random mesh, %d triangles (scene seed 1234, s = %g: about the headline scene's covered area per volume), PT_RGB, max_depth 15" % (ntri, spread)
         r["traversal_bytes"] = int(info["node_bytes"] + info["prim_bytes"])
+        r["traversal_bytes_over_infinity_cache"] = round((info["node_bytes"] + info["prim_bytes"]) / float(256 << 20), 2)
         r["setup_seconds_host_packing_and_build"] = round(t_setup, 2)
         r["gather_ceiling_GBps_for_this_working_set"] = round(ex.scene.ctx.micro_gather_rate(info["node_bytes"] + info["prim_bytes"], 1000), 1)
         if not os.environ.get("TIRT_BENCH_CTX_OPTS"):      # (not in the profiler children)
-            r["oracle_sample_identical"] = _oracle_run_identical(ex, W, H, spp, seed, hdr, (W // 2) * H + 128, 1024)
-            r["oracle_sample"] = "1024 pixels x 32 spp, bit for bit"
+            t1 = time.perf_counter()
+            r["oracle_sample_identical"] = _oracle_run_identical(ex, W, H, spp, seed, hdr, (W // 2) * H + 128, npx)
+            r["oracle_sample"] = "%d pixels x 32 spp, bit for bit (CPU oracle incl. its LBVH build: %.1f s)" % (npx, time.perf_counter() - t1)
         return r
     raise SystemExit("unknown config " + name)
 
 
-def big_scene_roofline(cfg):
+def big_scene_roofline(cfg, name="big_scene_4M_1024x1024_32spp"):
     """HBM-side traffic, L2 hit rate and L1 -> L2 request rate of k_trace on the 4 M-triangle scene (three rocprofv3 passes over a child run of the config on
     ONE lane): the `>= 40 % of the HBM roofline` question of north_star, asked where the tree does not fit in L2 / MALL."""
-    child = [sys.executable, os.path.abspath(__file__), "--configs-only", "big_scene_4M_1024x1024_32spp:overlap_lanes=1"]
+    child = [sys.executable, os.path.abspath(__file__), "--configs-only", name + ":overlap_lanes=1"]
     try:
-        k = rocprof_passes(child, [("FETCH_SIZE",), ("WRITE_SIZE",), ("TCP_TCC_READ_REQ_sum", "TCC_HIT_sum", "TCC_MISS_sum")], timeout_s=400)
+        k = rocprof_passes(child, [("FETCH_SIZE",), ("WRITE_SIZE",), ("TCP_TCC_READ_REQ_sum", "TCC_HIT_sum", "TCC_MISS_sum"), ("TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum")], timeout_s=600)
     except Exception as exc:            # noqa: BLE001
         return {"error": "%s: %s" % (type(exc).__name__, exc)}
     tot = {}
@@ -404,7 +409,7 @@ def big_scene_roofline(cfg):
     if "rays" in cfg and cfg.get("seconds"):
         out["hbm_bytes_per_ray"] = round(by / 2.0 / max(cfg["rays"], 1), 1)
     out["source"] = ("rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE | TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum over "
-                     "`bench.py --configs-only big_scene_4M_1024x1024_32spp:overlap_lanes=1` (one lane, profiled durations; FETCH_SIZE x 2: gfx950)")
+                     "`bench.py --configs-only %s:overlap_lanes=1` (one lane, profiled durations; FETCH_SIZE x 2: gfx950)" % name)
     return out
 
 
@@ -1008,7 +1013,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_configs:
         cfgs = {}
         for name in ("config1_cornell_512x512_512spp", "config2_teapot_1024x1024_64spp", "config5_veach_bdpt_512x512_64spp", "spectral_cornell_512x512_64spp",
-                     "prism_rainbow_bdpt_spec_512x512_64spp", "big_scene_4M_1024x1024_32spp"):
+                     "prism_rainbow_bdpt_spec_512x512_64spp", "big_scene_4M_1024x1024_32spp", "big_scene_16M_1024x1024_32spp"):
             try:
                 cfgs[name] = run_config(name, local_rank, args.seed)
             except Exception as exc:        # noqa: BLE001 -- one failing config must not hide the headline line
@@ -1017,8 +1022,9 @@ def main():
         cfgs["config3_headline"] = "this line's `value` (%d steps x %d frames of the 100k scene)" % (args.steps, fps)
         if not args.no_traffic:
             cfgs["config5_veach_bdpt_512x512_64spp"]["roofline"] = bdpt_roofline(local_rank)
-            if "error" not in cfgs["big_scene_4M_1024x1024_32spp"]:
-                cfgs["big_scene_4M_1024x1024_32spp"]["roofline"] = big_scene_roofline(cfgs["big_scene_4M_1024x1024_32spp"])
+            for big in BIG_SCENES:
+                if "error" not in cfgs[big]:
+                    cfgs[big]["roofline"] = big_scene_roofline(cfgs[big], big)
         # LBVH build (a4..a8) + traversal tree at 1 M primitives, second build of each kind (HIP events on the context's stream)
         try:
             big = scenes.synthetic(64, 64, 4, ntri=1000000, spread=0.012, device_id=local_rank)
