@@ -60,8 +60,9 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # one HW queue per render lane; before HIP initialises
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+EA_REQ_CEILING_G = 52.5         # G fabric read requests/s (128-byte lines) that streams and random record gathers alike reach from 0.5-2 GB working sets: profiles/r06_micro_hbm_gather.txt
 # configs whose traversal data does not fit on the die: name -> (triangles, vertex spread, pixels of the oracle sample)
-BIG_SCENES = {"big_scene_4M_1024x1024_32spp": (4000000, 0.006, 1024), "big_scene_16M_1024x1024_32spp": (16000000, 0.003, 512)}
+BIG_SCENES = {"big_scene_4M_1024x1024_32spp": (4000000, 0.006, 1024), "big_scene_8M_1024x1024_32spp": (8000000, 0.0042, 512)}    # (8 M: the largest this data format takes -- compact_node keeps node indices as f32, exact below 2^24 = 2 x 8.39 M nodes, as the reference does)
 
 
 def parse():
@@ -360,7 +361,7 @@ def run_config(name, device_id, seed=1):
         r["oracle_sample"] = "whole 48x48 film x 3 spp: rel-L2 %.2e (float-atomic splats)" % rel
         r["reference_pin"] = "structure pin against image/rainbow.png: tests/test_bdpt_spec.py, tests/test_gpu_bdpt_spec.py"
         return r
-    if name in BIG_SCENES:       # the regime north_star describes: a tree that does not fit on the die (4 M triangles: 0.30 GB of nodes + primitive records ~ the 256 MiB Infinity Cache; 16 M: 1.2 GB, far beyond it)
+    if name in BIG_SCENES:       # the regime north_star describes: a tree that does not fit on the die (4 M triangles: 0.30 GB of nodes + primitive records ~ the 256 MiB Infinity Cache; 8 M: 0.6 GB = 2.2 x it)
         ntri, spread, npx = BIG_SCENES[name]
         W = H = 1024; spp = 32
         t0 = time.perf_counter()
@@ -382,8 +383,13 @@ def run_config(name, device_id, seed=1):
 
 
 def big_scene_roofline(cfg, name="big_scene_4M_1024x1024_32spp"):
-    """HBM-side traffic, L2 hit rate and L1 -> L2 request rate of k_trace on the 4 M-triangle scene (three rocprofv3 passes over a child run of the config on
-    ONE lane): the `>= 40 % of the HBM roofline` question of north_star, asked where the tree does not fit in L2 / MALL."""
+    """Memory-side traffic of k_trace on a scene whose traversal data does not fit on the die (four rocprofv3 passes over a child run of the config on ONE lane): the
+    `>= 40 % of the HBM roofline` question of north_star.  What the counters mean was calibrated on k_trace's own access pattern (tools/micro/hbm_gather.hip,
+    profiles/r06_micro_hbm_gather.txt: random 64-byte and 128-byte record gathers and a coalesced stream over working sets of 2 MB .. 8 GB): FETCH_SIZE is 64 bytes
+    per read request the L2 sends to the fabric (TCC_EA0_RDREQ) for all three patterns -- half the bytes of a stream and of 128-byte records, all the bytes of
+    64-byte records -- and all three saturate at the same 52-53 G requests/s, i.e. a request moves a 128-byte line whatever part of it was asked for: bytes moved =
+    requests x 128 = FETCH_SIZE x 2, for gathers as for streams.  The same file shows FETCH_SIZE counting requests that hit in the 256 MiB Infinity Cache (a 128 MB
+    working set: 0.97 of the known bytes), so `hbm` below is fabric-side traffic, of which `infinity_cache_share_at_most` can have stopped short of HBM."""
     child = [sys.executable, os.path.abspath(__file__), "--configs-only", name + ":overlap_lanes=1"]
     try:
         k = rocprof_passes(child, [("FETCH_SIZE",), ("WRITE_SIZE",), ("TCP_TCC_READ_REQ_sum", "TCC_HIT_sum", "TCC_MISS_sum"), ("TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum")], timeout_s=600)
@@ -401,15 +407,30 @@ def big_scene_roofline(cfg, name="big_scene_4M_1024x1024_32spp"):
     hbm = by / tot["dur_ns"]
     out = {"bound": "hbm", "kernel": "k_trace", "achieved": round(hbm, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm / HBM_PEAK_GBS, 4),
            "traffic": round(by / tot["launches"]), "launches_per_job": int(n), "avg_launch_ms_profiled": round(tot["dur_ns"] / tot["launches"] / 1e6, 4),
-           "k_trace_ms_per_job_profiled": round(tot["dur_ns"] / 2e6, 3)}
+           "k_trace_ms_per_job_profiled": round(tot["dur_ns"] / 2e6, 3),
+           "fetch_correction": 2.0, "fetch_correction_calibrated_on": "gather (tools/micro/hbm_gather.hip, profiles/r06_micro_hbm_gather.txt: one fabric read request = one 128-byte line, "
+                                                                      "tallied as 64 bytes by FETCH_SIZE, for 64-byte record gathers, 128-byte record gathers and streams alike)"}
+    if tot.get("TCC_EA0_RDREQ_sum"):
+        rq = tot["TCC_EA0_RDREQ_sum"] / tot["dur_ns"]             # G requests/s
+        out["fabric_read_requests"] = {"G_per_s": round(rq, 2), "measured_ceiling_G_per_s": EA_REQ_CEILING_G, "frac_of_ceiling": round(rq / EA_REQ_CEILING_G, 4),
+                                       "bytes_x128_GBps": round(rq * 128.0, 1), "share_32B": round(tot.get("TCC_EA0_RDREQ_32B_sum", 0.0) / tot["TCC_EA0_RDREQ_sum"], 4),
+                                       "fetch_size_bytes_per_request": round(tot.get("FETCH_SIZE", 0.0) * 1024.0 / tot["TCC_EA0_RDREQ_sum"], 2),
+                                       "def": "TCC_EA0_RDREQ_sum / profiled k_trace time; ceiling: what random record gathers AND a coalesced stream reach on this device from "
+                                              "working sets of 0.5-2 GB (profiles/r06_micro_hbm_gather.txt) = 6.7 TB/s in 128-byte lines"}
     if tot.get("TCC_HIT_sum", 0) + tot.get("TCC_MISS_sum", 0) > 0:
         out["l2_hit_rate"] = round(tot["TCC_HIT_sum"] / (tot["TCC_HIT_sum"] + tot["TCC_MISS_sum"]), 4)
         out["l1_to_l2_read_requests_G_per_s"] = round(tot["TCP_TCC_READ_REQ_sum"] / tot["dur_ns"], 2)
         out["l2_miss_requests_G_per_s"] = round(tot["TCC_MISS_sum"] / tot["dur_ns"], 2)
+    if cfg.get("traversal_bytes"):
+        share = min(1.0, float(256 << 20) / cfg["traversal_bytes"])
+        out["infinity_cache_share_at_most"] = round(share, 3)
+        out["hbm_frac_if_the_infinity_cache_held_all_it_can"] = round(hbm / HBM_PEAK_GBS * (1.0 - share), 4)
+        out["infinity_cache_note"] = ("the L2's misses go to the deep nodes and the primitive records, spread over the whole working set: the Infinity Cache can hold at most "
+                                      "this share of it, and FETCH_SIZE / TCC_EA0_RDREQ count its hits with the HBM reads")
     if "rays" in cfg and cfg.get("seconds"):
         out["hbm_bytes_per_ray"] = round(by / 2.0 / max(cfg["rays"], 1), 1)
-    out["source"] = ("rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE | TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum over "
-                     "`bench.py --configs-only %s:overlap_lanes=1` (one lane, profiled durations; FETCH_SIZE x 2: gfx950)" % name)
+    out["source"] = ("rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE | TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum | TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum over "
+                     "`bench.py --configs-only %s:overlap_lanes=1` (one lane, profiled durations)" % name)
     return out
 
 
@@ -1013,7 +1034,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_configs:
         cfgs = {}
         for name in ("config1_cornell_512x512_512spp", "config2_teapot_1024x1024_64spp", "config5_veach_bdpt_512x512_64spp", "spectral_cornell_512x512_64spp",
-                     "prism_rainbow_bdpt_spec_512x512_64spp", "big_scene_4M_1024x1024_32spp", "big_scene_16M_1024x1024_32spp"):
+                     "prism_rainbow_bdpt_spec_512x512_64spp", "big_scene_4M_1024x1024_32spp", "big_scene_8M_1024x1024_32spp"):
             try:
                 cfgs[name] = run_config(name, local_rank, args.seed)
             except Exception as exc:        # noqa: BLE001 -- one failing config must not hide the headline line

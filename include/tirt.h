@@ -254,8 +254,10 @@ int tirt_trace_timeline(tirt_ctx *ctx, uint64_t *out, int max_waves, int *n_wave
  * traced by k_trace, out[4] = camera rays that went through the lists; since the last tirt_stats_reset: out[5] = list builds (one per change of build /
  * camera / film seen by a batch that uses lists, or after option "primary_beams_rebuild"), out[6] = their device time in nanoseconds (HIP events on the
  * context's stream: probe rays + the walk of the pixels' pyramids), out[7] = builds given up for lack of memory (the camera rays then take the ordinary
- * launch).  Waits for pending work.  (No reference counterpart: bench / tests.) */
-int tirt_primary_beam_stats(tirt_ctx *ctx, uint64_t out[8]);
+ * launch); with option "primary_beams_diag" (slow: an atomic per wave) the list pass counts since the lists were made out[8] = leaf steps of all camera rays,
+ * out[9] = rays that took more than one, out[10] = lane slots of the waves' trips (64 x the leaf steps of each wave's slowest ray), out[11] = rays that took more
+ * than two.  Waits for pending work.  (No reference counterpart: bench / tests.) */
+int tirt_primary_beam_stats(tirt_ctx *ctx, uint64_t out[12]);
 
 /* Fills *out.  Returns TIRT_ERR_STACK (with *out filled in) when stack_overflow > 0: rays dropped subtrees, what was
  * rendered since the last tirt_stats_reset is wrong -- the reference prints "overflow, need larger stack" (Scene.py:741). */

@@ -373,10 +373,11 @@ class Context:
 
     def primary_beam_stats(self):
         """Diagnostics of the camera rays' candidate lists (tirt.h, tirt_primary_beam_stats)."""
-        out = (C.c_uint64 * 8)()
+        out = (C.c_uint64 * 12)()
         check(lib().tirt_primary_beam_stats(self.handle, out))
         return {"pixels_with_list": int(out[0]), "leaves_listed": int(out[1]), "pixels_all_probes_hit": int(out[2]), "rays_to_k_trace": int(out[3]), "rays": int(out[4]),
-                "list_builds": int(out[5]), "list_build_ms": out[6] * 1.0e-6, "list_builds_skipped": int(out[7])}
+                "list_builds": int(out[5]), "list_build_ms": out[6] * 1.0e-6, "list_builds_skipped": int(out[7]),
+                "diag_leaf_steps": int(out[8]), "diag_rays_more_than_one_step": int(out[9]), "diag_lane_slots": int(out[10]), "diag_rays_more_than_two_steps": int(out[11])}
 
     def micro_gather_rate(self, working_set_bytes, iters=2000):
         v = C.c_double(0.0)

@@ -423,6 +423,7 @@ int tirt_set_option(tirt_ctx *c, const char *name, double value)
     if (!strcmp(name, "primary_beams")) { TIRT_REQUIRE(value == 0.0 || value == 1.0, "primary_beams: 0 or 1"); if (flush_pending(c)) return TIRT_ERR_HIP; c->primary_beams = (int)value; return TIRT_OK; }
     // "primary_beams_rebuild": forget the camera rays' candidate lists -- the next batch that uses lists makes them again (bench.py: a list build inside its clock)
     if (!strcmp(name, "primary_beams_rebuild")) { if (flush_pending(c)) return TIRT_ERR_HIP; c->pvb_valid = false; return TIRT_OK; }
+    if (!strcmp(name, "primary_beams_diag")) { if (flush_pending(c)) return TIRT_ERR_HIP; c->pvb_diag = value != 0.0; return TIRT_OK; }
     if (!strcmp(name, "primary_beams_min_frames")) { TIRT_REQUIRE(value >= 1.0 && value <= 1.0e6, "primary_beams_min_frames out of range"); if (flush_pending(c)) return TIRT_ERR_HIP; c->primary_beams_min_frames = (int)value; return TIRT_OK; }
     if (!strcmp(name, "bdpt_lanes")) { TIRT_REQUIRE(value >= 1.0 && value <= 4.0, "bdpt_lanes: 1..4"); if (sync_all(c)) return TIRT_ERR_HIP; c->bdpt_lanes = (int)value; return TIRT_OK; }
     if (!strcmp(name, "bdpt_batch_items")) { TIRT_REQUIRE(value >= 1.0 && value <= 1.0e9, "bdpt_batch_items out of range"); c->bdpt_batch_items = (size_t)value; return TIRT_OK; }
@@ -834,17 +835,18 @@ static void drain_pvb_events(tirt_ctx *c)
     (void)hipGetLastError();
 }
 
-int tirt_primary_beam_stats(tirt_ctx *c, uint64_t out[8])
+int tirt_primary_beam_stats(tirt_ctx *c, uint64_t out[12])
 {
     TIRT_REQUIRE(c && out, "tirt_primary_beam_stats: null arguments");
-    for (int k = 0; k < 8; k++) out[k] = 0;
+    for (int k = 0; k < 12; k++) out[k] = 0;
     if (sync_all(c)) return TIRT_ERR_HIP;
     drain_pvb_events(c);
     out[5] = c->pvb_builds; out[6] = c->pvb_build_ns; out[7] = c->pvb_skipped;
     if (!c->pvb_stat.p) return TIRT_OK;
-    unsigned long long h[5];
+    unsigned long long h[12];
     TIRT_HIP(hipMemcpy(h, c->pvb_stat.p, sizeof(h), hipMemcpyDeviceToHost));
     for (int k = 0; k < 5; k++) out[k] = h[k];
+    for (int k = 8; k < 12; k++) out[k] = h[k];
     return TIRT_OK;
 }
 

@@ -369,6 +369,7 @@ struct tirt_ctx {
     // (one set made every camera move wait for all earlier batches to drain); `busy` = film_done of the last batch that read the set
     struct PvbSet { tirt::DevBuf count, cand, bound; hipEvent_t busy = nullptr; } pvb_set[2];
     int pvb_cur = 0;                              // the set pvb_key describes
+    int pvb_diag = 0;                             // option "primary_beams_diag": k_pvb_cand counts its leaf steps (one atomic per wave: slow) -- tirt_primary_beam_stats out[8..11]
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pvb_ev;      // HIP events around every list build since the last tirt_stats_reset (read by tirt_primary_beam_stats)
     unsigned long long pvb_builds = 0, pvb_build_ns = 0, pvb_skipped = 0;      // list builds since the reset, their device time, builds given up for lack of memory
     tirt::DevBuf pvb_stat;

@@ -209,7 +209,7 @@ __global__ __launch_bounds__(64) void k_pvb_beam(BvhView b, CameraView cam, Tile
 // One camera ray against its pixel's list (see the header); the unresolved ones are appended to (fb_slot, fb_d*).
 __global__ __launch_bounds__(PVB_BLOCK) void k_pvb_cand(BvhView b, PvbView pv, const float *dx, const float *dy, const float *dz, v3 eye, TileMap tm, int P, int S,
                                                   float4 *hit, int *fb_count, int *fb_slot, float *fb_dx, float *fb_dy, float *fb_dz, DevCounters *ctr,
-                                                  unsigned long long *stat)
+                                                  unsigned long long *stat, unsigned long long *diag)
 {
     const int s = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
     const bool live = s < S;
@@ -234,6 +234,7 @@ __global__ __launch_bounds__(PVB_BLOCK) void k_pvb_cand(BvhView b, PvbView pv, c
     if (dead) { n = 0; resolved = true; }
     if (!resolved) n = 0;
     float hit_t = INF_VALUE, hit_u = 0.0f, hit_v = 0.0f; int hit_prim = -1, hit_leaf = -1;
+    int steps = 0, trips = 0;          // (diagnostics, option "primary_beams_diag")
     for (int c = 0; c < PVB_CMAX; c++) {
         // (the lists are sorted by the distance at which a ray of the pixel can reach the leaf's box at the earliest: beyond the hit so far, nothing on the rest of the list can win or tie)
         int2 en = make_int2(0, 0x7f800000);
@@ -241,6 +242,7 @@ __global__ __launch_bounds__(PVB_BLOCK) void k_pvb_cand(BvhView b, PvbView pv, c
         const bool go = c < n && __int_as_float(en.y) <= hit_t;
         if (!go) n = 0;
         if (__ballot(go) == 0ull) break;
+        trips++; if (go) steps++;
         if (go) (void)trace_leaf_step<true>(b, r, par, ~en.x, hit_t, hit_u, hit_v, hit_prim, hit_leaf);      // k_trace's leaf step itself (tirt_internal.h)
     }
     // within bound: k_trace's answer (a list made without a bound is complete: whatever it says holds)
@@ -274,6 +276,12 @@ __global__ __launch_bounds__(PVB_BLOCK) void k_pvb_cand(BvhView b, PvbView pv, c
     }
     if (s == 0 && ctr) atomicAdd(&ctr->rays_closest, (unsigned long long)S);
     if (stat && s == 0) atomicAdd(&stat[4], (unsigned long long)S);
+    if (diag) {
+        // leaf steps of all rays, rays with more than one, wave trips x 64 (lane slots), rays with more than two
+        unsigned long long a = (unsigned long long)steps, m1 = steps > 1 ? 1ull : 0ull, m2 = steps > 2 ? 1ull : 0ull;
+        for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o, 64); m1 += __shfl_down(m1, o, 64); m2 += __shfl_down(m2, o, 64); }
+        if (lane == 0) { atomicAdd(&diag[0], a); atomicAdd(&diag[1], m1); atomicAdd(&diag[2], (unsigned long long)trips * 64ull); atomicAdd(&diag[3], m2); }
+    }
 }
 
 __global__ void k_pvb_scatter(const int *fb_count, const int *fb_slot, const float4 *fb_hit, float4 *hit)
@@ -307,7 +315,7 @@ int pvb_prepare(tirt_ctx *c)
         if (tmp) (void)hipFreeAsync(tmp, st);
         return TIRT_OK;
     };
-    if (ps.count.ensure(sizeof(int) * (size_t)P) || ps.bound.ensure(sizeof(float) * (size_t)P) || ps.cand.ensure(sizeof(int2) * (size_t)PVB_CMAX * P) || c->pvb_stat.ensure(64))
+    if (ps.count.ensure(sizeof(int) * (size_t)P) || ps.bound.ensure(sizeof(float) * (size_t)P) || ps.cand.ensure(sizeof(int2) * (size_t)PVB_CMAX * P) || c->pvb_stat.ensure(128))
         return without("list memory");
     if (hipMallocAsync(&tmp, tmp_bytes, st) != hipSuccess) { tmp = nullptr; return without("probe scratch"); }
     if (trace_arrays_prepare(c, -1)) return without("traversal buffers");
@@ -317,7 +325,7 @@ int pvb_prepare(tirt_ctx *c)
     TileMap tm = {c->tile_rank, c->tile_count, c->tile_size, c->H, c->tile_blocked, 0};
     float4 *rays = (float4 *)tmp, *hits = rays + 10 * (size_t)P;
     const int B = 256;
-    if (hipMemsetAsync(c->pvb_stat.p, 0, 64, st) != hipSuccess) return without("memset");
+    if (hipMemsetAsync(c->pvb_stat.p, 0, 128, st) != hipSuccess) return without("memset");
     // what a list build costs on the device (tirt_primary_beam_stats: builds and their time since the last tirt_stats_reset -- bench.py puts a build inside its clock)
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) (void)hipEventRecord(e0, st);
@@ -345,7 +353,7 @@ void pvb_launch_cand(tirt_ctx *c, hipStream_t st, const BvhView &bv, const float
     v3 eye; eye.x = c->cam.eye[0]; eye.y = c->cam.eye[1]; eye.z = c->cam.eye[2];
     const int B = PVB_BLOCK;
     hipLaunchKernelGGL(k_pvb_cand, dim3((S + B - 1) / B), dim3(B), 0, st, bv, pv, dx, dy, dz, eye, tm, P, S, hit, fb_count, fb_slot, fb_dx, fb_dy, fb_dz,
-                       ctr, c->pvb_stat.as<unsigned long long>());
+                       ctr, c->pvb_stat.as<unsigned long long>(), c->pvb_diag ? c->pvb_stat.as<unsigned long long>() + 8 : nullptr);
 }
 void pvb_launch_scatter(hipStream_t st, const int *fb_count, const int *fb_slot, const float4 *fb_hit, float4 *hit)
 {
