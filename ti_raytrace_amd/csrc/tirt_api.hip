@@ -403,6 +403,8 @@ int tirt_set_option(tirt_ctx *c, const char *name, double value)
         TIRT_REQUIRE(value == 0.0 || value == 1.0, "traversal_tree: 0 (the reference's LBVH) or 1 (binned SAH)");
         c->use_sah = (int)value; return TIRT_OK;
     }
+    if (!strcmp(name, "plan_batches")) { TIRT_REQUIRE(value >= 0.0 && value <= 64.0, "plan_batches: 0 (automatic) .. 64"); if (flush_pending(c)) return TIRT_ERR_HIP; c->plan_nb = (int)value; return TIRT_OK; }
+    if (!strcmp(name, "plan_lanes")) { TIRT_REQUIRE(value >= 0.0 && value <= TIRT_MAX_LANES, "plan_lanes: 0 (automatic) .. the lane count"); if (flush_pending(c)) return TIRT_ERR_HIP; c->plan_lanes = (int)value; return TIRT_OK; }
     if (!strcmp(name, "job_frames")) { TIRT_REQUIRE(value >= 0.0 && value <= 1.0e9, "job_frames out of range"); c->job_frames = (long)value; return TIRT_OK; }
     if (!strcmp(name, "merge_paths")) { TIRT_REQUIRE(value >= 0.0 && value <= 1.0e9, "merge_paths out of range"); c->merge_paths = (size_t)value; c->merge_user = true; return TIRT_OK; }
     if (!strcmp(name, "batch_paths")) {

@@ -330,6 +330,7 @@ struct tirt_ctx {
     int split_lone = 0;                            // option "split_lone_batch": a job that is one batch runs as N parts on N lanes (off: with five traversal waves per SIMD and
                                                    // the shading beside them a lone batch fills the GPU better than its halves: 3.15 against 3.27 ms per step at 8 emulated ranks)
     bool grid_user = false;                        // trace_grid / shade_grid were set through tirt_set_option
+    int plan_nb = 0, plan_lanes = 0;              // options "plan_batches" / "plan_lanes": a hinted job as this many batches, this many at a time (0: plan_batches' own rule)
     bool batch_user = false, merge_user = false;   // batch_paths / merge_paths were set through tirt_set_option: no automatic sizing
     long job_frames = 0;                           // option "job_frames": expected frames of the whole job (0 = unknown); bounds the head-room
     struct { bool valid = false; uint32_t begin = 0; int count = 0; uint32_t seed = 0; int max_depth = 0, stack_size = 0, flags = 0; bool spectral = false; } pend;
@@ -411,10 +412,12 @@ inline BatchPlan plan_batches(const tirt_ctx *c)
         const size_t P = (size_t)c->npix_local, J = (size_t)c->job_frames * P, MAXB = (size_t)128 << 20;
         if (J >= ((size_t)24 << 20)) {
             const size_t nb_min = (J + MAXB - 1) / MAXB, L = (size_t)(c->n_lanes > 0 ? c->n_lanes : 1);
-            const size_t nb = nb_min <= 2 ? 2 : nb_min;
+            size_t nb = nb_min <= 2 ? 2 : nb_min;
+            if (c->plan_nb > 0 && (size_t)c->plan_nb >= nb_min) nb = (size_t)c->plan_nb;
             size_t frames = ((size_t)c->job_frames + nb - 1) / nb;
             p.batch = frames * P;
             p.lanes = (int)(L < 2 ? L : 2);
+            if (c->plan_lanes > 0) p.lanes = (int)(L < (size_t)c->plan_lanes ? L : (size_t)c->plan_lanes);
         }
     }
     return p;
