@@ -199,6 +199,50 @@ def _grazing_rays(ex, n, seed):
     return np.concatenate(rays, axis=0).astype(np.float32)
 
 
+def _leaf_box_fails_slabs(ex, rays, prim):
+    """mask of the hit rays whose hit triangle's exact box does NOT pass the reference's `slabs` (UtilsFunc.py:494-523, fp32, 1 / d hoisted as the device does):
+    the candidates k_trace accepts only after walking the leaf's ancestors (trace_leaf_step, tirt_internal.h) -- the path on which ROCm 7.2's register
+    allocator once overwrote the primitive id (toolchain note)"""
+    P, V = ex.scene.primitive_np, ex.scene.vertex_np[:, :3].astype(np.float32)
+    hit = (prim >= 0) & (P[np.maximum(prim, 0), 0] == 1)
+    vi = P[np.maximum(prim, 0), 1]
+    tri = np.stack([V[vi], V[vi + 1], V[vi + 2]], axis=1)
+    mn, mx = tri.min(axis=1), tri.max(axis=1)
+    o, d = rays[:, :3].astype(np.float32), rays[:, 3:6].astype(np.float32)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        inv = (np.float32(1.0) / d).astype(np.float32)
+        t1 = ((mn - o) * inv).astype(np.float32); t2 = ((mx - o) * inv).astype(np.float32)
+    lo, hi = np.minimum(t1, t2), np.maximum(t1, t2)
+    par = np.abs(d) < np.float32(0.000001)
+    outside = par & ((o < mn) | (o > mx))
+    lo = np.where(par, np.float32(0.0), lo); hi = np.where(par, np.float32(1.0e30), hi)
+    tmin = np.maximum(lo.max(axis=1), np.float32(0.0)); tmax = np.minimum(hi.min(axis=1), np.float32(1000000.0))
+    return hit & ((tmin > tmax) | outside.any(axis=1))
+
+
+def test_hits_accepted_through_the_ancestor_walk(gpu_ctx_ok):
+    """The rays of the grazing set whose hit lies OUTSIDE its leaf's exact box (to fp32 rounding): the ordered traversal accepts them only after `slabs` on every
+    ancestor, and reads the primitive id again after that walk.  There must be such rays in the set (else the walk is untested), and on exactly those the whole
+    hit record -- t, primitive id, position, both normals, uv: everything u and v go into -- equals the oracle's bit for bit (t / u / v / leaf live
+    across the same walk that once cost the primitive id its register)."""
+    n_walk = 0
+    for make, W in ((lambda: scenes.cornell_box(48, 48, 4, device_id=0), 48), (lambda: tiny_scene(3000, seed=31, W=48, H=48, spread=0.08, device_id=0), 48)):
+        ex = make(); ex.scene.setup_data_cpu()
+        rays = _grazing_rays(ex, 900, 17)
+        ex = make(); ex.build_scene()
+        o = oa.OracleScene(ex.scene, ex.cam); o.lbvh_build()
+        want, wprim, _ = o.closest_hit(rays)
+        walk = _leaf_box_fails_slabs(ex, rays, wprim)
+        got, gprim, _ = ex.scene.ctx.trace_closest(rays, 64, _native.TRAVERSE_ORDERED)
+        print("rays %d, hits %d, accepted through the ancestor walk %d" % (len(rays), (wprim >= 0).sum(), walk.sum()))
+        assert np.array_equal(gprim[walk], wprim[walk]) and bits_equal(got[walk], want[walk]).all()
+        # the same rays as shadow rays (closest hit's t and primitive) and from the candidate-list side of the leaf step: nothing else runs that code
+        st, sp, _ = o.shadow_hit(rays[walk]); gt, gp, _ = ex.scene.ctx.trace_shadow(rays[walk], 64, 0)
+        assert np.array_equal(gp, sp) and bits_equal(gt, st).all()
+        n_walk += int(walk.sum())
+    assert n_walk >= 50, "the grazing rays no longer reach the ancestor walk: the test tests nothing"
+
+
 def test_quantised_nodes_on_grazing_rays(gpu_ctx_ok):
     """The ordered traversal walks 16-bit quantised boxes that CONTAIN the reference's and re-checks the reference's
     own visiting condition before it accepts a hit (tirt_internal.h, BvhView): closest hits must equal the oracle's on
