@@ -16,7 +16,10 @@ A ray = one closet_hit or closet_hit_shadow call of the reference
 
 Timing: W untimed warm-up steps, then exactly K steps bracketed by barrier +
 torch.cuda.synchronize() + tirt_sync on both sides; MAX over ranks; rank 0 prints one JSON
-line.  Inputs (scene, BVH) are resident in HBM before the timed region.
+line.  Inputs (scene, BVH) are resident in HBM before the timed region; what belongs to the
+RENDER -- the camera rays' per-pixel candidate lists -- is forgotten when the clock starts and
+made again by the first timed batch (primary_beams.prepare_ms_in_timed_region).  N = 1 also
+prints value_cold_256spp: BASELINE config 3 as written (one camera set, 8 x 32 frames, sync).
 
 Extra objects:
   roofline      dominant kernel = the traversal kernel k_trace (closest hits of bounce b + NEE shadow
@@ -39,7 +42,9 @@ Extra objects:
                              algorithm would move, not what this kernel moves -- reported, not a fraction.
   configs       (N = 1) the other BASELINE.json configs after the timed region -- config 1 as the reference
                 committed it (Cornell 512^2 x 512 spp), config 2 (Teapot 1024^2 x 64 spp), config 5
-                (veach_bdpt 512^2 x 64 spp, with a roofline of the BDPT kernels) -- each: seconds, rays,
+                (veach_bdpt 512^2 x 64 spp, with a roofline of the BDPT kernels), the spectral configs, and the same
+                scene at 4 M and 8 M triangles (traversal data beyond L2 / beyond the Infinity Cache: k_trace's
+                fabric-side traffic with counters calibrated on gathers) -- each: seconds, rays,
                 Mrays/s, NaN pixels, a film sample checked against the CPU oracle; LBVH build at 100k / 1 M.
   distributed   (N > 1) rccl_ranks (an all-reduce of ones), equality of the replicated BVH builds (hash
                 all-gather), reduce_ms of the one film reduce.
