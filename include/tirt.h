@@ -65,7 +65,7 @@ typedef struct {
     /* timeline of the traversal waves (TIRT_COUNT_NODES only), 100 MHz ticks: their lifetimes summed, the part of a lifetime after the wave
      * found the ray queue empty (it only finishes the rays it holds), and how many waves ran */
     uint64_t diag_wave_ticks, diag_drain_ticks, diag_waves;
-    uint64_t launches_tail;   /* PT_RGB batches whose last bounces ran as one persistent launch (option "tail_paths") */
+    uint64_t launches_tail;   /* always 0 since round 6 (rounds 4-5, experiments builds: PT_RGB batches whose last bounces ran as one persistent launch); kept for the layout */
 } tirt_stats_t;
 
 const char *tirt_last_error(void);
@@ -98,8 +98,9 @@ int tirt_sync(tirt_ctx *ctx);
  *          "path_order_blocks" (0/1, default 1 since round 5) -- the paths of a wavefront batch numbered pixel-block major (64-path chunk = one 8 x 8 pixel block
  *            of one frame, the frames of a block next to each other) instead of frame major: +1.5 % on the headline scene, +5 % on a 4 M-triangle one; same film
  *          "slices_contiguous" (0/1, default 0) -- k_trace's ray-fetch slices as contiguous stretches of the queue (each XCD one region of the film); no gain measured
- *          "tail_paths" / "tail_bounce", "wide_collapse" -- EXPERIMENTS (the last bounces of a batch as one persistent launch; cost-optimal grouping into 4-wide nodes):
- *            only in a library built with -DTIRT_EXPERIMENTS (`make experiments`); the product library answers them with an error unless the value means "off"
+ *          "wide_collapse" -- EXPERIMENT (cost-optimal grouping into 4-wide nodes): only in a library built with -DTIRT_EXPERIMENTS (`make experiments`); the product
+ *            library answers it with an error unless the value means "off".  (Rounds 4-5 also carried "tail_paths" / "tail_bounce" there: the last bounces of a batch as one
+ *            persistent launch -- bit-identical, slower at every switch point; tools/exp/patches/r06_persistent_tail_kernel.patch)
  *          "traversal_tree" (0/1, default 1) -- the tree tirt_lbvh_build collapses into the 4-wide traversal nodes: 1 = a binned-SAH
  *            tree over the same primitives built on the device after the LBVH, 0 = the reference's LBVH itself; results are
  *            bit-identical either way (tirt_traversal_tree_download) -- except for rays that lie, to fp32 rounding, IN the plane of a

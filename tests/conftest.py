@@ -30,13 +30,13 @@ def gpu_ctx_ok():
 
 @pytest.fixture(scope="session")
 def experiments_lib(gpu_ctx_ok):
-    """Tests of the EXPERIMENTS (persistent tail kernel, cost-optimal wide collapse: built, bit-identical, not faster -- docs/HISTORY.md) need the
+    """Tests of the EXPERIMENTS (cost-optimal wide collapse: built, bit-identical, not faster -- docs/HISTORY.md) need the
     library built with -DTIRT_EXPERIMENTS (`make -C ti_raytrace_amd/csrc experiments`, then TIRT_LIB_PATH=.../libtirt_exp.so): the product
     library does not carry them, and these tests are skipped on it."""
     from ti_raytrace_amd import _native
     ctx = _native.Context(0)
     try:
-        ctx.set_option("tail_bounce", 1)
+        ctx.set_option("wide_collapse", 1); ctx.set_option("wide_collapse", 0)
     except _native.TirtError as exc:
         if "TIRT_EXPERIMENTS" in str(exc):
             pytest.skip("the loaded libtirt.so is the product build (no -DTIRT_EXPERIMENTS)")

@@ -434,47 +434,6 @@ def test_path_order_and_slice_layout_change_no_bit(gpu_ctx_ok, integrator):
             assert np.array_equal(film.view(np.uint32), base.view(np.uint32)), opts
 
 
-@pytest.mark.parametrize("scene", ["cornell", "teapot", "synthetic", "lasers"])
-def test_tail_launch_changes_no_bit(gpu_ctx_ok, experiments_lib, scene):
-    """tirt_render.hip k_trace<KIND_TAIL>: from some bounce on, what is left of a batch runs as ONE persistent launch in which a lane keeps a path
-    (shade, shadow ray, next ray, ...) instead of one launch per bounce and kind.  Wherever the switch happens -- given ("tail_bounce"), or chosen from
-    the path counts of the batches before ("tail_paths") --: the same film bit for bit, the same ray and shading counts."""
-    W = H = 96
-    frames = 5
-    def make():
-        if scene == "cornell": ex = scenes.cornell_box(W, H, frames, device_id=0)
-        elif scene == "teapot": ex = scenes.single_model(W, H, frames, device_id=0)        # glass (extinction), environment map, sphere light
-        elif scene == "synthetic": ex = scenes.synthetic(W, H, frames, device_id=0)
-        else: ex = spot_laser_scene(W, H, device_id=0)
-        ex.build_scene()
-        return ex
-    def run(opts, flags=0, calls=(frames,)):
-        ex = make(); ctx = ex.scene.ctx
-        for k, v in opts.items(): ctx.set_option(k, v)
-        ctx.stats_reset()
-        f = 0
-        for n in calls:
-            ctx.pt_rgb_render(f, n, ex.integrator.seed, 15, 64, flags); f += n
-            if len(calls) > 1: ctx.film_download(W, H)          # (waits for the batch: its path counts are back when the next call looks)
-        st = ctx.stats()
-        return ctx.film_download(W, H)[0], st
-    base, st0 = run({"tail_bounce": 0})
-    assert st0["launches_tail"] == 0
-    key = lambda st: (st["paths"], st["rays_closest"], st["rays_shadow"], st["shaded"])
-    for tb in (1, 2, 5, 14):
-        film, st = run({"tail_bounce": tb})
-        assert st["launches_tail"] == 1, tb
-        assert np.array_equal(film.view(np.uint32), base.view(np.uint32)), tb
-        assert key(st) == key(st0), (tb, key(st), key(st0))
-    # chosen from the counts of earlier batches: the first call has nothing to go by, the later ones do
-    film, st = run({"tail_paths": 4000, "merge_paths": 0}, calls=(1, 1, 1, 1, 1))
-    assert np.array_equal(film.view(np.uint32), base.view(np.uint32))
-    assert 1 <= st["launches_tail"] <= 4 and key(st) == key(st0)
-    # with the traversal counters on (the counting variant of the kernel)
-    film, st = run({"tail_bounce": 3}, flags=_native.COUNT_NODES)
-    assert np.array_equal(film.view(np.uint32), base.view(np.uint32)) and st["launches_tail"] == 1
-
-
 def test_blocked_tile_order_changes_no_bit(gpu_ctx_ok):
     """tirt_internal.h local_to_pixel: inside a tile of 8 whole columns the device walks 8 x 8 pixel blocks; any other tile size keeps the
     linear order.  Same film, and the tiles of three ranks still re-assemble to it."""

@@ -351,8 +351,6 @@ void tirt_destroy(tirt_ctx *c)
         DevBuf *lb[] = {&L.path_mem, &L.counters_mem, &L.spill};
         for (DevBuf *b : lb) b->release();
         if (L.film_done) (void)hipEventDestroy(L.film_done);
-        if (L.counts_done) (void)hipEventDestroy(L.counts_done);
-        if (L.host_counts) (void)hipHostFree(L.host_counts);
         if (L.stream) (void)hipStreamDestroy(L.stream);
     }
     c->spec_mem.release(); c->spec_dev.release();
@@ -390,13 +388,11 @@ int tirt_set_option(tirt_ctx *c, const char *name, double value)
     if (!strcmp(name, "time_kernels")) { c->time_kernels = value != 0.0; return TIRT_OK; }
     if (!strcmp(name, "overlap_lanes")) { TIRT_REQUIRE(value >= 1.0 && value <= (double)TIRT_MAX_LANES, "overlap_lanes: 1..8"); if (sync_all(c)) return TIRT_ERR_HIP; c->n_lanes = (int)value; return TIRT_OK; }
 #ifndef TIRT_EXPERIMENTS
-    if (!strcmp(name, "tail_paths") || !strcmp(name, "tail_bounce") || !strcmp(name, "wide_collapse")) {
-        TIRT_REQUIRE(value == (strcmp(name, "tail_bounce") ? 0.0 : value < 0.0 ? value : 0.0), "this option is an experiment (persistent tail kernel / cost-optimal wide collapse): build with -DTIRT_EXPERIMENTS (make experiments)");
+    if (!strcmp(name, "wide_collapse")) {
+        TIRT_REQUIRE(value == 0.0, "this option is an experiment (cost-optimal wide collapse): build with -DTIRT_EXPERIMENTS (make experiments)");
         return TIRT_OK;
     }
 #endif
-    if (!strcmp(name, "tail_paths")) { TIRT_REQUIRE(value >= 0.0 && value <= 2147483647.0, "tail_paths: 0 (off) .. 2^31-1"); c->tail_paths = (long)value; return TIRT_OK; }
-    if (!strcmp(name, "tail_bounce")) { TIRT_REQUIRE(value >= -1.0 && value <= 4095.0, "tail_bounce: -1 (chosen from tail_paths), 0 (off) or the bounce 1..max_depth-1"); c->tail_bounce = (int)value; return TIRT_OK; }
     if (!strcmp(name, "split_lone_batch")) { TIRT_REQUIRE(value >= 0.0 && value <= 8.0, "split_lone_batch: 0 (off) or the number of parts, 2..8"); c->split_lone = (int)value; return TIRT_OK; }
     if (!strcmp(name, "wide_collapse")) { TIRT_REQUIRE(value == 0.0 || value == 1.0, "wide_collapse: 0 (greedy) or 1 (cost-optimal)"); c->wide_dp_on = (int)value; return TIRT_OK; }
     if (!strcmp(name, "traversal_tree")) {       // takes effect at the next tirt_lbvh_build
@@ -815,7 +811,7 @@ int tirt_stats(tirt_ctx *c, tirt_stats_t *out)
     out->ms_build = c->ms_build; out->ms_render = c->ms_render;
     out->ms_trace_closest = c->ms_trace_closest; out->ms_trace_shadow = c->ms_trace_shadow; out->ms_shade = c->ms_shade;
     out->launches_trace_closest = c->launches_trace_closest; out->launches_trace_shadow = c->launches_trace_shadow;
-    out->launches_shade = c->launches_shade; out->launches_tail = c->launches_tail;
+    out->launches_shade = c->launches_shade; out->launches_tail = 0;      // (the persistent tail kernel left the library in round 6; the field stays for the ABI)
     if (h.stack_overflow > 0) {      // results are wrong (subtrees were dropped): the statistics are filled in, the call reports it
         set_error("traversal stack overflow on " + std::to_string((unsigned long long)h.stack_overflow) + " rays: raise stack_size");
         // reported once: the counter is cleared, so that later tirt_stats calls of unrelated consumers do not keep failing
@@ -872,7 +868,7 @@ int tirt_stats_reset(tirt_ctx *c)
     TIRT_HIP(hipMemsetAsync(c->dev_counters.p, 0, sizeof(DevCounters), c->stream));
     TIRT_HIP(hipStreamSynchronize(c->stream));
     c->ms_render = c->ms_trace_closest = c->ms_trace_shadow = c->ms_shade = 0.0;
-    c->launches_trace_closest = c->launches_trace_shadow = c->launches_shade = 0; c->launches_tail = 0;
+    c->launches_trace_closest = c->launches_trace_shadow = c->launches_shade = 0;
     drain_pvb_events(c); c->pvb_builds = c->pvb_build_ns = c->pvb_skipped = 0;
     return TIRT_OK;
 }

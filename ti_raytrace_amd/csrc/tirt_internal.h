@@ -266,10 +266,6 @@ struct Lane {
     size_t path_capacity = 0;
     DevBuf path_mem, counters_mem, spill;
     PathState ps;
-    // how many paths of the lane's last batch entered each bounce (pinned host memory, copied after the film update; read by a LATER render call
-    // once `counts_done` has passed, never waited for): what the next batches choose their tail bounce from (tirt_ctx::live_frac)
-    unsigned long long *host_counts = nullptr; int host_counts_cap = 0;
-    hipEvent_t counts_done = nullptr; bool counts_pending = false; int counts_S = 0, counts_known = 0;
 };
 
 }  // namespace tirt
@@ -341,12 +337,6 @@ struct tirt_ctx {
     int tr_grid_alone = 1280;                     // "trace_grid_alone" / "trace_grid": persistent k_trace blocks of a batch submitted to an idle / a busy GPU. Both five per CU
                                                   // (tirt_create scales them by the device's CU count): blocks of the next batch's launch move in as this one's drain
     tirt::DevBuf counters_mem, spill;            // used by the batch trace entry points (main stream)
-    // The end of a PT_RGB batch as ONE persistent launch (k_trace<KIND_TAIL>, tirt_render.hip): options "tail_paths" = from the first bounce that no more than
-    // this many paths enter (0 = never), "tail_bounce" = that bounce given (-1 = chosen from tail_paths and live_frac, 0 = never).  live_frac[b] = share of a
-    // batch's paths that entered bounce b in the last batch whose counters have come back (Lane::host_counts); forgotten when the scene changes.
-    long tail_paths = 0; int tail_bounce = -1;
-    std::vector<float> live_frac;
-    uint64_t launches_tail = 0;
     int cu_count = 256;
 
     // BDPT_RGB: persistent per-pixel vertex arrays + per-frame radiance (splat target)

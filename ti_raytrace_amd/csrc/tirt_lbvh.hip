@@ -653,7 +653,7 @@ int lbvh_build(tirt_ctx *c)
     TIRT_REQUIRE(c->n >= 1, "tirt_lbvh_build: no primitives uploaded");
     const int n = c->n, N = 2 * n - 1;
     hipStream_t st = c->stream, st0 = st;
-    c->built = false; c->built_sah = 0; c->live_frac.clear();
+    c->built = false; c->built_sah = 0;
     if (c->morton_unsorted.ensure(sizeof(int2) * (size_t)n)) return TIRT_ERR_HIP;
     if (c->morton_sorted.ensure(sizeof(int2) * (size_t)n)) return TIRT_ERR_HIP;
     if (c->keys_a.ensure(sizeof(int) * (size_t)n) || c->keys_b.ensure(sizeof(int) * (size_t)n) ||

@@ -36,30 +36,16 @@ namespace tirt {
 
 constexpr int TR_GRID_MAX = 2048;      // upper bound on persistent blocks (sizes the spill buffer)
 
-enum { KIND_CLOSEST = 0, KIND_SHADOW_ACC = 1, KIND_MIXED = 2, KIND_QUERY = 3, KIND_TAIL = 4 };
-// The product library is built WITHOUT -DTIRT_EXPERIMENTS: no persistent tail kernel (KIND_TAIL: built in round 4, bit-identical, slower at every
-// switch point) and no bound ladder (TR_PAD / TR_PADG).  `make experiments` builds libtirt_exp.so with them; tools/ and the tests that exercise them
-// load that library through TIRT_LIB_PATH.  The A/B switches of rounds 3-5 whose question is settled (stash, drained-slices count, node-loop
-// threshold, quad-cooperative fetch, non-temporal streams, asm record fetch, drain diagnostics, no-verify) left this file in round 6:
-// tools/exp/patches/r06_settled_ab_switches_of_k_trace.patch puts them back.
+enum { KIND_CLOSEST = 0, KIND_SHADOW_ACC = 1, KIND_MIXED = 2, KIND_QUERY = 3 };
+// The bound ladder (TR_PAD / TR_PADG) is compiled only with -DTIRT_EXPERIMENTS (`make experiments` -> libtirt_exp.so).  What rounds 3-5 built, measured and did not adopt
+// left this file in round 6 and can be put back from tools/exp/patches/: the settled A/B switches (stash, drained-slices count, node-loop threshold, quad-cooperative fetch,
+// non-temporal streams, asm record fetch, drain diagnostics, no-verify: r06_settled_ab_switches_of_k_trace.patch) and the persistent tail kernel (KIND_TAIL: the rest of a
+// batch in one launch, a lane keeping a PATH through shade / shadow ray / next ray; bit-identical, slower at every switch point: r06_persistent_tail_kernel.patch).
 #if !defined(TIRT_EXPERIMENTS) && (defined(TR_PAD) || defined(TR_PADG))
 #error "the bound ladder (TR_PAD / TR_PADG) needs an experiments build: add -DTIRT_EXPERIMENTS"
 #endif
 // MIXED: closest rays of bounce b + shadow rays of bounce b-1 in one launch.  QUERY: connection rays of BDPT -- "is sprim[q] the closest
 // hit, about sdist[q] away?" walked like a shadow ray (bounded), answered with the hit record (t, u, v, prim) instead of an accumulation.
-// TAIL: the rest of a PT_RGB batch in ONE launch, once few paths are left (see TailArgs): a lane keeps a PATH -- shades its hit (shade_path,
-// the same code as k_shade), walks its NEE shadow ray, then its next ray, bounce after bounce -- and fetches another path when this one ends.
-
-// KIND_TAIL.  The queue holds `*count_ptr` PATHS whose closest hit of bounce `bounce0` is in `hit` (an ordinary launch traced it, together with
-// the shadow rays of the bounce before).  State of path q in place at index q of the arrays the launch was given: ray (ox .. dz), throughput,
-// radiance (rr, rg, rb), brdf pdf, flags, slot; its pending shadow ray at index q of (sox .. sdz, scr .. scb, sprim, sdist).  Every path adds
-// exactly what the per-bounce launches add, in the same order (emission, then the NEE sample of that bounce once its ray has arrived), so the
-// film is the same bit for bit; random numbers are a function of (pixel, frame, bounce), not of who asks when.
-struct TailArgs {
-    SceneView sc; TileMap tm; int P; uint32_t frame_begin, seed; int bounce0, max_depth;
-    float *tr, *tg, *tb, *brdf_pdf; uint32_t *flags; const int *slot;
-};
-
 struct TraceArgs {
     BvhView bvh;
     const float *ox, *oy, *oz, *dx, *dy, *dz;    // rays, dense: ray q at index q
@@ -92,15 +78,11 @@ struct TraceArgs {
     // loads per ray where the arrays take six to eight (the BDPT ray lists: their kernels are bound by the number of memory instructions)
     const float4 *ray4;
     const int *ray_index;                        // KIND_QUERY: ray q is record ray_index[q] of ray4 (BDPT: the connection rays stay where they were staged; the queue is a list of places)
-#ifdef TIRT_EXPERIMENTS
-    TailArgs tail;                               // KIND_TAIL (by value: only experiments builds carry the larger kernel-argument segment)
-#endif
 };
 
 // One path at one bounce: what integrator/PT_RGB.py:66-132 does between the closest hit and the next one -- emission (with MIS), the glass / disney
 // branch, the NEE sample (its shadow ray and the contribution it adds IF the ray arrives), the next ray and the throughput, the environment
-// for a miss.  Shared by k_shade (one launch per bounce) and by the persistent tail kernel (k_trace<KIND_TAIL>), so that both apply the
-// same instructions to a path.  `radiance`, `throughout`, `brdf_pdf`, `perfect_spec` are the path's state coming in; `radiance` is updated in place.
+// for a miss.  The body of k_shade, kept apart from its queue handling.  `radiance`, `throughout`, `brdf_pdf`, `perfect_spec` are the path's state coming in; `radiance` is updated in place.
 struct ShadeStep {
     bool want_next = false, want_shadow = false, shaded = false;
     v3 next_o = V(0.0f, 0.0f, 0.0f), next_d = next_o, next_thr = next_o, sh_o = next_o, sh_d = next_o, sh_c = next_o;
@@ -302,9 +284,8 @@ typedef const __attribute__((address_space(4))) TraceArgs *cold_args_t;
 #define TR_LADDER_PADS(where) do { } while (0)
 #endif
 
-constexpr int TR_TAIL_WAVES = 3;       // the tail kernel carries the shading code: 168 VGPRs, three 256-thread blocks per CU
 template <int MODE, bool COUNT, int KIND>
-__global__ __launch_bounds__(TR_BLOCK, KIND == KIND_TAIL ? TR_TAIL_WAVES : TR_MIN_WAVES) void k_trace(TraceArgs a)
+__global__ __launch_bounds__(TR_BLOCK, TR_MIN_WAVES) void k_trace(TraceArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) int lds_stack[];      // [lds_depth][TR_BLOCK]
     const int TR_LDS_DEPTH = a.lds_depth;
@@ -312,7 +293,7 @@ __global__ __launch_bounds__(TR_BLOCK, KIND == KIND_TAIL ? TR_TAIL_WAVES : TR_MI
     constexpr bool STASH = (MODE != TIRT_TRAVERSE_EXHAUSTIVE);
     constexpr bool BOUNDED = MAY_SHADOW && (MODE != TIRT_TRAVERSE_EXHAUSTIVE);
     const int count_c = (KIND == KIND_SHADOW_ACC || KIND == KIND_QUERY) ? 0 : (a.count_ptr ? *a.count_ptr : a.count_fixed);
-    const int count_s = (KIND == KIND_CLOSEST || KIND == KIND_TAIL) ? 0 : (KIND == KIND_MIXED ? *a.scount_ptr : (a.count_ptr ? *a.count_ptr : a.count_fixed));
+    const int count_s = (KIND == KIND_CLOSEST) ? 0 : (KIND == KIND_MIXED ? *a.scount_ptr : (a.count_ptr ? *a.count_ptr : a.count_fixed));
     const int count = count_c + count_s;
     const int tid = threadIdx.x, lane = tid & 63;
     const size_t gstride = (size_t)gridDim.x * TR_BLOCK, gtid = (size_t)blockIdx.x * TR_BLOCK + tid;
@@ -328,10 +309,6 @@ __global__ __launch_bounds__(TR_BLOCK, KIND == KIND_TAIL ? TR_TAIL_WAVES : TR_MI
     float lim = INF_VALUE;                      // ordered mode: min(hit_t * 1.0001, cull_far, INF_VALUE), entry distances beyond it are skipped
     // (ordered mode: a NEGATIVE cull_far marks a ray whose origin is more than TR_FAR_RHO root-box extents away -- no distance culling for it, see the set-up code)
     unsigned nbox = 0, nleaf = 0;
-    // KIND_TAIL: what the lane's path waits for.  0 no path; 1 closest-hit ray under way; 2 hit found (hit_t .. hit_prim), to be shaded;
-    // 3 / 6 shadow ray under way (3: a next ray follows, 6: the path ends with it); 4 next ray to be set up; 5 / 7 shadow ray to be set up (-> 3 / 6)
-    int st = 0, bounce_l = 0; (void)bounce_l;
-    unsigned n_rc = 0, n_rs = 0, n_sh = 0;
     RayCtx r = {};
     // ordered mode: the ray in the grid of the quantised nodes.  Plane h (fp16, in cells) of axis a is crossed at
     // t = h * gA + gB (gA = cell / d, gB = (grid_min - o) / d); gBn / gBf are gB moved outward by a margin of
@@ -403,8 +380,7 @@ __global__ __launch_bounds__(TR_BLOCK, KIND == KIND_TAIL ? TR_TAIL_WAVES : TR_MI
     for (;;) {
         // ---- refill idle lanes -------------------------------------------------------------
         const unsigned long long idle = ballot64(!have);
-        const bool tail_waiting = (KIND == KIND_TAIL) && wave_any(!have && st != 0);
-        if (idle != 0ull && (!exhausted || tail_waiting) && (__popcll(idle) >= a.refill_min || idle == ~0ull)) {
+        if (idle != 0ull && !exhausted && (__popcll(idle) >= a.refill_min || idle == ~0ull)) {
             TR_COLD(ca);
             // (all of them read here, in one batch of scalar loads with one wait: left to itself the compiler loads each where it is used,
             // a chain of a dozen dependent round trips per refill)
@@ -426,8 +402,7 @@ __global__ __launch_bounds__(TR_BLOCK, KIND == KIND_TAIL ? TR_TAIL_WAVES : TR_MI
                          "s"(c_ic0), "s"(c_ic1), "s"(c_ic2), "s"(c_ce0), "s"(c_ce1), "s"(c_ce2), "s"(c_rn0), "s"(c_rn1), "s"(c_rn2), "s"(c_rx0), "s"(c_rx1), "s"(c_rx2));
             if (MAY_SHADOW) asm volatile("" :: "s"(c_sox), "s"(c_soy), "s"(c_soz), "s"(c_sdx), "s"(c_sdy), "s"(c_sdz), "s"(c_sprim), "s"(c_sdist));
             if (KIND == KIND_CLOSEST || KIND == KIND_QUERY) asm volatile("" :: "s"(c_ray4), "s"(c_rindex));
-            // (KIND_TAIL: only lanes without a path fetch one)
-            const unsigned long long fm = (KIND == KIND_TAIL) ? ballot64(!have && st == 0) : idle;
+            const unsigned long long fm = idle;
             int my = count;
             if (fm != 0ull && !exhausted) {
             const int n_idle = __popcll(fm);
@@ -458,58 +433,11 @@ __global__ __launch_bounds__(TR_BLOCK, KIND == KIND_TAIL ? TR_TAIL_WAVES : TR_MI
                 if (++tried > S_MASK) { exhausted = true; if (COUNT) tk_exh = wall_clock64(); }
             }
             }
-#ifdef TIRT_EXPERIMENTS
-            if (KIND == KIND_TAIL) {
-                // a new path arrives with the closest hit of bounce `bounce0` found
-                if (!have && st == 0 && my < count) {
-                    q = my; bounce_l = ca->tail.bounce0; st = 2;
-                    const float4 h0 = ca->hit[q];
-                    hit_t = h0.x; hit_u = h0.y; hit_v = h0.z; hit_prim = __float_as_int(h0.w);
-                }
-                const bool sh_now = !have && st == 2;
-                if (wave_any(sh_now)) {
-                    if (sh_now) {
-                        float *const w_ox = (float *)c_ox, *const w_oy = (float *)c_oy, *const w_oz = (float *)c_oz, *const w_dx = (float *)c_dx, *const w_dy = (float *)c_dy, *const w_dz = (float *)c_dz;
-                        float *const c_tr = ca->tail.tr, *const c_tg = ca->tail.tg, *const c_tb = ca->tail.tb, *const c_pdf = ca->tail.brdf_pdf;
-                        float *const c_rr = ca->rr, *const c_rg = ca->rg, *const c_rb = ca->rb;
-                        uint32_t *const c_flags = ca->tail.flags; const int *const c_slot = ca->tail.slot;
-                        asm volatile("" :: "s"(c_tr), "s"(c_tg), "s"(c_tb), "s"(c_pdf), "s"(c_rr), "s"(c_rg), "s"(c_rb), "s"(c_flags), "s"(c_slot));
-                        const int slot = c_slot[q];
-                        const v3 p_o = V(w_ox[q], w_oy[q], w_oz[q]), p_d = V(w_dx[q], w_dy[q], w_dz[q]);
-                        const v3 p_thr = V(c_tr[q], c_tg[q], c_tb[q]);
-                        v3 p_rad = V(c_rr[q], c_rg[q], c_rb[q]);
-                        const float p_pdf = c_pdf[q]; const int p_spec = (int)(c_flags[q] & 1u);
-                        ShadeStep ss;
-                        shade_path(a.tail.sc, a.tail.tm, a.tail.P, a.tail.frame_begin, a.tail.seed, bounce_l, bounce_l == a.tail.max_depth - 1 ? 1 : 0, slot,
-                                   p_o, p_d, make_float4(hit_t, hit_u, hit_v, __int_as_float(hit_prim)), p_thr, p_rad, p_pdf, p_spec, ss);
-                        if (ss.shaded) n_sh++;
-                        if (ss.want_next) {
-                            w_ox[q] = ss.next_o.x; w_oy[q] = ss.next_o.y; w_oz[q] = ss.next_o.z; w_dx[q] = ss.next_d.x; w_dy[q] = ss.next_d.y; w_dz[q] = ss.next_d.z;
-                            c_tr[q] = ss.next_thr.x; c_tg[q] = ss.next_thr.y; c_tb[q] = ss.next_thr.z; c_pdf[q] = ss.next_pdf; c_flags[q] = (uint32_t)ss.next_spec;
-                            c_rr[q] = p_rad.x; c_rg[q] = p_rad.y; c_rb[q] = p_rad.z;
-                        } else {
-                            float *const f_r = ca->fr, *const f_g = ca->fg, *const f_b = ca->fb;
-                            f_r[slot] = p_rad.x; f_g[slot] = p_rad.y; f_b[slot] = p_rad.z;
-                        }
-                        if (ss.want_shadow) {
-                            float *const s_ox = (float *)c_sox, *const s_oy = (float *)c_soy, *const s_oz = (float *)c_soz, *const s_dx = (float *)c_sdx, *const s_dy = (float *)c_sdy, *const s_dz = (float *)c_sdz;
-                            float *const s_cr = (float *)ca->scr, *const s_cg = (float *)ca->scg, *const s_cb = (float *)ca->scb, *const s_dist = (float *)c_sdist; int *const s_prim = (int *)c_sprim;
-                            s_ox[q] = ss.sh_o.x; s_oy[q] = ss.sh_o.y; s_oz[q] = ss.sh_o.z; s_dx[q] = ss.sh_d.x; s_dy[q] = ss.sh_d.y; s_dz[q] = ss.sh_d.z;
-                            s_cr[q] = ss.sh_c.x; s_cg[q] = ss.sh_c.y; s_cb[q] = ss.sh_c.z; s_prim[q] = ss.sh_expect; s_dist[q] = ss.sh_dist;
-                        }
-                        st = ss.want_shadow ? (ss.want_next ? 5 : 7) : (ss.want_next ? 4 : 0);
-                    }
-                }
-            }
-#endif
-            const bool setup_now = (KIND == KIND_TAIL) ? (!have && st >= 4) : (!have && my < count);
+            const bool setup_now = !have && my < count;
             if (setup_now) {
-                if (KIND == KIND_TAIL) {
-                    is_sh = st != 4;
-                    if (is_sh) { n_rs++; st = (st == 5) ? 3 : 6; } else { n_rc++; st = 1; bounce_l++; }
-                } else q = my;
+                q = my;
                 if (KIND == KIND_MIXED) { is_sh = my >= count_c; if (is_sh) q = my - count_c; }
-                const bool mixed_sh = (KIND == KIND_MIXED || KIND == KIND_TAIL) && is_sh;
+                const bool mixed_sh = (KIND == KIND_MIXED) && is_sh;
                 v3 o, d; int rec_expect = -3; float rec_bound = -1.0f;
                 const bool from_rec = (KIND == KIND_CLOSEST || KIND == KIND_QUERY) && c_ray4 != nullptr;          // wave-uniform
                 if (from_rec) {
@@ -582,7 +510,7 @@ __global__ __launch_bounds__(TR_BLOCK, KIND == KIND_TAIL ? TR_TAIL_WAVES : TR_MI
                 have = true;
             }
         }
-        if (ballot64(have) == 0ull) { if (exhausted && !(KIND == KIND_TAIL && wave_any(st != 0))) break; continue; }
+        if (ballot64(have) == 0ull) { if (exhausted) break; continue; }
 
         // ---- inner nodes.  Lanes that reached a leaf (or finished) wait here; the loop goes on
         // while at least node_min lanes still have inner-node work, or nobody is waiting at all.
@@ -751,25 +679,6 @@ __global__ __launch_bounds__(TR_BLOCK, KIND == KIND_TAIL ? TR_TAIL_WAVES : TR_MI
         }
 
         // ---- finished rays write back and free their lane ---------------------------------------
-#ifdef TIRT_EXPERIMENTS
-        if (KIND == KIND_TAIL) {
-            if (have && cur == TR_SENT && pend == 0) {
-                if (is_sh) {
-                    if (hit_prim == expect) {                     // integrator/PT_RGB.py:105-109: the sample arrives
-                        TR_COLD(ca);
-                        const bool to_film = st == 6;
-                        const int dst = to_film ? ca->tail.slot[q] : q;
-                        float *pr = (to_film ? ca->fr : ca->rr) + dst, *pg = (to_film ? ca->fg : ca->rg) + dst, *pb = (to_film ? ca->fb : ca->rb) + dst;
-                        *pr = *pr + ca->scr[q]; *pg = *pg + ca->scg[q]; *pb = *pb + ca->scb[q];
-                    }
-                    st = (st == 3) ? 4 : 0;
-                } else st = 2;
-                if (COUNT) { if (is_sh) { sum_box_s += nbox; sum_leaf_s += nleaf; } else { sum_box += nbox; sum_leaf += nleaf; } }
-                if (n_overflow) n_over++;
-                have = false; sa = sa_bottom;
-            }
-        } else
-#endif
         if (have && cur == TR_SENT && pend == 0) {
             TR_COLD(ca);
             float4 *const c_hit = ca->hit;
@@ -821,14 +730,6 @@ __global__ __launch_bounds__(TR_BLOCK, KIND == KIND_TAIL ? TR_TAIL_WAVES : TR_MI
             }
         }
         if (n_over) atomicAdd(&ca->ctr->stack_overflow, n_over);
-        if (KIND == KIND_TAIL) {
-            const unsigned long long t_rc = wave_sum((unsigned long long)n_rc), t_rs = wave_sum((unsigned long long)n_rs), t_sh = wave_sum((unsigned long long)n_sh);
-            if (lane == 0) {
-                if (t_rc) atomicAdd(&ca->ctr->rays_closest, t_rc);
-                if (t_rs) atomicAdd(&ca->ctr->rays_shadow, t_rs);
-                if (t_sh) atomicAdd(&ca->ctr->shaded, t_sh);
-            }
-        } else
         if (gtid == 0 && !ca->no_ray_count) {
             if (count_c) atomicAdd(&ca->ctr->rays_closest, (unsigned long long)count_c);
             if (count_s) atomicAdd(&ca->ctr->rays_shadow, (unsigned long long)count_s);
@@ -872,65 +773,6 @@ static int launch_trace(tirt_ctx *c, hipStream_t stream, const TraceArgs &a, int
     if (exh) return launch_trace_as<TIRT_TRAVERSE_EXHAUSTIVE, false, KIND>(c, stream, a, g, b, lds);
     if (cnt) return launch_trace_as<TIRT_TRAVERSE_ORDERED, true, KIND>(c, stream, a, g, b, lds);
     return launch_trace_as<TIRT_TRAVERSE_ORDERED, false, KIND>(c, stream, a, g, b, lds);
-}
-
-#ifdef TIRT_EXPERIMENTS
-// KIND_TAIL: ordered traversal only; as many persistent blocks as are resident at once (a block that had to wait for another to end would start when the work is gone)
-static int launch_tail(tirt_ctx *c, hipStream_t stream, const TraceArgs &a, int flags, int grid_cap)
-{
-    const bool cnt = (flags & TIRT_COUNT_NODES) != 0;
-    const size_t lds = trace_lds_bytes(a.lds_depth);
-    static int per_cu[TIRT_MAX_DEVICES][2] = {}; static size_t per_cu_lds[TIRT_MAX_DEVICES][2] = {};
-    const int dev = (c->device >= 0 && c->device < TIRT_MAX_DEVICES) ? c->device : 0;
-    if (per_cu[dev][cnt] == 0 || per_cu_lds[dev][cnt] != lds) {      // (again when trace_lds_depth changed: the resident block count depends on it)
-        per_cu_lds[dev][cnt] = lds;
-        int nb = 0;
-        const void *fn = cnt ? reinterpret_cast<const void *>(&k_trace<TIRT_TRAVERSE_ORDERED, true, KIND_TAIL>) : reinterpret_cast<const void *>(&k_trace<TIRT_TRAVERSE_ORDERED, false, KIND_TAIL>);
-        TIRT_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        TIRT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, TR_BLOCK, lds));
-        per_cu[dev][cnt] = nb > 0 ? nb : 1;
-    }
-    int grid = per_cu[dev][cnt] * c->cu_count; if (grid > grid_cap) grid = grid_cap; if (grid < 1) grid = 1;
-    dim3 g(grid), b(TR_BLOCK);
-    if (cnt) return launch_trace_as<TIRT_TRAVERSE_ORDERED, true, KIND_TAIL>(c, stream, a, g, b, lds);
-    return launch_trace_as<TIRT_TRAVERSE_ORDERED, false, KIND_TAIL>(c, stream, a, g, b, lds);
-}
-
-#endif
-
-// The bounce from which a batch of S paths runs as one tail launch (-1: no tail).  Chosen from what earlier batches of this scene did: the first
-// bounce that no more than tail_paths paths are expected to enter.
-static int choose_tail_bounce(const tirt_ctx *c, size_t S, int max_depth, int flags, bool spectral)
-{
-#ifndef TIRT_EXPERIMENTS
-    (void)c; (void)S; (void)max_depth; (void)flags; (void)spectral;
-    return -1;
-#endif
-    if (spectral || (flags & TIRT_TRAVERSE_EXHAUSTIVE) || c->time_kernels || max_depth < 2) return -1;
-    if (c->tail_bounce == 0) return -1;
-    if (c->tail_bounce > 0) return c->tail_bounce < max_depth ? c->tail_bounce : -1;
-    if (c->tail_paths <= 0 || c->live_frac.size() < 2) return -1;
-    const double want = (double)c->tail_paths / (double)S;
-    const int known = (int)c->live_frac.size() - 1;              // live_frac[0 .. known]
-    for (int b = 1; b <= known && b < max_depth; b++) if (c->live_frac[b] <= want) return b;
-    // beyond what was seen: the last survival ratio carries on
-    double f = c->live_frac[known], r = known >= 1 && c->live_frac[known - 1] > 0.0f ? f / c->live_frac[known - 1] : 0.7;
-    if (r > 0.95) r = 0.95;
-    for (int b = known + 1; b < max_depth; b++) { f *= r; if (f <= want) return b; }
-    return -1;
-}
-static void collect_live_counts(tirt_ctx *c)
-{
-    for (int k = 0; k < c->n_lanes; k++) {
-        Lane &L = c->lanes[k];
-        if (!L.counts_pending || hipEventQuery(L.counts_done) != hipSuccess) continue;
-        L.counts_pending = false;
-        if (L.counts_S <= 0 || L.counts_known < 1) continue;
-        c->live_frac.assign((size_t)L.counts_known + 1, 0.0f);
-        c->live_frac[0] = 1.0f;
-        for (int b = 1; b <= L.counts_known; b++) c->live_frac[b] = (float)((double)(unsigned)(L.host_counts[b - 1] & 0xffffffffull) / (double)L.counts_S);
-    }
-    (void)hipGetLastError();           // hipEventQuery's hipErrorNotReady is not an error
 }
 
 static int ensure_spill(tirt_ctx *c, DevBuf &spill, int stack_size, int &spill_depth)
@@ -1509,7 +1351,6 @@ int pt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed,
     TileMap tm = {c->tile_rank, c->tile_count, c->tile_size, c->H, c->tile_blocked, 0};
     DevCounters *ctr = c->dev_counters.as<DevCounters>();
     const int B = 256;
-    collect_live_counts(c);
     // the pixels' candidate lists for the camera rays (tirt_pvb.hip), made on the main stream when the scene, the camera or the film changed since
     bool beams_ready = false;
     if (c->primary_beams && FB >= c->primary_beams_min_frames && !(flags & TIRT_TRAVERSE_EXHAUSTIVE)) {
@@ -1584,8 +1425,6 @@ int pt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed,
         const int sh_cap = two_big ? 2 * c->sh_grid : c->sh_grid;
         int grid_shade = (S + SH_BLOCK - 1) / SH_BLOCK; if (grid_shade > sh_cap) grid_shade = sh_cap;
         v3 eye_v; eye_v.x = c->cam.eye[0]; eye_v.y = c->cam.eye[1]; eye_v.z = c->cam.eye[2];
-        const int tail_b = choose_tail_bounce(c, (size_t)S, max_depth, flags, spec != nullptr);
-        int counts_known = 0;
         for (int b = 0; b < max_depth; b++) {
             const PathSoA &in = L.ps.st[b & 1], &out = L.ps.st[(b + 1) & 1];
             // closest hits of bounce b, together with the NEE shadow rays of bounce b-1 (they add into
@@ -1622,24 +1461,6 @@ int pt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed,
             if (int rc = (b == 0) ? launch_trace<KIND_CLOSEST>(c, st, a, flags, grid_full) : launch_trace<KIND_MIXED>(c, st, a, flags, grid_full)) return rc;
             if (!(b == 0 && use_beams)) stamp(evc, false);
             c->launches_trace_closest++;
-            counts_known = b;              // append_ctr(b - 1), the paths that entered bounce b, has been written by now
-
-#ifdef TIRT_EXPERIMENTS
-            if (b == tail_b) {
-                // everything that is left of the batch in one launch: the paths' state stays where it is (`in`), their shadow rays go to index q of the shadow arrays
-                TraceArgs t = a;
-                t.count_ptr = cnt_path(b); t.count_fixed = 0; t.scount_ptr = nullptr;
-                t.fetch = fetch(b + 1);    // (the cursors of a launch this batch no longer makes)
-                t.timeline = nullptr; t.no_ray_count = 1;
-                t.tail.sc = sv; t.tail.tm = tm; t.tail.P = P; t.tail.frame_begin = f0; t.tail.seed = seed; t.tail.bounce0 = b; t.tail.max_depth = max_depth;
-                t.tail.tr = in.tr; t.tail.tg = in.tg; t.tail.tb = in.tb; t.tail.brdf_pdf = in.brdf_pdf; t.tail.flags = in.flags; t.tail.slot = in.slot;
-                if (int rc = launch_tail(c, st, t, flags, grid_full)) return rc;
-                c->launches_tail++;
-                break;
-            }
-#else
-            (void)tail_b;
-#endif
 
             stamp(evh, true);
             if (spec)
@@ -1676,18 +1497,6 @@ int pt_render(tirt_ctx *c, uint32_t frame_begin, int frame_count, uint32_t seed,
         else hipLaunchKernelGGL(k_film, dim3((P + B - 1) / B), dim3(B), 0, st, L.ps, tm, P, F, f0, c->hdr.as<float>());
         TIRT_HIP(hipEventRecord(L.film_done, st));
         L.film_recorded = true;
-        if (!spec && c->tail_bounce < 0 && c->tail_paths > 0 && counts_known >= 1) {      // the batch's per-bounce path counts, for the batches to come (never waited for)
-            if (L.host_counts_cap < max_depth) {
-                if (L.host_counts) (void)hipHostFree(L.host_counts);
-                L.host_counts = nullptr; L.host_counts_cap = 0;
-                TIRT_HIP(hipHostMalloc((void **)&L.host_counts, sizeof(unsigned long long) * (size_t)max_depth, hipHostMallocDefault));
-                L.host_counts_cap = max_depth;
-            }
-            if (!L.counts_done) TIRT_HIP(hipEventCreateWithFlags(&L.counts_done, hipEventDisableTiming));
-            TIRT_HIP(hipMemcpy2DAsync(L.host_counts, sizeof(unsigned long long), L.counters_mem.p, LINE, sizeof(unsigned long long), (size_t)counts_known, hipMemcpyDeviceToHost, st));
-            TIRT_HIP(hipEventRecord(L.counts_done, st));
-            L.counts_pending = true; L.counts_S = S; L.counts_known = counts_known;
-        }
         c->last_film = L.film_done;
         if (use_beams) c->pvb_set[c->pvb_cur].busy = L.film_done;      // the last batch that reads this set of candidate lists (pvb_prepare)
         TIRT_HIP(hipEventRecord(r1, st));
