@@ -89,6 +89,8 @@ def parse():
     ap.add_argument("--save-png", default="")
     ap.add_argument("--emulate-world", type=int, default=0, help="render only rank 0's tiles of an N-rank job (scaling study on one GPU)")
     ap.add_argument("--opt", action="append", default=[], help="name=value passed to tirt_set_option (tuning)")
+    ap.add_argument("--keep-lists", action="store_true", help="internal (profiler children): do not rebuild the camera rays' candidate lists at the start of the timed region -- "
+                                                              "their counters are those of a steady-state step, not of one step plus a list build")
     return ap.parse_args()
 
 
@@ -179,7 +181,7 @@ def measure_trace_counters(args):
     Returns a dict (per k_trace launch), or {"error": ...}."""
     fps, P = args.frames_per_step, args.size * args.size
     child = [sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "1", "--frames-per-step", str(fps),
-             "--size", str(args.size), "--ntri", str(args.ntri), "--seed", str(args.seed), "--no-cpu-baseline", "--no-roofline", "--no-configs",
+             "--size", str(args.size), "--ntri", str(args.ntri), "--seed", str(args.seed), "--no-cpu-baseline", "--no-roofline", "--no-configs", "--keep-lists",
              "--opt", "overlap_lanes=1",
              # one batch per step, as in the instrumented pass whose launch duration the bytes are divided by
              "--opt", "batch_paths=%d" % (fps * P), "--opt", "merge_paths=%d" % (fps * P)] + sum((["--opt", o] for o in args.opt), [])
@@ -712,7 +714,8 @@ def main():
     # Everything a render pays for is inside the clock: the camera rays' candidate lists are a per-camera structure -- render work, not scene build --
     # so the ones the warm-up made are forgotten here and the first timed batch makes them again (probe rays + the walk of the pixels' pyramids, on the
     # context's stream: `primary_beams.prepare_ms_in_timed_region`).  The reference's loop has no warm-up either (example/Example.py:38-59).
-    ctx.set_option("primary_beams_rebuild", 1)
+    if not args.keep_lists:
+        ctx.set_option("primary_beams_rebuild", 1)
     t_begin = time.perf_counter()
     run_steps(args.steps)
     t_submitted = time.perf_counter()             # the host has queued everything (the last, deferred batch goes out with the sync below)
