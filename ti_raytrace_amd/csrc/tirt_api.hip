@@ -339,7 +339,7 @@ void tirt_destroy(tirt_ctx *c)
                       &c->keys_b, &c->vals_a, &c->vals_b, &c->hist, &c->morton_sorted, &c->bvh_node, &c->compact, &c->parent,
                       &c->flag, &c->subtree, &c->build_status, &c->leaf_compact, &c->wnode, &c->tri, &c->prim_slot, &c->cnode, &c->cparent, &c->csize, &c->wide_queue, &c->wide_levels, &c->sah_compact, &c->sah_csize, &c->sah_parent, &c->wide_dp, &c->sah_box, &c->sah_idx, &c->sah_tasks, &c->sah_counts, &c->hdr, &c->rgb,
                       &c->counters_mem, &c->spill, &c->tr_rays,
-                      &c->tr_out, &c->tr_prim, &c->tr_counts, &c->dev_counters, &c->bdpt_px, &c->timeline, &c->pvb_set[0].count, &c->pvb_set[0].cand, &c->pvb_set[0].bound, &c->pvb_set[1].count, &c->pvb_set[1].cand, &c->pvb_set[1].bound, &c->pvb_stat};
+                      &c->tr_out, &c->tr_prim, &c->tr_counts, &c->dev_counters, &c->bdpt_px, &c->timeline, &c->pvb_set[0].count, &c->pvb_set[0].cand, &c->pvb_set[0].bound, &c->pvb_set[1].count, &c->pvb_set[1].cand, &c->pvb_set[1].bound, &c->pvb_stat, &c->pvb_tmp};
     for (DevBuf *b : bufs) b->release();
     for (auto &bl : c->bd) {
         DevBuf *bb[] = {&bl.items, &bl.state, &bl.rays, &bl.hits, &bl.qidx, &bl.ctr, &bl.rad};

@@ -363,7 +363,7 @@ struct tirt_ctx {
     int pvb_diag = 0;                             // option "primary_beams_diag": k_pvb_cand counts its leaf steps (one atomic per wave: slow) -- tirt_primary_beam_stats out[8..11]
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pvb_ev;      // HIP events around every list build since the last tirt_stats_reset (read by tirt_primary_beam_stats)
     unsigned long long pvb_builds = 0, pvb_build_ns = 0, pvb_skipped = 0;      // list builds since the reset, their device time, builds given up for lack of memory
-    tirt::DevBuf pvb_stat;
+    tirt::DevBuf pvb_stat, pvb_tmp;               // (pvb_tmp: the probe scratch where the runtime has no stream-ordered allocation)
 
     // PT_Spec tables (tirt_spectral_upload): CIE observer, spectra, Rgb2Spec table, sky configuration -- one buffer, views in spec_host
     tirt::DevBuf spec_dev;                      // the SpecView again, in device memory (BDPT_SPEC)

@@ -306,18 +306,23 @@ int pvb_prepare(tirt_ctx *c)
     tirt_ctx::PvbSet &ps = c->pvb_set[c->pvb_cur ^ 1];          // the set no batch submitted since the last rebuild reads
     hipStream_t st = c->stream;
     // the probe rays, their hit records: scratch of this call only (stream-ordered allocation: no synchronisation, gone when the walk is over)
-    void *tmp = nullptr;
+    void *tmp = nullptr; bool tmp_async = true;
     const size_t tmp_bytes = (sizeof(float4) * 2 + sizeof(float4)) * 5 * (size_t)P;
     auto without = [&](const char *what) {
         (void)hipGetLastError();                               // the failure is handled: leave no sticky error behind
         c->pvb_skipped++;
         set_error(std::string("primary_beams: no candidate lists for this camera (") + what + "); the camera rays take the ordinary launch");
-        if (tmp) (void)hipFreeAsync(tmp, st);
+        if (tmp && tmp_async) (void)hipFreeAsync(tmp, st);
         return TIRT_OK;
     };
     if (ps.count.ensure(sizeof(int) * (size_t)P) || ps.bound.ensure(sizeof(float) * (size_t)P) || ps.cand.ensure(sizeof(int2) * (size_t)PVB_CMAX * P) || c->pvb_stat.ensure(128))
         return without("list memory");
-    if (hipMallocAsync(&tmp, tmp_bytes, st) != hipSuccess) { tmp = nullptr; return without("probe scratch"); }
+    if (hipMallocAsync(&tmp, tmp_bytes, st) != hipSuccess) {
+        // (a runtime or device without stream-ordered allocation: an ordinary buffer, kept for the next build)
+        (void)hipGetLastError(); tmp = nullptr; tmp_async = false;
+        if (c->pvb_tmp.ensure(tmp_bytes)) return without("probe scratch");
+        tmp = c->pvb_tmp.p;
+    }
     if (trace_arrays_prepare(c, -1)) return without("traversal buffers");
     // batches still in flight read the OTHER set (a camera move submits what is pending and does not wait); this one was last read by the batches of the camera
     // before last: the film updates are chained in submission order, so the event of the last of them covers them all
@@ -331,12 +336,12 @@ int pvb_prepare(tirt_ctx *c)
     if (hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) (void)hipEventRecord(e0, st);
     else { if (e0) (void)hipEventDestroy(e0); e0 = e1 = nullptr; (void)hipGetLastError(); }
     hipLaunchKernelGGL(k_pvb_probes, dim3((P + B - 1) / B), dim3(B), 0, st, c->cam, tm, P, rays);
-    if (int rc = trace_arrays(c, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 5 * P, nullptr, hits, nullptr, nullptr, false, -1, rays)) { (void)hipFreeAsync(tmp, st); if (e0) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); } return rc; }
+    if (int rc = trace_arrays(c, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 5 * P, nullptr, hits, nullptr, nullptr, false, -1, rays)) { if (tmp_async) (void)hipFreeAsync(tmp, st); if (e0) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); } return rc; }
     hipLaunchKernelGGL(k_pvb_beam, dim3((P + 63) / 64), dim3(64), 0, st, bvh_view(c), c->cam, tm, P, hits, ps.count.as<int>(), ps.cand.as<int2>(),
                        ps.bound.as<float>(), c->pvb_stat.as<unsigned long long>());
     if (e0) { (void)hipEventRecord(e1, st); c->pvb_ev.push_back({e0, e1}); }
     c->pvb_builds++;
-    TIRT_HIP(hipFreeAsync(tmp, st));
+    if (tmp_async) TIRT_HIP(hipFreeAsync(tmp, st));
     TIRT_HIP(hipGetLastError());
     c->pvb_cur ^= 1; ps.busy = nullptr;
     memcpy(&c->pvb_key, &key, sizeof(key)); c->pvb_valid = true;
