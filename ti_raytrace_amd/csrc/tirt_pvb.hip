@@ -340,6 +340,12 @@ int pvb_prepare(tirt_ctx *c)
     hipLaunchKernelGGL(k_pvb_beam, dim3((P + 63) / 64), dim3(64), 0, st, bvh_view(c), c->cam, tm, P, hits, ps.count.as<int>(), ps.cand.as<int2>(),
                        ps.bound.as<float>(), c->pvb_stat.as<unsigned long long>());
     if (e0) { (void)hipEventRecord(e1, st); c->pvb_ev.push_back({e0, e1}); }
+    if (c->pvb_ev.size() > 64) {           // a caller that moves the camera for hours and never asks for statistics: the oldest pair is long finished
+        auto pr = c->pvb_ev.front(); c->pvb_ev.erase(c->pvb_ev.begin());
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) c->pvb_build_ns += (unsigned long long)((double)ms * 1.0e6);
+        (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); (void)hipGetLastError();
+    }
     c->pvb_builds++;
     if (tmp_async) TIRT_HIP(hipFreeAsync(tmp, st));
     TIRT_HIP(hipGetLastError());
