@@ -147,3 +147,15 @@ def test_default_tile_size():
     from ti_raytrace_amd.PT_RGB import default_tile_size
     assert default_tile_size(1024) == 8192 and default_tile_size(512) == 4096 and default_tile_size(2048) == 16384
     assert default_tile_size(4096) == 4096 and default_tile_size(100) == 4096 and default_tile_size(516) == 4096
+
+
+def test_bench_big_scenes_fit_the_reference_node_format():
+    """compact_node keeps node indices as f32 (SceneData.py / UtilsFunc.py: exact below 2^24), as the reference does: 2 n - 1 nodes for n primitives, so
+    bench.py's big-scene configs (triangles + the sphere light) must stay below 2^23 primitives -- 16 M triangles would not build (tirt_scene_upload refuses them)."""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    assert bench.BIG_SCENES, "no big-scene configs"
+    for name, (ntri, spread, npx) in bench.BIG_SCENES.items():
+        assert 2 * (ntri + 1) - 1 < 2 ** 24, name
+        assert ("%dM" % (ntri // 1000000)) in name and npx >= 256 and 0.0 < spread < 0.03
